@@ -1,0 +1,281 @@
+/*
+ * spectro_oracle.c — CPU ORACLE (test infrastructure only; see spectro_oracle.h).
+ *
+ * Plain-C restatement of the reference CPU algorithm.  Every function cites the
+ * reference file:line (under /root/reference/) it follows.  Build with
+ * -ffp-contract=off so `a*b + c` is two roundings, as in the Rust source
+ * (rustc never contracts); the explicit `mul_add`s of the reference are fma().
+ */
+#include "spectro_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+static int fail(char *err, size_t errlen, int code, const char *msg) {
+    if (err && errlen) snprintf(err, errlen, "%s", msg);
+    return code;
+}
+
+/* ---- parameter validation ------------------------------------------------ */
+/* StftParams::new  src/spectrogram.rs:3479-3506
+ * SpectrogramParams::new :4129-4140; MelParams::with_norm :3793-3813;
+ * LogParams::new :4071-4077; mel_plan Nyquist check :954-959; n_mels cap :1696-1700;
+ * build_mel_filterbank_matrix argument checks :2310-2323 */
+int orc_validate(const orc_params *p, char *err, size_t errlen) {
+    if (!p) return fail(err, errlen, ORC_INVALID_INPUT, "null params");
+    if (p->n_fft == 0) return fail(err, errlen, ORC_INVALID_INPUT, "n_fft must be > 0");
+    if (p->hop == 0) return fail(err, errlen, ORC_INVALID_INPUT, "hop_size must be > 0");
+    if (p->hop > p->n_fft) return fail(err, errlen, ORC_INVALID_INPUT, "hop_size must be <= n_fft");
+    if (p->window_kind < ORC_WIN_RECT || p->window_kind > ORC_WIN_CUSTOM)
+        return fail(err, errlen, ORC_INVALID_INPUT, "unknown window kind");
+    if (p->window_kind == ORC_WIN_CUSTOM && !p->custom_window)
+        return fail(err, errlen, ORC_INVALID_INPUT, "Custom window size must match n_fft");
+    if (!(p->sample_rate > 0.0 && isfinite(p->sample_rate)))
+        return fail(err, errlen, ORC_INVALID_INPUT, "sample_rate_hz must be finite and > 0");
+    if (p->freq_scale == ORC_FREQ_MEL) {
+        if (p->n_mels == 0) return fail(err, errlen, ORC_INVALID_INPUT, "n_mels must be > 0");
+        if (p->f_min < 0.0) return fail(err, errlen, ORC_INVALID_INPUT, "f_min must be >= 0");
+        if (p->f_max <= p->f_min) return fail(err, errlen, ORC_INVALID_INPUT, "f_max must be > f_min");
+        if (p->f_max > p->sample_rate * 0.5)
+            return fail(err, errlen, ORC_INVALID_INPUT, "mel f_max must be <= Nyquist");
+        if (p->n_mels > 10000) return fail(err, errlen, ORC_INVALID_INPUT, "n_mels is unreasonably large");
+        if (isinf(p->f_min)) return fail(err, errlen, ORC_INVALID_INPUT, "f_min must be >= 0");
+    } else if (p->freq_scale != ORC_FREQ_LINEAR) {
+        return fail(err, errlen, ORC_INVALID_INPUT, "unknown frequency scale");
+    }
+    if (p->amp_scale < ORC_AMP_POWER || p->amp_scale > ORC_AMP_DECIBELS)
+        return fail(err, errlen, ORC_INVALID_INPUT, "unknown amplitude scale");
+    if (p->has_db && !isfinite(p->floor_db))
+        return fail(err, errlen, ORC_INVALID_INPUT, "floor_db must be finite");
+    return ORC_OK;
+}
+
+/* StftPlan::frame_count  src/spectrogram.rs:1230-1250 */
+size_t orc_frame_count(size_t n_samples, size_t n_fft, size_t hop, int centre) {
+    size_t pad = centre ? n_fft / 2 : 0;
+    size_t padded_len = n_samples + 2 * pad;
+    if (padded_len < n_fft) return 1;
+    size_t remaining = padded_len - n_fft;
+    return remaining / hop + 1;
+}
+
+size_t orc_n_bins(const orc_params *p) {
+    /* FrequencyMapping::output_bins src/spectrogram.rs:1809-1820; r2c_output_size fft_backend.rs:16-18 */
+    return p->freq_scale == ORC_FREQ_MEL ? (size_t)p->n_mels : (size_t)p->n_fft / 2 + 1;
+}
+
+/* modified_bessel_i0  src/spectrogram.rs:2237-2259 (Abramowitz-Stegun polynomial, not exact I0) */
+static double bessel_i0_poly(double x) {
+    double ax = fabs(x);
+    if (ax <= 3.75) {
+        double t = x / 3.75;
+        double t2 = t * t;
+        return 1.0 + t2 * (3.5156229 + t2 * (3.0899424 + t2 * (1.2067492 +
+                     t2 * (0.2659732 + t2 * (0.0360768 + t2 * 0.0045813)))));
+    } else {
+        double t = 3.75 / ax;
+        double poly = 0.39894228 + t * (0.01328592 + t * (0.00225319 + t * (-0.00157565 +
+                      t * (0.00916281 + t * (-0.02057706 + t * (0.02635537 +
+                      t * (-0.01647633 + t * 0.00392377)))))));
+        return (exp(ax) / (sqrt(ax) * sqrt(2.0 * M_PI))) * poly;
+    }
+}
+
+/* make_window  src/spectrogram.rs:2159-2235 (coefficients in f64; caller casts to T, :2232) */
+int orc_make_window(int kind, double param, const double *custom, size_t n, double *w) {
+    if (n == 0 || !w) return ORC_INVALID_INPUT;
+    switch (kind) {
+    case ORC_WIN_RECT:
+        for (size_t i = 0; i < n; i++) w[i] = 1.0;
+        break;
+    case ORC_WIN_HANNING: {
+        double n1 = (double)(n - 1);
+        for (size_t i = 0; i < n; i++) w[i] = fma(0.5, -cos(2.0 * M_PI * (double)i / n1), 0.5);
+        break;
+    }
+    case ORC_WIN_HAMMING: {
+        double n1 = (double)(n - 1);
+        for (size_t i = 0; i < n; i++) w[i] = fma(0.46, -cos(2.0 * M_PI * (double)i / n1), 0.54);
+        break;
+    }
+    case ORC_WIN_BLACKMAN: {
+        double n1 = (double)(n - 1);
+        for (size_t i = 0; i < n; i++) {
+            double a = 2.0 * M_PI * (double)i / n1;
+            w[i] = fma(0.08, cos(2.0 * a), fma(0.5, -cos(a), 0.42));
+        }
+        break;
+    }
+    case ORC_WIN_KAISER: {
+        if (n == 1) { w[0] = 1.0; break; }
+        double denom = bessel_i0_poly(param);
+        double n_max = (double)(n - 1) / 2.0;
+        for (size_t i = 0; i < n; i++) {
+            double x = (double)i - n_max;
+            double ratio;
+            if (n_max == 0.0) ratio = 0.0;
+            else { double nr = x / n_max; ratio = fmax(1.0 - nr * nr, 0.0); }
+            double arg = param * sqrt(ratio);
+            w[i] = (denom == 0.0) ? 0.0 : bessel_i0_poly(arg) / denom;
+        }
+        break;
+    }
+    case ORC_WIN_GAUSSIAN: {
+        double center = (double)(n - 1) / 2.0;
+        for (size_t i = 0; i < n; i++) {
+            double q = ((double)i - center) / param;
+            double e = -0.5 * (q * q); /* powi(2) */
+            w[i] = exp(e);
+        }
+        break;
+    }
+    case ORC_WIN_CUSTOM:
+        if (!custom) return ORC_INVALID_INPUT;
+        memcpy(w, custom, n * sizeof(double));
+        break;
+    default:
+        return ORC_INVALID_INPUT;
+    }
+    return ORC_OK;
+}
+
+/* hz_to_mel / mel_to_hz  src/spectrogram.rs:2268-2300 (Slaney) */
+#define MEL_F_SP (200.0 / 3.0)
+#define MEL_MIN_LOG_HZ 1000.0
+#define MEL_MIN_LOG_MEL (MEL_MIN_LOG_HZ / MEL_F_SP)
+#define MEL_LOGSTEP 0.06875177742094923
+double orc_hz_to_mel(double hz) {
+    if (hz >= MEL_MIN_LOG_HZ) return MEL_MIN_LOG_MEL + log(hz / MEL_MIN_LOG_HZ) / MEL_LOGSTEP;
+    return (hz - 0.0) / MEL_F_SP;
+}
+double orc_mel_to_hz(double mel) {
+    if (mel >= MEL_MIN_LOG_MEL) return MEL_MIN_LOG_HZ * exp(MEL_LOGSTEP * (mel - MEL_MIN_LOG_MEL));
+    return fma(MEL_F_SP, mel, 0.0);
+}
+
+/* build_mel_filterbank_matrix  src/spectrogram.rs:2302-2432, SparseMatrix::set :69-87 */
+long orc_mel_filterbank(double sr, size_t n_fft, size_t n_mels, double f_min, double f_max, int norm,
+                        size_t *row_ptr, uint32_t *cols, double *vals, size_t cap) {
+    if (sr <= 0.0 || !isfinite(sr)) return -ORC_INVALID_INPUT;
+    if (f_min < 0.0 || isinf(f_min)) return -ORC_INVALID_INPUT;
+    if (f_max <= f_min) return -ORC_INVALID_INPUT;
+    if (f_max > sr * 0.5) return -ORC_INVALID_INPUT;
+    size_t out_len = n_fft / 2 + 1;
+    double df = sr / (double)n_fft;
+    double mel_min = orc_hz_to_mel(f_min), mel_max = orc_hz_to_mel(f_max);
+    size_t n_points = n_mels + 2;
+    double step = (mel_max - mel_min) / (double)(n_points - 1);
+    double *mel_points = (double *)malloc(n_points * sizeof(double));
+    double *hz_points = (double *)malloc(n_points * sizeof(double));
+    if (!mel_points || !hz_points) { free(mel_points); free(hz_points); return -ORC_INTERNAL; }
+    for (size_t i = 0; i < n_points; i++) mel_points[i] = fma((double)i, step, mel_min);
+    for (size_t i = 0; i < n_points; i++) hz_points[i] = orc_mel_to_hz(mel_points[i]);
+
+    size_t nnz = 0;
+    long rc = 0;
+    for (size_t m = 0; m < n_mels; m++) {
+        row_ptr[m] = nnz;
+        double fl = hz_points[m], fc = hz_points[m + 1], fr = hz_points[m + 2];
+        double dl = fc - fl, dr = fr - fc;
+        if (dl == 0.0 || dr == 0.0) continue; /* degenerate triangle */
+        for (size_t k = 0; k < out_len; k++) {
+            double bf = (double)k * df;
+            double lower = (bf - fl) / dl;
+            double upper = (fr - bf) / dr;
+            double wgt = fmin(lower, upper);
+            wgt = wgt < 0.0 ? 0.0 : (wgt > 1.0 ? 1.0 : wgt);
+            if (wgt > 0.0 && fabs(wgt) > 1e-10) { /* set(): only store |v| > 1e-10 (:83) */
+                if (nnz >= cap) { rc = -ORC_DIM_MISMATCH; goto done; }
+                cols[nnz] = (uint32_t)k;
+                vals[nnz] = wgt;
+                nnz++;
+            }
+        }
+    }
+    row_ptr[n_mels] = nnz;
+    for (size_t m = 0; m < n_mels; m++) {
+        size_t a = row_ptr[m], b = row_ptr[m + 1];
+        if (norm == ORC_MELNORM_SLANEY) {
+            double hz_left = orc_mel_to_hz(mel_points[m]);
+            double hz_right = orc_mel_to_hz(mel_points[m + 2]);
+            double enorm = 2.0 / (hz_right - hz_left);
+            for (size_t i = a; i < b; i++) vals[i] *= enorm;
+        } else if (norm == ORC_MELNORM_L1) {
+            double s = 0.0;
+            for (size_t i = a; i < b; i++) s += vals[i];
+            if (s > 0.0) { double nz = 1.0 / s; for (size_t i = a; i < b; i++) vals[i] *= nz; }
+        } else if (norm == ORC_MELNORM_L2) {
+            double s = 0.0;
+            for (size_t i = a; i < b; i++) s += vals[i] * vals[i];
+            s = sqrt(s);
+            if (s > 0.0) { double nz = 1.0 / s; for (size_t i = a; i < b; i++) vals[i] *= nz; }
+        }
+    }
+    rc = (long)nnz;
+done:
+    free(mel_points);
+    free(hz_points);
+    return rc;
+}
+
+/* axes: build_time_axis_seconds :2128-2139; frequencies_hz :1909-1931;
+ * mel_band_centres_hz :2510-2530 (ignores MelParams f_min/f_max — S10) */
+int orc_axes(const orc_params *p, size_t n_frames, double *freqs, double *times) {
+    if (!p) return ORC_INVALID_INPUT;
+    if (times) {
+        double dt = (double)p->hop / p->sample_rate;
+        for (size_t i = 0; i < n_frames; i++) times[i] = (double)i * dt;
+    }
+    if (freqs) {
+        if (p->freq_scale == ORC_FREQ_MEL) {
+            double nyq = p->sample_rate * 0.5;
+            double f_max = fmin(nyq, p->sample_rate * 0.5);
+            double mel_min = orc_hz_to_mel(0.0), mel_max = orc_hz_to_mel(f_max);
+            double step = (mel_max - mel_min) / (double)(p->n_mels + 1);
+            for (size_t i = 0; i < p->n_mels; i++)
+                freqs[i] = orc_mel_to_hz(fma((double)i + 1.0, step, mel_min));
+        } else {
+            double df = p->sample_rate / (double)p->n_fft;
+            for (size_t k = 0; k < (size_t)p->n_fft / 2 + 1; k++) freqs[k] = (double)k * df;
+        }
+    }
+    return ORC_OK;
+}
+
+int orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ---- typed part (T = f32 / f64), see oracle_typed.inc --------------------- */
+#define REAL float
+#define SUF(x) x##_f32
+#define R_SQRT sqrtf
+#define R_LOG10 log10f
+#include "oracle_typed.inc"
+#undef REAL
+#undef SUF
+#undef R_SQRT
+#undef R_LOG10
+
+#define REAL double
+#define SUF(x) x##_f64
+#define R_SQRT sqrt
+#define R_LOG10 log10
+#include "oracle_typed.inc"
+#undef REAL
+#undef SUF
+#undef R_SQRT
+#undef R_LOG10

@@ -1,0 +1,102 @@
+/*
+ * spectro_oracle.h — CPU ORACLE for the STFT / Mel-spectrogram hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain-C restatement of the reference's
+ * (jmg049/Spectrograms, crate `spectrograms` v2.1.0) CPU algorithm for the hot
+ * path.  Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline`
+ * leg may load it — as the checker / the timed CPU baseline, never as the thing
+ * shipped.  The product library (spectrograms_amd/csrc → libspectro_hip.so) does
+ * not link, include or call anything in this directory.
+ *
+ * Parity pinning: the 1-D FFT arithmetic of the reference lives in the external
+ * crates realfft 3.5.0 / rustfft 6.4.1 (Cargo.lock:920-922,1002-1004), which are
+ * not vendored under /root/reference and cannot be built here (no cargo/rustc).
+ * The oracle therefore restates the published DFT definition
+ * X[k] = sum_n x[n] e^{-2 pi i k n / N} (src/fft_backend.rs:16-18,128) and is
+ * pinned (tests/test_oracle_golden.py) against
+ *   (i)  golden vectors generated in the build container by importing the
+ *        reference's own python/examples/numpy_impls.py (stft / hann_window /
+ *        power_spectrogram / magnitude_spectrogram — identical semantics to the
+ *        Rust path) — tests/golden/make_golden.py, and
+ *   (ii) every numeric known-answer test the reference's test-suite holds for
+ *        this path.
+ * Bit-level parity with RustFFT output itself is UNPINNED (no golden values
+ * exist in the reference); tolerances are stated in the tests.
+ */
+#ifndef SPECTRO_ORACLE_H
+#define SPECTRO_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORC_OK = 0, ORC_INVALID_INPUT = 1, ORC_DIM_MISMATCH = 2, ORC_BACKEND = 3, ORC_INTERNAL = 4 };
+
+enum { ORC_WIN_RECT = 0, ORC_WIN_HANNING = 1, ORC_WIN_HAMMING = 2, ORC_WIN_BLACKMAN = 3,
+       ORC_WIN_KAISER = 4, ORC_WIN_GAUSSIAN = 5, ORC_WIN_CUSTOM = 6 };
+enum { ORC_FREQ_LINEAR = 0, ORC_FREQ_MEL = 1 };
+enum { ORC_MELNORM_NONE = 0, ORC_MELNORM_SLANEY = 1, ORC_MELNORM_L1 = 2, ORC_MELNORM_L2 = 3 };
+enum { ORC_AMP_POWER = 0, ORC_AMP_MAGNITUDE = 1, ORC_AMP_DECIBELS = 2 };
+
+typedef struct {
+    uint32_t n_fft, hop;
+    int32_t centre;
+    int32_t window_kind;
+    double window_param;          /* kaiser beta / gaussian std (samples) */
+    const double *custom_window;  /* n_fft coefficients when window_kind == CUSTOM */
+    double sample_rate;
+    int32_t freq_scale;
+    uint32_t n_mels;
+    double f_min, f_max;
+    int32_t mel_norm;
+    int32_t amp_scale;
+    int32_t has_db;               /* LogParams supplied? (S6: dB only applied if so) */
+    double floor_db;
+} orc_params;
+
+/* spectrogram.rs:3479-3506, 4129-4140, 3793-3813, 4071-4077, 944-959 */
+int orc_validate(const orc_params *p, char *err, size_t errlen);
+/* spectrogram.rs:1230-1250 */
+size_t orc_frame_count(size_t n_samples, size_t n_fft, size_t hop, int centre);
+size_t orc_n_bins(const orc_params *p);
+/* spectrogram.rs:2159-2259 */
+int orc_make_window(int kind, double param, const double *custom, size_t n, double *out);
+/* spectrogram.rs:2268-2432; CSR output. returns nnz (>=0) or -status. */
+long orc_mel_filterbank(double sample_rate, size_t n_fft, size_t n_mels, double f_min, double f_max,
+                        int norm, size_t *row_ptr /*n_mels+1*/, uint32_t *cols, double *vals,
+                        size_t cap);
+double orc_hz_to_mel(double hz);
+double orc_mel_to_hz(double mel);
+/* spectrogram.rs:2128-2139,1909-1931,2510-2530 */
+int orc_axes(const orc_params *p, size_t n_frames, double *freqs, double *times);
+
+/* forward real DFT, n real -> n/2+1 complex (interleaved re,im); any n >= 1 */
+int orc_rfft_f32(const float *in, size_t n, float *out);
+int orc_rfft_f64(const double *in, size_t n, double *out);
+
+/* spectrogram.rs:1424-1458: complex STFT, out[(bin*n_frames + frame)*2 + {0,1}] */
+int orc_stft_f32(const orc_params *p, const float *x, size_t n, float *out);
+int orc_stft_f64(const orc_params *p, const double *x, size_t n, double *out);
+/* spectrogram.rs:240-294: out[bin*n_frames + frame] */
+int orc_spectrogram_f32(const orc_params *p, const float *x, size_t n, float *out);
+int orc_spectrogram_f64(const orc_params *p, const double *x, size_t n, double *out);
+
+/* the reference's batch idiom (src/lib.rs:228-236): one plan, loop over signals;
+ * nthreads > 1 = one plan per thread over utterances (OpenMP). */
+int orc_spectrogram_batch_f32(const orc_params *p, const float *x, size_t batch, size_t n,
+                              size_t stride, float *out, int nthreads);
+int orc_spectrogram_batch_f64(const orc_params *p, const double *x, size_t batch, size_t n,
+                              size_t stride, double *out, int nthreads);
+int orc_stft_batch_f32(const orc_params *p, const float *x, size_t batch, size_t n, size_t stride,
+                       float *out, int nthreads);
+int orc_stft_batch_f64(const orc_params *p, const double *x, size_t batch, size_t n, size_t stride,
+                       double *out, int nthreads);
+int orc_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
