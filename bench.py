@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py — STFT frames/s (f32, n_fft=1024, hop=256) on N MI355X, with roofline and CPU-baseline objects.
+
+A "step" is one pass of the hot path (one batched kernel launch through the C ABI) over one batch of synthetic
+signals that is already resident in HBM.  Default workload = BASELINE.json configs[1]: 256 x 10 s 16 kHz f32,
+linear-power STFT, Hanning, centre.  `--workload mel_db` runs configs[2] (Mel-80 + dB) instead.
+
+Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL).  Utterances shard by rank with no data-path
+collective (weak scaling: every rank owns a full 256-utterance batch); `--gather` adds the RCCL all-gather that
+reassembles the batched output on every rank (BASELINE.json configs[3]) inside the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak is ~6290 GB/s
+SR, N_FFT, HOP, N_SAMPLES, BATCH = 16000.0, 1024, 256, 160000, 256
+
+
+def cfg_signal(b: int) -> np.ndarray:
+    """BASELINE.md §2 generator: even rows sine 0.5*sin(2*pi*f_b*i/16000), odd rows N(0, 0.1^2), seed 1234+b."""
+    if b % 2 == 0:
+        f = 110.0 * 2.0 ** ((b % 48) / 12.0)
+        return (0.5 * np.sin(2.0 * np.pi * f * np.arange(N_SAMPLES, dtype=np.float64) / SR)).astype(np.float32)
+    return (0.1 * np.random.default_rng(1234 + b).standard_normal(N_SAMPLES)).astype(np.float32)
+
+
+def bytes_per_frame(workload: str, n_frames: int) -> float:
+    """Algorithmic HBM bytes per frame: every input sample read once, every output written once."""
+    read = N_SAMPLES * 4.0 / n_frames
+    write = {"linear_power": 513 * 4.0, "mel_db": 80 * 4.0, "mel_power": 80 * 4.0, "stft": 513 * 8.0}[workload]
+    return read + write
+
+
+def cpu_baseline(workload: str, budget_s: float = 12.0):
+    """Times the CPU restatement of the reference algorithm (oracle/, kind 'port': per-frame window -> real FFT ->
+    |.|^2 -> [sparse Mel -> dB], one plan per thread over utterances — the reference's batch idiom) on this host."""
+    from oracle import oracle as orc
+
+    cores = orc.max_threads()
+    nsig = 64
+    x = np.stack([cfg_signal(b) for b in range(nsig)])
+    if workload == "linear_power":
+        op = orc.Params(n_fft=N_FFT, hop=HOP)
+    elif workload == "mel_power":
+        op = orc.Params(n_fft=N_FFT, hop=HOP, n_mels=80)
+    elif workload == "stft":
+        op = orc.Params(n_fft=N_FFT, hop=HOP)
+    else:
+        op = orc.Params(n_fft=N_FFT, hop=HOP, n_mels=80, amp="db", floor_db=-80.0)
+    fn = orc.stft_batch if workload == "stft" else orc.spectrogram_batch
+    fn(op, x[:cores], nthreads=cores)  # warm-up
+    frames = 0
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        out = fn(op, x, nthreads=cores)
+        frames += out.shape[0] * out.shape[2]
+        reps += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    o1 = fn(op, x[:8], nthreads=1)
+    dt1 = time.perf_counter() - t1
+    return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} x {nsig} utterances of the same workload ({frames} frames, {dt:.1f} s wall, "
+                      f"one plan per thread); single-thread rate {o1.shape[0] * o1.shape[2] / dt1:.0f} frames/s",
+            "single_thread_value": o1.shape[0] * o1.shape[2] / dt1}
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="linear_power", choices=["linear_power", "mel_db", "mel_power", "stft"])
+    ap.add_argument("--gather", action="store_true", help="RCCL all-gather of the output shards inside the timed region")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import spectrograms_amd as sg
+    from spectrograms_amd import _ffi
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes", file=sys.stderr)
+            return 2
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible — the product path has no CPU fallback", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- plan + synthetic device-resident batch (weak scaling: every rank owns BATCH utterances)
+    params = sg.SpectrogramParams(sg.StftParams(N_FFT, HOP, sg.WindowType.hanning, True), SR)
+    planner = sg.SpectrogramPlanner()
+    if args.workload == "linear_power":
+        plan = planner.linear_power_plan(params, dtype="float32")
+    elif args.workload == "mel_power":
+        plan = planner.mel_power_plan(params, sg.MelParams(80, 0.0, 8000.0), dtype="float32")
+    elif args.workload == "stft":
+        plan = planner.stft_plan(params, dtype="float32")
+    else:
+        plan = planner.mel_db_plan(params, sg.MelParams(80, 0.0, 8000.0), sg.LogParams(-80.0), dtype="float32")
+    n_bins, n_frames = plan.output_shape(N_SAMPLES)
+    host = np.stack([cfg_signal(rank * BATCH + b) for b in range(BATCH)])
+    nsets = 2  # rotate buffer sets so a step never re-reads its own input out of the 256 MiB Infinity Cache
+    xs = [torch.from_numpy(host).to(dev) for _ in range(nsets)]
+    oshape = (BATCH, n_bins, n_frames, 2) if args.workload == "stft" else (BATCH, n_bins, n_frames)
+    outs = [torch.empty(oshape, dtype=torch.float32, device=dev) for _ in range(nsets)]
+    gathered = None
+    if args.gather and world > 1:
+        gathered = torch.empty((world,) + oshape, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def step(i: int) -> None:
+        plan.compute_batch(xs[i % nsets], out=outs[i % nsets])
+        if gathered is not None:
+            dist.all_gather_into_tensor(gathered, outs[i % nsets])
+
+    def fence() -> None:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)  # same stream the kernels are launched on (the plan launches on torch's current stream)
+    for i in range(args.steps):
+        step(i)
+    ev1.record(stream)
+    fence()
+    dt = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1) / args.steps  # mean device time per step over the timed region
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    frames_per_step = BATCH * n_frames * world
+    value = frames_per_step * args.steps / dt
+    bpf = bytes_per_frame(args.workload, n_frames)
+    alg_bytes_per_launch = bpf * BATCH * n_frames  # one launch = one rank's batch
+    achieved = alg_bytes_per_launch / (dev_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(args.workload)
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        line = {
+            "metric": "STFT frames/sec (f32, n_fft=1024 hop=256)",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[{1 if args.workload == 'linear_power' else 2}]: {BATCH} x 10 s 16 kHz f32 per GPU, "
+                                   f"{args.workload} n_fft=1024 hop=256 Hanning centre", "batch_per_gpu": BATCH,
+                       "n_samples": N_SAMPLES, "frames_per_step": frames_per_step, "kernel": plan.kernel_name,
+                       "gather": bool(gathered is not None), "parallelism": f"utterance-shard x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": dev_ms,
+                         "algorithmic_bytes_per_frame": bpf, "frames_per_launch": BATCH * n_frames},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,139 @@
+/*
+ * spectro_hip.h — C ABI of libspectro_hip.so, the MI355X (gfx950) engine for the
+ * batched STFT / Mel-spectrogram hot path of the `spectrograms` crate
+ * (jmg049/Spectrograms v2.1.0).  All reference citations are file:line under the
+ * reference repository root.
+ *
+ * This header is the drop-in boundary: a `fft_backend::hip_backend` variant in
+ * the reference (the analogue of its FFTW variant, src/fft_backend.rs:1084-1871)
+ * binds exactly these symbols — see INTEGRATION.md for the Rust `extern "C"`
+ * block and the ctypes binding used by the Python host mirror.
+ *
+ * Conventions
+ *  - Plain C types only; no C++/torch types cross the boundary.
+ *  - A plan is the analogue of the reference's `&mut self` plans
+ *    (src/fft_backend.rs:21-24: "own scratch, reusable, no heap allocation in
+ *    process"): it owns every device table (window, twiddles, filterbank) and all
+ *    scratch; it is NOT thread-safe (one caller at a time, like `&mut self`;
+ *    Python plan objects are `unsendable`, src/python/planner.rs:674).  Distinct
+ *    plans are independent.
+ *  - No function aborts or throws across the ABI.  Status codes mirror
+ *    `SpectrogramError` (src/error.rs:13-28); the message text is available
+ *    from sgx_last_error() / sgx_last_create_error().
+ *  - There is no CPU fallback: without a usable HIP device every compute entry
+ *    point returns SGX_BACKEND.
+ */
+#ifndef SPECTRO_HIP_H
+#define SPECTRO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGX_ABI_VERSION 1
+
+typedef struct sgx_plan sgx_plan; /* opaque */
+
+/* src/error.rs:13-28  InvalidInput / DimensionMismatch / FftBackendError{backend:"hip"} / InternalError */
+typedef enum {
+    SGX_OK = 0,
+    SGX_INVALID_INPUT = 1,
+    SGX_DIM_MISMATCH = 2,
+    SGX_BACKEND = 3,
+    SGX_INTERNAL = 4
+} sgx_status;
+
+/* src/window.rs:19-50 WindowType */
+enum { SGX_WIN_RECTANGULAR = 0, SGX_WIN_HANNING = 1, SGX_WIN_HAMMING = 2, SGX_WIN_BLACKMAN = 3,
+       SGX_WIN_KAISER = 4, SGX_WIN_GAUSSIAN = 5, SGX_WIN_CUSTOM = 6 };
+/* src/spectrogram.rs:3374-3442 frequency-scale markers (LinearHz, Mel) */
+enum { SGX_FREQ_LINEAR = 0, SGX_FREQ_MEL = 1 };
+/* MelNorm src/spectrogram.rs:2385-2429 */
+enum { SGX_MELNORM_NONE = 0, SGX_MELNORM_SLANEY = 1, SGX_MELNORM_L1 = 2, SGX_MELNORM_L2 = 3 };
+/* AmpScaleSpec impls src/spectrogram.rs:1986-2037; COMPLEX = StftPlan::compute (:1424-1458) */
+enum { SGX_AMP_POWER = 0, SGX_AMP_MAGNITUDE = 1, SGX_AMP_DECIBELS = 2, SGX_AMP_COMPLEX = 3 };
+/* Sample impls src/sample.rs:23-86 */
+enum { SGX_F32 = 0, SGX_F64 = 1 };
+enum { SGX_MEM_HOST = 0, SGX_MEM_DEVICE = 1 };
+
+/* StftParams (src/spectrogram.rs:3452-3506) + SpectrogramParams (:4108-4140) + MelParams (:3744-3813)
+ * + LogParams (:4052-4077) + the `T: Sample` choice, flattened. */
+typedef struct {
+    uint32_t n_fft;
+    uint32_t hop_size;
+    int32_t centre;               /* zero padding of n_fft/2 on both sides (S1) */
+    int32_t window_kind;          /* SGX_WIN_* */
+    double window_param;          /* Kaiser beta / Gaussian std in samples */
+    const double *custom_window;  /* n_fft coefficients (copied) or NULL */
+    uint32_t custom_window_len;   /* must equal n_fft for SGX_WIN_CUSTOM (:3490-3498) */
+    double sample_rate_hz;
+    int32_t freq_scale;           /* SGX_FREQ_* */
+    uint32_t n_mels;
+    double f_min, f_max;
+    int32_t mel_norm;             /* SGX_MELNORM_* */
+    int32_t amp_scale;            /* SGX_AMP_* */
+    int32_t has_log_params;       /* Option<&LogParams>: dB applied only when set (S6) */
+    double floor_db;
+    int32_t dtype;                /* SGX_F32 / SGX_F64 */
+    int32_t device;               /* HIP device ordinal; -1 = current device */
+} sgx_params;
+
+/* Replaces StftPlan::new (:1204-1228), SpectrogramPlanner::{linear_plan :893-917, mel_plan :944-977}:
+ * validates exactly like the reference constructors, builds window / twiddles / CSR filterbank on the
+ * host in f64, casts to T and uploads.  On failure *out is NULL and sgx_last_create_error() has the text. */
+sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out);
+void sgx_plan_destroy(sgx_plan *plan);
+
+/* StftPlan::frame_count (:1230-1250) + SpectrogramPlan::output_shape (:512-519) */
+sgx_status sgx_output_shape(const sgx_plan *plan, size_t n_samples, size_t *n_bins, size_t *n_frames);
+
+/* The batched fast path replacing the per-signal loop `for s in signals { plan.compute(s) }`
+ * (src/lib.rs:228-236) over SpectrogramPlan::compute (:240-294) / StftPlan::compute (:1424-1458).
+ *   samples : batch rows of n_samples elements of T, row r at samples + r*sample_stride elements
+ *   out     : [batch][n_bins][n_frames] row-major T (frames contiguous, S9); for SGX_AMP_COMPLEX
+ *             interleaved (re,im) pairs, out_elems counts T elements (2 per complex value)
+ *   out_elems != batch*n_bins*n_frames*(1|2)  ->  SGX_DIM_MISMATCH (compute_into, :423-434)
+ *   mem_kind: SGX_MEM_HOST (plan-owned staging + copies, synchronous) or SGX_MEM_DEVICE
+ *             (asynchronous on `hip_stream`, a hipStream_t; NULL = the null stream) */
+sgx_status sgx_execute(sgx_plan *plan, const void *samples, size_t batch, size_t n_samples,
+                       size_t sample_stride, void *out, size_t out_elems, int32_t mem_kind,
+                       void *hip_stream);
+
+/* Same as sgx_execute with device pointers, but launches `iters` times back-to-back between two
+ * hipEvents recorded on `hip_stream` and returns the mean device time per launch in milliseconds
+ * (used by bench.py for the roofline line).  Synchronises the stream. */
+sgx_status sgx_execute_timed(sgx_plan *plan, const void *samples, size_t batch, size_t n_samples,
+                             size_t sample_stride, void *out, size_t out_elems, void *hip_stream,
+                             int32_t iters, float *ms_per_launch);
+
+/* build_time_axis_seconds (:2128-2139), frequencies_hz (:1909-1931), mel_band_centres_hz (:2510-2530) */
+sgx_status sgx_axes(const sgx_plan *plan, size_t n_frames, double *freqs /*n_bins*/, double *times /*n_frames*/);
+
+/* Conforming per-call R2cPlan::process (src/fft_backend.rs:25-44, 423-431): host pointers, one frame,
+ * in_len must be n_fft and out_len n_fft/2+1 complex values else SGX_DIM_MISMATCH (:264-282). */
+sgx_status sgx_r2c(sgx_plan *plan, const void *in, size_t in_len, void *out, size_t out_len);
+
+/* make_window (:2159-2235): the plan's window coefficients as built (f64, before the cast to T). */
+sgx_status sgx_window(const sgx_plan *plan, double *out /*n_fft*/);
+/* build_mel_filterbank_matrix (:2302-2432) as CSR; pass NULL arrays to query nnz only. */
+sgx_status sgx_mel_weights(const sgx_plan *plan, size_t *nnz, uint32_t *row_ptr /*n_mels+1*/,
+                           uint32_t *cols, double *vals);
+
+/* Utterance sharding for one-process-per-GPU runs: contiguous blocks, remainder to
+ * the low ranks. */
+sgx_status sgx_shard_range(size_t batch, int32_t world_size, int32_t rank, size_t *start, size_t *count);
+
+const char *sgx_last_error(const sgx_plan *plan);
+const char *sgx_last_create_error(void);
+/* Name of the kernel variant the plan dispatches to ("r32x16_f32", "lds_radix2", "direct_dft"). */
+const char *sgx_kernel_name(const sgx_plan *plan);
+int32_t sgx_abi_version(void);
+int32_t sgx_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPECTRO_HIP_H */

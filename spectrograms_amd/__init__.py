@@ -1,0 +1,22 @@
+"""spectrograms_amd — MI355X (gfx950) engine for the batched STFT / Mel-spectrogram hot path of the
+`spectrograms` crate, behind the reference's own parameter / plan / function names.
+
+The compute path is hand-written HIP in libspectro_hip.so reached through the C ABI of
+include/spectro_hip.h.  There is no CPU fallback: if the library is not built, or no HIP device is present,
+compute calls raise FFTBackendError.
+"""
+from ._ffi import (DimensionMismatchError, FFTBackendError, InternalError, InvalidInputError, SpectrogramError)
+from .functions import (compute_linear_db_spectrogram, compute_linear_magnitude_spectrogram,
+                        compute_linear_power_spectrogram, compute_mel_db_spectrogram,
+                        compute_mel_magnitude_spectrogram, compute_mel_power_spectrogram, compute_stft)
+from .params import LogParams, MelNorm, MelParams, SpectrogramParams, StftParams, WindowType
+from .planner import Plan, Spectrogram, SpectrogramPlanner, StftResult
+
+__all__ = [
+    "SpectrogramError", "InvalidInputError", "DimensionMismatchError", "FFTBackendError", "InternalError",
+    "WindowType", "StftParams", "SpectrogramParams", "MelParams", "MelNorm", "LogParams",
+    "SpectrogramPlanner", "Plan", "Spectrogram", "StftResult",
+    "compute_linear_power_spectrogram", "compute_linear_magnitude_spectrogram", "compute_linear_db_spectrogram",
+    "compute_mel_power_spectrogram", "compute_mel_magnitude_spectrogram", "compute_mel_db_spectrogram",
+    "compute_stft",
+]

@@ -1,0 +1,251 @@
+// kernels_generic.hip — shape-generic STFT kernels (any n_fft, f32 and f64) for gfx950.
+//
+// These are the correctness/coverage kernels: every (n_fft, hop, window, centre, mapping, amp, dtype)
+// the reference accepts runs on the GPU through one of them.  The BASELINE shape (f32, n_fft = 1024)
+// dispatches to the tuned kernel in kernels_r32x16.hip instead.
+//
+//   k_lds_radix2  : power-of-two n_fft >= 4.  One 256-thread workgroup per tile of `ft` frames of one
+//                   signal; z[n] = x[2n] + i x[2n+1] (windowed, zero-padded per S1) is loaded bit-reversed
+//                   into LDS, log2(n/2) in-LDS radix-2 DIT stages, then the real split, then the epilogue.
+//   k_direct_dft  : every other n_fft (the reference accepts arbitrary sizes, e.g. 400 —
+//                   tests/mfcc_tests.rs:133).  Windowed frames in LDS, O(n^2) direct sum per bin.
+//
+// Epilogue (shared): |X|^2 (spectrogram.rs:1332-1334) -> identity or CSR Mel bank with sequential
+// accumulation in T in ascending-bin order (:102-117) -> Power / sqrt / 10*log10(max(p, eps))
+// (:1986-2036, :2068-2080) -> out[b][bin][frame] with the frame axis contiguous (S9).  Threads are
+// mapped (bin, frame) with frame fastest so global stores are contiguous along frames.
+#include "sgx_internal.h"
+
+namespace sgx {
+
+template <typename T>
+struct Cx {
+    T re, im;
+};
+
+__device__ inline float t_sqrt(float v) { return sqrtf(v); }
+__device__ inline double t_sqrt(double v) { return sqrt(v); }
+__device__ inline float t_log10(float v) { return log10f(v); }
+__device__ inline double t_log10(double v) { return log10(v); }
+__device__ inline float t_max(float a, float b) { return fmaxf(a, b); }
+__device__ inline double t_max(double a, double b) { return fmax(a, b); }
+// un-fused multiply-add: the reference's `acc += T::from_f64(w) * x` is two roundings (rustc never contracts)
+__device__ inline float t_mul_add_unfused(float a, float b, float c) { return __fadd_rn(__fmul_rn(a, b), c); }
+__device__ inline double t_mul_add_unfused(double a, double b, double c) { return __dadd_rn(__dmul_rn(a, b), c); }
+
+template <typename T>
+__device__ inline T amp_apply(T p, int amp, T eps) {
+    if (amp == AMP_MAGNITUDE) return t_sqrt(p);
+    if (amp == AMP_DB) return T(10) * t_log10(t_max(p, eps));
+    return p;
+}
+
+template <typename T>
+__device__ inline T load_sample(const T *xb, long long s, unsigned long long n) {
+    return (s >= 0 && (unsigned long long)s < n) ? xb[s] : T(0);
+}
+
+// One spectrum value X[k] of frame f (tile-local) is ready: route it by output mode.
+template <typename T>
+__device__ inline void emit_bin(const StftArgs &a, unsigned b, unsigned frame, unsigned f, unsigned k, T re, T im,
+                                T *pw, T eps) {
+    if (a.out_mode == OUT_COMPLEX) {
+        Cx<T> *o = (Cx<T> *)a.out;
+        o[((size_t)b * a.n_out + k) * a.n_frames + frame] = Cx<T>{re, im};
+    } else {
+        T p = re * re + im * im;
+        if (a.out_mode == OUT_MEL) {
+            pw[(size_t)f * a.nb_fft + k] = p;
+        } else {
+            T *o = (T *)a.out;
+            o[((size_t)b * a.n_out + k) * a.n_frames + frame] = amp_apply(p, a.amp, eps);
+        }
+    }
+}
+
+// Mel stage: pw[f][k] holds the power spectrum of the tile's frames.
+template <typename T>
+__device__ inline void mel_stage(const StftArgs &a, unsigned b, unsigned f0, unsigned nf, const T *pw, T eps) {
+    const T *val = (const T *)a.mel_val;
+    T *o = (T *)a.out;
+    for (unsigned idx = threadIdx.x; idx < nf * a.n_mels; idx += blockDim.x) {
+        unsigned f = idx % nf, mm = idx / nf;
+        T acc = T(0);
+        unsigned i0 = a.mel_ptr[mm], i1 = a.mel_ptr[mm + 1];
+        for (unsigned i = i0; i < i1; i++) acc = t_mul_add_unfused(val[i], pw[(size_t)f * a.nb_fft + a.mel_col[i]], acc);
+        o[((size_t)b * a.n_out + mm) * a.n_frames + f0 + f] = amp_apply(acc, a.amp, eps);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_lds_radix2(StftArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned m = a.m, fs = m + 1;
+    Cx<T> *buf = (Cx<T> *)smem;           // [ft][m+1]
+    T *pw = (T *)(buf + (size_t)a.ft * fs);  // [ft][nb_fft] (Mel only)
+    const unsigned tile = blockIdx.x % a.tiles, b = blockIdx.x / a.tiles;
+    const unsigned f0 = tile * a.ft;
+    const unsigned nf = min(a.ft, a.n_frames - f0);
+    const T *xb = (const T *)a.x + (size_t)b * a.sample_stride;
+    const T *w = (const T *)a.window;
+    const Cx<T> *tw = (const Cx<T> *)a.tw;
+    const T eps = (T)a.eps;
+    const unsigned tid = threadIdx.x;
+
+    // 1. framing + window (S1, S4), bit-reversed placement of z[i] = x[2i] + i x[2i+1]
+    for (unsigned idx = tid; idx < nf * m; idx += 256) {
+        unsigned f = idx >> a.log2m, i = idx & (m - 1);
+        long long s = (long long)(f0 + f) * a.hop + 2ll * i - (long long)a.pad;
+        T x0 = load_sample(xb, s, a.n_samples) * w[2 * i];
+        T x1 = load_sample(xb, s + 1, a.n_samples) * w[2 * i + 1];
+        unsigned r = __brev(i) >> (32 - a.log2m);
+        buf[f * fs + r] = Cx<T>{x0, x1};
+    }
+    __syncthreads();
+
+    // 2. radix-2 DIT stages; W_{2h}^j = tw[j * n_fft / (2h)]
+    const unsigned halfm = m >> 1, lhm = a.log2m - 1;
+    for (unsigned h = 1, lh = 0; h < m; h <<= 1, lh++) {
+        const unsigned twstep = a.n_fft >> (lh + 1);
+        for (unsigned idx = tid; idx < nf * halfm; idx += 256) {
+            unsigned f = idx >> lhm, q = idx & (halfm - 1);
+            unsigned j = q & (h - 1), blk = q >> lh;
+            unsigned p0 = f * fs + (blk << (lh + 1)) + j, p1 = p0 + h;
+            Cx<T> wv = tw[j * twstep];
+            Cx<T> u = buf[p0], v = buf[p1];
+            T tr = v.re * wv.re - v.im * wv.im;
+            T ti = v.re * wv.im + v.im * wv.re;
+            buf[p0] = Cx<T>{u.re + tr, u.im + ti};
+            buf[p1] = Cx<T>{u.re - tr, u.im - ti};
+        }
+        __syncthreads();
+    }
+
+    // 3. real split X[k] = E[k] + W_n^k O[k], k = 0..m, frame index fastest across threads
+    for (unsigned idx = tid; idx < nf * (m + 1); idx += 256) {
+        unsigned f = idx % nf, k = idx / nf;
+        T re, im;
+        if (k == 0 || k == m) {
+            Cx<T> z = buf[f * fs];
+            re = (k == 0) ? z.re + z.im : z.re - z.im;
+            im = T(0);
+        } else {
+            Cx<T> z = buf[f * fs + k], y = buf[f * fs + m - k];
+            const T half = T(0.5);
+            T er = (z.re + y.re) * half, ei = (z.im - y.im) * half;
+            T orr = (z.im + y.im) * half, oi = (y.re - z.re) * half;
+            Cx<T> wv = tw[k];
+            re = er + (orr * wv.re - oi * wv.im);
+            im = ei + (orr * wv.im + oi * wv.re);
+        }
+        emit_bin<T>(a, b, f0 + f, f, k, re, im, pw, eps);
+    }
+    if (a.out_mode == OUT_MEL) {
+        __syncthreads();
+        mel_stage<T>(a, b, f0, nf, pw, eps);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_direct_dft(StftArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned n = a.n_fft;
+    T *fr = (T *)smem;                  // [ft][n_fft]
+    T *pw = fr + (size_t)a.ft * n;      // [ft][nb_fft] (Mel only)
+    const unsigned tile = blockIdx.x % a.tiles, b = blockIdx.x / a.tiles;
+    const unsigned f0 = tile * a.ft;
+    const unsigned nf = min(a.ft, a.n_frames - f0);
+    const T *xb = (const T *)a.x + (size_t)b * a.sample_stride;
+    const T *w = (const T *)a.window;
+    const Cx<T> *tw = (const Cx<T> *)a.tw;
+    const T eps = (T)a.eps;
+
+    for (unsigned idx = threadIdx.x; idx < nf * n; idx += 256) {
+        unsigned f = idx / n, i = idx % n;
+        long long s = (long long)(f0 + f) * a.hop + (long long)i - (long long)a.pad;
+        fr[(size_t)f * n + i] = load_sample(xb, s, a.n_samples) * w[i];
+    }
+    __syncthreads();
+    for (unsigned idx = threadIdx.x; idx < nf * a.nb_fft; idx += 256) {
+        unsigned f = idx % nf, k = idx / nf;
+        const T *x = fr + (size_t)f * n;
+        T sr = T(0), si = T(0);
+        unsigned t = 0;
+        for (unsigned j = 0; j < n; j++) {
+            Cx<T> c = tw[t];
+            sr += x[j] * c.re;
+            si += x[j] * c.im;
+            t += k;
+            if (t >= n) t -= n;
+        }
+        emit_bin<T>(a, b, f0 + f, f, k, sr, si, pw, eps);
+    }
+    if (a.out_mode == OUT_MEL) {
+        __syncthreads();
+        mel_stage<T>(a, b, f0, nf, pw, eps);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+static const size_t kLdsBudget = 64 * 1024;
+
+static size_t elem_size(int dtype) { return dtype == SGX_F64 ? 8 : 4; }
+
+bool plan_geometry_lds_radix2(StftArgs &a, int dtype) {
+    if (a.n_fft < 4 || (a.n_fft & (a.n_fft - 1))) return false;
+    size_t es = elem_size(dtype);
+    for (unsigned ft = 16; ft >= 1; ft >>= 1) {
+        size_t bytes = (size_t)ft * (a.m + 1) * 2 * es + (a.out_mode == OUT_MEL ? (size_t)ft * a.nb_fft * es : 0);
+        if (bytes <= kLdsBudget) {
+            a.ft = ft;
+            return true;
+        }
+    }
+    return false;
+}
+
+bool plan_geometry_direct_dft(StftArgs &a, int dtype) {
+    size_t es = elem_size(dtype);
+    for (unsigned ft = 16; ft >= 1; ft >>= 1) {
+        size_t bytes = (size_t)ft * a.n_fft * es + (a.out_mode == OUT_MEL ? (size_t)ft * a.nb_fft * es : 0);
+        if (bytes <= kLdsBudget) {
+            a.ft = ft;
+            return true;
+        }
+    }
+    return false;
+}
+
+static bool grid_ok(const StftArgs &a, unsigned long long *blocks) {
+    unsigned long long g = (unsigned long long)a.tiles * a.batch;
+    *blocks = g;
+    return g > 0 && g < 0x7fffffffull;
+}
+
+hipError_t launch_lds_radix2(const StftArgs &a, int dtype, hipStream_t s) {
+    unsigned long long g;
+    if (!grid_ok(a, &g)) return hipErrorInvalidConfiguration;
+    size_t es = elem_size(dtype);
+    size_t lds = (size_t)a.ft * (a.m + 1) * 2 * es + (a.out_mode == OUT_MEL ? (size_t)a.ft * a.nb_fft * es : 0);
+    if (dtype == SGX_F64)
+        hipLaunchKernelGGL(k_lds_radix2<double>, dim3((unsigned)g), dim3(256), lds, s, a);
+    else
+        hipLaunchKernelGGL(k_lds_radix2<float>, dim3((unsigned)g), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_direct_dft(const StftArgs &a, int dtype, hipStream_t s) {
+    unsigned long long g;
+    if (!grid_ok(a, &g)) return hipErrorInvalidConfiguration;
+    size_t es = elem_size(dtype);
+    size_t lds = (size_t)a.ft * a.n_fft * es + (a.out_mode == OUT_MEL ? (size_t)a.ft * a.nb_fft * es : 0);
+    if (dtype == SGX_F64)
+        hipLaunchKernelGGL(k_direct_dft<double>, dim3((unsigned)g), dim3(256), lds, s, a);
+    else
+        hipLaunchKernelGGL(k_direct_dft<float>, dim3((unsigned)g), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace sgx

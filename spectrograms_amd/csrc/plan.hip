@@ -1,0 +1,614 @@
+// plan.hip — host side of libspectro_hip.so: the C ABI of include/spectro_hip.h.
+//
+// Plan construction mirrors the reference constructors (validation order and error texts follow
+// src/spectrogram.rs), builds window / twiddle / filterbank tables on the host in f64, casts to the
+// plan's scalar type T and uploads them.  Execution dispatches one batched kernel launch per call.
+// There is no CPU compute path in this library: without a HIP device, compute entry points return
+// SGX_BACKEND.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "sgx_internal.h"
+
+using namespace sgx;
+
+namespace {
+
+thread_local std::string g_create_err;
+
+constexpr double kPi = 3.14159265358979323846264338327950288;
+
+sgx_status set_err(const sgx_plan *p, sgx_status st, const std::string &msg) {
+    if (p) p->err = msg;
+    return st;
+}
+
+sgx_status create_fail(sgx_status st, const std::string &msg) {
+    g_create_err = msg;
+    return st;
+}
+
+#define SGX_HIP(plan, call)                                                                        \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return set_err(plan, SGX_BACKEND, std::string("hip -- FFT backend error: ") + #call +  \
+                                                  ": " + hipGetErrorString(e_));                   \
+    } while (0)
+
+// ---- window coefficients (make_window, src/spectrogram.rs:2159-2235), f64 ------------------------
+double i0_polynomial(double x) {  // modified_bessel_i0 :2237-2259 — the reference's A&S polynomial, incl. its
+    const double ax = std::fabs(x);  // extra 1/sqrt(2 pi) in the large-argument branch (kept for parity)
+    if (ax <= 3.75) {
+        const double t = x / 3.75, t2 = t * t;
+        static const double c[] = {3.5156229, 3.0899424, 1.2067492, 0.2659732, 0.0360768, 0.0045813};
+        double acc = c[5];
+        for (int i = 4; i >= 0; --i) acc = c[i] + t2 * acc;
+        return 1.0 + t2 * acc;
+    }
+    const double t = 3.75 / ax;
+    static const double d[] = {0.39894228, 0.01328592, 0.00225319, -0.00157565, 0.00916281,
+                               -0.02057706, 0.02635537, -0.01647633, 0.00392377};
+    double acc = d[8];
+    for (int i = 7; i >= 0; --i) acc = d[i] + t * acc;
+    return (std::exp(ax) / (std::sqrt(ax) * std::sqrt(2.0 * kPi))) * acc;
+}
+
+void build_window(const sgx_params &p, const std::vector<double> &custom, std::vector<double> &w) {
+    const size_t n = p.n_fft;
+    w.assign(n, 0.0);
+    const double n1 = double(n - 1);
+    switch (p.window_kind) {
+    case SGX_WIN_RECTANGULAR:
+        std::fill(w.begin(), w.end(), 1.0);
+        break;
+    case SGX_WIN_HANNING:
+        for (size_t i = 0; i < n; ++i) w[i] = std::fma(0.5, -std::cos(2.0 * kPi * double(i) / n1), 0.5);
+        break;
+    case SGX_WIN_HAMMING:
+        for (size_t i = 0; i < n; ++i) w[i] = std::fma(0.46, -std::cos(2.0 * kPi * double(i) / n1), 0.54);
+        break;
+    case SGX_WIN_BLACKMAN:
+        for (size_t i = 0; i < n; ++i) {
+            const double a = 2.0 * kPi * double(i) / n1;
+            w[i] = std::fma(0.08, std::cos(2.0 * a), std::fma(0.5, -std::cos(a), 0.42));
+        }
+        break;
+    case SGX_WIN_KAISER: {
+        if (n == 1) { w[0] = 1.0; break; }
+        const double beta = p.window_param, denom = i0_polynomial(beta), half = n1 / 2.0;
+        for (size_t i = 0; i < n; ++i) {
+            const double u = (double(i) - half) / half;
+            const double ratio = std::max(1.0 - u * u, 0.0);
+            w[i] = denom == 0.0 ? 0.0 : i0_polynomial(beta * std::sqrt(ratio)) / denom;
+        }
+        break;
+    }
+    case SGX_WIN_GAUSSIAN: {
+        const double centre = n1 / 2.0;
+        for (size_t i = 0; i < n; ++i) {
+            const double q = (double(i) - centre) / p.window_param;
+            w[i] = std::exp(-0.5 * (q * q));
+        }
+        break;
+    }
+    case SGX_WIN_CUSTOM:
+        w = custom;
+        break;
+    }
+}
+
+// ---- Slaney mel scale + Hz-space triangular bank (src/spectrogram.rs:2268-2432) as CSR -------------
+constexpr double kFsp = 200.0 / 3.0, kMinLogHz = 1000.0, kMinLogMel = kMinLogHz / kFsp;
+constexpr double kLogStep = 0.06875177742094923;  // ln(6.4)/27
+double hz2mel(double hz) { return hz >= kMinLogHz ? kMinLogMel + std::log(hz / kMinLogHz) / kLogStep : hz / kFsp; }
+double mel2hz(double mel) {
+    return mel >= kMinLogMel ? kMinLogHz * std::exp(kLogStep * (mel - kMinLogMel)) : std::fma(kFsp, mel, 0.0);
+}
+
+void build_mel_csr(const sgx_params &p, std::vector<uint32_t> &ptr, std::vector<uint32_t> &col,
+                   std::vector<double> &val) {
+    const size_t n_mels = p.n_mels, nb = p.n_fft / 2 + 1;
+    const double df = p.sample_rate_hz / double(p.n_fft);
+    const double mel_lo = hz2mel(p.f_min), mel_hi = hz2mel(p.f_max);
+    const double step = (mel_hi - mel_lo) / double(n_mels + 1);
+    std::vector<double> mel_pts(n_mels + 2), edge(n_mels + 2);
+    for (size_t i = 0; i < n_mels + 2; ++i) {
+        mel_pts[i] = std::fma(double(i), step, mel_lo);
+        edge[i] = mel2hz(mel_pts[i]);
+    }
+    ptr.assign(n_mels + 1, 0);
+    col.clear();
+    val.clear();
+    for (size_t m = 0; m < n_mels; ++m) {
+        ptr[m] = uint32_t(col.size());
+        const double lo = edge[m], mid = edge[m + 1], hi = edge[m + 2];
+        const double rise = mid - lo, fall = hi - mid;
+        if (rise == 0.0 || fall == 0.0) continue;  // degenerate triangle (:2360-2363)
+        for (size_t k = 0; k < nb; ++k) {
+            const double f = double(k) * df;
+            double wgt = std::min((f - lo) / rise, (hi - f) / fall);
+            wgt = std::min(std::max(wgt, 0.0), 1.0);
+            if (wgt > 0.0 && std::fabs(wgt) > 1e-10) {  // SparseMatrix::set drops |v| <= 1e-10 (:83)
+                col.push_back(uint32_t(k));
+                val.push_back(wgt);
+            }
+        }
+    }
+    ptr[n_mels] = uint32_t(col.size());
+    for (size_t m = 0; m < n_mels; ++m) {
+        double *v = val.data() + ptr[m];
+        const size_t cnt = ptr[m + 1] - ptr[m];
+        double scale = 1.0;
+        bool apply = false;
+        if (p.mel_norm == SGX_MELNORM_SLANEY) {
+            scale = 2.0 / (mel2hz(mel_pts[m + 2]) - mel2hz(mel_pts[m]));
+            apply = true;
+        } else if (p.mel_norm == SGX_MELNORM_L1) {
+            double s = 0.0;
+            for (size_t i = 0; i < cnt; ++i) s += v[i];
+            if (s > 0.0) { scale = 1.0 / s; apply = true; }
+        } else if (p.mel_norm == SGX_MELNORM_L2) {
+            double s = 0.0;
+            for (size_t i = 0; i < cnt; ++i) s += v[i] * v[i];
+            s = std::sqrt(s);
+            if (s > 0.0) { scale = 1.0 / s; apply = true; }
+        }
+        if (apply)
+            for (size_t i = 0; i < cnt; ++i) v[i] *= scale;
+    }
+}
+
+// ---- validation (same conditions and texts as the reference constructors) ------------------------
+sgx_status validate(const sgx_params &p, std::string &msg) {
+    auto bad = [&](const char *m) { msg = std::string("Invalid input: ") + m; return SGX_INVALID_INPUT; };
+    if (p.n_fft == 0) return bad("n_fft must be > 0");
+    if (p.hop_size == 0) return bad("hop_size must be > 0");
+    if (p.hop_size > p.n_fft) return bad("hop_size must be <= n_fft");  // spectrogram.rs:3485-3487
+    if (p.window_kind < SGX_WIN_RECTANGULAR || p.window_kind > SGX_WIN_CUSTOM) return bad("unknown window type");
+    if (p.window_kind == SGX_WIN_CUSTOM && (!p.custom_window || p.custom_window_len != p.n_fft)) {
+        msg = "Invalid input: Custom window size (" + std::to_string(p.custom_window ? p.custom_window_len : 0) +
+              ") must match n_fft (" + std::to_string(p.n_fft) + ")";  // :3490-3498
+        return SGX_INVALID_INPUT;
+    }
+    if (!(p.sample_rate_hz > 0.0 && std::isfinite(p.sample_rate_hz)))
+        return bad("sample_rate_hz must be finite and > 0");  // :4130-4134
+    if (p.freq_scale == SGX_FREQ_MEL) {
+        if (p.n_mels == 0) return bad("n_mels must be > 0");
+        if (p.f_min < 0.0) return bad("f_min must be >= 0");         // :3799-3801
+        if (p.f_max <= p.f_min) return bad("f_max must be > f_min");  // :3803-3805
+        if (p.f_max > p.sample_rate_hz * 0.5) return bad("mel f_max must be <= Nyquist");  // :954-959
+        if (p.n_mels > 10000) return bad("n_mels is unreasonably large");                  // :1696-1700
+        if (std::isinf(p.f_min)) return bad("f_min must be >= 0");                         // :2315
+    } else if (p.freq_scale != SGX_FREQ_LINEAR) {
+        return bad("unknown frequency scale");
+    }
+    if (p.amp_scale < SGX_AMP_POWER || p.amp_scale > SGX_AMP_COMPLEX) return bad("unknown amplitude scale");
+    if (p.amp_scale == SGX_AMP_COMPLEX && p.freq_scale != SGX_FREQ_LINEAR)
+        return bad("complex STFT output requires the linear frequency scale");
+    if (p.has_log_params && !std::isfinite(p.floor_db)) return bad("floor_db must be finite");  // :4072-4074
+    if (p.dtype != SGX_F32 && p.dtype != SGX_F64) return bad("dtype must be f32 or f64");
+    return SGX_OK;
+}
+
+size_t frame_count(const sgx_params &p, size_t n_samples) {  // StftPlan::frame_count :1230-1250
+    const size_t pad = p.centre ? p.n_fft / 2 : 0;
+    const size_t padded = n_samples + 2 * pad;
+    if (padded < p.n_fft) return 1;
+    return (padded - p.n_fft) / p.hop_size + 1;
+}
+
+template <typename T>
+sgx_status upload(sgx_plan *pl, void **dst, const std::vector<T> &src) {
+    if (src.empty()) { *dst = nullptr; return SGX_OK; }
+    SGX_HIP(pl, hipMalloc(dst, src.size() * sizeof(T)));
+    SGX_HIP(pl, hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return SGX_OK;
+}
+
+template <typename T>
+sgx_status upload_cast(sgx_plan *pl, void **dst, const std::vector<double> &src) {
+    std::vector<T> tmp(src.size());
+    for (size_t i = 0; i < src.size(); ++i) tmp[i] = T(src[i]);  // T::from_f64
+    return upload<T>(pl, dst, tmp);
+}
+
+template <typename T>
+sgx_status build_device_tables(sgx_plan *pl) {
+    const unsigned n = pl->p.n_fft;
+    sgx_status st;
+    if ((st = upload_cast<T>(pl, &pl->d_window, pl->window)) != SGX_OK) return st;
+    std::vector<T> tw(2 * size_t(n));
+    for (unsigned k = 0; k < n; ++k) {  // tw[k] = exp(-2 pi i k / n), evaluated in f64
+        const double a = -2.0 * kPi * double(k) / double(n);
+        tw[2 * k] = T(std::cos(a));
+        tw[2 * k + 1] = T(std::sin(a));
+    }
+    if ((st = upload<T>(pl, &pl->d_tw, tw)) != SGX_OK) return st;
+    if (pl->out_mode == OUT_MEL) {
+        if ((st = upload<uint32_t>(pl, &pl->d_mel_ptr, pl->mel_ptr)) != SGX_OK) return st;
+        if ((st = upload<uint32_t>(pl, &pl->d_mel_col, pl->mel_col)) != SGX_OK) return st;
+        if ((st = upload_cast<T>(pl, &pl->d_mel_val, pl->mel_val)) != SGX_OK) return st;
+    }
+    if (pl->kind == K_R32X16_F32) {
+        // tw1[k1][n2] = W_512^(k1*n2) (pass-1 twiddles), tw2[j][k2] = W_1024^(j + 32*k2) (real-split twiddles)
+        std::vector<float> t1(2 * 32 * 16), t2(2 * 17 * 16);
+        for (unsigned k1 = 0; k1 < 32; ++k1)
+            for (unsigned n2 = 0; n2 < 16; ++n2) {
+                const double a = -2.0 * kPi * double(k1 * n2) / 512.0;
+                t1[2 * (k1 * 16 + n2)] = float(std::cos(a));
+                t1[2 * (k1 * 16 + n2) + 1] = float(std::sin(a));
+            }
+        for (unsigned j = 0; j < 17; ++j)
+            for (unsigned k2 = 0; k2 < 16; ++k2) {
+                const double a = -2.0 * kPi * double(j + 32 * k2) / 1024.0;
+                t2[2 * (j * 16 + k2)] = float(std::cos(a));
+                t2[2 * (j * 16 + k2) + 1] = float(std::sin(a));
+            }
+        if ((st = upload<float>(pl, &pl->d_tw1, t1)) != SGX_OK) return st;
+        if ((st = upload<float>(pl, &pl->d_tw2, t2)) != SGX_OK) return st;
+    }
+    return SGX_OK;
+}
+
+void fill_args(const sgx_plan *pl, StftArgs &a, const void *x, void *out, size_t batch, size_t n_samples,
+               size_t stride, size_t n_frames) {
+    std::memset(&a, 0, sizeof(a));
+    const sgx_params &p = pl->p;
+    a.x = x;
+    a.out = out;
+    a.sample_stride = stride;
+    a.n_samples = n_samples;
+    a.batch = unsigned(batch);
+    a.n_fft = p.n_fft;
+    a.m = p.n_fft / 2;
+    unsigned l = 0;
+    while ((1u << l) < a.m) ++l;
+    a.log2m = l;
+    a.hop = p.hop_size;
+    a.pad = p.centre ? p.n_fft / 2 : 0;
+    a.n_frames = unsigned(n_frames);
+    a.nb_fft = pl->nb_fft;
+    a.n_out = pl->n_out;
+    a.window = pl->d_window;
+    a.tw = pl->d_tw;
+    a.tw1 = pl->d_tw1;
+    a.tw2 = pl->d_tw2;
+    a.mel_ptr = (const unsigned *)pl->d_mel_ptr;
+    a.mel_col = (const unsigned *)pl->d_mel_col;
+    a.mel_val = pl->d_mel_val;
+    a.n_mels = p.n_mels;
+    a.out_mode = pl->out_mode;
+    a.amp = pl->amp;
+    a.eps = pl->eps;
+}
+
+bool set_geometry(const sgx_plan *pl, StftArgs &a, KernelKind kind) {
+    bool ok = false;
+    switch (kind) {
+    case K_R32X16_F32: ok = plan_geometry_r32x16_f32(a); break;
+    case K_LDS_RADIX2: ok = plan_geometry_lds_radix2(a, pl->dtype); break;
+    case K_DIRECT_DFT: ok = plan_geometry_direct_dft(a, pl->dtype); break;
+    }
+    if (ok) a.tiles = (a.n_frames + a.ft - 1) / a.ft;
+    return ok;
+}
+
+hipError_t launch(const sgx_plan *pl, const StftArgs &a, KernelKind kind, hipStream_t s) {
+    switch (kind) {
+    case K_R32X16_F32: return launch_r32x16_f32(a, s);
+    case K_LDS_RADIX2: return launch_lds_radix2(a, pl->dtype, s);
+    default: return launch_direct_dft(a, pl->dtype, s);
+    }
+}
+
+// The tuned kernel needs 8-byte aligned float2 loads: even hop, aligned base and even row stride.
+KernelKind pick_kernel(const sgx_plan *pl, const void *x, size_t stride) {
+    if (pl->kind == K_R32X16_F32) {
+        const bool aligned = (reinterpret_cast<uintptr_t>(x) % 8 == 0) && (stride % 2 == 0);
+        return aligned ? K_R32X16_F32 : K_LDS_RADIX2;
+    }
+    return pl->kind;
+}
+
+sgx_status check_call(sgx_plan *pl, const void *samples, size_t batch, size_t n_samples, size_t stride,
+                      void *out, size_t out_elems, size_t *n_frames_out) {
+    if (!pl) return SGX_INVALID_INPUT;
+    if (!samples || !out) return set_err(pl, SGX_INVALID_INPUT, "Invalid input: null buffer");
+    if (batch == 0 || n_samples == 0)
+        return set_err(pl, SGX_INVALID_INPUT, "Invalid input: samples must be non-empty");  // NonEmptySlice
+    if (stride < n_samples) return set_err(pl, SGX_INVALID_INPUT, "Invalid input: sample_stride < n_samples");
+    if (batch > 0xffffffffull) return set_err(pl, SGX_INVALID_INPUT, "Invalid input: batch too large");
+    const size_t nf = frame_count(pl->p, n_samples);
+    if (nf > 0x7fffffffull) return set_err(pl, SGX_INVALID_INPUT, "Invalid input: too many frames");
+    const size_t expect = batch * size_t(pl->n_out) * nf * (pl->out_mode == OUT_COMPLEX ? 2 : 1);
+    if (out_elems != expect)  // compute_into: DimensionMismatch{expected, got} (:423-434)
+        return set_err(pl, SGX_DIM_MISMATCH, "Dimension mismatch: expected " + std::to_string(expect) + ", got " +
+                                                 std::to_string(out_elems));
+    if (!pl->device_ready)
+        return set_err(pl, SGX_BACKEND, "hip -- FFT backend error: plan has no HIP device (host-only plan)");
+    *n_frames_out = nf;
+    return SGX_OK;
+}
+
+sgx_status run_device(sgx_plan *pl, const void *x, size_t batch, size_t n_samples, size_t stride, void *out,
+                      size_t n_frames, hipStream_t s, int iters, float *ms) {
+    StftArgs a;
+    fill_args(pl, a, x, out, batch, n_samples, stride, n_frames);
+    KernelKind kind = pick_kernel(pl, x, stride);
+    if (!set_geometry(pl, a, kind)) {
+        kind = (kind == K_R32X16_F32) ? K_LDS_RADIX2 : K_DIRECT_DFT;
+        if (!set_geometry(pl, a, kind))
+            return set_err(pl, SGX_BACKEND, "hip -- FFT backend error: n_fft too large for the on-chip frame tile");
+    }
+    SGX_HIP(pl, hipSetDevice(pl->device));
+    if (ms) SGX_HIP(pl, hipEventRecord(pl->ev0, s));
+    for (int i = 0; i < iters; ++i) SGX_HIP(pl, launch(pl, a, kind, s));
+    if (ms) {
+        SGX_HIP(pl, hipEventRecord(pl->ev1, s));
+        SGX_HIP(pl, hipEventSynchronize(pl->ev1));
+        float t = 0.f;
+        SGX_HIP(pl, hipEventElapsedTime(&t, pl->ev0, pl->ev1));
+        *ms = t / float(iters);
+    }
+    return SGX_OK;
+}
+
+sgx_status grow(sgx_plan *pl, void **buf, size_t *have, size_t need) {
+    if (*have >= need) return SGX_OK;
+    if (*buf) SGX_HIP(pl, hipFree(*buf));
+    *buf = nullptr;
+    *have = 0;
+    SGX_HIP(pl, hipMalloc(buf, need));
+    *have = need;
+    return SGX_OK;
+}
+
+void free_device(sgx_plan *pl) {
+    void **bufs[] = {&pl->d_window, &pl->d_tw, &pl->d_tw1, &pl->d_tw2, &pl->d_mel_ptr, &pl->d_mel_col,
+                     &pl->d_mel_val, &pl->d_ones, &pl->d_in, &pl->d_out};
+    for (void **b : bufs)
+        if (*b) { (void)hipFree(*b); *b = nullptr; }
+    if (pl->ev0) (void)hipEventDestroy(pl->ev0);
+    if (pl->ev1) (void)hipEventDestroy(pl->ev1);
+    pl->ev0 = pl->ev1 = nullptr;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t sgx_abi_version(void) { return SGX_ABI_VERSION; }
+
+int32_t sgx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *sgx_last_create_error(void) { return g_create_err.c_str(); }
+const char *sgx_last_error(const sgx_plan *plan) { return plan ? plan->err.c_str() : g_create_err.c_str(); }
+
+const char *sgx_kernel_name(const sgx_plan *plan) {
+    if (!plan) return "";
+    switch (plan->kind) {
+    case K_R32X16_F32: return "r32x16_f32";
+    case K_LDS_RADIX2: return "lds_radix2";
+    default: return "direct_dft";
+    }
+}
+
+sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
+    if (out) *out = nullptr;
+    if (!params || !out) return create_fail(SGX_INVALID_INPUT, "Invalid input: null argument");
+    std::string msg;
+    sgx_status st = validate(*params, msg);
+    if (st != SGX_OK) return create_fail(st, msg);
+    sgx_plan *pl = new (std::nothrow) sgx_plan();
+    if (!pl) return create_fail(SGX_INTERNAL, "Internal error: out of memory");
+    pl->p = *params;
+    if (params->window_kind == SGX_WIN_CUSTOM) {
+        pl->custom_window.assign(params->custom_window, params->custom_window + params->n_fft);
+    }
+    pl->p.custom_window = nullptr;
+    pl->dtype = params->dtype;
+    pl->elem = params->dtype == SGX_F64 ? 8 : 4;
+    pl->nb_fft = params->n_fft / 2 + 1;
+    pl->out_mode = params->amp_scale == SGX_AMP_COMPLEX ? OUT_COMPLEX
+                   : params->freq_scale == SGX_FREQ_MEL ? OUT_MEL : OUT_LINEAR;
+    pl->n_out = pl->out_mode == OUT_MEL ? params->n_mels : pl->nb_fft;
+    // S6: dB is applied only when LogParams were supplied; Decibels without them returns power
+    pl->amp = params->amp_scale == SGX_AMP_MAGNITUDE ? AMP_MAGNITUDE
+              : (params->amp_scale == SGX_AMP_DECIBELS && params->has_log_params) ? AMP_DB : AMP_POWER;
+    pl->eps = pl->amp == AMP_DB ? std::pow(10.0, params->floor_db / 10.0) : 0.0;
+    build_window(pl->p, pl->custom_window, pl->window);
+    if (pl->out_mode == OUT_MEL) build_mel_csr(pl->p, pl->mel_ptr, pl->mel_col, pl->mel_val);
+
+    const bool pow2 = params->n_fft >= 4 && (params->n_fft & (params->n_fft - 1)) == 0;
+    pl->kind = pow2 ? K_LDS_RADIX2 : K_DIRECT_DFT;
+    if (params->dtype == SGX_F32 && params->n_fft == 1024 && params->hop_size % 2 == 0) pl->kind = K_R32X16_F32;
+    {
+        StftArgs probe;
+        fill_args(pl, probe, nullptr, nullptr, 1, params->n_fft, params->n_fft, 1);
+        bool ok = set_geometry(pl, probe, pl->kind);
+        while (!ok && pl->kind != K_DIRECT_DFT) {
+            pl->kind = (pl->kind == K_R32X16_F32 && pow2) ? K_LDS_RADIX2 : K_DIRECT_DFT;
+            ok = set_geometry(pl, probe, pl->kind);
+        }
+        if (!ok) {
+            delete pl;
+            return create_fail(SGX_BACKEND, "hip -- FFT backend error: n_fft too large for the on-chip frame tile");
+        }
+    }
+
+    pl->device = params->device;
+    if (params->device != -2) {
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev <= 0) {
+            delete pl;
+            return create_fail(SGX_BACKEND, std::string("hip -- FFT backend error: no HIP device available (") +
+                                                hipGetErrorString(e) + ")");
+        }
+        int dev = params->device;
+        if (dev == -1 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+        if (dev < 0 || dev >= ndev) {
+            delete pl;
+            return create_fail(SGX_INVALID_INPUT, "Invalid input: device ordinal out of range");
+        }
+        pl->device = dev;
+        auto dev_init = [&]() -> sgx_status {
+            SGX_HIP(pl, hipSetDevice(dev));
+            SGX_HIP(pl, hipEventCreate(&pl->ev0));
+            SGX_HIP(pl, hipEventCreate(&pl->ev1));
+            return pl->dtype == SGX_F64 ? build_device_tables<double>(pl) : build_device_tables<float>(pl);
+        };
+        st = dev_init();
+        if (st != SGX_OK) {
+            g_create_err = pl->err;
+            free_device(pl);
+            delete pl;
+            return st;
+        }
+        pl->device_ready = true;
+    }
+    *out = pl;
+    return SGX_OK;
+}
+
+void sgx_plan_destroy(sgx_plan *plan) {
+    if (!plan) return;
+    if (plan->device_ready) {
+        (void)hipSetDevice(plan->device);
+        free_device(plan);
+    }
+    delete plan;
+}
+
+sgx_status sgx_output_shape(const sgx_plan *plan, size_t n_samples, size_t *n_bins, size_t *n_frames) {
+    if (!plan) return SGX_INVALID_INPUT;
+    if (n_samples == 0) return set_err(plan, SGX_INVALID_INPUT, "Invalid input: signal length must be non-zero");
+    if (n_bins) *n_bins = plan->n_out;
+    if (n_frames) *n_frames = frame_count(plan->p, n_samples);
+    return SGX_OK;
+}
+
+sgx_status sgx_execute(sgx_plan *plan, const void *samples, size_t batch, size_t n_samples, size_t sample_stride,
+                       void *out, size_t out_elems, int32_t mem_kind, void *hip_stream) {
+    size_t nf = 0;
+    sgx_status st = check_call(plan, samples, batch, n_samples, sample_stride, out, out_elems, &nf);
+    if (st != SGX_OK) return st;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if (mem_kind == SGX_MEM_DEVICE) return run_device(plan, samples, batch, n_samples, sample_stride, out, nf, s, 1, nullptr);
+    if (mem_kind != SGX_MEM_HOST) return set_err(plan, SGX_INVALID_INPUT, "Invalid input: unknown mem_kind");
+    // host pointers: plan-owned staging (grown on demand, reused across calls), synchronous
+    SGX_HIP(plan, hipSetDevice(plan->device));
+    const size_t in_bytes = ((batch - 1) * sample_stride + n_samples) * plan->elem;
+    const size_t out_bytes = out_elems * plan->elem;
+    if ((st = grow(plan, &plan->d_in, &plan->d_in_bytes, in_bytes)) != SGX_OK) return st;
+    if ((st = grow(plan, &plan->d_out, &plan->d_out_bytes, out_bytes)) != SGX_OK) return st;
+    SGX_HIP(plan, hipMemcpyAsync(plan->d_in, samples, in_bytes, hipMemcpyHostToDevice, s));
+    if ((st = run_device(plan, plan->d_in, batch, n_samples, sample_stride, plan->d_out, nf, s, 1, nullptr)) != SGX_OK)
+        return st;
+    SGX_HIP(plan, hipMemcpyAsync(out, plan->d_out, out_bytes, hipMemcpyDeviceToHost, s));
+    SGX_HIP(plan, hipStreamSynchronize(s));
+    return SGX_OK;
+}
+
+sgx_status sgx_execute_timed(sgx_plan *plan, const void *samples, size_t batch, size_t n_samples,
+                             size_t sample_stride, void *out, size_t out_elems, void *hip_stream, int32_t iters,
+                             float *ms_per_launch) {
+    size_t nf = 0;
+    sgx_status st = check_call(plan, samples, batch, n_samples, sample_stride, out, out_elems, &nf);
+    if (st != SGX_OK) return st;
+    if (iters < 1 || !ms_per_launch) return set_err(plan, SGX_INVALID_INPUT, "Invalid input: iters must be >= 1");
+    return run_device(plan, samples, batch, n_samples, sample_stride, out, nf, static_cast<hipStream_t>(hip_stream),
+                      iters, ms_per_launch);
+}
+
+sgx_status sgx_axes(const sgx_plan *plan, size_t n_frames, double *freqs, double *times) {
+    if (!plan) return SGX_INVALID_INPUT;
+    const sgx_params &p = plan->p;
+    if (times) {  // build_time_axis_seconds :2128-2139 — no centre offset (S10)
+        const double dt = double(p.hop_size) / p.sample_rate_hz;
+        for (size_t i = 0; i < n_frames; ++i) times[i] = double(i) * dt;
+    }
+    if (freqs) {
+        if (plan->out_mode == OUT_MEL) {  // mel_band_centres_hz :2510-2530 — 0..Nyquist, ignores f_min/f_max
+            const double lo = hz2mel(0.0), hi = hz2mel(p.sample_rate_hz * 0.5);
+            const double step = (hi - lo) / double(p.n_mels + 1);
+            for (size_t i = 0; i < p.n_mels; ++i) freqs[i] = mel2hz(std::fma(double(i) + 1.0, step, lo));
+        } else {  // :1911-1923 / :1446-1448
+            const double df = p.sample_rate_hz / double(p.n_fft);
+            for (size_t k = 0; k < plan->nb_fft; ++k) freqs[k] = double(k) * df;
+        }
+    }
+    return SGX_OK;
+}
+
+sgx_status sgx_r2c(sgx_plan *plan, const void *in, size_t in_len, void *out, size_t out_len) {
+    if (!plan) return SGX_INVALID_INPUT;
+    if (!in || !out) return set_err(plan, SGX_INVALID_INPUT, "Invalid input: null buffer");
+    const size_t n = plan->p.n_fft, nb = plan->nb_fft;
+    if (in_len != n)  // validate_fft_io src/fft_backend.rs:264-282
+        return set_err(plan, SGX_DIM_MISMATCH, "Dimension mismatch: expected " + std::to_string(n) + ", got " + std::to_string(in_len));
+    if (out_len != nb)
+        return set_err(plan, SGX_DIM_MISMATCH, "Dimension mismatch: expected " + std::to_string(nb) + ", got " + std::to_string(out_len));
+    if (!plan->device_ready)
+        return set_err(plan, SGX_BACKEND, "hip -- FFT backend error: plan has no HIP device (host-only plan)");
+    SGX_HIP(plan, hipSetDevice(plan->device));
+    sgx_status st;
+    if (!plan->d_ones) {
+        std::vector<double> ones(n, 1.0);
+        st = plan->dtype == SGX_F64 ? upload_cast<double>(plan, &plan->d_ones, ones)
+                                    : upload_cast<float>(plan, &plan->d_ones, ones);
+        if (st != SGX_OK) return st;
+    }
+    if ((st = grow(plan, &plan->d_in, &plan->d_in_bytes, n * plan->elem)) != SGX_OK) return st;
+    if ((st = grow(plan, &plan->d_out, &plan->d_out_bytes, 2 * nb * plan->elem)) != SGX_OK) return st;
+    SGX_HIP(plan, hipMemcpy(plan->d_in, in, n * plan->elem, hipMemcpyHostToDevice));
+    StftArgs a;
+    fill_args(plan, a, plan->d_in, plan->d_out, 1, n, n, 1);
+    a.window = plan->d_ones;
+    a.pad = 0;
+    a.out_mode = OUT_COMPLEX;
+    a.n_out = plan->nb_fft;
+    a.amp = AMP_POWER;
+    KernelKind kind = plan->kind;
+    if (!set_geometry(plan, a, kind)) {
+        kind = K_DIRECT_DFT;
+        if (!set_geometry(plan, a, kind)) return set_err(plan, SGX_BACKEND, "hip -- FFT backend error: n_fft too large");
+    }
+    SGX_HIP(plan, launch(plan, a, kind, nullptr));
+    SGX_HIP(plan, hipMemcpy(out, plan->d_out, 2 * nb * plan->elem, hipMemcpyDeviceToHost));
+    return SGX_OK;
+}
+
+sgx_status sgx_window(const sgx_plan *plan, double *out) {
+    if (!plan || !out) return SGX_INVALID_INPUT;
+    std::copy(plan->window.begin(), plan->window.end(), out);
+    return SGX_OK;
+}
+
+sgx_status sgx_mel_weights(const sgx_plan *plan, size_t *nnz, uint32_t *row_ptr, uint32_t *cols, double *vals) {
+    if (!plan) return SGX_INVALID_INPUT;
+    if (plan->out_mode != OUT_MEL) return set_err(plan, SGX_INVALID_INPUT, "Invalid input: plan has no Mel filterbank");
+    if (nnz) *nnz = plan->mel_col.size();
+    if (row_ptr) std::copy(plan->mel_ptr.begin(), plan->mel_ptr.end(), row_ptr);
+    if (cols) std::copy(plan->mel_col.begin(), plan->mel_col.end(), cols);
+    if (vals) std::copy(plan->mel_val.begin(), plan->mel_val.end(), vals);
+    return SGX_OK;
+}
+
+sgx_status sgx_shard_range(size_t batch, int32_t world_size, int32_t rank, size_t *start, size_t *count) {
+    if (world_size <= 0 || rank < 0 || rank >= world_size || !start || !count) return SGX_INVALID_INPUT;
+    const size_t base = batch / size_t(world_size), rem = batch % size_t(world_size);
+    const size_t r = size_t(rank);
+    *count = base + (r < rem ? 1 : 0);
+    *start = r * base + std::min(r, rem);
+    return SGX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+// sgx_internal.h — shared between the host plan code and the HIP kernels of libspectro_hip.so.
+// Product code: nothing here includes, links or calls the CPU oracle (oracle/).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "spectro_hip.h"
+
+namespace sgx {
+
+enum OutMode : int { OUT_LINEAR = 0, OUT_MEL = 1, OUT_COMPLEX = 2 };
+enum AmpMode : int { AMP_POWER = 0, AMP_MAGNITUDE = 1, AMP_DB = 2 };
+enum KernelKind : int { K_DIRECT_DFT = 0, K_LDS_RADIX2 = 1, K_R32X16_F32 = 2 };
+
+// Kernel arguments (POD, passed by value).  Layouts in HBM:
+//   x      : [batch][sample_stride] T, row b valid for n_samples elements
+//   out    : [batch][n_out][n_frames] T  (frames contiguous — reference S9), complex: (re,im) pairs
+//   window : [n_fft] T            tw : [n_fft] complex<T>, tw[k] = exp(-2 pi i k / n_fft)
+//   mel    : CSR, row_ptr[n_mels+1], cols ascending within a row, vals already cast to T
+struct StftArgs {
+    const void *x;
+    void *out;
+    unsigned long long sample_stride;
+    unsigned long long n_samples;
+    unsigned batch;
+    unsigned n_fft, m, log2m, hop, pad;
+    unsigned n_frames, nb_fft, n_out;
+    unsigned ft, tiles;  // frames per workgroup tile, tiles per signal
+    const void *window;
+    const void *tw;
+    const unsigned *mel_ptr;
+    const unsigned *mel_col;
+    const void *mel_val;
+    unsigned n_mels;
+    int out_mode;
+    int amp;
+    double eps;  // 10^(floor_db/10) in f64; cast to T in the kernel (T::from_f64, spectrogram.rs:2028)
+    // tuned-kernel tables (K_R32X16_F32)
+    const void *tw1;  // [32][16] complex<f32>: W_512^(k1*n2)
+    const void *tw2;  // [16][16] complex<f32>: W_1024^(j + 32*k2) etc.
+};
+
+// launchers (kernels_generic.hip / kernels_r32x16.hip); return hipSuccess or the launch error
+hipError_t launch_direct_dft(const StftArgs &a, int dtype, hipStream_t s);
+hipError_t launch_lds_radix2(const StftArgs &a, int dtype, hipStream_t s);
+hipError_t launch_r32x16_f32(const StftArgs &a, hipStream_t s);
+// tile geometry chosen per kernel (fills a.ft / a.tiles); returns false if the kernel cannot run the shape
+bool plan_geometry_direct_dft(StftArgs &a, int dtype);
+bool plan_geometry_lds_radix2(StftArgs &a, int dtype);
+bool plan_geometry_r32x16_f32(StftArgs &a);
+
+}  // namespace sgx
+
+struct sgx_plan {
+    sgx_params p{};
+    std::vector<double> custom_window;
+    int device = -1;       // -2: host-only plan
+    bool device_ready = false;
+    int dtype = SGX_F32;
+    size_t elem = 4;
+    unsigned nb_fft = 0, n_out = 0;
+    int out_mode = 0, amp = 0;
+    double eps = 0.0;
+    sgx::KernelKind kind = sgx::K_DIRECT_DFT;
+
+    // host tables (f64, as the reference builds them)
+    std::vector<double> window;
+    std::vector<uint32_t> mel_ptr, mel_col;
+    std::vector<double> mel_val;
+
+    // device tables
+    void *d_window = nullptr, *d_tw = nullptr, *d_tw1 = nullptr, *d_tw2 = nullptr;
+    void *d_mel_ptr = nullptr, *d_mel_col = nullptr, *d_mel_val = nullptr;
+    void *d_ones = nullptr;  // rectangular window for sgx_r2c
+
+    // plan-owned staging for host-pointer execution
+    void *d_in = nullptr, *d_out = nullptr;
+    size_t d_in_bytes = 0, d_out_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    mutable std::string err;
+};

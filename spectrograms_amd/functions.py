@@ -1,0 +1,33 @@
+"""One-shot functions with the reference's names and argument order (src/python/functions.rs:92-266, 757-773)."""
+from __future__ import annotations
+
+from . import _ffi
+from .planner import Plan
+
+
+def compute_linear_power_spectrogram(samples, params, db=None, dtype=None):
+    return Plan(params, _ffi.AMP_POWER, None, db, dtype).compute(samples)
+
+
+def compute_linear_magnitude_spectrogram(samples, params, db=None, dtype=None):
+    return Plan(params, _ffi.AMP_MAGNITUDE, None, db, dtype).compute(samples)
+
+
+def compute_linear_db_spectrogram(samples, params, db=None, dtype=None):
+    return Plan(params, _ffi.AMP_DECIBELS, None, db, dtype).compute(samples)
+
+
+def compute_mel_power_spectrogram(samples, params, mel_params, db=None, dtype=None):
+    return Plan(params, _ffi.AMP_POWER, mel_params, db, dtype).compute(samples)
+
+
+def compute_mel_magnitude_spectrogram(samples, params, mel_params, db=None, dtype=None):
+    return Plan(params, _ffi.AMP_MAGNITUDE, mel_params, db, dtype).compute(samples)
+
+
+def compute_mel_db_spectrogram(samples, params, mel_params, db=None, dtype=None):
+    return Plan(params, _ffi.AMP_DECIBELS, mel_params, db, dtype).compute(samples)
+
+
+def compute_stft(samples, params, dtype=None):
+    return Plan(params, _ffi.AMP_COMPLEX, None, None, dtype).compute(samples)

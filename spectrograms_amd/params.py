@@ -1,0 +1,146 @@
+"""Parameter types mirroring the reference's Python classes (src/python/params.rs; names and argument order from
+python/spectrograms/__init__.pyi).  Validation happens at the same API point and with the same message text as the
+reference constructors (src/spectrogram.rs:3479-3506, 3793-3813, 4071-4077, 4129-4140; src/window.rs:134-203)."""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+
+from . import _ffi
+
+
+class WindowType:
+    """src/window.rs:19-50; Python surface src/python/params.rs:43-174."""
+
+    __slots__ = ("kind", "param", "coefficients")
+
+    def __init__(self, kind: int, param: float = 0.0, coefficients: Optional[np.ndarray] = None):
+        self.kind, self.param, self.coefficients = kind, float(param), coefficients
+
+    @classmethod
+    def kaiser(cls, beta: float) -> "WindowType":
+        return cls(_ffi.WIN_KAISER, beta)
+
+    @classmethod
+    def gaussian(cls, std: float) -> "WindowType":
+        return cls(_ffi.WIN_GAUSSIAN, std)
+
+    @classmethod
+    def custom(cls, coefficients, normalize: Optional[str] = None) -> "WindowType":
+        # WindowType::custom_with_normalization, src/window.rs:134-203
+        c = np.array(coefficients, dtype=np.float64).reshape(-1)
+        if c.size == 0:
+            raise ValueError("Custom window coefficients cannot be empty")
+        bad = np.flatnonzero(~np.isfinite(c))
+        if bad.size:
+            raise ValueError(f"Window coefficient at index {int(bad[0])} is not finite: {c[bad[0]]}")
+        if normalize is not None:
+            if normalize == "sum":
+                s = float(c.sum())
+                if s == 0.0:
+                    raise ValueError("Cannot normalize window by sum: sum is zero")
+                c = c / s
+            elif normalize in ("peak", "max"):
+                m = float(c.max())
+                if m == 0.0:
+                    raise ValueError("Cannot normalize window by peak: maximum is zero")
+                c = c / m
+            elif normalize in ("energy", "rms"):
+                e = float((c * c).sum())
+                if e == 0.0:
+                    raise ValueError("Cannot normalize window by energy: energy is zero")
+                c = c / math.sqrt(e)
+            else:
+                raise ValueError(f"Unknown normalization mode '{normalize}'. Valid modes: 'sum', 'peak', 'energy'")
+        return cls(_ffi.WIN_CUSTOM, 0.0, np.ascontiguousarray(c))
+
+    def __repr__(self) -> str:
+        names = ["Rectangular", "Hanning", "Hamming", "Blackman", f"Kaiser(beta={self.param})",
+                 f"Gaussian(std={self.param})", f"Custom(n={0 if self.coefficients is None else self.coefficients.size})"]
+        return f"WindowType.{names[self.kind]}"
+
+
+WindowType.rectangular = WindowType(_ffi.WIN_RECTANGULAR)
+WindowType.hanning = WindowType(_ffi.WIN_HANNING)
+WindowType.hamming = WindowType(_ffi.WIN_HAMMING)
+WindowType.blackman = WindowType(_ffi.WIN_BLACKMAN)
+
+
+class StftParams:
+    """StftParams(n_fft, hop_size, window, centre=True) — src/python/params.rs:487-503."""
+
+    def __init__(self, n_fft: int, hop_size: int, window: WindowType, centre: bool = True):
+        n_fft, hop_size = int(n_fft), int(hop_size)
+        if n_fft <= 0 or hop_size <= 0:
+            raise ValueError("n_fft and hop_size must be > 0")  # NonZeroUsize
+        if hop_size > n_fft:
+            raise _ffi.InvalidInputError("Invalid input: hop_size must be <= n_fft")
+        if window.kind == _ffi.WIN_CUSTOM and window.coefficients.size != n_fft:
+            raise _ffi.InvalidInputError(
+                f"Invalid input: Custom window size ({window.coefficients.size}) must match n_fft ({n_fft})")
+        self.n_fft, self.hop_size, self.window, self.centre = n_fft, hop_size, window, bool(centre)
+
+
+class LogParams:
+    """LogParams(floor_db) — src/python/params.rs:583-585."""
+
+    def __init__(self, floor_db: float):
+        if not math.isfinite(floor_db):
+            raise _ffi.InvalidInputError("Invalid input: floor_db must be finite")
+        self.floor_db = float(floor_db)
+
+
+class SpectrogramParams:
+    """SpectrogramParams(stft, sample_rate) — src/python/params.rs:630-635."""
+
+    def __init__(self, stft: StftParams, sample_rate: float):
+        if not (sample_rate > 0.0 and math.isfinite(sample_rate)):
+            raise _ffi.InvalidInputError("Invalid input: sample_rate_hz must be finite and > 0")
+        self.stft, self.sample_rate = stft, float(sample_rate)
+
+    @classmethod
+    def speech_default(cls, sample_rate: float) -> "SpectrogramParams":
+        return cls(StftParams(512, 160, WindowType.hanning, True), sample_rate)
+
+    @classmethod
+    def music_default(cls, sample_rate: float) -> "SpectrogramParams":
+        return cls(StftParams(2048, 512, WindowType.hanning, True), sample_rate)
+
+
+class MelNorm:
+    """MelNorm — src/spectrogram.rs:2385-2429."""
+
+    def __init__(self, code: int):
+        self.code = code
+
+
+MelNorm.none = MelNorm(_ffi.MELNORM_NONE)
+MelNorm.slaney = MelNorm(_ffi.MELNORM_SLANEY)
+MelNorm.l1 = MelNorm(_ffi.MELNORM_L1)
+MelNorm.l2 = MelNorm(_ffi.MELNORM_L2)
+
+
+class MelParams:
+    """MelParams(n_mels, f_min, f_max, norm=None) — src/python/params.rs:812-850."""
+
+    def __init__(self, n_mels: int, f_min: float, f_max: float, norm: Optional[MelNorm] = None):
+        if int(n_mels) <= 0:
+            raise ValueError("n_mels must be > 0")
+        if f_min < 0.0:
+            raise _ffi.InvalidInputError("Invalid input: f_min must be >= 0")
+        if f_max <= f_min:
+            raise _ffi.InvalidInputError("Invalid input: f_max must be > f_min")
+        self.n_mels, self.f_min, self.f_max = int(n_mels), float(f_min), float(f_max)
+        self.norm = norm if norm is not None else MelNorm.none
+
+
+def parse_dtype(dtype: Optional[str]) -> int:
+    """src/python/dtype.rs:34-42."""
+    d = "float64" if dtype is None else dtype
+    if d in ("float64", "f64", "double"):
+        return _ffi.F64
+    if d in ("float32", "f32", "single"):
+        return _ffi.F32
+    raise ValueError(f"unsupported dtype {d!r}; expected 'float32' or 'float64'")

@@ -1,0 +1,267 @@
+"""Plan objects over the C ABI: the Python mirror of SpectrogramPlanner / *Plan (src/python/planner.rs:107-350,
+671-750) plus the batched entry point the HIP engine adds (`compute_batch`)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _ffi
+from .params import LogParams, MelParams, SpectrogramParams, parse_dtype
+
+
+class Spectrogram:
+    """Result container (src/spectrogram.rs:2547-2832; Python class src/python/spectrogram.rs)."""
+
+    def __init__(self, data: np.ndarray, frequencies: np.ndarray, times: np.ndarray, params: SpectrogramParams,
+                 db_floor: Optional[float]):
+        self._data, self._freqs, self._times, self._params, self._db_floor = data, frequencies, times, params, db_floor
+
+    data = property(lambda s: s._data)
+    dtype = property(lambda s: "float32" if s._data.dtype == np.float32 else "float64")
+    frequencies = property(lambda s: s._freqs.tolist())
+    times = property(lambda s: s._times.tolist())
+    n_bins = property(lambda s: s._data.shape[0])
+    n_frames = property(lambda s: s._data.shape[1])
+    shape = property(lambda s: s._data.shape)
+    params = property(lambda s: s._params)
+    T = property(lambda s: s._data.T)
+
+    def frequency_range(self) -> Tuple[float, float]:
+        return float(self._freqs[0]), float(self._freqs[-1])
+
+    def duration(self) -> float:
+        return float(self._times[-1]) if self._times.size else 0.0
+
+    def db_range(self):
+        return None if self._db_floor is None else (float(self._data.min()), float(self._data.max()))
+
+    def __len__(self) -> int:
+        return self._data.shape[0]
+
+    def __getitem__(self, idx):
+        return self._data[idx]
+
+    def __array__(self, dtype=None, copy=None):
+        return self._data if dtype is None else self._data.astype(dtype)
+
+    def astype(self, dtype):
+        return self._data.astype(dtype)
+
+
+class StftResult:
+    """StftResult (src/spectrogram.rs:534-630)."""
+
+    def __init__(self, data: np.ndarray, frequencies: np.ndarray, sample_rate: float, params):
+        self._data, self._freqs, self.sample_rate, self.params = data, frequencies, sample_rate, params
+
+    data = property(lambda s: s._data)
+    dtype = property(lambda s: "float32" if s._data.dtype == np.complex64 else "float64")
+    frequencies = property(lambda s: s._freqs.tolist())
+    n_bins = property(lambda s: s._data.shape[0])
+    n_frames = property(lambda s: s._data.shape[1])
+    shape = property(lambda s: s._data.shape)
+
+    def norm(self) -> np.ndarray:
+        return np.abs(self._data)
+
+    def __array__(self, dtype=None, copy=None):
+        return self._data if dtype is None else self._data.astype(dtype)
+
+
+class Plan:
+    """One sgx_plan.  Not thread-safe (mirrors `&mut self`; reference plan classes are `unsendable`)."""
+
+    def __init__(self, params: SpectrogramParams, amp: int, mel: Optional[MelParams] = None,
+                 db: Optional[LogParams] = None, dtype: Optional[str] = None, device: int = _ffi.DEVICE_CURRENT):
+        self._lib = _ffi.lib()
+        self._params, self._mel, self._db = params, mel, db
+        self._dt = parse_dtype(dtype)
+        self._np = np.float32 if self._dt == _ffi.F32 else np.float64
+        self._amp = amp
+        st = params.stft
+        p = _ffi.SgxParams()
+        p.n_fft, p.hop_size, p.centre = st.n_fft, st.hop_size, int(st.centre)
+        p.window_kind, p.window_param = st.window.kind, st.window.param
+        self._cw = None
+        if st.window.kind == _ffi.WIN_CUSTOM:
+            self._cw = np.ascontiguousarray(st.window.coefficients, np.float64)
+            p.custom_window = self._cw.ctypes.data_as(C.POINTER(C.c_double))
+            p.custom_window_len = self._cw.size
+        p.sample_rate_hz = params.sample_rate
+        p.freq_scale = _ffi.FREQ_MEL if mel is not None else _ffi.FREQ_LINEAR
+        if mel is not None:
+            p.n_mels, p.f_min, p.f_max, p.mel_norm = mel.n_mels, mel.f_min, mel.f_max, mel.norm.code
+        p.amp_scale = amp
+        p.has_log_params = int(db is not None)
+        p.floor_db = db.floor_db if db is not None else 0.0
+        p.dtype, p.device = self._dt, device
+        h = C.c_void_p()
+        _ffi.raise_status(self._lib.sgx_plan_create(C.byref(p), C.byref(h)))
+        self._h = h
+        self.n_fft = st.n_fft
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.sgx_plan_destroy(h)
+            self._h = None
+
+    # ---- queries
+    @property
+    def dtype(self) -> str:
+        return "float32" if self._dt == _ffi.F32 else "float64"
+
+    @property
+    def is_complex(self) -> bool:
+        return self._amp == _ffi.AMP_COMPLEX
+
+    @property
+    def kernel_name(self) -> str:
+        return self._lib.sgx_kernel_name(self._h).decode()
+
+    def output_shape(self, signal_length: int) -> Tuple[int, int]:
+        if int(signal_length) <= 0:
+            raise ValueError("signal_length must be > 0")
+        nb, nf = C.c_size_t(), C.c_size_t()
+        _ffi.raise_status(self._lib.sgx_output_shape(self._h, int(signal_length), C.byref(nb), C.byref(nf)), self._h)
+        return nb.value, nf.value
+
+    def axes(self, n_frames: int):
+        nb = self.output_shape(self.n_fft)[0]
+        f, t = np.empty(nb, np.float64), np.empty(n_frames, np.float64)
+        _ffi.raise_status(self._lib.sgx_axes(self._h, n_frames, f.ctypes.data_as(C.POINTER(C.c_double)),
+                                             t.ctypes.data_as(C.POINTER(C.c_double))), self._h)
+        return f, t
+
+    def window(self) -> np.ndarray:
+        w = np.empty(self.n_fft, np.float64)
+        _ffi.raise_status(self._lib.sgx_window(self._h, w.ctypes.data_as(C.POINTER(C.c_double))), self._h)
+        return w
+
+    def mel_weights(self):
+        nnz = C.c_size_t()
+        _ffi.raise_status(self._lib.sgx_mel_weights(self._h, C.byref(nnz), None, None, None), self._h)
+        ptr = np.empty(self._mel.n_mels + 1, np.uint32)
+        col = np.empty(nnz.value, np.uint32)
+        val = np.empty(nnz.value, np.float64)
+        _ffi.raise_status(self._lib.sgx_mel_weights(self._h, None, ptr.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                    col.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                    val.ctypes.data_as(C.POINTER(C.c_double))), self._h)
+        return ptr, col, val
+
+    # ---- compute
+    def _host_samples(self, samples, ndim: int) -> np.ndarray:
+        x = np.ascontiguousarray(samples, dtype=self._np)  # np.ascontiguousarray(samples, T), functions.rs:29-59
+        if x.ndim != ndim:
+            raise ValueError(f"samples must be a {ndim}-D array")
+        if x.size == 0:
+            raise ValueError("samples must be non-empty")  # functions.rs:52-54
+        return x
+
+    def compute_batch(self, samples, out=None, stream: int = 0):
+        """[B, N] -> [B, n_bins, n_frames] in one launch.  numpy in -> numpy out (host path, plan-owned staging);
+        torch CUDA tensor in -> torch CUDA tensor out (zero-copy device path on `stream`/torch's current stream)."""
+        if type(samples).__module__.startswith("torch"):
+            return self._compute_batch_torch(samples, out, stream)
+        x = self._host_samples(samples, 2)
+        b, n = x.shape
+        nb, nf = self.output_shape(n)
+        cdt = (np.complex64 if self._dt == _ffi.F32 else np.complex128) if self.is_complex else self._np
+        if out is None:
+            out = np.empty((b, nb, nf), cdt)
+        elif out.dtype != cdt or not out.flags.c_contiguous:
+            raise ValueError("out must be C-contiguous with the plan's dtype")
+        elems = out.size * (2 if self.is_complex else 1)
+        _ffi.raise_status(self._lib.sgx_execute(self._h, x.ctypes.data, b, n, n, out.ctypes.data, elems,
+                                                _ffi.MEM_HOST, None), self._h)
+        return out
+
+    def _compute_batch_torch(self, x, out, stream):
+        import torch
+        tdt = torch.float32 if self._dt == _ffi.F32 else torch.float64
+        if not x.is_cuda or x.dtype != tdt or x.dim() != 2 or x.stride(1) != 1:
+            raise ValueError("device path needs a 2-D CUDA tensor of the plan's dtype with unit inner stride")
+        if x.numel() == 0:
+            raise ValueError("samples must be non-empty")
+        b, n = x.shape
+        nb, nf = self.output_shape(n)
+        shape = (b, nb, nf, 2) if self.is_complex else (b, nb, nf)
+        if out is None:
+            out = torch.empty(shape, dtype=tdt, device=x.device)
+        elif tuple(out.shape) != shape or out.dtype != tdt or not out.is_contiguous():
+            raise _ffi.DimensionMismatchError(f"Dimension mismatch: expected {shape}, got {tuple(out.shape)}")
+        s = stream or torch.cuda.current_stream(x.device).cuda_stream
+        _ffi.raise_status(self._lib.sgx_execute(self._h, x.data_ptr(), b, n, x.stride(0), out.data_ptr(), out.numel(),
+                                                _ffi.MEM_DEVICE, C.c_void_p(s)), self._h)
+        return torch.view_as_complex(out) if self.is_complex else out
+
+    def time_batch_torch(self, x, out, iters: int, stream: int = 0) -> float:
+        """Mean device milliseconds per launch over `iters` back-to-back launches (hipEvents on the launch stream)."""
+        import torch
+        s = stream or torch.cuda.current_stream(x.device).cuda_stream
+        ms = C.c_float()
+        b, n = x.shape
+        _ffi.raise_status(self._lib.sgx_execute_timed(self._h, x.data_ptr(), b, n, x.stride(0), out.data_ptr(),
+                                                      out.numel(), C.c_void_p(s), iters, C.byref(ms)), self._h)
+        return float(ms.value)
+
+    def compute(self, samples):
+        """Per-signal compute (SpectrogramPlan::compute :240-294 / StftPlan::compute :1424-1458)."""
+        x = self._host_samples(samples, 1)
+        data = self.compute_batch(x[None, :])[0]
+        freqs, times = self.axes(data.shape[1])
+        if self.is_complex:
+            return StftResult(data, freqs, self._params.sample_rate, self._params.stft)
+        return Spectrogram(data, freqs, times, self._params, self._db.floor_db if self._db else None)
+
+    def compute_frame(self, samples, frame_idx: int) -> np.ndarray:
+        """SpectrogramPlan::compute_frame (:335-372): one column.  Computed from the n_fft-sample span it covers."""
+        x = self._host_samples(samples, 1)
+        st = self._params.stft
+        pad = st.n_fft // 2 if st.centre else 0
+        lo = frame_idx * st.hop_size - pad
+        seg = np.zeros(st.n_fft, self._np)
+        a, b = max(lo, 0), min(lo + st.n_fft, x.size)
+        if b > a:
+            seg[a - lo:b - lo] = x[a:b]
+        tmp = Plan(SpectrogramParams(type(st)(st.n_fft, st.hop_size, st.window, False), self._params.sample_rate),
+                   self._amp, self._mel, self._db, self.dtype)
+        return tmp.compute_batch(seg[None, :])[0][:, 0]
+
+    def r2c(self, frame) -> np.ndarray:
+        """Conforming R2cPlan::process (src/fft_backend.rs:423-431) on one frame of n_fft reals."""
+        x = np.ascontiguousarray(frame, dtype=self._np)
+        out = np.empty(self.n_fft // 2 + 1, np.complex64 if self._dt == _ffi.F32 else np.complex128)
+        _ffi.raise_status(self._lib.sgx_r2c(self._h, x.ctypes.data, x.size, out.ctypes.data, out.size), self._h)
+        return out
+
+
+class SpectrogramPlanner:
+    """src/python/planner.rs:107-350 — same method names and argument order."""
+
+    def __init__(self, device: int = _ffi.DEVICE_CURRENT):
+        self._device = device
+
+    def linear_power_plan(self, params, dtype=None):
+        return Plan(params, _ffi.AMP_POWER, None, None, dtype, self._device)
+
+    def linear_magnitude_plan(self, params, dtype=None):
+        return Plan(params, _ffi.AMP_MAGNITUDE, None, None, dtype, self._device)
+
+    def linear_db_plan(self, params, db_params, dtype=None):
+        return Plan(params, _ffi.AMP_DECIBELS, None, db_params, dtype, self._device)
+
+    def mel_power_plan(self, params, mel_params, dtype=None):
+        return Plan(params, _ffi.AMP_POWER, mel_params, None, dtype, self._device)
+
+    def mel_magnitude_plan(self, params, mel_params, dtype=None):
+        return Plan(params, _ffi.AMP_MAGNITUDE, mel_params, None, dtype, self._device)
+
+    def mel_db_plan(self, params, mel_params, db_params, dtype=None):
+        return Plan(params, _ffi.AMP_DECIBELS, mel_params, db_params, dtype, self._device)
+
+    def stft_plan(self, params, dtype=None):
+        """StftPlan::new (src/spectrogram.rs:1204-1228)."""
+        return Plan(params, _ffi.AMP_COMPLEX, None, None, dtype, self._device)

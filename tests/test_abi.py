@@ -1,0 +1,173 @@
+"""CPU tests: the C-ABI library loads, exports every symbol include/spectro_hip.h declares, and its host logic
+(validation, window / Mel tables, framing, axes, sharding) agrees with the oracle.  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import spectrograms_amd as sg
+from oracle import oracle as orc
+from spectrograms_amd import _ffi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = _ffi.DEVICE_HOST_ONLY
+
+
+def host_plan(n_fft=512, hop=256, window=None, centre=True, sr=16000.0, mel=None, amp=_ffi.AMP_POWER, db=None,
+              dtype="float64"):
+    p = sg.SpectrogramParams(sg.StftParams(n_fft, hop, window or sg.WindowType.hanning, centre), sr)
+    return sg.Plan(p, amp, mel, db, dtype, device=HOST)
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "spectro_hip.h")).read()
+    declared = set(re.findall(r"\b(sgx_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"sgx_plan"}
+    assert declared == set(_ffi.SYMBOLS), declared ^ set(_ffi.SYMBOLS)
+    L = C.CDLL(_ffi.LIB_PATH)
+    for s in declared:
+        assert hasattr(L, s), s
+    assert _ffi.lib().sgx_abi_version() == 1
+
+
+def test_params_struct_layout_matches_header():
+    # field order / types of sgx_params as declared in the header
+    hdr = open(os.path.join(ROOT, "include", "spectro_hip.h")).read()
+    body = hdr[hdr.index("typedef struct {"):hdr.index("} sgx_params;")]
+    names = re.findall(r"\b(?:uint32_t|int32_t|double|const double \*)\s*\*?([a-z_0-9, ]+);", body)
+    flat = [n.strip() for grp in names for n in grp.split(",")]
+    assert flat == [f[0] for f in _ffi.SgxParams._fields_]
+
+
+@pytest.mark.parametrize("kind,param", [("rectangular", 0), ("hanning", 0), ("hamming", 0), ("blackman", 0),
+                                        ("kaiser", 5.0), ("kaiser", 2.5), ("gaussian", 100.0)])
+@pytest.mark.parametrize("n", [1, 2, 8, 400, 1024])
+def test_window_tables_match_oracle(kind, param, n):
+    w = {"rectangular": sg.WindowType.rectangular, "hanning": sg.WindowType.hanning, "hamming": sg.WindowType.hamming,
+         "blackman": sg.WindowType.blackman, "kaiser": sg.WindowType.kaiser(param),
+         "gaussian": sg.WindowType.gaussian(param)}[kind]
+    got = host_plan(n, max(1, n // 2), w).window()
+    ref = orc.make_window(kind, n, param)
+    assert np.max(np.abs(got - ref)) <= 4e-16 or np.allclose(got, ref, rtol=1e-15, atol=0, equal_nan=True)
+
+
+def test_custom_window_roundtrip_and_normalisation():
+    c = np.hamming(64)
+    assert np.array_equal(host_plan(64, 32, sg.WindowType.custom(c)).window(), c)
+    assert abs(sg.WindowType.custom(c, "sum").coefficients.sum() - 1.0) < 1e-15
+    assert abs(sg.WindowType.custom(c, "peak").coefficients.max() - 1.0) < 1e-15
+    assert abs((sg.WindowType.custom(c, "energy").coefficients ** 2).sum() - 1.0) < 1e-15
+    with pytest.raises(ValueError):
+        sg.WindowType.custom(c, "bogus")
+    with pytest.raises(ValueError):
+        sg.WindowType.custom([1.0, float("nan")])
+    with pytest.raises(sg.InvalidInputError):  # src/spectrogram.rs:3490-3498
+        sg.StftParams(128, 64, sg.WindowType.custom(c))
+
+
+@pytest.mark.parametrize("norm", [None, sg.MelNorm.slaney, sg.MelNorm.l1, sg.MelNorm.l2])
+@pytest.mark.parametrize("sr,n_fft,n_mels,fmin,fmax", [(16000, 1024, 80, 0.0, 8000.0), (22050, 400, 64, 20.0, 7600.0),
+                                                        (16000, 512, 40, 0.0, 8000.0)])
+def test_mel_tables_match_oracle(sr, n_fft, n_mels, fmin, fmax, norm):
+    ptr, col, val = host_plan(n_fft, n_fft // 4, sr=float(sr), mel=sg.MelParams(n_mels, fmin, fmax, norm)).mel_weights()
+    oname = {None: None, sg.MelNorm.slaney: "slaney", sg.MelNorm.l1: "l1", sg.MelNorm.l2: "l2"}[norm]
+    optr, ocol, oval, _ = orc.mel_filterbank(sr, n_fft, n_mels, fmin, fmax, oname)
+    assert np.array_equal(ptr.astype(np.int64), optr.astype(np.int64))
+    assert np.array_equal(col, ocol)
+    assert np.allclose(val, oval, rtol=1e-15, atol=0)
+
+
+@pytest.mark.parametrize("n,n_fft,hop,centre", [(16000, 512, 256, True), (160000, 1024, 256, True), (5, 512, 256, True),
+                                                (5, 512, 256, False), (1000, 400, 160, False), (1023, 1024, 1024, False),
+                                                (4096, 1024, 1024, True), (777, 7, 3, True)])
+def test_output_shape_and_axes_match_oracle(n, n_fft, hop, centre):
+    pl = host_plan(n_fft, hop, centre=centre)
+    nb, nf = pl.output_shape(n)
+    assert nb == n_fft // 2 + 1
+    assert nf == orc.frame_count(n, n_fft, hop, centre)
+    f, t = pl.axes(nf)
+    of, ot = orc.axes(orc.Params(n_fft=n_fft, hop=hop, centre=centre), nf)
+    assert np.array_equal(f, of) and np.array_equal(t, ot)
+    plm = host_plan(n_fft if n_fft > 16 else 64, hop if n_fft > 16 else 16, mel=sg.MelParams(12, 50.0, 4000.0))
+    fm, _ = plm.axes(3)
+    ofm, _ = orc.axes(orc.Params(n_fft=64, hop=16, n_mels=12, f_min=50.0, f_max=4000.0), 3)
+    assert np.allclose(fm, ofm, rtol=1e-15)
+
+
+def test_doc_kat_shape():
+    assert host_plan(512, 256).output_shape(16000) == (257, 63)  # src/spectrogram.rs:505-507
+    assert host_plan(512, 256, mel=sg.MelParams(40, 0.0, 8000.0)).output_shape(16000) == (40, 63)
+
+
+def test_constructor_errors_match_reference_points():
+    with pytest.raises(sg.InvalidInputError, match="hop_size must be <= n_fft"):
+        sg.StftParams(512, 513, sg.WindowType.hanning)
+    with pytest.raises(sg.InvalidInputError, match="sample_rate_hz"):
+        sg.SpectrogramParams(sg.StftParams(512, 256, sg.WindowType.hanning), 0.0)
+    with pytest.raises(sg.InvalidInputError, match="f_min"):
+        sg.MelParams(40, -1.0, 100.0)
+    with pytest.raises(sg.InvalidInputError, match="f_max must be > f_min"):
+        sg.MelParams(40, 100.0, 100.0)
+    with pytest.raises(sg.InvalidInputError, match="floor_db"):
+        sg.LogParams(float("inf"))
+    with pytest.raises(sg.InvalidInputError, match="Nyquist"):  # tests/spectrogram_tests.rs:147-158
+        host_plan(512, 256, mel=sg.MelParams(40, 0.0, 9000.0))
+    with pytest.raises(sg.InvalidInputError, match="unreasonably large"):
+        host_plan(512, 256, mel=sg.MelParams(10001, 0.0, 8000.0))
+    with pytest.raises(ValueError):
+        sg.Plan(sg.SpectrogramParams(sg.StftParams(512, 256, sg.WindowType.hanning), 16000.0), _ffi.AMP_POWER,
+                dtype="float16", device=HOST)
+
+
+def test_raw_abi_rejects_bad_params_without_aborting():
+    L = _ffi.lib()
+    p = _ffi.SgxParams()
+    p.n_fft, p.hop_size, p.sample_rate_hz, p.device = 512, 600, 16000.0, HOST
+    h = C.c_void_p()
+    assert L.sgx_plan_create(C.byref(p), C.byref(h)) == _ffi.SGX_INVALID_INPUT and not h.value
+    assert b"hop_size" in L.sgx_last_create_error()
+    p.hop_size, p.window_kind = 256, _ffi.WIN_CUSTOM
+    assert L.sgx_plan_create(C.byref(p), C.byref(h)) == _ffi.SGX_INVALID_INPUT
+    assert b"Custom window size (0) must match n_fft (512)" in L.sgx_last_create_error()
+    assert L.sgx_plan_create(None, C.byref(h)) == _ffi.SGX_INVALID_INPUT
+
+
+def test_host_only_plan_refuses_compute_loudly():
+    pl = host_plan(256, 64, dtype="float32")
+    with pytest.raises(sg.FFTBackendError, match="no HIP device"):
+        pl.compute_batch(np.zeros((2, 1000), np.float32))
+    with pytest.raises(sg.FFTBackendError):
+        pl.r2c(np.zeros(256, np.float32))
+    with pytest.raises(sg.DimensionMismatchError, match="expected 256, got 100"):  # validate_fft_io
+        pl.r2c(np.zeros(100, np.float32))
+    bad = np.empty((2, 129, 3), np.float32)
+    with pytest.raises(sg.DimensionMismatchError):  # compute_into shape check comes before the device check
+        pl.compute_batch(np.zeros((2, 1000), np.float32), out=bad)
+    with pytest.raises(ValueError):
+        pl.compute_batch(np.zeros((0, 10), np.float32))
+
+
+def test_kernel_selection():
+    assert host_plan(1024, 256, dtype="float32").kernel_name in ("r32x16_f32", "lds_radix2")
+    assert host_plan(1024, 256, dtype="float64").kernel_name == "lds_radix2"
+    assert host_plan(400, 160).kernel_name == "direct_dft"
+    assert host_plan(2, 1).kernel_name == "direct_dft"
+
+
+def test_shard_range_partitions_batch():
+    L = _ffi.lib()
+    for batch in (1, 7, 8, 256, 8192, 1000):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                s, c = C.c_size_t(), C.c_size_t()
+                assert L.sgx_shard_range(batch, world, r, C.byref(s), C.byref(c)) == 0
+                seen.append((s.value, c.value))
+            assert seen[0][0] == 0 and sum(c for _, c in seen) == batch
+            for (s0, c0), (s1, _) in zip(seen, seen[1:]):
+                assert s0 + c0 == s1
+            assert max(c for _, c in seen) - min(c for _, c in seen) <= 1
+    s, c = C.c_size_t(), C.c_size_t()
+    assert L.sgx_shard_range(8, 0, 0, C.byref(s), C.byref(c)) == _ffi.SGX_INVALID_INPUT

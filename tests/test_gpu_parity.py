@@ -1,0 +1,325 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against the CPU oracle
+and the committed golden vectors.
+
+Tolerances (SURVEY.md §8c / BASELINE.json north_star):
+  f64            : <= 1e-10 * max(1, max|ref|)   (the reference's own f64 round-trip bound, fft_backend.rs:1886-1907)
+  f32 complex    : <= 1e-4 * max|X| abs          (north_star: within 1e-4 rel. of RustFFT)
+  f32 power/mel  : <= 1e-4 relative where ref > 1e-6 * max(ref); <= 1e-4 * max(ref) abs everywhere
+  dB             : <= 1e-3 dB abs where the power is within 60 dB of the peak; >= floor everywhere
+A tighter regression guard (GUARD) is asserted as well so that a numerically sloppy kernel cannot hide in the slack.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import spectrograms_amd as sg
+from oracle import oracle as orc
+from spectrograms_amd import _ffi
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+TOL32 = 1e-4
+GUARD32 = 2e-5
+TOL64 = 1e-10
+
+WINDOWS = {
+    "hanning": (sg.WindowType.hanning, {}),
+    "hamming": (sg.WindowType.hamming, {}),
+    "blackman": (sg.WindowType.blackman, {}),
+    "rectangular": (sg.WindowType.rectangular, {}),
+    "kaiser": (sg.WindowType.kaiser(5.0), {"window_param": 5.0}),
+    "gaussian": (sg.WindowType.gaussian(60.0), {"window_param": 60.0}),
+}
+
+
+def signals(batch, n, dtype, seed=0):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / 16000.0
+    rows = []
+    for b in range(batch):
+        if b % 2 == 0:
+            rows.append(0.5 * np.sin(2 * np.pi * (110.0 * 2 ** (b / 3.0)) * t) + 0.05 * rng.standard_normal(n))
+        else:
+            rows.append(0.3 * rng.standard_normal(n))
+    return np.stack(rows).astype(dtype)
+
+
+def make(n_fft, hop, window="hanning", centre=True, n_mels=0, fmin=0.0, fmax=8000.0, norm=None, amp="power",
+         floor=None, dtype="float32", sr=16000.0):
+    w, okw = WINDOWS[window]
+    params = sg.SpectrogramParams(sg.StftParams(n_fft, hop, w, centre), sr)
+    mel = None
+    if n_mels:
+        mn = {None: None, "slaney": sg.MelNorm.slaney, "l1": sg.MelNorm.l1, "l2": sg.MelNorm.l2}[norm]
+        mel = sg.MelParams(n_mels, fmin, fmax, mn)
+    db = sg.LogParams(floor) if floor is not None else None
+    code = {"power": _ffi.AMP_POWER, "magnitude": _ffi.AMP_MAGNITUDE, "db": _ffi.AMP_DECIBELS, "complex": _ffi.AMP_COMPLEX}[amp]
+    plan = sg.Plan(params, code, mel, db, dtype)
+    op = orc.Params(n_fft=n_fft, hop=hop, window=window, centre=centre, sample_rate=sr, n_mels=n_mels, f_min=fmin,
+                    f_max=fmax, mel_norm=norm, amp="power" if amp == "complex" else amp, floor_db=floor, **okw)
+    return plan, op
+
+
+def check(got, ref64, kind, dtype, floor=None, pow64=None):
+    got = np.asarray(got)
+    assert got.shape == ref64.shape, (got.shape, ref64.shape)
+    assert np.all(np.isfinite(got))
+    scale = max(float(np.max(np.abs(ref64))), 1e-300)
+    if dtype == "float64":
+        if kind == "db":
+            m = pow64 > 1e-12 * pow64.max()
+            assert np.max(np.abs(got[m] - ref64[m])) < 1e-8
+        else:
+            assert np.max(np.abs(got - ref64)) <= TOL64 * max(1.0, scale)
+        return
+    g = got.astype(np.complex128 if np.iscomplexobj(got) else np.float64)
+    if kind == "complex":
+        err = np.max(np.abs(g - ref64)) / scale
+        assert err <= TOL32, err
+        assert err <= GUARD32, f"regression guard: {err}"
+    elif kind == "db":
+        assert g.min() >= floor - 1e-3
+        m = pow64 > 1e-6 * pow64.max()
+        assert np.max(np.abs(g[m] - ref64[m])) <= 1e-3
+    else:
+        err_abs = np.max(np.abs(g - ref64)) / scale
+        m = ref64 > 1e-6 * scale
+        err_rel = np.max(np.abs(g[m] - ref64[m]) / ref64[m])
+        assert err_abs <= TOL32 and err_rel <= TOL32, (err_abs, err_rel)
+        assert err_abs <= GUARD32, f"regression guard: {err_abs}"
+
+
+def run_case(n, batch=3, seed=0, **kw):
+    dtype = kw.get("dtype", "float32")
+    amp = kw.get("amp", "power")
+    plan, op = make(**kw)
+    x = signals(batch, n, np.float32 if dtype == "float32" else np.float64, seed)
+    got = plan.compute_batch(x)
+    x64 = x.astype(np.float64)
+    if amp == "complex":
+        ref = orc.stft_batch(op, x64)
+        check(got, ref, "complex", dtype)
+    else:
+        ref = orc.spectrogram_batch(op, x64)
+        pow64 = None
+        if amp == "db":
+            pop = orc.Params(**{**op.__dict__, "amp": "power", "floor_db": None, "_keep": []})
+            pow64 = orc.spectrogram_batch(pop, x64)
+        check(got, ref, amp, dtype, kw.get("floor"), pow64)
+    return plan, got
+
+
+# ------------------------------------------------------------------ pow2 sizes, both kernels, both dtypes
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("n_fft,hop", [(4, 2), (8, 3), (64, 16), (256, 128), (512, 256), (1024, 256), (1024, 512),
+                                       (2048, 512), (4096, 1024)])
+@pytest.mark.parametrize("amp", ["complex", "power"])
+def test_pow2_sizes(n_fft, hop, amp, dtype):
+    run_case(n=6000, n_fft=n_fft, hop=hop, amp=amp, dtype=dtype)
+
+
+# ------------------------------------------------------------------ arbitrary sizes (reference accepts any n_fft)
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("n_fft,hop", [(1, 1), (2, 1), (3, 2), (7, 3), (10, 10), (100, 33), (400, 160), (1000, 250)])
+def test_non_pow2_sizes(n_fft, hop, dtype):
+    run_case(n=3000, n_fft=n_fft, hop=hop, amp="complex", dtype=dtype)
+    run_case(n=3000, n_fft=n_fft, hop=hop, amp="power", dtype=dtype)
+
+
+# ------------------------------------------------------------------ windows / centre / amp scales
+@pytest.mark.parametrize("window", sorted(WINDOWS))
+@pytest.mark.parametrize("centre", [True, False])
+def test_windows_and_centre(window, centre):
+    run_case(n=5000, n_fft=1024, hop=256, window=window, centre=centre, amp="complex")
+    run_case(n=5000, n_fft=512, hop=128, window=window, centre=centre, amp="magnitude", dtype="float64")
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("amp,floor", [("power", None), ("magnitude", None), ("db", -80.0), ("db", -100.0), ("db", None)])
+@pytest.mark.parametrize("n_fft,hop", [(1024, 256), (512, 256), (400, 160)])
+def test_linear_amp_scales(n_fft, hop, amp, floor, dtype):
+    run_case(n=8000, n_fft=n_fft, hop=hop, amp=amp, floor=floor, dtype=dtype)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("amp,floor", [("power", None), ("magnitude", None), ("db", -80.0)])
+@pytest.mark.parametrize("n_fft,hop,n_mels,fmin,fmax,norm", [
+    (1024, 256, 80, 0.0, 8000.0, None), (1024, 256, 128, 20.0, 7600.0, "slaney"), (512, 256, 40, 0.0, 8000.0, "l1"),
+    (400, 160, 64, 0.0, 8000.0, "l2"), (2048, 512, 80, 0.0, 8000.0, None)])
+def test_mel(n_fft, hop, n_mels, fmin, fmax, norm, amp, floor, dtype):
+    run_case(n=9000, n_fft=n_fft, hop=hop, n_mels=n_mels, fmin=fmin, fmax=fmax, norm=norm, amp=amp, floor=floor,
+             dtype=dtype)
+
+
+# ------------------------------------------------------------------ golden vectors (reference numpy_impls) through the C ABI
+def test_golden_config1_f64(golden_dir):
+    g = np.load(os.path.join(golden_dir, "config1_ref.npz"))
+    x = np.sin(2.0 * np.pi * 440.0 * np.arange(16000, dtype=np.float64) / 16000.0)
+    for n_fft, hop in ((512, 256), (256, 128)):
+        params = sg.SpectrogramParams(sg.StftParams(n_fft, hop, sg.WindowType.hanning, True), 16000.0)
+        S = sg.compute_stft(x, params)  # dtype default = float64, as in the reference
+        assert S.data.dtype == np.complex128
+        assert np.max(np.abs(S.data - g[f"c1_{n_fft}_{hop}_stft"])) < 1e-10
+        P = sg.compute_linear_power_spectrogram(x, params)
+        assert np.max(np.abs(P.data - g[f"c1_{n_fft}_{hop}_power"])) < 1e-10 * g[f"c1_{n_fft}_{hop}_power"].max()
+        M = sg.compute_linear_magnitude_spectrogram(x, params)
+        assert np.max(np.abs(M.data - g[f"c1_{n_fft}_{hop}_magnitude"])) < 1e-10
+        assert np.allclose(P.frequencies, g[f"c1_{n_fft}_{hop}_freqs"])
+        assert np.allclose(P.times, np.arange(P.n_frames) * hop / 16000.0)
+        pn = sg.SpectrogramParams(sg.StftParams(n_fft, hop, sg.WindowType.hanning, False), 16000.0)
+        Pn = sg.compute_linear_power_spectrogram(x, pn)
+        ref = g[f"c1_{n_fft}_{hop}_nocentre_power"]
+        assert Pn.shape == ref.shape and np.max(np.abs(Pn.data - ref)) < 1e-10 * ref.max()
+
+
+@pytest.mark.parametrize("b", [0, 1])
+def test_golden_config2_f32(golden_dir, b):
+    g = np.load(os.path.join(golden_dir, "config2_ref.npz"))
+    x = H.cfg2_signal(b)
+    params = sg.SpectrogramParams(sg.StftParams(1024, 256, sg.WindowType.hanning, True), 16000.0)
+    S = sg.compute_stft(x, params, dtype="float32")
+    assert S.shape == (513, 626) and S.data.dtype == np.complex64
+    ref = g[f"c2_b{b}_stft"]
+    err = np.max(np.abs(S.data[:, g[f"c2_b{b}_frames"]].astype(np.complex128) - ref)) / np.max(np.abs(ref))
+    assert err <= GUARD32, err
+    P = sg.compute_linear_power_spectrogram(x, params, dtype="float32")
+    rs = g[f"c2_b{b}_power_rowsum"]
+    assert np.max(np.abs(P.data.astype(np.float64).sum(axis=1) - rs)) <= GUARD32 * rs.max()
+
+
+def test_golden_short_inputs(golden_dir):
+    g = np.load(os.path.join(golden_dir, "short_ref.npz"))
+    params = sg.SpectrogramParams(sg.StftParams(512, 256, sg.WindowType.hanning, True), 16000.0)
+    for n in (5, 300, 511, 512, 513, 1000):
+        S = sg.compute_stft(g[f"short_{n}_x"], params)
+        ref = g[f"short_{n}_stft"]
+        assert S.shape == ref.shape
+        assert np.max(np.abs(S.data - ref)) < 1e-10 * max(1.0, np.max(np.abs(ref)))
+
+
+# ------------------------------------------------------------------ edge cases of the boundary
+@pytest.mark.parametrize("n", [1, 5, 255, 256, 257, 1023, 1024, 1025, 1279, 1280, 1281, 4097])
+@pytest.mark.parametrize("centre", [True, False])
+def test_ragged_lengths_1024(n, centre):
+    run_case(n=n, batch=2, n_fft=1024, hop=256, centre=centre, amp="complex")
+    run_case(n=n, batch=2, n_fft=1024, hop=256, centre=centre, n_mels=80, amp="db", floor=-80.0)
+
+
+def test_hop_equals_n_fft_and_odd_hop():
+    run_case(n=10000, n_fft=1024, hop=1024, amp="power")
+    run_case(n=10000, n_fft=1024, hop=255, amp="complex")  # odd hop: 8-byte loads impossible -> generic kernel
+    run_case(n=10001, n_fft=1024, hop=256, amp="complex")  # odd length: last float2 straddles the end
+
+
+def test_strided_rows_and_device_path_match_host_path():
+    torch = pytest.importorskip("torch")
+    plan, op = make(1024, 256, n_mels=80, amp="db", floor=-80.0)
+    x = signals(5, 7000, np.float32, 3)
+    host = plan.compute_batch(x)
+    big = torch.zeros((5, 7424), dtype=torch.float32, device="cuda")
+    big[:, :7000] = torch.from_numpy(x).cuda()
+    dev = plan.compute_batch(big[:, :7000])  # row stride 7424 != n_samples
+    torch.cuda.synchronize()
+    assert np.array_equal(dev.cpu().numpy(), host)
+    # odd row stride / misaligned base -> falls back to the generic kernel, same numbers within f32 tolerance
+    odd = torch.zeros((5, 7001), dtype=torch.float32, device="cuda")
+    odd[:, :7000] = torch.from_numpy(x).cuda()
+    dev2 = plan.compute_batch(odd[:, :7000]).cpu().numpy()
+    ref = orc.spectrogram_batch(op, x.astype(np.float64))
+    assert np.max(np.abs(dev2 - ref)) < 1e-2  # dB units
+    sp, _ = make(1024, 256, amp="complex")
+    a = sp.compute_batch(big[:, :7000]).cpu().numpy()
+    b = sp.compute_batch(odd[:, :7000]).cpu().numpy()
+    assert np.max(np.abs(a - b)) <= GUARD32 * np.max(np.abs(a))
+
+
+def test_dimension_mismatch_and_r2c():
+    plan, _ = make(1024, 256)
+    x = signals(2, 5000, np.float32)
+    with pytest.raises(sg.DimensionMismatchError):
+        plan.compute_batch(x, out=np.empty((2, 513, 5), np.float32))
+    # conforming R2cPlan::process: DC of ones = N (fft_backend.rs:1880-1907), [1,1,1] padded -> 3 (fft_padding_tests.rs:149-158)
+    for dtype, tol in (("float32", 1e-5), ("float64", 1e-12)):
+        for n in (8, 1024, 400):
+            p, _ = make(n, max(1, n // 4), dtype=dtype)
+            X = p.r2c(np.ones(n))
+            assert abs(X[0] - n) < tol * n and np.max(np.abs(X[1:])) < tol * n
+            rng = np.random.default_rng(n)
+            v = rng.standard_normal(n)
+            assert np.max(np.abs(p.r2c(v) - np.fft.rfft(v))) < tol * 40
+        p8, _ = make(8, 4, dtype=dtype)
+        v = np.zeros(8)
+        v[:3] = 1
+        assert abs(p8.r2c(v)[0] - 3.0) < tol
+        with pytest.raises(sg.DimensionMismatchError):
+            p8.r2c(np.ones(9))
+
+
+def test_plan_reuse_and_one_shot_agree():
+    # tests/stft_plan_tests.rs:60-82: plan == one-shot
+    params = sg.SpectrogramParams(sg.StftParams(512, 256, sg.WindowType.hanning, True), 16000.0)
+    x = signals(1, 16000, np.float64)[0]
+    plan = sg.SpectrogramPlanner().mel_db_plan(params, sg.MelParams(40, 0.0, 8000.0), sg.LogParams(-80.0))
+    a = plan.compute(x).data
+    b = plan.compute(x).data
+    c = sg.compute_mel_db_spectrogram(x, params, sg.MelParams(40, 0.0, 8000.0), sg.LogParams(-80.0)).data
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+    assert a.min() >= -80.0
+    fr = plan.compute_frame(x, 7)
+    assert np.max(np.abs(fr - a[:, 7])) < 1e-9
+
+
+def test_f32_tone_peak_bin():
+    # tests/f32_smoke_tests.rs:28-50
+    x = np.sin(2 * np.pi * np.arange(4096) / 8.0).astype(np.float32)
+    params = sg.SpectrogramParams(sg.StftParams(1024, 256, sg.WindowType.hanning, True), 16000.0)
+    P = sg.compute_linear_power_spectrogram(x, params, dtype="float32").data
+    assert abs(int(np.argmax(P[:, P.shape[1] // 2])) - 128) <= 1
+
+
+# ------------------------------------------------------------------ BASELINE full sizes: whole-output parity + properties
+@pytest.fixture(scope="module")
+def cfg2_x():
+    return H.cfg2_batch(256)
+
+
+def test_config2_full_size_linear_power(cfg2_x):
+    plan, op = make(1024, 256)
+    got = plan.compute_batch(cfg2_x)
+    assert got.shape == (256, 513, 626)
+    ref32 = orc.spectrogram_batch(op, cfg2_x, nthreads=orc.max_threads())  # the f32 CPU restatement, all rows
+    scale = ref32.max(axis=(1, 2), keepdims=True)
+    assert np.max(np.abs(got - ref32) / scale) <= GUARD32
+    # Parseval per frame: sum_k c_k |X_k|^2 = N * sum_n (x_n w_n)^2  (size-independent property)
+    w = orc.make_window("hanning", 1024).astype(np.float32)
+    for b in (0, 1, 128, 255):
+        fr = H.np_frames(cfg2_x[b], 1024, 256, True).astype(np.float64) * w[None, :].astype(np.float64)
+        lhs = 2.0 * got[b].astype(np.float64).sum(axis=0) - got[b, 0] - got[b, 512]
+        rhs = 1024.0 * (fr ** 2).sum(axis=1)
+        assert np.max(np.abs(lhs - rhs)) <= 1e-4 * rhs.max()
+
+
+def test_config3_full_size_mel_db(cfg2_x):
+    plan, op = make(1024, 256, n_mels=80, amp="db", floor=-80.0)
+    got = plan.compute_batch(cfg2_x)
+    assert got.shape == (256, 80, 626) and got.min() >= -80.0
+    ref = orc.spectrogram_batch(op, cfg2_x.astype(np.float64), nthreads=orc.max_threads())
+    pop = orc.Params(n_fft=1024, hop=256, n_mels=80)
+    pw = orc.spectrogram_batch(pop, cfg2_x.astype(np.float64), nthreads=orc.max_threads())
+    m = pw > 1e-6 * pw.max(axis=(1, 2), keepdims=True)
+    assert np.max(np.abs(got[m] - ref[m])) <= 1e-3
+    mp, _ = make(1024, 256, n_mels=80)
+    gp = mp.compute_batch(cfg2_x)
+    rel = np.abs(gp[m] - pw[m]) / pw[m]
+    assert rel.max() <= TOL32
+
+
+def test_linearity_full_size(cfg2_x):
+    sp, _ = make(1024, 256, amp="complex")
+    a, b = cfg2_x[:8], cfg2_x[8:16]
+    Sa, Sb = sp.compute_batch(a), sp.compute_batch(b)
+    Sab = sp.compute_batch((0.5 * a + 0.25 * b).astype(np.float32))
+    ref = 0.5 * Sa.astype(np.complex128) + 0.25 * Sb.astype(np.complex128)
+    assert np.max(np.abs(Sab - ref)) <= GUARD32 * np.max(np.abs(ref))
