@@ -72,6 +72,12 @@ def lib() -> C.CDLL:
         raise FFTBackendError(
             f"hip -- FFT backend error: {LIB_PATH} is not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `python -m spectrograms_amd.build`); this package has no CPU fallback")
+    try:
+        # torch wheels bundle their own HIP/HSA runtime.  Load it first so libspectro_hip.so binds to that same
+        # copy (same SONAME) instead of pulling /opt/rocm's: two HIP runtimes in one process cannot both see the GPU.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, sz = C.c_void_p, C.c_size_t
     L.sgx_plan_create.argtypes = [C.POINTER(SgxParams), C.POINTER(vp)]

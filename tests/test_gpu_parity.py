@@ -82,11 +82,12 @@ def check(got, ref64, kind, dtype, floor=None, pow64=None):
     elif kind == "db":
         assert g.min() >= floor - 1e-3
         m = pow64 > 1e-6 * pow64.max()
-        assert np.max(np.abs(g[m] - ref64[m])) <= 1e-3
+        assert not m.any() or np.max(np.abs(g[m] - ref64[m])) <= 1e-3
     else:
         err_abs = np.max(np.abs(g - ref64)) / scale
-        m = ref64 > 1e-6 * scale
-        err_rel = np.max(np.abs(g[m] - ref64[m]) / ref64[m])
+        # relative check where the POWER is within 60 dB of the peak (magnitude = sqrt(power) -> 1e-3 of its peak)
+        m = ref64 > (1e-3 if kind == "magnitude" else 1e-6) * scale
+        err_rel = np.max(np.abs(g[m] - ref64[m]) / ref64[m]) if m.any() else 0.0
         assert err_abs <= TOL32 and err_rel <= TOL32, (err_abs, err_rel)
         assert err_abs <= GUARD32, f"regression guard: {err_abs}"
 
@@ -104,6 +105,8 @@ def run_case(n, batch=3, seed=0, **kw):
     else:
         ref = orc.spectrogram_batch(op, x64)
         pow64 = None
+        if amp == "db" and kw.get("floor") is None:
+            amp = "power"  # S6: Decibels without LogParams returns power
         if amp == "db":
             pop = orc.Params(**{**op.__dict__, "amp": "power", "floor_db": None, "_keep": []})
             pow64 = orc.spectrogram_batch(pop, x64)
@@ -124,8 +127,9 @@ def test_pow2_sizes(n_fft, hop, amp, dtype):
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
 @pytest.mark.parametrize("n_fft,hop", [(1, 1), (2, 1), (3, 2), (7, 3), (10, 10), (100, 33), (400, 160), (1000, 250)])
 def test_non_pow2_sizes(n_fft, hop, dtype):
-    run_case(n=3000, n_fft=n_fft, hop=hop, amp="complex", dtype=dtype)
-    run_case(n=3000, n_fft=n_fft, hop=hop, amp="power", dtype=dtype)
+    window = "rectangular" if n_fft == 1 else "hanning"  # symmetric Hann of length 1 is 0/0 = NaN in the reference too
+    run_case(n=3000, n_fft=n_fft, hop=hop, amp="complex", dtype=dtype, window=window)
+    run_case(n=3000, n_fft=n_fft, hop=hop, amp="power", dtype=dtype, window=window)
 
 
 # ------------------------------------------------------------------ windows / centre / amp scales
