@@ -249,6 +249,10 @@ sgx_status build_device_tables(sgx_plan *pl) {
             }
         if ((st = upload<float>(pl, &pl->d_tw1, t1)) != SGX_OK) return st;
         if ((st = upload<float>(pl, &pl->d_tw2, t2)) != SGX_OK) return st;
+        std::vector<float> wh(n), oh(n, 0.5f);
+        for (unsigned i = 0; i < n; ++i) wh[i] = 0.5f * float(pl->window[i]);  // exact scaling of the f32 window
+        if ((st = upload<float>(pl, &pl->d_window_half, wh)) != SGX_OK) return st;
+        if ((st = upload<float>(pl, &pl->d_ones_half, oh)) != SGX_OK) return st;
     }
     return SGX_OK;
 }
@@ -343,6 +347,7 @@ sgx_status run_device(sgx_plan *pl, const void *x, size_t batch, size_t n_sample
         if (!set_geometry(pl, a, kind))
             return set_err(pl, SGX_BACKEND, "hip -- FFT backend error: n_fft too large for the on-chip frame tile");
     }
+    if (kind == K_R32X16_F32) a.window = pl->d_window_half;
     SGX_HIP(pl, hipSetDevice(pl->device));
     if (ms) SGX_HIP(pl, hipEventRecord(pl->ev0, s));
     for (int i = 0; i < iters; ++i) SGX_HIP(pl, launch(pl, a, kind, s));
@@ -368,7 +373,7 @@ sgx_status grow(sgx_plan *pl, void **buf, size_t *have, size_t need) {
 
 void free_device(sgx_plan *pl) {
     void **bufs[] = {&pl->d_window, &pl->d_tw, &pl->d_tw1, &pl->d_tw2, &pl->d_mel_ptr, &pl->d_mel_col,
-                     &pl->d_mel_val, &pl->d_ones, &pl->d_in, &pl->d_out};
+                     &pl->d_mel_val, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half};
     for (void **b : bufs)
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
@@ -581,6 +586,7 @@ sgx_status sgx_r2c(sgx_plan *plan, const void *in, size_t in_len, void *out, siz
         kind = K_DIRECT_DFT;
         if (!set_geometry(plan, a, kind)) return set_err(plan, SGX_BACKEND, "hip -- FFT backend error: n_fft too large");
     }
+    if (kind == K_R32X16_F32) a.window = plan->d_ones_half;
     SGX_HIP(plan, launch(plan, a, kind, nullptr));
     SGX_HIP(plan, hipMemcpy(out, plan->d_out, 2 * nb * plan->elem, hipMemcpyDeviceToHost));
     return SGX_OK;

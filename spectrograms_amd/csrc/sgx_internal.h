@@ -77,6 +77,7 @@ struct sgx_plan {
     void *d_window = nullptr, *d_tw = nullptr, *d_tw1 = nullptr, *d_tw2 = nullptr;
     void *d_mel_ptr = nullptr, *d_mel_col = nullptr, *d_mel_val = nullptr;
     void *d_ones = nullptr;  // rectangular window for sgx_r2c
+    void *d_window_half = nullptr, *d_ones_half = nullptr;  // 0.5*window (exact) for the tuned kernel's real split
 
     // plan-owned staging for host-pointer execution
     void *d_in = nullptr, *d_out = nullptr;

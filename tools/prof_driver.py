@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Runs the hot path a few times on device-resident synthetic data so rocprofv3 can attach:
+    rocprofv3 --kernel-trace --stats -d out -- python3 tools/prof_driver.py linear_power 5
+Same workload as bench.py (BASELINE configs[1]/[2])."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import numpy as np
+import torch
+
+import bench
+import spectrograms_amd as sg
+
+
+def main():
+    workload = sys.argv[1] if len(sys.argv) > 1 else "linear_power"
+    iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    batch = int(sys.argv[3]) if len(sys.argv) > 3 else bench.BATCH
+    params = sg.SpectrogramParams(sg.StftParams(bench.N_FFT, bench.HOP, sg.WindowType.hanning, True), bench.SR)
+    pl = sg.SpectrogramPlanner()
+    if workload == "linear_power":
+        plan = pl.linear_power_plan(params, dtype="float32")
+    elif workload == "mel_power":
+        plan = pl.mel_power_plan(params, sg.MelParams(80, 0.0, 8000.0), dtype="float32")
+    elif workload == "stft":
+        plan = pl.stft_plan(params, dtype="float32")
+    else:
+        plan = pl.mel_db_plan(params, sg.MelParams(80, 0.0, 8000.0), sg.LogParams(-80.0), dtype="float32")
+    host = np.stack([bench.cfg_signal(b) for b in range(batch)])
+    x = torch.from_numpy(host).cuda()
+    out = None
+    for _ in range(iters):
+        out = plan.compute_batch(x, out=None if out is None else (torch.view_as_real(out) if out.is_complex() else out))
+    torch.cuda.synchronize()
+    print(workload, plan.kernel_name, tuple(out.shape))
+
+
+if __name__ == "__main__":
+    main()
