@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libspectro_hip.so")
+# SGX_LIB_PATH lets kernel A/B experiments (tools/ablate.sh) load an alternative build of the same ABI
+LIB_PATH = os.environ.get("SGX_LIB_PATH") or os.path.join(_PKG, "libspectro_hip.so")
 
 SGX_OK, SGX_INVALID_INPUT, SGX_DIM_MISMATCH, SGX_BACKEND, SGX_INTERNAL = range(5)
 WIN_RECTANGULAR, WIN_HANNING, WIN_HAMMING, WIN_BLACKMAN, WIN_KAISER, WIN_GAUSSIAN, WIN_CUSTOM = range(7)

@@ -1,13 +1,15 @@
 // kernels_r32x16.hip — tuned f32, n_fft = 1024 STFT kernel for gfx950 (the BASELINE shape).
 //
-// Structure (one 256-thread workgroup = 4 wave64 = one tile of 16 consecutive frames of one signal):
+// Structure (one 256-thread workgroup = 4 wave64; persistent, loops over tiles of 16 consecutive frames of one signal):
 //
 //   pass 1  lane (f = tid/16, n2 = tid%16) owns z[16*n1 + n2], n1 = 0..31, of frame f, where
 //           z[n] = w[2n] x[2n] + i w[2n+1] x[2n+1] is the half-length complex sequence of the real frame
 //           (window pre-scaled by 1/2 on the host — exact — so the real split needs no halving).
-//           float2 global loads (16 lanes = 128 contiguous bytes; overlapping frames are served by L1/L2),
-//           one 32-point FFT entirely in registers, twiddle by W_512^(k1*n2), one ds_write_b64 per value.
+//           float2 global loads (16 lanes = 128 contiguous bytes; overlapping frames are served by L1/L2), issued one
+//           tile ahead so HBM latency hides under pass 2; window multiply fused into the first butterflies; one
+//           32-point FFT entirely in registers; twiddle by W_512^(k1*n2); one ds_write_b64 per value.
 //   LDS     ex[f][k1][n2] complex f32, frame stride 4096+16 B.  This is the ONLY exchange of the transform.
+//           Window and twiddle tables also live in LDS (loaded once per persistent workgroup).
 //   pass 2  lane (jq = lane/16, f = lane%16) of wave w owns "job" j = w + 4*jq of frame f: rows k1 = j and
 //           32-j (job 0: rows 0 and 16).  8 + 8 ds_read_b128 (conflict-free by the frame-stride / job-to-wave
 //           choice), two 16-point FFTs in registers -> Z[j+32*k2], Z[32-j+32*k2], and — because a job holds both
@@ -17,6 +19,10 @@
 //           transpose.  Mel: |X|^2 goes to LDS pw[f][k] (overlaying ex), then a (mel, frame)-per-lane CSR
 //           reduction in ascending-bin order (spectrogram.rs:102-117) and the dB/sqrt epilogue.
 //
+// All complex arithmetic is written on 2-float vectors so it compiles to packed-f32 VALU (v_pk_add/mul/fma_f32 with
+// op_sel / neg modifiers): measured on MI355X a packed op issues at the same cost as a scalar one for a single wave,
+// which matters because the 64 KiB exchange buffer caps occupancy at 2 waves per SIMD (tools/ubench/valu_rate.hip).
+//
 // Reference semantics implemented: spectrogram.rs:1301-1334 (framing, window, R2C, |.|^2), :1845-1865,
 // :2068-2080; replaces the per-frame `R2cPlan::process` call at :1323 (fft_backend.rs:423-431).
 #include "sgx_internal.h"
@@ -24,195 +30,332 @@
 namespace sgx {
 namespace {
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
 constexpr double kCos64[64] = {1.0, 0.9951847266721969, 0.9807852804032304, 0.9569403357322088, 0.9238795325112867, 0.881921264348355, 0.8314696123025452, 0.773010453362737, 0.7071067811865476, 0.6343932841636455, 0.5555702330196023, 0.4713967368259978, 0.38268343236508984, 0.29028467725446233, 0.19509032201612833, 0.09801714032956077, 6.123233995736766e-17, -0.09801714032956065, -0.1950903220161282, -0.29028467725446216, -0.3826834323650897, -0.4713967368259977, -0.555570233019602, -0.6343932841636454, -0.7071067811865475, -0.773010453362737, -0.8314696123025453, -0.8819212643483549, -0.9238795325112867, -0.9569403357322088, -0.9807852804032304, -0.9951847266721968, -1.0, -0.9951847266721969, -0.9807852804032304, -0.9569403357322089, -0.9238795325112868, -0.881921264348355, -0.8314696123025455, -0.7730104533627371, -0.7071067811865477, -0.6343932841636459, -0.5555702330196022, -0.47139673682599786, -0.38268343236509034, -0.29028467725446244, -0.19509032201612866, -0.09801714032956045, -1.8369701987210297e-16, 0.09801714032956009, 0.1950903220161283, 0.29028467725446205, 0.38268343236509, 0.4713967368259976, 0.5555702330196018, 0.6343932841636456, 0.7071067811865474, 0.7730104533627367, 0.8314696123025452, 0.8819212643483548, 0.9238795325112865, 0.9569403357322088, 0.9807852804032303, 0.9951847266721969};
 constexpr double kSin64[64] = {0.0, 0.0980171403295606, 0.19509032201612825, 0.29028467725446233, 0.3826834323650898, 0.47139673682599764, 0.5555702330196022, 0.6343932841636455, 0.7071067811865475, 0.773010453362737, 0.8314696123025452, 0.8819212643483549, 0.9238795325112867, 0.9569403357322089, 0.9807852804032304, 0.9951847266721968, 1.0, 0.9951847266721969, 0.9807852804032304, 0.9569403357322089, 0.9238795325112867, 0.881921264348355, 0.8314696123025455, 0.7730104533627371, 0.7071067811865476, 0.6343932841636455, 0.5555702330196022, 0.47139673682599786, 0.3826834323650899, 0.2902846772544624, 0.1950903220161286, 0.09801714032956083, 1.2246467991473532e-16, -0.09801714032956059, -0.19509032201612836, -0.2902846772544621, -0.38268343236508967, -0.47139673682599764, -0.555570233019602, -0.6343932841636453, -0.7071067811865475, -0.7730104533627367, -0.8314696123025452, -0.8819212643483549, -0.9238795325112865, -0.9569403357322088, -0.9807852804032303, -0.9951847266721969, -1.0, -0.9951847266721969, -0.9807852804032304, -0.9569403357322089, -0.9238795325112866, -0.881921264348355, -0.8314696123025455, -0.7730104533627369, -0.7071067811865477, -0.6343932841636459, -0.5555702330196022, -0.4713967368259979, -0.3826834323650904, -0.2902846772544625, -0.19509032201612872, -0.0980171403295605};
 
-constexpr int kFS = 4096 + 16;   // LDS bytes per frame of ex (odd multiple of 16 -> conflict-free b128 reads)
-constexpr int kPS = 513;         // floats per frame of pw
-constexpr int kLds = 16 * kFS;   // 65792 B
+constexpr int kFS = 4096 + 16;        // LDS bytes per frame of ex (odd multiple of 16 -> conflict-free b128 reads)
+constexpr int kPS = 513;              // floats per frame of pw (overlays ex)
+constexpr int kExBytes = 16 * kFS;    // 65792
+constexpr int kWinOff = kExBytes;     // float  win[1024]        (0.5 * window)
+constexpr int kTw2Off = kWinOff + 4096;  // float4 tw2[17][17]   (wr, wi, wi, -wr) of W_1024^(row + 32*idx)
+constexpr int kTw2Stride = 17;           // row stride in float4 (bank spread between the 4 jobs of a wave)
+constexpr int kTw2Bytes = 17 * 17 * 16;  // 4624
+constexpr int kLds = kTw2Off + kTw2Bytes;  // 78608 B -> two workgroups per CU (160 KiB LDS)
 
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 w) {
-    return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
-}
+__device__ __forceinline__ v2f swp(v2f a) { return __builtin_shufflevector(a, a, 1, 0); }
+__device__ __forceinline__ v2f lo2(v2f a) { return __builtin_shufflevector(a, a, 0, 0); }
+__device__ __forceinline__ v2f hi2(v2f a) { return __builtin_shufflevector(a, a, 1, 1); }
+__device__ __forceinline__ v2f pfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
-// v * W_N^K with the twiddle a compile-time constant (trivial ones cost no multiplies)
+// x0 = e + W o, x1 = e - W o, W = W_N^K a compile-time constant; every case is 2-4 packed instructions
 template <int N, int K>
-__device__ __forceinline__ float2 mul_tw(float2 v) {
+__device__ __forceinline__ void bfly(v2f e, v2f o, v2f &x0, v2f &x1) {
     constexpr int idx = K * (64 / N);
     if constexpr (idx == 0) {
-        return v;
-    } else if constexpr (idx == 16) {
-        return make_float2(v.y, -v.x);
-    } else if constexpr (idx == 8) {
+        x0 = e + o;
+        x1 = e - o;
+    } else if constexpr (idx == 16) {  // W = -i : W o = (o.y, -o.x)
+        const v2f so = swp(o);
+        x0 = pfma(so, (v2f){1.f, -1.f}, e);
+        x1 = pfma(so, (v2f){-1.f, 1.f}, e);
+    } else if constexpr (idx == 8) {  // W = c(1 - i): W o = c (o.x + o.y, o.y - o.x)
         constexpr float c = 0.70710678118654752440f;
-        return make_float2((v.x + v.y) * c, (v.y - v.x) * c);
-    } else if constexpr (idx == 24) {
+        const v2f s = pfma(swp(o), (v2f){1.f, -1.f}, o);
+        x0 = pfma(s, (v2f){c, c}, e);
+        x1 = pfma(s, (v2f){-c, -c}, e);
+    } else if constexpr (idx == 24) {  // W = c(-1 - i): W o = c (o.y - o.x, -o.x - o.y)
         constexpr float c = 0.70710678118654752440f;
-        return make_float2((v.y - v.x) * c, -(v.x + v.y) * c);
+        const v2f s = pfma(swp(o), (v2f){1.f, -1.f}, -o);
+        x0 = pfma(s, (v2f){c, c}, e);
+        x1 = pfma(s, (v2f){-c, -c}, e);
     } else {
         constexpr float wr = (float)kCos64[idx], wi = (float)(-kSin64[idx]);
-        return make_float2(v.x * wr - v.y * wi, v.x * wi + v.y * wr);
+        const v2f so = swp(o);
+        x0 = pfma(so, (v2f){-wi, wi}, pfma(o, (v2f){wr, wr}, e));
+        x1 = pfma(so, (v2f){wi, -wi}, pfma(o, (v2f){-wr, -wr}, e));
     }
 }
-
 template <int N, int K>
-struct Combine {
-    static __device__ __forceinline__ void run(float2 (&x)[N], const float2 (&e)[N / 2], const float2 (&o)[N / 2]) {
-        const float2 t = mul_tw<N, K>(o[K]);
-        x[K] = cadd(e[K], t);
-        x[K + N / 2] = csub(e[K], t);
-        if constexpr (K + 1 < N / 2) Combine<N, K + 1>::run(x, e, o);
+struct Comb {
+    static __device__ __forceinline__ void run(v2f (&x)[N], const v2f (&e)[N / 2], const v2f (&o)[N / 2]) {
+        bfly<N, K>(e[K], o[K], x[K], x[K + N / 2]);
+        if constexpr (K + 1 < N / 2) Comb<N, K + 1>::run(x, e, o);
     }
 };
-
-// in-register radix-2 DIT, natural order in and out; all indices and twiddles are compile-time
-template <int N>
+// in-register radix-2 DIT, natural order in and out; all indices and twiddles are compile-time.
+// WIN: x holds raw samples and w the window; the multiply is fused into the first butterfly.
+template <int N, bool WIN>
 struct Fft {
-    static __device__ __forceinline__ void run(float2 (&x)[N]) {
-        float2 e[N / 2], o[N / 2];
+    static __device__ __forceinline__ void run(v2f (&x)[N], const v2f (&w)[N]) {
+        if constexpr (N == 2) {
+            if constexpr (WIN) {
+                const v2f t = x[0] * w[0];
+                const v2f u = x[1];
+                x[0] = pfma(u, w[1], t);
+                x[1] = pfma(-u, w[1], t);
+            } else {
+                const v2f a = x[0], b = x[1];
+                x[0] = a + b;
+                x[1] = a - b;
+            }
+        } else {
+            v2f e[N / 2], o[N / 2], we[N / 2], wo[N / 2];
 #pragma unroll
-        for (int k = 0; k < N / 2; ++k) {
-            e[k] = x[2 * k];
-            o[k] = x[2 * k + 1];
+            for (int k = 0; k < N / 2; ++k) {
+                e[k] = x[2 * k];
+                o[k] = x[2 * k + 1];
+                we[k] = w[2 * k];
+                wo[k] = w[2 * k + 1];
+            }
+            Fft<N / 2, WIN>::run(e, we);
+            Fft<N / 2, WIN>::run(o, wo);
+            Comb<N, 0>::run(x, e, o);
         }
-        Fft<N / 2>::run(e);
-        Fft<N / 2>::run(o);
-        Combine<N, 0>::run(x, e, o);
     }
 };
-template <>
-struct Fft<1> {
-    static __device__ __forceinline__ void run(float2 (&)[1]) {}
-};
 
-__device__ __forceinline__ float2 csel(bool c, float2 a, float2 b) { return make_float2(c ? a.x : b.x, c ? a.y : b.y); }
+#ifdef SGX_STAMPS  // diagnostic build only (tools/stamps.py): where does a wave spend its cycles, per tile phase
+__device__ unsigned long long g_stamps[16];
+#define SGX_STAMP(i)                                                                         \
+    do {                                                                                     \
+        unsigned long long t_;                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        st_acc[i] += t_ - st_prev;                                                           \
+        st_prev = t_;                                                                        \
+    } while (0)
+#else
+#define SGX_STAMP(i)
+#endif
 
-__device__ __forceinline__ float amp_f32(float p, int amp, float eps) {
-    if (amp == AMP_MAGNITUDE) return sqrtf(p);
-    if (amp == AMP_DB) return 10.0f * log10f(fmaxf(p, eps));
-    return p;
+template <int AMP>
+__device__ __forceinline__ float amp_f32(float p, float eps) {
+    if constexpr (AMP == AMP_MAGNITUDE) return sqrtf(p);
+    else if constexpr (AMP == AMP_DB) return 10.0f * log10f(fmaxf(p, eps));
+    else return p;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void k_r32x16(StftArgs a, unsigned per_xcd, unsigned total) {
+__device__ __forceinline__ float power_of(v2f x) { return __builtin_fmaf(x.x, x.x, x.y * x.y); }
+
+// Persistent workgroups: each loops over its tiles; the next tile's samples are requested from HBM right after
+// pass 1 has consumed the current ones, so their latency hides under pass 2 (2 waves/SIMD cannot hide it by
+// occupancy alone: the 64 KiB exchange buffer limits a CU to two workgroups).
+template <int MODE, int AMP>
+__global__ __launch_bounds__(256, 2) void k_r32x16(StftArgs a, unsigned per_xcd, unsigned total, unsigned slots) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned tid = threadIdx.x;
-    // XCD-aware work mapping: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a contiguous
-    // run of tiles — neighbouring tiles share the 768-sample halo and the output lines they both touch in L2.
-    const unsigned wid = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    if (wid >= total) return;
-    const unsigned b = wid / a.tiles, tile = wid - b * a.tiles;
-    const unsigned f0 = tile * 16u;
-    const unsigned nf = min(16u, a.n_frames - f0);
-    const float *xb = (const float *)a.x + (size_t)b * a.sample_stride;
 
-    // ------------------------------------------------------------------ pass 1
+    // ---- one-time: tables -> LDS
     {
-        const unsigned f = tid >> 4, n2 = tid & 15u;
-        float2 v[32];
-        const float2 *w2 = (const float2 *)a.window + n2;  // pre-scaled by 1/2
-        const long long s0 = (long long)(f0 + f) * a.hop - (long long)a.pad + 2 * n2;
+        ((v4f *)(smem + kWinOff))[tid] = ((const v4f *)a.window)[tid];
+        for (unsigned i = tid; i < kTw2Bytes / 16; i += 256) ((v4f *)(smem + kTw2Off))[i] = ((const v4f *)a.tw2)[i];
+    }
+
+    // XCD-aware work mapping: blocks g and g+8 share an XCD (round-robin dispatch).  XCD x owns the contiguous run of
+    // work ids [x*per_xcd, (x+1)*per_xcd); its `slots` resident workgroups walk that run with stride `slots`, so tiles
+    // in flight on one XCD are neighbours: they share the 768-sample halo and the output lines they both touch in L2.
+    const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const unsigned lo = xcd * per_xcd;
+    const unsigned hi = min(lo + per_xcd, total);
+    unsigned wid = lo + slot;
+
+    const unsigned p1f = tid >> 4, n2 = tid & 15u;  // pass-1 identity
+    const unsigned lane = tid & 63u, wv_ = tid >> 6, jq = lane >> 4, p2f = lane & 15u;  // pass-2 identity
+    const unsigned j = wv_ + 4u * jq;
+    const bool j0 = (j == 0);
+    const unsigned ra = j, rb = j0 ? 16u : 32u - j;
+    const float eps = (float)a.eps;
+
+    // pass-1 twiddles W_512^(k1*n2), k1 = 8a + b, kept in registers as two short per-lane tables (10 values) instead
+    // of 31 LDS reads per tile: W(k1) = Wa[a] * Wb[b]
+    v2f twa[4], twb[8];
+    {
+        const v2f *t1 = (const v2f *)a.tw1 + n2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) twa[q] = t1[16 * 8 * q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) twb[q] = t1[16 * q];
+    }
+
+    v2f xr[32];  // raw samples of the tile being (pre)fetched
+    auto load_tile = [&](unsigned w) {
+        const unsigned b = w / a.tiles, tile = w - b * a.tiles;
+        const unsigned f0 = tile * 16u;
+        const float *xb = (const float *)a.x + (size_t)b * a.sample_stride;
+        const long long s0 = (long long)(f0 + p1f) * a.hop - (long long)a.pad + 2 * n2;
         const long long tile_lo = (long long)f0 * a.hop - (long long)a.pad;
         const long long tile_hi = (long long)(f0 + 15u) * a.hop - (long long)a.pad + 1024;
         if (tile_lo >= 0 && tile_hi <= (long long)a.n_samples) {  // interior tile (wave-uniform): no bounds checks
-            const float2 *xp = (const float2 *)(xb + s0);
+            const v2f *xp = (const v2f *)(xb + s0);
+#ifdef SGX_ABL_NOLOAD  // timing experiment only: no HBM reads
 #pragma unroll
-            for (int n1 = 0; n1 < 32; ++n1) {
-                const float2 xv = xp[16 * n1];
-                const float2 wv = w2[16 * n1];
-                v[n1] = make_float2(xv.x * wv.x, xv.y * wv.y);
-            }
+            for (int n1 = 0; n1 < 32; ++n1) xr[n1] = (v2f){(float)(s0 + n1), 1.0f};
+            asm volatile("" ::"v"(xp));
+#else
+#pragma unroll
+            for (int n1 = 0; n1 < 32; ++n1) xr[n1] = xp[16 * n1];
+#endif
         } else {  // edge tile: zero padding (S1) by predication
             const long long n = (long long)a.n_samples;
 #pragma unroll
             for (int n1 = 0; n1 < 32; ++n1) {
-                const long long s = s0 + 32 * n1;
-                const float x0 = (s >= 0 && s < n) ? xb[s] : 0.0f;
-                const float x1 = (s + 1 >= 0 && s + 1 < n) ? xb[s + 1] : 0.0f;
-                const float2 wv = w2[16 * n1];
-                v[n1] = make_float2(x0 * wv.x, x1 * wv.y);
+                const long long sx = s0 + 32 * n1;
+                xr[n1].x = (sx >= 0 && sx < n) ? xb[sx] : 0.0f;
+                xr[n1].y = (sx + 1 >= 0 && sx + 1 < n) ? xb[sx + 1] : 0.0f;
             }
         }
-        Fft<32>::run(v);
-        const float2 *t1 = (const float2 *)a.tw1 + n2;
-        unsigned char *dst = smem + f * kFS + n2 * 8;
-        *(float2 *)dst = v[0];
-#pragma unroll
-        for (int k1 = 1; k1 < 32; ++k1) *(float2 *)(dst + k1 * 128) = cmul(v[k1], t1[16 * k1]);
+    };
+
+    if (wid < hi) load_tile(wid);
+    __syncthreads();  // tables visible
+#ifdef SGX_STAGGER  // experiment: offset the two co-resident workgroups of a CU by about half a tile period
+    if (slot & 1u) {
+        for (int q = 0; q < SGX_STAGGER; ++q) __builtin_amdgcn_s_sleep(127);
     }
-    __syncthreads();
+#endif
+#ifdef SGX_STAMPS
+    unsigned long long st_acc[12] = {0}, st_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+#endif
 
-    // ------------------------------------------------------------------ pass 2 + real split + epilogue
-    {
-        const unsigned lane = tid & 63u, w = tid >> 6, jq = lane >> 4, f = lane & 15u;
-        const unsigned j = w + 4u * jq;
-        const bool j0 = (j == 0);
-        const unsigned ra = j, rb = j0 ? 16u : 32u - j;
-        float2 A[16], B[16];
+    while (wid < hi) {
+        SGX_STAMP(0);
+        const unsigned b = wid / a.tiles, tile = wid - b * a.tiles;
+        const unsigned f0 = tile * 16u;
+        const unsigned nf = min(16u, a.n_frames - f0);
+
+        // ------------------------------------------------------------------ pass 1
         {
-            const float4 *pa = (const float4 *)(smem + f * kFS + ra * 128);
-            const float4 *pb = (const float4 *)(smem + f * kFS + rb * 128);
+            v2f v[32], wn[32];
+            const v2f *w2 = (const v2f *)(smem + kWinOff) + n2;
+#pragma unroll
+            for (int n1 = 0; n1 < 32; ++n1) {
+                wn[n1] = w2[16 * n1];
+                v[n1] = xr[n1];
+            }
+#ifdef SGX_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            SGX_STAMP(1);
+#endif
+#ifndef SGX_ABL_NOFFT32  // timing experiment only
+            Fft<32, true>::run(v, wn);
+#endif
+#ifdef SGX_STAMPS
+#pragma unroll
+            for (int q = 0; q < 32; ++q) asm volatile("" : "+v"(v[q]));
+            SGX_STAMP(2);
+#endif
+            unsigned char *dst = smem + p1f * kFS + n2 * 8;
+            auto cm = [](v2f x, v2f t) { return pfma(swp(x), (v2f){-t.y, t.y}, x * lo2(t)); };
+#pragma unroll
+            for (int k1 = 0; k1 < 32; ++k1) {
+                const int qa = k1 >> 3, qb = k1 & 7;
+                v2f r = v[k1];
+#ifndef SGX_ABL_NOTW1
+                if (qb) r = cm(r, twb[qb]);
+                if (qa) r = cm(r, twa[qa]);
+#endif
+                *(v2f *)(dst + k1 * 128) = r;
+            }
+        }
+        SGX_STAMP(3);
+        const unsigned next = wid + slots;
+        if (next < hi) load_tile(next);  // in flight during pass 2
+        SGX_STAMP(4);
+#ifndef SGX_ABL_NOBARRIER
+        __syncthreads();
+#endif
+
+        SGX_STAMP(5);
+        // ------------------------------------------------------------------ pass 2 + real split + epilogue
+        v2f A[16], B[16];
+        {
+            const v4f *pa = (const v4f *)(smem + p2f * kFS + ra * 128);
+            const v4f *pb = (const v4f *)(smem + p2f * kFS + rb * 128);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const float4 q = pa[c];
-                A[2 * c] = make_float2(q.x, q.y);
-                A[2 * c + 1] = make_float2(q.z, q.w);
+                const v4f q = pa[c];
+                A[2 * c] = (v2f){q.x, q.y};
+                A[2 * c + 1] = (v2f){q.z, q.w};
             }
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const float4 q = pb[c];
-                B[2 * c] = make_float2(q.x, q.y);
-                B[2 * c + 1] = make_float2(q.z, q.w);
+                const v4f q = pb[c];
+                B[2 * c] = (v2f){q.x, q.y};
+                B[2 * c + 1] = (v2f){q.z, q.w};
             }
         }
-        if constexpr (MODE == OUT_MEL) __syncthreads();  // ex fully consumed before pw overlays it
-        Fft<16>::run(A);
-        Fft<16>::run(B);
+        SGX_STAMP(6);
+#ifndef SGX_ABL_NOBARRIER
+        __syncthreads();  // ex consumed: the next pass 1 (or the pw overlay) may overwrite it
+#endif
+        SGX_STAMP(7);
 
-        const float eps = (float)a.eps;
-        const float2 *t2 = (const float2 *)a.tw2;
-        const bool live = f < nf;
-        float *pw = (float *)smem + f * kPS;
-        float *ol = (float *)a.out + ((size_t)b * 513u) * a.n_frames + f0 + f;
-        float2 *oc = (float2 *)a.out + ((size_t)b * 513u) * a.n_frames + f0 + f;
+        if (p2f < nf) {
+#ifndef SGX_ABL_NOFFT16  // timing experiment only
+            Fft<16, false>::run(A, A);
+            Fft<16, false>::run(B, B);
+#endif
+#ifdef SGX_STAMPS
+#pragma unroll
+            for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(A[q]), "+v"(B[q]));
+            SGX_STAMP(8);
+#endif
 
-        auto emit = [&](unsigned k, float re, float im) {
-            if constexpr (MODE == OUT_COMPLEX) {
-                if (live) oc[(size_t)k * a.n_frames] = make_float2(re, im);
-            } else if constexpr (MODE == OUT_MEL) {
-                pw[k] = re * re + im * im;
-            } else {
-                if (live) ol[(size_t)k * a.n_frames] = amp_f32(re * re + im * im, a.amp, eps);
+            const v4f *t2 = (const v4f *)(smem + kTw2Off);
+            float *pw = (float *)smem + p2f * kPS;
+            // 32-bit element offsets from a wave-uniform base (host guarantees 513*n_frames*2 < 2^31)
+            float *ob = (float *)a.out + ((size_t)b * 513u) * a.n_frames * (MODE == OUT_COMPLEX ? 2 : 1);
+            const unsigned ofs = f0 + p2f;
+
+            auto emit = [&](unsigned k, v2f X, bool conj) {
+#ifdef SGX_ABL_NOSTORE  // timing experiment only (tools/ablate.sh): keep the value alive, drop the store
+                asm volatile("" ::"v"(X), "v"(k));
+                return;
+#endif
+                if constexpr (MODE == OUT_COMPLEX) {
+                    ((v2f *)ob)[k * a.n_frames + ofs] = conj ? (v2f){X.x, -X.y} : X;
+                } else if constexpr (MODE == OUT_MEL) {
+                    pw[k] = power_of(X);
+                } else {
+                    ob[k * a.n_frames + ofs] = amp_f32<AMP>(power_of(X), eps);
+                }
+            };
+            // pair (P, Q) = (Z[k], Z[512-k]), W = W_1024^k given as (wr, wi, wi, -wr):
+            //   E = (P.x+Q.x, P.y-Q.y), D = (P.x-Q.x, P.y+Q.y) = (-O.y, O.x), T = W O, X[k] = E + T, X[512-k] = conj(E - T)
+            auto split = [&](unsigned k, v2f P, v2f Q, v4f w4) {
+                const v2f E = pfma(Q, (v2f){1.f, -1.f}, P);
+                const v2f D = pfma(Q, (v2f){-1.f, 1.f}, P);
+                const v2f T = pfma(lo2(D), (v2f){w4.z, w4.w}, hi2(D) * (v2f){w4.x, w4.y});
+                emit(k, E + T, false);
+                emit(512u - k, E - T, true);
+            };
+#ifdef SGX_ABL_NOSPLIT
+            emit(j, A[0] + B[1] + A[5] + B[7] + A[15] + B[12], false);
+#else
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                // general job: (A[i], B[15-i]) at k = j + 32 i;  job 0: (B[i], B[15-i]) at k = 16 + 32 i (row 16)
+                const v2f P = j0 ? B[i] : A[i];
+                const unsigned k = (j0 ? 16u : j) + 32u * i;
+                const v4f w4 = t2[(j0 ? 16u : j) * kTw2Stride + i];
+                split(k, P, B[15 - i], w4);
             }
-        };
-        // pair (P, Q) = (Z[k], Z[512-k]), twiddle W_1024^k:  X[k] = E + W O,  X[512-k] = conj(E - W O)
-        auto split = [&](unsigned k, float2 P, float2 Q, float2 wv) {
-            const float er = P.x + Q.x, ei = P.y - Q.y, orr = P.y + Q.y, oi = Q.x - P.x;
-            const float tr = orr * wv.x - oi * wv.y, ti = orr * wv.y + oi * wv.x;
-            emit(k, er + tr, ei + ti);
-            emit(512u - k, er - tr, ti - ei);
-        };
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            // general job: (A[i], B[15-i]) at k = j + 32 i;  job 0: (B[i], B[15-i]) at k = 16 + 32 i (row 16)
-            const float2 P = csel(j0, B[i], A[i]);
-            const unsigned k = j0 ? 16u + 32u * i : j + 32u * i;
-            const float2 wv = t2[j0 ? 16u * 16u + i : j * 16u + i];
-            split(k, P, B[15 - i], wv);
-        }
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            // general job: (A[8+t], B[7-t]) at k = j + 32 (8+t);  job 0: (A[t], A[(16-t)%16]) at k = 32 t (row 0)
-            const float2 P = csel(j0, A[t], A[8 + t]);
-            const float2 Q = csel(j0, A[(16 - t) & 15], B[7 - t]);
-            const unsigned k = j0 ? 32u * t : j + 32u * (8 + t);
-            const float2 wv = t2[j0 ? (unsigned)t : j * 16u + 8u + t];
-            split(k, P, Q, wv);
-        }
-        if (j0) {  // bin 256 pairs with itself: X[256] = 2 conj(Z[256]) (Z at half scale)
-            emit(256u, 2.0f * A[8].x, -2.0f * A[8].y);
+            for (int t = 0; t < 8; ++t) {
+                // general job: (A[8+t], B[7-t]) at k = j + 32 (8+t);  job 0: (A[t], A[(16-t)%16]) at k = 32 t (row 0)
+                const v2f P = j0 ? A[t] : A[8 + t];
+                const v2f Q = j0 ? A[(16 - t) & 15] : B[7 - t];
+                const unsigned k = j0 ? 32u * t : j + 32u * (8 + t);
+                const v4f w4 = t2[j0 ? (unsigned)t : j * kTw2Stride + 8u + t];
+                split(k, P, Q, w4);
+            }
+            if (j0) emit(256u, A[8] * (v2f){2.f, -2.f}, false);  // bin 256 pairs with itself: X[256] = 2 conj(Z[256])
+#endif
         }
 
         if constexpr (MODE == OUT_MEL) {
@@ -226,40 +369,70 @@ __global__ __launch_bounds__(256, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
                 const unsigned i0 = a.mel_ptr[mm], i1 = a.mel_ptr[mm + 1];
                 for (unsigned i = i0; i < i1; ++i)
                     acc = __fadd_rn(__fmul_rn(val[i], pwall[ff * kPS + a.mel_col[i]]), acc);
-                if (ff < nf) o[(size_t)mm * a.n_frames + ff] = amp_f32(acc, a.amp, eps);
+                if (ff < nf) o[mm * a.n_frames + ff] = amp_f32<AMP>(acc, eps);
             }
+            __syncthreads();  // pw consumed before the next pass 1 overwrites ex
         }
+        SGX_STAMP(9);
+        wid = next;
     }
+#ifdef SGX_STAMPS
+    if ((tid & 63u) == 0) {
+        for (int q = 0; q < 10; ++q) atomicAdd(&g_stamps[q], st_acc[q]);
+        atomicAdd(&g_stamps[15], 1ull);
+    }
+#endif
+}
+
+template <int MODE, int AMP>
+hipError_t launch_variant(const StftArgs &a, hipStream_t s, unsigned per_xcd, unsigned total, unsigned slots) {
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_r32x16<MODE, AMP>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_r32x16<MODE, AMP>), dim3(slots * 8), dim3(256), kLds, s, a, per_xcd, total, slots);
+    return hipGetLastError();
 }
 
 }  // namespace
 
+#ifdef SGX_STAMPS
+extern "C" int sgx_debug_read_stamps(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
+
 bool plan_geometry_r32x16_f32(StftArgs &a) {
     if (a.n_fft != 1024 || (a.hop & 1u)) return false;
     if (a.n_samples >= (1ull << 40)) return false;
+    if ((unsigned long long)a.n_frames * 513ull * 2ull >= 0x7fffffffull) return false;  // 32-bit store offsets
     a.ft = 16;
     return true;
 }
 
 hipError_t launch_r32x16_f32(const StftArgs &a, hipStream_t s) {
-    const unsigned long long total = (unsigned long long)a.tiles * a.batch;
-    if (total == 0 || total >= 0x7ffffff0ull) return hipErrorInvalidConfiguration;
-    const unsigned per_xcd = (unsigned)((total + 7) / 8);
-    const unsigned grid = per_xcd * 8;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e;
-        if ((e = hipFuncSetAttribute((const void *)k_r32x16<OUT_LINEAR>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds)) != hipSuccess) return e;
-        if ((e = hipFuncSetAttribute((const void *)k_r32x16<OUT_MEL>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds)) != hipSuccess) return e;
-        if ((e = hipFuncSetAttribute((const void *)k_r32x16<OUT_COMPLEX>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds)) != hipSuccess) return e;
-        attr_set = true;
+    const unsigned long long total64 = (unsigned long long)a.tiles * a.batch;
+    if (total64 == 0 || total64 >= 0x7ffffff0ull) return hipErrorInvalidConfiguration;
+    const unsigned total = (unsigned)total64;
+    const unsigned per_xcd = (total + 7) / 8;
+    // persistent grid: 2 workgroups per CU (LDS-limited) on 256 CUs = 64 slots per XCD
+    const unsigned slots = per_xcd < 64u ? per_xcd : 64u;
+    if (a.out_mode == OUT_COMPLEX) return launch_variant<OUT_COMPLEX, AMP_POWER>(a, s, per_xcd, total, slots);
+    if (a.out_mode == OUT_MEL) {
+        if (a.amp == AMP_MAGNITUDE) return launch_variant<OUT_MEL, AMP_MAGNITUDE>(a, s, per_xcd, total, slots);
+        if (a.amp == AMP_DB) return launch_variant<OUT_MEL, AMP_DB>(a, s, per_xcd, total, slots);
+        return launch_variant<OUT_MEL, AMP_POWER>(a, s, per_xcd, total, slots);
     }
-    switch (a.out_mode) {
-    case OUT_MEL: hipLaunchKernelGGL(k_r32x16<OUT_MEL>, dim3(grid), dim3(256), kLds, s, a, per_xcd, (unsigned)total); break;
-    case OUT_COMPLEX: hipLaunchKernelGGL(k_r32x16<OUT_COMPLEX>, dim3(grid), dim3(256), kLds, s, a, per_xcd, (unsigned)total); break;
-    default: hipLaunchKernelGGL(k_r32x16<OUT_LINEAR>, dim3(grid), dim3(256), kLds, s, a, per_xcd, (unsigned)total); break;
-    }
-    return hipGetLastError();
+    if (a.amp == AMP_MAGNITUDE) return launch_variant<OUT_LINEAR, AMP_MAGNITUDE>(a, s, per_xcd, total, slots);
+    if (a.amp == AMP_DB) return launch_variant<OUT_LINEAR, AMP_DB>(a, s, per_xcd, total, slots);
+    return launch_variant<OUT_LINEAR, AMP_POWER>(a, s, per_xcd, total, slots);
 }
 
 }  // namespace sgx

@@ -234,7 +234,8 @@ sgx_status build_device_tables(sgx_plan *pl) {
     }
     if (pl->kind == K_R32X16_F32) {
         // tw1[k1][n2] = W_512^(k1*n2) (pass-1 twiddles), tw2[j][k2] = W_1024^(j + 32*k2) (real-split twiddles)
-        std::vector<float> t1(2 * 32 * 16), t2(2 * 17 * 16);
+        // tw1[k1][n2] = W_512^(k1*n2); tw2[row][idx] = (wr, wi, wi, -wr) of W_1024^(row + 32*idx), row stride 17 float4
+        std::vector<float> t1(2 * 32 * 16), t2(17 * 17 * 4, 0.0f);
         for (unsigned k1 = 0; k1 < 32; ++k1)
             for (unsigned n2 = 0; n2 < 16; ++n2) {
                 const double a = -2.0 * kPi * double(k1 * n2) / 512.0;
@@ -244,8 +245,11 @@ sgx_status build_device_tables(sgx_plan *pl) {
         for (unsigned j = 0; j < 17; ++j)
             for (unsigned k2 = 0; k2 < 16; ++k2) {
                 const double a = -2.0 * kPi * double(j + 32 * k2) / 1024.0;
-                t2[2 * (j * 16 + k2)] = float(std::cos(a));
-                t2[2 * (j * 16 + k2) + 1] = float(std::sin(a));
+                float *q = &t2[4 * (j * 17 + k2)];
+                q[0] = float(std::cos(a));
+                q[1] = float(std::sin(a));
+                q[2] = q[1];
+                q[3] = -q[0];
             }
         if ((st = upload<float>(pl, &pl->d_tw1, t1)) != SGX_OK) return st;
         if ((st = upload<float>(pl, &pl->d_tw2, t2)) != SGX_OK) return st;

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Diagnostic: build the library with -DSGX_STAMPS (s_memtime stamps around the phases of the tuned kernel), run the
+BASELINE workload and print each phase's share of a wave's cycles.  Shares only — a stamped build forbids overlaps."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+lib = "/tmp/libsgx_stamps.so"
+flags = sys.argv[2:] if len(sys.argv) > 2 else []
+subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-DSGX_STAMPS", *flags,
+                "-I" + ROOT + "/include", "-I" + ROOT + "/spectrograms_amd/csrc", "-o", lib] +
+               [ROOT + "/spectrograms_amd/csrc/" + f for f in ("plan.hip", "kernels_generic.hip", "kernels_r32x16.hip")], check=True)
+os.environ["SGX_LIB_PATH"] = lib
+import numpy as np
+import torch
+import bench
+import spectrograms_amd as sg
+from spectrograms_amd import _ffi
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "linear_power"
+params = sg.SpectrogramParams(sg.StftParams(1024, 256, sg.WindowType.hanning, True), 16000.0)
+pl = sg.SpectrogramPlanner()
+plan = {"linear_power": lambda: pl.linear_power_plan(params, dtype="float32"),
+        "mel_db": lambda: pl.mel_db_plan(params, sg.MelParams(80, 0.0, 8000.0), sg.LogParams(-80.0), dtype="float32"),
+        "stft": lambda: pl.stft_plan(params, dtype="float32")}[wl]()
+x = torch.from_numpy(np.stack([bench.cfg_signal(b) for b in range(256)])).cuda()
+out = plan.compute_batch(x)
+torch.cuda.synchronize()
+L = _ffi.lib()
+buf = (C.c_ulonglong * 16)()
+L.sgx_debug_read_stamps(buf, 1)
+iters = 5
+o = torch.view_as_real(out) if out.is_complex() else out
+ms = plan.time_batch_torch(x, o, iters)
+L.sgx_debug_read_stamps(buf, 1)
+names = ["loop top/wait", "win LDS reads + x wait", "FFT32 (+window)", "tw1 + ex writes", "prefetch issue", "barrier 1",
+         "ex reads", "barrier 2", "FFT16 x2", "split + stores"]
+waves = buf[15]
+tot = sum(buf[i] for i in range(10))
+print(f"workload={wl} flags={flags} kernel_ms(stamped)={ms:.4f} waves={waves}")
+for i, n in enumerate(names):
+    print(f"  {n:26s} {buf[i] / waves / 20:10.0f} cyc/wave/tile  {100.0 * buf[i] / tot:5.1f} %")
+print(f"  total {tot / waves / 20:.0f} cycles per wave per tile (20 tiles per wave per launch)")
