@@ -144,7 +144,11 @@ __device__ __forceinline__ float power_of(v2f x) { return __builtin_fmaf(x.x, x.
 // Persistent workgroups: each loops over its tiles; the next tile's samples are requested from HBM right after
 // pass 1 has consumed the current ones, so their latency hides under pass 2 (2 waves/SIMD cannot hide it by
 // occupancy alone: the 64 KiB exchange buffer limits a CU to two workgroups).
-template <int MODE, int AMP>
+// ROUNDS > 0: the tile's (15*hop + 1024) samples are fetched ONCE with coalesced 16-byte loads (ROUNDS per thread,
+// issued one tile ahead), staged in LDS (xs, overlaying ex) and re-read per frame from there: per-lane float2 loads
+// straight from global re-request every line ~4 times (frames overlap by 75 %) and their issue stalls on the L1 miss
+// queue (tools/stamps.py).  ROUNDS == 0 keeps the direct per-lane loads (any even hop).
+template <int MODE, int AMP, int ROUNDS>
 __global__ __launch_bounds__(256, 2) void k_r32x16(StftArgs a, unsigned per_xcd, unsigned total, unsigned slots) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned tid = threadIdx.x;
@@ -181,31 +185,50 @@ __global__ __launch_bounds__(256, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
         for (int q = 0; q < 8; ++q) twb[q] = t1[16 * q];
     }
 
-    v2f xr[32];  // raw samples of the tile being (pre)fetched
+    v2f xr[32];                          // raw samples of this lane's (frame, n2) column
+    v4f creg[ROUNDS > 0 ? ROUNDS : 1];   // staged path: this thread's 16-byte chunks of the tile being prefetched
+    const unsigned chunks = (15u * a.hop + 1024u) >> 2;
+    const bool xs_pad = (a.hop & 255u) == 0;  // +128 B per KiB keeps the 4 frames of a wave on distinct banks
     auto load_tile = [&](unsigned w) {
         const unsigned b = w / a.tiles, tile = w - b * a.tiles;
         const unsigned f0 = tile * 16u;
         const float *xb = (const float *)a.x + (size_t)b * a.sample_stride;
-        const long long s0 = (long long)(f0 + p1f) * a.hop - (long long)a.pad + 2 * n2;
         const long long tile_lo = (long long)f0 * a.hop - (long long)a.pad;
         const long long tile_hi = (long long)(f0 + 15u) * a.hop - (long long)a.pad + 1024;
-        if (tile_lo >= 0 && tile_hi <= (long long)a.n_samples) {  // interior tile (wave-uniform): no bounds checks
-            const v2f *xp = (const v2f *)(xb + s0);
-#ifdef SGX_ABL_NOLOAD  // timing experiment only: no HBM reads
+        const bool interior = tile_lo >= 0 && tile_hi <= (long long)a.n_samples;  // wave-uniform
+        if constexpr (ROUNDS > 0) {
+            if (interior) {
+                const v4f *xp = (const v4f *)(xb + tile_lo) + tid;
 #pragma unroll
-            for (int n1 = 0; n1 < 32; ++n1) xr[n1] = (v2f){(float)(s0 + n1), 1.0f};
-            asm volatile("" ::"v"(xp));
-#else
+                for (int r = 0; r < ROUNDS; ++r)
+                    if (r * 256u + tid < chunks) creg[r] = xp[r * 256];
+            } else {  // edge tile: zero padding (S1) by predication
+                const long long n = (long long)a.n_samples;
 #pragma unroll
-            for (int n1 = 0; n1 < 32; ++n1) xr[n1] = xp[16 * n1];
-#endif
-        } else {  // edge tile: zero padding (S1) by predication
-            const long long n = (long long)a.n_samples;
+                for (int r = 0; r < ROUNDS; ++r) {
+                    const long long sx = tile_lo + 4ll * (r * 256u + tid);
+                    v4f c;
+                    c.x = (sx >= 0 && sx < n) ? xb[sx] : 0.0f;
+                    c.y = (sx + 1 >= 0 && sx + 1 < n) ? xb[sx + 1] : 0.0f;
+                    c.z = (sx + 2 >= 0 && sx + 2 < n) ? xb[sx + 2] : 0.0f;
+                    c.w = (sx + 3 >= 0 && sx + 3 < n) ? xb[sx + 3] : 0.0f;
+                    creg[r] = c;
+                }
+            }
+        } else {
+            const long long s0 = (long long)(f0 + p1f) * a.hop - (long long)a.pad + 2 * n2;
+            if (interior) {
+                const v2f *xp = (const v2f *)(xb + s0);
 #pragma unroll
-            for (int n1 = 0; n1 < 32; ++n1) {
-                const long long sx = s0 + 32 * n1;
-                xr[n1].x = (sx >= 0 && sx < n) ? xb[sx] : 0.0f;
-                xr[n1].y = (sx + 1 >= 0 && sx + 1 < n) ? xb[sx + 1] : 0.0f;
+                for (int n1 = 0; n1 < 32; ++n1) xr[n1] = xp[16 * n1];
+            } else {
+                const long long n = (long long)a.n_samples;
+#pragma unroll
+                for (int n1 = 0; n1 < 32; ++n1) {
+                    const long long sx = s0 + 32 * n1;
+                    xr[n1].x = (sx >= 0 && sx < n) ? xb[sx] : 0.0f;
+                    xr[n1].y = (sx + 1 >= 0 && sx + 1 < n) ? xb[sx + 1] : 0.0f;
+                }
             }
         }
     };
@@ -229,14 +252,36 @@ __global__ __launch_bounds__(256, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
         const unsigned nf = min(16u, a.n_frames - f0);
 
         // ------------------------------------------------------------------ pass 1
+        if constexpr (ROUNDS > 0) {
+            // stage: chunk c of the tile -> xs (ex is free here: barrier 2 of the previous tile / the prologue barrier)
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                const unsigned c = r * 256u + tid;
+                if (c < chunks) *(v4f *)(smem + c * 16u + (xs_pad ? (c >> 6) * 128u : 0u)) = creg[r];
+            }
+            __syncthreads();
+            const unsigned o = p1f * a.hop + 2u * n2;  // float offset of this lane's column inside the tile
+            if (xs_pad) {
+                const unsigned char *src = smem + o * 4u + p1f * (a.hop >> 8) * 128u;
+#pragma unroll
+                for (int n1 = 0; n1 < 32; ++n1) xr[n1] = *(const v2f *)(src + n1 * 128 + (n1 >> 3) * 128);
+            } else {
+                const unsigned char *src = smem + o * 4u;
+#pragma unroll
+                for (int n1 = 0; n1 < 32; ++n1) xr[n1] = *(const v2f *)(src + n1 * 128);
+            }
+        }
         {
             v2f v[32], wn[32];
             const v2f *w2 = (const v2f *)(smem + kWinOff) + n2;
 #pragma unroll
-            for (int n1 = 0; n1 < 32; ++n1) {
-                wn[n1] = w2[16 * n1];
-                v[n1] = xr[n1];
+            for (int n1 = 0; n1 < 32; ++n1) wn[n1] = w2[16 * n1];
+            if constexpr (ROUNDS > 0) {
+                __syncthreads();  // every wave has read xs: pass 1 may overwrite it with ex
+                if (wid + slots < hi) load_tile(wid + slots);  // next tile's chunks: in flight for the whole tile
             }
+#pragma unroll
+            for (int n1 = 0; n1 < 32; ++n1) v[n1] = xr[n1];
 #ifdef SGX_STAMPS
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             SGX_STAMP(1);
@@ -264,7 +309,9 @@ __global__ __launch_bounds__(256, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
         }
         SGX_STAMP(3);
         const unsigned next = wid + slots;
-        if (next < hi) load_tile(next);  // in flight during pass 2
+        if constexpr (ROUNDS == 0) {
+            if (next < hi) load_tile(next);  // in flight during pass 2
+        }
         SGX_STAMP(4);
 #ifndef SGX_ABL_NOBARRIER
         __syncthreads();
@@ -384,16 +431,26 @@ __global__ __launch_bounds__(256, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
 #endif
 }
 
-template <int MODE, int AMP>
-hipError_t launch_variant(const StftArgs &a, hipStream_t s, unsigned per_xcd, unsigned total, unsigned slots) {
+template <int MODE, int AMP, int ROUNDS>
+hipError_t launch_variant3(const StftArgs &a, hipStream_t s, unsigned per_xcd, unsigned total, unsigned slots) {
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_r32x16<MODE, AMP>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        hipError_t e = hipFuncSetAttribute((const void *)k_r32x16<MODE, AMP, ROUNDS>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_r32x16<MODE, AMP>), dim3(slots * 8), dim3(256), kLds, s, a, per_xcd, total, slots);
+    hipLaunchKernelGGL((k_r32x16<MODE, AMP, ROUNDS>), dim3(slots * 8), dim3(256), kLds, s, a, per_xcd, total, slots);
     return hipGetLastError();
+}
+
+template <int MODE, int AMP>
+hipError_t launch_variant(const StftArgs &a, hipStream_t s, unsigned per_xcd, unsigned total, unsigned slots) {
+    // staged loads need 16-byte aligned rows (x base and row stride) and hop % 4 == 0; ROUNDS = chunks per thread
+    const bool aligned16 = (reinterpret_cast<uintptr_t>(a.x) % 16 == 0) && (a.sample_stride % 4 == 0) && (a.hop % 4 == 0);
+    const unsigned chunks = (15u * a.hop + 1024u) >> 2;
+    if (aligned16 && chunks <= 5u * 256u) return launch_variant3<MODE, AMP, 5>(a, s, per_xcd, total, slots);
+    if (aligned16 && chunks <= 9u * 256u) return launch_variant3<MODE, AMP, 9>(a, s, per_xcd, total, slots);
+    return launch_variant3<MODE, AMP, 0>(a, s, per_xcd, total, slots);
 }
 
 }  // namespace
