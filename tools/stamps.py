@@ -30,17 +30,19 @@ x = torch.from_numpy(np.stack([bench.cfg_signal(b) for b in range(256)])).cuda()
 out = plan.compute_batch(x)
 torch.cuda.synchronize()
 L = _ffi.lib()
-buf = (C.c_ulonglong * 16)()
+buf = (C.c_ulonglong * 32)()
 L.sgx_debug_read_stamps(buf, 1)
 iters = 5
 o = torch.view_as_real(out) if out.is_complex() else out
 ms = plan.time_batch_torch(x, o, iters)
 L.sgx_debug_read_stamps(buf, 1)
-names = ["loop top/wait", "win LDS reads + x wait", "FFT32 (+window)", "tw1 + ex writes", "prefetch issue", "barrier 1",
-         "ex reads", "barrier 2", "FFT16 x2", "split + stores"]
-waves = buf[15]
-tot = sum(buf[i] for i in range(10))
-print(f"workload={wl} flags={flags} kernel_ms(stamped)={ms:.4f} waves={waves}")
-for i, n in enumerate(names):
-    print(f"  {n:26s} {buf[i] / waves / 20:10.0f} cyc/wave/tile  {100.0 * buf[i] / tot:5.1f} %")
-print(f"  total {tot / waves / 20:.0f} cycles per wave per tile (20 tiles per wave per launch)")
+names = ["phase R (LDS reads)", "barrier M wait", "phase C (compute/store)", "barrier E wait", "  C: stage xs (+vmcnt wait)", "  C: fetch issue", "-"]
+print(f"workload={wl} flags={flags} kernel_ms(stamped)={ms:.4f}")
+for role, base in (("producer", 0), ("consumer", 8)):
+    waves = buf[base + 7]
+    tot = sum(buf[base + i] for i in range(7))
+    ticks = 41.0
+    print(f" {role}: waves={waves}")
+    for i, n in enumerate(names):
+        print(f"  {n:26s} {buf[base + i] / max(waves, 1) / ticks:10.0f} cyc/wave/tick  {100.0 * buf[base + i] / max(tot, 1):5.1f} %")
+    print(f"  total {tot / max(waves, 1) / ticks:.0f} cycles per wave per tick")

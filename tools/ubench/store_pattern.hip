@@ -18,7 +18,7 @@ __global__ void k(float *out, int n_frames, int tiles, int total) {
             float *p = ob + (size_t)r * n_frames + lf;
             if (f0 + lf + VEC <= n_frames) {
                 if constexpr (VEC == 1) p[0] = v;
-                else if constexpr (VEC == 2) { __builtin_nontemporal_store(v, p); p[1] = v; }
+                else if constexpr (VEC == 2) { *(float2*)p = make_float2(v, v); }
                 else { p[0] = v; p[1] = v; p[2] = v; p[3] = v; }
             }
         }
@@ -29,7 +29,7 @@ template <int F, int VEC>
 void run(float *d, int n_frames, int batch) {
     const int tiles = (n_frames + F - 1) / F, total = tiles * batch;
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int grid : {512, 1024, 2048}) {
+    for (int grid : {256, 512, 1024}) {
         hipLaunchKernelGGL((k<F, VEC>), dim3(grid), dim3(256), 0, 0, d, n_frames, tiles, total);
         (void)hipEventRecord(e0);
         for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((k<F, VEC>), dim3(grid), dim3(256), 0, 0, d, n_frames, tiles, total);
@@ -44,13 +44,11 @@ int main() {
     const int n_frames = 626, batch = 256;
     float *d; (void)hipMalloc(&d, (size_t)batch * 513 * n_frames * 4 + 4096);
     run<16, 1>(d, n_frames, batch);
-    run<32, 1>(d, n_frames, batch);
-    run<64, 1>(d, n_frames, batch);
     run<16, 2>(d, n_frames, batch);
+    run<32, 1>(d, n_frames, batch);
     run<32, 2>(d, n_frames, batch);
-    run<64, 2>(d, n_frames, batch);
-    run<64, 4>(d, n_frames, batch);
     // aligned variant: 640 frames per row (rows 16-B aligned, tiles never straddle)
+    return 0;
     printf("-- n_frames = 640 (aligned rows)\n");
     float *d2; (void)hipMalloc(&d2, (size_t)batch * 513 * 640 * 4 + 4096);
     run<16, 1>(d2, 640, batch);
