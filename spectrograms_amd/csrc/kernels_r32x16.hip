@@ -46,14 +46,18 @@ constexpr double kCos64[64] = {1.0, 0.9951847266721969, 0.9807852804032304, 0.95
 constexpr double kSin64[64] = {0.0, 0.0980171403295606, 0.19509032201612825, 0.29028467725446233, 0.3826834323650898, 0.47139673682599764, 0.5555702330196022, 0.6343932841636455, 0.7071067811865475, 0.773010453362737, 0.8314696123025452, 0.8819212643483549, 0.9238795325112867, 0.9569403357322089, 0.9807852804032304, 0.9951847266721968, 1.0, 0.9951847266721969, 0.9807852804032304, 0.9569403357322089, 0.9238795325112867, 0.881921264348355, 0.8314696123025455, 0.7730104533627371, 0.7071067811865476, 0.6343932841636455, 0.5555702330196022, 0.47139673682599786, 0.3826834323650899, 0.2902846772544624, 0.1950903220161286, 0.09801714032956083, 1.2246467991473532e-16, -0.09801714032956059, -0.19509032201612836, -0.2902846772544621, -0.38268343236508967, -0.47139673682599764, -0.555570233019602, -0.6343932841636453, -0.7071067811865475, -0.7730104533627367, -0.8314696123025452, -0.8819212643483549, -0.9238795325112865, -0.9569403357322088, -0.9807852804032303, -0.9951847266721969, -1.0, -0.9951847266721969, -0.9807852804032304, -0.9569403357322089, -0.9238795325112866, -0.881921264348355, -0.8314696123025455, -0.7730104533627369, -0.7071067811865477, -0.6343932841636459, -0.5555702330196022, -0.4713967368259979, -0.3826834323650904, -0.2902846772544625, -0.19509032201612872, -0.0980171403295605};
 
 constexpr int kFS = 4096 + 16;        // LDS bytes per frame of ex (odd multiple of 16 -> conflict-free b128 reads)
-constexpr int kPS = 513;              // floats per frame of pw (overlays a free ex buffer)
+constexpr int kPS = 516;              // floats per frame of pw (overlays a free ex buffer); multiple of 4: 16-B rows
 constexpr int kExBytes = 16 * kFS;    // 65792
 constexpr int kTw2Stride = 17;        // row stride of tw2 in float4 (bank spread between the 4 jobs of a wave)
 constexpr int kTw2Bytes = 17 * 17 * 16;  // float4 tw2[17][17] = (wr, wi, wi, -wr) of W_1024^(row + 32*idx)
 // k_r32x16: ex | win | tw2
 constexpr int kWinOff = kExBytes;
 constexpr int kTw2Off = kWinOff + 4096;
-constexpr int kLds = kTw2Off + kTw2Bytes;  // 74512 B -> two workgroups per CU (160 KiB LDS)
+constexpr int kMelOff = kTw2Off + kTw2Bytes;   // padded Mel bank (Mel modes): w4[chunks] (float4) | pptr[n_mels+1] | pcol[n_mels]
+constexpr int kMelMaxRows = 160, kMelMaxChunks = 512;
+constexpr int kMelBytes = kMelMaxChunks * 16 + (2 * kMelMaxRows + 1) * 4 + 12;  // 9488
+constexpr int kLds = kTw2Off + kTw2Bytes;      // 74512 B -> two workgroups per CU (160 KiB LDS)
+constexpr int kLdsMel = kMelOff + kMelBytes;   // 82208 B -> still two per CU
 // k_ws: ex0 | ex1 | xs
 constexpr int kWsXsOff = 2 * kExBytes;      // 131584
 constexpr int kWsXsBytes = 23040;           // 1280 chunks * 16 B + 128 B per KiB of padding
@@ -221,7 +225,11 @@ __device__ __forceinline__ void pass2_compute(const StftArgs &a, v2f (&A)[16], v
         if constexpr (MODE == OUT_COMPLEX) {
             *(v2f *)(ob + off) = conj ? (v2f){X.x, -X.y} : X;
         } else if constexpr (MODE == OUT_MEL) {
+#ifdef SGX_ABL_NOPW
+            asm volatile("" ::"v"(X), "v"(k));
+#else
             pw[k] = power_of(X);
+#endif
         } else {
             *(float *)(ob + off) = amp_f32<AMP>(power_of(X), eps);
         }
@@ -268,6 +276,30 @@ __device__ __forceinline__ void mel_tile(const StftArgs &a, const float *pwall, 
     }
 }
 
+// Same reduction with the 4-wide padded band table resident in LDS: 16-byte reads of weights and powers.  The padding
+// weights are +0, and w*p = +0 added to a non-negative partial sum leaves it unchanged, so the result is bit-identical
+// to the sequential ascending-bin accumulation of the reference (spectrogram.rs:102-117; unfused multiply-add).
+template <int AMP>
+__device__ __forceinline__ void mel_tile_lds(const StftArgs &a, const float *pwall, const v4f *lw4, const unsigned *lptr,
+                                             const unsigned *lcol, unsigned b, unsigned f0, unsigned nf, float eps,
+                                             unsigned t, unsigned nthreads) {
+    float *o = (float *)a.out + ((size_t)b * a.n_out) * a.n_frames + f0;
+    for (unsigned idx = t; idx < 16u * a.n_mels; idx += nthreads) {
+        const unsigned ff = idx & 15u, mm = idx >> 4;
+        const unsigned c0 = lptr[mm], c1 = lptr[mm + 1];
+        const v4f *p4 = (const v4f *)(pwall + ff * kPS + lcol[mm]);
+        float acc = 0.0f;
+        for (unsigned c = c0; c < c1; ++c) {
+            const v4f w = lw4[c], p = p4[c - c0];
+            acc = __fadd_rn(__fmul_rn(w.x, p.x), acc);
+            acc = __fadd_rn(__fmul_rn(w.y, p.y), acc);
+            acc = __fadd_rn(__fmul_rn(w.z, p.z), acc);
+            acc = __fadd_rn(__fmul_rn(w.w, p.w), acc);
+        }
+        if (ff < nf) o[mm * a.n_frames + ff] = amp_f32<AMP>(acc, eps);
+    }
+}
+
 // ====================================================================================================================
 // k_r32x16: persistent 256-thread workgroups (two per CU), both passes in every wave; per-lane float2 loads issued one
 // tile ahead.  Handles any even hop and 8-byte aligned rows.
@@ -278,6 +310,15 @@ __global__ __launch_bounds__(256, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
     const unsigned tid = threadIdx.x;
     ((v4f *)(smem + kWinOff))[tid] = ((const v4f *)a.window)[tid];
     for (unsigned i = tid; i < kTw2Bytes / 16; i += 256) ((v4f *)(smem + kTw2Off))[i] = ((const v4f *)a.tw2)[i];
+    v4f *lw4 = (v4f *)(smem + kMelOff);
+    unsigned *lptr = (unsigned *)(lw4 + a.mel_pchunks);
+    unsigned *lcol = lptr + a.n_mels + 1;
+    const bool mel_lds = MODE == OUT_MEL && a.mel_pw && a.n_mels <= kMelMaxRows && a.mel_pchunks <= kMelMaxChunks;
+    if (mel_lds) {
+        for (unsigned i = tid; i < a.mel_pchunks; i += 256) lw4[i] = ((const v4f *)a.mel_pw)[i];
+        for (unsigned i = tid; i <= a.n_mels; i += 256) lptr[i] = a.mel_pptr[i];
+        for (unsigned i = tid; i < a.n_mels; i += 256) lcol[i] = a.mel_pcol[i];
+    }
 
     // XCD-aware work mapping: blocks g and g+8 share an XCD (round-robin dispatch).  XCD x owns the contiguous run of
     // work ids [x*per_xcd, (x+1)*per_xcd); its `slots` resident workgroups walk that run with stride `slots`, so tiles
@@ -348,7 +389,10 @@ __global__ __launch_bounds__(256, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
         }
         if constexpr (MODE == OUT_MEL) {
             __syncthreads();
-            mel_tile<AMP>(a, (const float *)smem, b, f0, nf, eps, tid, 256u);
+#ifndef SGX_ABL_NOMELTILE
+            if (mel_lds) mel_tile_lds<AMP>(a, (const float *)smem, lw4, lptr, lcol, b, f0, nf, eps, tid, 256u);
+            else mel_tile<AMP>(a, (const float *)smem, b, f0, nf, eps, tid, 256u);
+#endif
             __syncthreads();  // pw consumed before the next pass 1 overwrites ex
         }
         wid = next;
@@ -568,9 +612,10 @@ hipError_t launch_variant(const StftArgs &a, hipStream_t s) {
         hipLaunchKernelGGL((k_ws<MODE, AMP>), dim3(slots * 8), dim3(512), kWsLds, s, a, per_xcd, total, slots);
     } else {
         static bool done = false;
-        if ((e = set_lds_once(k_r32x16<MODE, AMP>, kLds, done)) != hipSuccess) return e;
+        constexpr int lds = MODE == OUT_MEL ? kLdsMel : kLds;
+        if ((e = set_lds_once(k_r32x16<MODE, AMP>, lds, done)) != hipSuccess) return e;
         const unsigned slots = per_xcd < 64u ? per_xcd : 64u;  // two workgroups per CU (LDS-limited)
-        hipLaunchKernelGGL((k_r32x16<MODE, AMP>), dim3(slots * 8), dim3(256), kLds, s, a, per_xcd, total, slots);
+        hipLaunchKernelGGL((k_r32x16<MODE, AMP>), dim3(slots * 8), dim3(256), lds, s, a, per_xcd, total, slots);
     }
     return hipGetLastError();
 }

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstring>
 #include <new>
+#include <type_traits>
 
 #include "sgx_internal.h"
 
@@ -231,6 +232,30 @@ sgx_status build_device_tables(sgx_plan *pl) {
         if ((st = upload<uint32_t>(pl, &pl->d_mel_ptr, pl->mel_ptr)) != SGX_OK) return st;
         if ((st = upload<uint32_t>(pl, &pl->d_mel_col, pl->mel_col)) != SGX_OK) return st;
         if ((st = upload_cast<T>(pl, &pl->d_mel_val, pl->mel_val)) != SGX_OK) return st;
+        // triangular bands are contiguous column runs; for the tuned f32 kernel build a 4-wide padded copy (16-byte
+        // aligned column groups, zero weights outside the true band) so the reduction reads LDS 16 bytes at a time
+        bool contig = true;
+        for (size_t m = 0; m < pl->p.n_mels && contig; ++m)
+            for (uint32_t i = pl->mel_ptr[m]; i + 1 < pl->mel_ptr[m + 1]; ++i)
+                contig = contig && (pl->mel_col[i + 1] == pl->mel_col[i] + 1);
+        if (contig && std::is_same<T, float>::value) {
+            std::vector<uint32_t> pptr(pl->p.n_mels + 1, 0), pcol(pl->p.n_mels, 0);
+            std::vector<float> pw;
+            for (size_t m = 0; m < pl->p.n_mels; ++m) {
+                pptr[m] = uint32_t(pw.size() / 4);
+                const uint32_t a = pl->mel_ptr[m], b = pl->mel_ptr[m + 1];
+                if (b == a) continue;
+                const uint32_t c0 = pl->mel_col[a], c1 = pl->mel_col[b - 1];
+                const uint32_t s0 = c0 & ~3u, s1 = (c1 | 3u) + 1u;  // [s0, s1) multiple-of-4 cover
+                pcol[m] = s0;
+                for (uint32_t c = s0; c < s1; ++c) pw.push_back(c >= c0 && c <= c1 ? float(pl->mel_val[a + (c - c0)]) : 0.0f);
+            }
+            pptr[pl->p.n_mels] = uint32_t(pw.size() / 4);
+            pl->mel_pchunks = uint32_t(pw.size() / 4);
+            if ((st = upload<uint32_t>(pl, &pl->d_mel_pptr, pptr)) != SGX_OK) return st;
+            if ((st = upload<uint32_t>(pl, &pl->d_mel_pcol, pcol)) != SGX_OK) return st;
+            if ((st = upload<float>(pl, &pl->d_mel_pw, pw)) != SGX_OK) return st;
+        }
     }
     if (pl->kind == K_R32X16_F32) {
         // tw1[k1][n2] = W_512^(k1*n2) (pass-1 twiddles), tw2[j][k2] = W_1024^(j + 32*k2) (real-split twiddles)
@@ -287,7 +312,12 @@ void fill_args(const sgx_plan *pl, StftArgs &a, const void *x, void *out, size_t
     a.mel_ptr = (const unsigned *)pl->d_mel_ptr;
     a.mel_col = (const unsigned *)pl->d_mel_col;
     a.mel_val = pl->d_mel_val;
+    a.mel_pptr = (const unsigned *)pl->d_mel_pptr;
+    a.mel_pcol = (const unsigned *)pl->d_mel_pcol;
+    a.mel_pw = pl->d_mel_pw;
+    a.mel_pchunks = pl->mel_pchunks;
     a.n_mels = p.n_mels;
+    a.mel_nnz = unsigned(pl->mel_col.size());
     a.out_mode = pl->out_mode;
     a.amp = pl->amp;
     a.eps = pl->eps;
@@ -377,7 +407,7 @@ sgx_status grow(sgx_plan *pl, void **buf, size_t *have, size_t need) {
 
 void free_device(sgx_plan *pl) {
     void **bufs[] = {&pl->d_window, &pl->d_tw, &pl->d_tw1, &pl->d_tw2, &pl->d_mel_ptr, &pl->d_mel_col,
-                     &pl->d_mel_val, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half};
+                     &pl->d_mel_val, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half};
     for (void **b : bufs)
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);

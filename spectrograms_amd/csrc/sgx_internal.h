@@ -36,7 +36,14 @@ struct StftArgs {
     const unsigned *mel_ptr;
     const unsigned *mel_col;
     const void *mel_val;
+    // 4-wide padded band table (contiguous bands only, else nullptr): band m covers columns mel_pcol[m] + 4*c + {0..3}
+    // for c in [mel_pptr[m], mel_pptr[m+1]) with weights mel_pw[4*c + {0..3}] (zeros outside the true band)
+    const unsigned *mel_pptr;
+    const unsigned *mel_pcol;
+    const void *mel_pw;
+    unsigned mel_pchunks;
     unsigned n_mels;
+    unsigned mel_nnz;
     int out_mode;
     int amp;
     double eps;  // 10^(floor_db/10) in f64; cast to T in the kernel (T::from_f64, spectrogram.rs:2028)
@@ -75,7 +82,8 @@ struct sgx_plan {
 
     // device tables
     void *d_window = nullptr, *d_tw = nullptr, *d_tw1 = nullptr, *d_tw2 = nullptr;
-    void *d_mel_ptr = nullptr, *d_mel_col = nullptr, *d_mel_val = nullptr;
+    void *d_mel_ptr = nullptr, *d_mel_col = nullptr, *d_mel_val = nullptr, *d_mel_pptr = nullptr, *d_mel_pcol = nullptr, *d_mel_pw = nullptr;
+    unsigned mel_pchunks = 0;
     void *d_ones = nullptr;  // rectangular window for sgx_r2c
     void *d_window_half = nullptr, *d_ones_half = nullptr;  // 0.5*window (exact) for the tuned kernel's real split
 
