@@ -219,13 +219,15 @@ def spectrogram(p: Params, x: np.ndarray) -> np.ndarray:
     return out
 
 
-def spectrogram_batch(p: Params, x: np.ndarray, nthreads: int = 1) -> np.ndarray:
+def spectrogram_batch(p: Params, x: np.ndarray, nthreads: int = 1, out: Optional[np.ndarray] = None) -> np.ndarray:
     x = np.ascontiguousarray(x)
     assert x.ndim == 2
     suf = _suf(x.dtype)
     b, n = x.shape
     nf = frame_count(n, p.n_fft, p.hop, p.centre)
-    out = np.empty((b, p.n_bins, nf), x.dtype)
+    if out is None:
+        out = np.empty((b, p.n_bins, nf), x.dtype)
+    assert out.shape == (b, p.n_bins, nf) and out.dtype == x.dtype and out.flags.c_contiguous
     cp = p.c()
     rc = getattr(lib(), f"orc_spectrogram_batch_{suf}")(C.byref(cp), _ptr(x), b, n, n, _ptr(out), nthreads)
     if rc:

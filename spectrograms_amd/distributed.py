@@ -1,0 +1,72 @@
+"""One process per GPU: utterances shard across ranks (contiguous blocks, remainder to the low ranks — SURVEY.md
+§8e); every rank runs the single-GPU plan on its shard; the only collective is the optional all-gather that
+reassembles the batched output on every rank (RCCL over xGMI with backend "nccl"; gloo on CPU tensors in tests).
+
+The path has no exchange step inside the transform, so there is no data-path collective: `gather_outputs` exists for
+callers that need the whole [B, n_bins, n_frames] tensor on every rank (BASELINE.json configs[3])."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+from . import _ffi
+
+
+def shard_range(batch: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """(start, count) of rank's utterances; sgx_shard_range in include/spectro_hip.h."""
+    s, c = C.c_size_t(), C.c_size_t()
+    _ffi.raise_status(_ffi.lib().sgx_shard_range(batch, world_size, rank, C.byref(s), C.byref(c)))
+    return s.value, c.value
+
+
+def gather_outputs(local, batch_total: int, group=None):
+    """All-gather per-rank output shards [count_r, ...] into [batch_total, ...] on every rank.
+
+    Shards are the contiguous blocks of `shard_range`; when batch_total does not divide evenly the shorter shards are
+    padded to the longest for one `all_gather_into_tensor` and the padding rows are dropped afterwards."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    if world == 1:
+        return local
+    counts = [shard_range(batch_total, world, r)[1] for r in range(world)]
+    cmax = max(counts)
+    if local.shape[0] != counts[dist.get_rank(group)]:
+        raise ValueError(f"local shard has {local.shape[0]} rows, expected {counts[dist.get_rank(group)]}")
+    tail = tuple(local.shape[1:])
+    send = local
+    if local.shape[0] != cmax:
+        send = torch.zeros((cmax,) + tail, dtype=local.dtype, device=local.device)
+        send[: local.shape[0]] = local
+    buf = torch.empty((world * cmax,) + tail, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(buf, send.contiguous(), group=group)
+    if all(c == cmax for c in counts):
+        return buf
+    parts = [buf[r * cmax: r * cmax + counts[r]] for r in range(world)]
+    return torch.cat(parts, dim=0)
+
+
+class ShardedPlan:
+    """Wraps a single-GPU `Plan`: `compute(x_full_or_local)` on this rank's utterances (+ optional gather)."""
+
+    def __init__(self, plan, group=None):
+        import torch.distributed as dist
+
+        self.plan, self.group = plan, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def local_slice(self, batch_total: int) -> slice:
+        s, c = shard_range(batch_total, self.world, self.rank)
+        return slice(s, s + c)
+
+    def compute_local(self, x_local, out=None):
+        return self.plan.compute_batch(x_local, out=out)
+
+    def compute(self, x_local, batch_total: int, gather: bool = False, out=None):
+        y = self.compute_local(x_local, out=out)
+        if gather and self.world > 1:
+            import torch
+            y = gather_outputs(torch.view_as_real(y) if y.is_complex() else y, batch_total, self.group)
+        return y

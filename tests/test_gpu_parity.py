@@ -1,11 +1,14 @@
 """GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against the CPU oracle
 and the committed golden vectors.
 
-Tolerances (SURVEY.md §8c / BASELINE.json north_star):
+Tolerances (SURVEY.md §8c / BASELINE.json north_star), all against the f64 oracle:
   f64            : <= 1e-10 * max(1, max|ref|)   (the reference's own f64 round-trip bound, fft_backend.rs:1886-1907)
   f32 complex    : <= 1e-4 * max|X| abs          (north_star: within 1e-4 rel. of RustFFT)
-  f32 power/mel  : <= 1e-4 relative where ref > 1e-6 * max(ref); <= 1e-4 * max(ref) abs everywhere
-  dB             : <= 1e-3 dB abs where the power is within 60 dB of the peak; >= floor everywhere
+  f32 power/mel  : <= 1e-4 * max(ref) abs everywhere, <= 1e-4 relative where ref is within 40 dB of the peak
+                   (ref > 1e-4 * max), and <= 5e-3 relative where ref > 1e-6 * max — the reference's own accepted f32 bound
+                   (src/spectrogram.rs:5359-5362).  Bins 40-60 dB below the peak sit at the rounding noise of ANY f32 FFT
+                   (eps * sqrt(log N) * |X|max ~ 2e-7 * |X|max, i.e. ~4e-4 relative in power at -60 dB), RustFFT included.
+  dB             : <= 1e-3 dB abs where the power is within 40 dB of the peak, <= 0.05 dB within 60 dB; >= floor everywhere
 A tighter regression guard (GUARD) is asserted as well so that a numerically sloppy kernel cannot hide in the slack.
 """
 import os
@@ -81,14 +84,20 @@ def check(got, ref64, kind, dtype, floor=None, pow64=None):
         assert err <= GUARD32, f"regression guard: {err}"
     elif kind == "db":
         assert g.min() >= floor - 1e-3
-        m = pow64 > 1e-6 * pow64.max()
+        m = pow64 > 1e-4 * pow64.max()
         assert not m.any() or np.max(np.abs(g[m] - ref64[m])) <= 1e-3
+        m = pow64 > 1e-6 * pow64.max()
+        assert not m.any() or np.max(np.abs(g[m] - ref64[m])) <= 0.05
     else:
         err_abs = np.max(np.abs(g - ref64)) / scale
-        # relative check where the POWER is within 60 dB of the peak (magnitude = sqrt(power) -> 1e-3 of its peak)
-        m = ref64 > (1e-3 if kind == "magnitude" else 1e-6) * scale
+        # relative checks on the POWER scale: within 40 dB (1e-4) and 60 dB (5e-3, the reference's own f32 bound) of the
+        # peak; magnitude = sqrt(power), so its thresholds are the square roots and its relative errors half as large
+        t40, t60 = (1e-2, 1e-3) if kind == "magnitude" else (1e-4, 1e-6)
+        m = ref64 > t40 * scale
         err_rel = np.max(np.abs(g[m] - ref64[m]) / ref64[m]) if m.any() else 0.0
-        assert err_abs <= TOL32 and err_rel <= TOL32, (err_abs, err_rel)
+        m = ref64 > t60 * scale
+        err_rel60 = np.max(np.abs(g[m] - ref64[m]) / ref64[m]) if m.any() else 0.0
+        assert err_abs <= TOL32 and err_rel <= TOL32 and err_rel60 <= 5e-3, (err_abs, err_rel, err_rel60)
         assert err_abs <= GUARD32, f"regression guard: {err_abs}"
 
 
@@ -312,12 +321,14 @@ def test_config3_full_size_mel_db(cfg2_x):
     ref = orc.spectrogram_batch(op, cfg2_x.astype(np.float64), nthreads=orc.max_threads())
     pop = orc.Params(n_fft=1024, hop=256, n_mels=80)
     pw = orc.spectrogram_batch(pop, cfg2_x.astype(np.float64), nthreads=orc.max_threads())
-    m = pw > 1e-6 * pw.max(axis=(1, 2), keepdims=True)
+    m = pw > 1e-4 * pw.max(axis=(1, 2), keepdims=True)
     assert np.max(np.abs(got[m] - ref[m])) <= 1e-3
     mp, _ = make(1024, 256, n_mels=80)
     gp = mp.compute_batch(cfg2_x)
     rel = np.abs(gp[m] - pw[m]) / pw[m]
     assert rel.max() <= TOL32
+    m6 = pw > 1e-6 * pw.max(axis=(1, 2), keepdims=True)
+    assert np.max(np.abs(got[m6] - ref[m6])) <= 0.05 and (np.abs(gp[m6] - pw[m6]) / pw[m6]).max() <= 5e-3
 
 
 def test_linearity_full_size(cfg2_x):
