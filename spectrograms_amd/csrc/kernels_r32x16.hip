@@ -300,24 +300,48 @@ __device__ __forceinline__ void mel_tile_lds(const StftArgs &a, const float *pwa
     }
 }
 
+#ifdef SGX_STAMPS  // diagnostic build only (tools/stamps.py): share of a wave's cycles per phase, per role
+__device__ unsigned long long g_stamps[32];
+#define SGX_STAMP(i)                                                                        \
+    do {                                                                                    \
+        unsigned long long t_;                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        st_acc[i] += t_ - st_prev;                                                          \
+        st_prev = t_;                                                                       \
+    } while (0)
+#else
+#define SGX_STAMP(i)
+#endif
+
 // ====================================================================================================================
 // k_r32x16: persistent 256-thread workgroups (two per CU), both passes in every wave; per-lane float2 loads issued one
 // tile ahead.  Handles any even hop and 8-byte aligned rows.
 // ====================================================================================================================
-template <int MODE, int AMP>
-__global__ __launch_bounds__(256, 2) void k_r32x16(StftArgs a, unsigned per_xcd, unsigned total, unsigned slots) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const unsigned tid = threadIdx.x;
-    ((v4f *)(smem + kWinOff))[tid] = ((const v4f *)a.window)[tid];
-    for (unsigned i = tid; i < kTw2Bytes / 16; i += 256) ((v4f *)(smem + kTw2Off))[i] = ((const v4f *)a.tw2)[i];
-    v4f *lw4 = (v4f *)(smem + kMelOff);
+// HALVES = 2: one 512-thread workgroup per CU whose two halves each own a tile and an ex buffer and move through the
+// phases in lockstep (shared barriers) — a CU then alternates cleanly between arithmetic and memory phases.
+// ROUNDS > 0: the tile's (15*hop + 1024) samples are fetched ONCE with coalesced 16-byte loads (ROUNDS per thread, one tile
+// ahead), staged in LDS (xs, overlaying this half's ex) and re-read per frame from there: a per-lane float2 load costs the
+// CU's memory pipe ~17 cycles per wave-instruction (4 x 128-byte segments; tools/ubench/vmem_issue.hip) and every line is
+// requested ~4 times because frames overlap by 75 %.  ROUNDS == 0 keeps the direct loads (any even hop, 8-byte alignment).
+template <int MODE, int AMP, int HALVES, int ROUNDS>
+__global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned per_xcd, unsigned total, unsigned slots) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    const unsigned half = HALVES == 2 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0u;
+    const unsigned tid = threadIdx.x & 255u;
+    unsigned char *smem = smem_all + half * kExBytes;           // this half's ex / pw buffer
+    unsigned char *tabs = smem_all + (HALVES - 1) * kExBytes;   // tables sit behind the last ex buffer (kWinOff etc. are relative to ex0 of a 1-half layout)
+    if (threadIdx.x < 256u) ((v4f *)(tabs + kWinOff))[threadIdx.x] = ((const v4f *)a.window)[threadIdx.x];
+    for (unsigned i = threadIdx.x; i < kTw2Bytes / 16; i += 256 * HALVES) ((v4f *)(tabs + kTw2Off))[i] = ((const v4f *)a.tw2)[i];
+    v4f *lw4 = (v4f *)(tabs + kMelOff);
     unsigned *lptr = (unsigned *)(lw4 + a.mel_pchunks);
     unsigned *lcol = lptr + a.n_mels + 1;
     const bool mel_lds = MODE == OUT_MEL && a.mel_pw && a.n_mels <= kMelMaxRows && a.mel_pchunks <= kMelMaxChunks;
     if (mel_lds) {
-        for (unsigned i = tid; i < a.mel_pchunks; i += 256) lw4[i] = ((const v4f *)a.mel_pw)[i];
-        for (unsigned i = tid; i <= a.n_mels; i += 256) lptr[i] = a.mel_pptr[i];
-        for (unsigned i = tid; i < a.n_mels; i += 256) lcol[i] = a.mel_pcol[i];
+        for (unsigned i = threadIdx.x; i < a.mel_pchunks; i += 256 * HALVES) lw4[i] = ((const v4f *)a.mel_pw)[i];
+        for (unsigned i = threadIdx.x; i <= a.n_mels; i += 256 * HALVES) lptr[i] = a.mel_pptr[i];
+        for (unsigned i = threadIdx.x; i < a.n_mels; i += 256 * HALVES) lcol[i] = a.mel_pcol[i];
     }
 
     // XCD-aware work mapping: blocks g and g+8 share an XCD (round-robin dispatch).  XCD x owns the contiguous run of
@@ -326,7 +350,8 @@ __global__ __launch_bounds__(256, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
     const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
     const unsigned lo = xcd * per_xcd;
     const unsigned hi = min(lo + per_xcd, total);
-    unsigned wid = lo + slot;
+    unsigned wid = lo + slot * HALVES + half;
+    unsigned lead = lo + slot * HALVES;  // the first half's tile: uniform loop control for the whole workgroup
 
     const unsigned p1f = tid >> 4, n2 = tid & 15u;  // pass-1 identity
     const unsigned lane = tid & 63u, wv_ = tid >> 6, jq = lane >> 4, p2f = lane & 15u;  // pass-2 identity
@@ -337,51 +362,112 @@ __global__ __launch_bounds__(256, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
     v2f twa[4], twb[8];
     load_tw1(a, n2, twa, twb);
 
-    v2f xr[32];
+    v2f xr[32];                          // raw samples of this lane's (frame, n2) column
+    v4f creg[ROUNDS > 0 ? ROUNDS : 1];   // staged path: this thread's 16-byte chunks of the tile being prefetched
+    const unsigned chunks = (15u * a.hop + 1024u) >> 2;
+    const bool xs_pad = (a.hop & 255u) == 0;  // +128 B per KiB keeps the 4 frames of a wave on distinct banks
     auto load_tile = [&](unsigned w) {
         const unsigned b = w / a.tiles, tile = w - b * a.tiles;
         const unsigned f0 = tile * 16u;
         const float *xb = (const float *)a.x + (size_t)b * a.sample_stride;
-        const long long s0 = (long long)(f0 + p1f) * a.hop - (long long)a.pad + 2 * n2;
         const long long tile_lo = (long long)f0 * a.hop - (long long)a.pad;
         const long long tile_hi = (long long)(f0 + 15u) * a.hop - (long long)a.pad + 1024;
-        if (tile_lo >= 0 && tile_hi <= (long long)a.n_samples) {  // interior tile (wave-uniform): no bounds checks
-            const v2f *xp = (const v2f *)(xb + s0);
+        const bool interior = tile_lo >= 0 && tile_hi <= (long long)a.n_samples;  // wave-uniform
+        if constexpr (ROUNDS > 0) {
+            if (interior) {
+                const v4f *xp = (const v4f *)(xb + tile_lo) + tid;
 #pragma unroll
-            for (int n1 = 0; n1 < 32; ++n1) xr[n1] = xp[16 * n1];
-        } else {  // edge tile: zero padding (S1) by predication
-            const long long n = (long long)a.n_samples;
+                for (int r = 0; r < ROUNDS; ++r)
+                    if (r * 256u + tid < chunks) creg[r] = xp[r * 256];
+            } else {  // edge tile: zero padding (S1) by predication
+                const long long n = (long long)a.n_samples;
 #pragma unroll
-            for (int n1 = 0; n1 < 32; ++n1) {
-                const long long sx = s0 + 32 * n1;
-                xr[n1].x = (sx >= 0 && sx < n) ? xb[sx] : 0.0f;
-                xr[n1].y = (sx + 1 >= 0 && sx + 1 < n) ? xb[sx + 1] : 0.0f;
+                for (int r = 0; r < ROUNDS; ++r) {
+                    const long long sx = tile_lo + 4ll * (r * 256u + tid);
+                    v4f c;
+                    c.x = (sx >= 0 && sx < n) ? xb[sx] : 0.0f;
+                    c.y = (sx + 1 >= 0 && sx + 1 < n) ? xb[sx + 1] : 0.0f;
+                    c.z = (sx + 2 >= 0 && sx + 2 < n) ? xb[sx + 2] : 0.0f;
+                    c.w = (sx + 3 >= 0 && sx + 3 < n) ? xb[sx + 3] : 0.0f;
+                    creg[r] = c;
+                }
+            }
+        } else {
+            const long long s0 = (long long)(f0 + p1f) * a.hop - (long long)a.pad + 2 * n2;
+            if (interior) {
+                const v2f *xp = (const v2f *)(xb + s0);
+#pragma unroll
+                for (int n1 = 0; n1 < 32; ++n1) xr[n1] = xp[16 * n1];
+            } else {
+                const long long n = (long long)a.n_samples;
+#pragma unroll
+                for (int n1 = 0; n1 < 32; ++n1) {
+                    const long long sx = s0 + 32 * n1;
+                    xr[n1].x = (sx >= 0 && sx < n) ? xb[sx] : 0.0f;
+                    xr[n1].y = (sx + 1 >= 0 && sx + 1 < n) ? xb[sx + 1] : 0.0f;
+                }
             }
         }
     };
 
     if (wid < hi) load_tile(wid);
     __syncthreads();  // tables visible
+#ifdef SGX_STAMPS
+    unsigned long long st_acc[8] = {0}, st_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+#endif
 
-    while (wid < hi) {
-        const unsigned b = wid / a.tiles, tile = wid - b * a.tiles;
+    while (lead < hi) {
+        const bool active = wid < hi;  // (HALVES = 2) the second half may run out one tile earlier; it still joins the barriers
+        const unsigned b = (active ? wid : lead) / a.tiles, tile = (active ? wid : lead) - b * a.tiles;
         const unsigned f0 = tile * 16u;
         const unsigned nf = min(16u, a.n_frames - f0);
+        if constexpr (ROUNDS > 0) {
+            // stage: chunk c of the tile -> xs (this half's ex is free: barrier 2 of the previous tile / the prologue)
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                const unsigned c = r * 256u + tid;
+                if (c < chunks) *(v4f *)(smem + c * 16u + (xs_pad ? (c >> 6) * 128u : 0u)) = creg[r];
+            }
+            __syncthreads();
+            const unsigned o = p1f * a.hop + 2u * n2;  // float offset of this lane's column inside the tile
+            if (xs_pad) {
+                const unsigned char *src = smem + o * 4u + p1f * (a.hop >> 8) * 128u;
+#pragma unroll
+                for (int n1 = 0; n1 < 32; ++n1) xr[n1] = *(const v2f *)(src + n1 * 128 + (n1 >> 3) * 128);
+            } else {
+                const unsigned char *src = smem + o * 4u;
+#pragma unroll
+                for (int n1 = 0; n1 < 32; ++n1) xr[n1] = *(const v2f *)(src + n1 * 128);
+            }
+        }
         {
             v2f wn[32];
-            const v2f *w2 = (const v2f *)(smem + kWinOff) + n2;
+            const v2f *w2 = (const v2f *)(tabs + kWinOff) + n2;
 #pragma unroll
             for (int n1 = 0; n1 < 32; ++n1) wn[n1] = w2[16 * n1];
-            pass1_compute(xr, wn, twa, twb, smem + p1f * kFS + n2 * 8);
+            if constexpr (ROUNDS > 0) {
+                __syncthreads();  // every wave has read xs: pass 1 may overwrite it with ex
+                if (wid + slots * HALVES < hi) load_tile(wid + slots * HALVES);  // next tile's chunks: in flight all tile long
+            }
+            SGX_STAMP(0);
+            if (active) pass1_compute(xr, wn, twa, twb, smem + p1f * kFS + n2 * 8);
+            SGX_STAMP(1);
         }
-        const unsigned next = wid + slots;
-        if (next < hi) load_tile(next);  // in flight during pass 2
+        const unsigned next = wid + slots * HALVES;
+        if constexpr (ROUNDS == 0) {
+            if (next < hi) load_tile(next);  // in flight during pass 2
+        }
+        SGX_STAMP(2);
         __syncthreads();
+        SGX_STAMP(3);
         v2f A[16], B[16];
         read_rows(smem + p2f * kFS, ra, rb, A, B);
+        SGX_STAMP(4);
         __syncthreads();  // ex consumed: the next pass 1 (or the pw overlay) may overwrite it
-        if (p2f < nf) {
-            const v4f *t2 = (const v4f *)(smem + kTw2Off);
+        SGX_STAMP(5);
+        if (active && p2f < nf) {
+            const v4f *t2 = (const v4f *)(tabs + kTw2Off);
             auto tw = [&](int i) {  // read from LDS where consumed (this kernel has no registers to keep them)
                 return i < 8 ? t2[(j == 0 ? 16u : j) * kTw2Stride + i] : t2[j == 0 ? (unsigned)(i - 8) : j * kTw2Stride + i];
             };
@@ -390,13 +476,23 @@ __global__ __launch_bounds__(256, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
         if constexpr (MODE == OUT_MEL) {
             __syncthreads();
 #ifndef SGX_ABL_NOMELTILE
-            if (mel_lds) mel_tile_lds<AMP>(a, (const float *)smem, lw4, lptr, lcol, b, f0, nf, eps, tid, 256u);
-            else mel_tile<AMP>(a, (const float *)smem, b, f0, nf, eps, tid, 256u);
+            if (active) {
+                if (mel_lds) mel_tile_lds<AMP>(a, (const float *)smem, lw4, lptr, lcol, b, f0, nf, eps, tid, 256u);
+                else mel_tile<AMP>(a, (const float *)smem, b, f0, nf, eps, tid, 256u);
+            }
 #endif
             __syncthreads();  // pw consumed before the next pass 1 overwrites ex
         }
+        SGX_STAMP(6);
         wid = next;
+        lead += slots * HALVES;
     }
+#ifdef SGX_STAMPS
+    if ((threadIdx.x & 63u) == 0) {
+        for (int q = 0; q < 7; ++q) atomicAdd(&g_stamps[q], st_acc[q]);
+        atomicAdd(&g_stamps[7], 1ull);
+    }
+#endif
 }
 
 // ====================================================================================================================
@@ -414,21 +510,6 @@ __global__ __launch_bounds__(256, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
 //   [Mel: barrier X, consumers reduce pw (in ex[(t-1)&1]) to Mel bands]
 //   barrier E   (ex[t&1] and xs(t+1) complete)
 // ====================================================================================================================
-#ifdef SGX_STAMPS  // diagnostic build only (tools/stamps.py): share of a wave's cycles per phase, per role
-__device__ unsigned long long g_stamps[32];
-#define SGX_STAMP(i)                                                                        \
-    do {                                                                                    \
-        unsigned long long t_;                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                  \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
-        __builtin_amdgcn_sched_barrier(0);                                                  \
-        st_acc[i] += t_ - st_prev;                                                          \
-        st_prev = t_;                                                                       \
-    } while (0)
-#else
-#define SGX_STAMP(i)
-#endif
-
 template <int MODE, int AMP>
 __global__ __launch_bounds__(512, 2) void k_ws(StftArgs a, unsigned per_xcd, unsigned total, unsigned slots) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -611,11 +692,34 @@ hipError_t launch_variant(const StftArgs &a, hipStream_t s) {
         const unsigned slots = per_xcd < 32u ? per_xcd : 32u;  // one workgroup per CU: 32 per XCD
         hipLaunchKernelGGL((k_ws<MODE, AMP>), dim3(slots * 8), dim3(512), kWsLds, s, a, per_xcd, total, slots);
     } else {
-        static bool done = false;
         constexpr int lds = MODE == OUT_MEL ? kLdsMel : kLds;
-        if ((e = set_lds_once(k_r32x16<MODE, AMP>, lds, done)) != hipSuccess) return e;
-        const unsigned slots = per_xcd < 64u ? per_xcd : 64u;  // two workgroups per CU (LDS-limited)
-        hipLaunchKernelGGL((k_r32x16<MODE, AMP>), dim3(slots * 8), dim3(256), lds, s, a, per_xcd, total, slots);
+        static const bool want_single = [] {
+            const char *v = getenv("SGX_KERNEL");
+            return v && v[0] == 's';  // "single": two independent 256-thread workgroups per CU (round-1 first design)
+        }();
+        static const bool want_direct = [] {
+            const char *v = getenv("SGX_LOADS");
+            return v && v[0] == 'd';  // "direct": per-lane float2 loads even when staging is possible
+        }();
+        const bool stage5 = !want_direct && aligned16 && chunks <= 5u * 256u;
+        if (want_single) {
+            static bool done = false;
+            if ((e = set_lds_once(k_r32x16<MODE, AMP, 1, 0>, lds, done)) != hipSuccess) return e;
+            const unsigned slots = per_xcd < 64u ? per_xcd : 64u;  // two workgroups per CU (LDS-limited)
+            hipLaunchKernelGGL((k_r32x16<MODE, AMP, 1, 0>), dim3(slots * 8), dim3(256), lds, s, a, per_xcd, total, slots);
+        } else {
+            const unsigned pairs = (per_xcd + 1) / 2;
+            const unsigned slots = pairs < 32u ? pairs : 32u;  // one 512-thread workgroup per CU
+            if (stage5) {
+                static bool done = false;
+                if ((e = set_lds_once(k_r32x16<MODE, AMP, 2, 5>, lds + kExBytes, done)) != hipSuccess) return e;
+                hipLaunchKernelGGL((k_r32x16<MODE, AMP, 2, 5>), dim3(slots * 8), dim3(512), lds + kExBytes, s, a, per_xcd, total, slots);
+            } else {
+                static bool done = false;
+                if ((e = set_lds_once(k_r32x16<MODE, AMP, 2, 0>, lds + kExBytes, done)) != hipSuccess) return e;
+                hipLaunchKernelGGL((k_r32x16<MODE, AMP, 2, 0>), dim3(slots * 8), dim3(512), lds + kExBytes, s, a, per_xcd, total, slots);
+            }
+        }
     }
     return hipGetLastError();
 }

@@ -36,13 +36,19 @@ iters = 5
 o = torch.view_as_real(out) if out.is_complex() else out
 ms = plan.time_batch_torch(x, o, iters)
 L.sgx_debug_read_stamps(buf, 1)
-names = ["phase R (LDS reads)", "barrier M wait", "phase C (compute/store)", "barrier E wait", "  C: stage xs (+vmcnt wait)", "  C: fetch issue", "-"]
+ws = os.environ.get("SGX_KERNEL", "") == "ws"
+if ws:
+    names = ["phase R (LDS reads)", "barrier M wait", "phase C (compute/store)", "barrier E wait", "  C: stage xs (+vmcnt wait)", "  C: fetch issue", "-"]
+    roles = (("producer", 0), ("consumer", 8))
+else:
+    names = ["window reads + x wait", "pass 1 (FFT32, tw, ex writes)", "prefetch issue", "barrier 1", "ex reads", "barrier 2", "pass 2 (+stores, Mel)"]
+    roles = (("all waves", 0),)
 print(f"workload={wl} flags={flags} kernel_ms(stamped)={ms:.4f}")
-for role, base in (("producer", 0), ("consumer", 8)):
+for role, base in roles:
     waves = buf[base + 7]
     tot = sum(buf[base + i] for i in range(7))
-    ticks = 41.0
+    ticks = 41.0 if ws else 20.0
     print(f" {role}: waves={waves}")
     for i, n in enumerate(names):
-        print(f"  {n:26s} {buf[base + i] / max(waves, 1) / ticks:10.0f} cyc/wave/tick  {100.0 * buf[base + i] / max(tot, 1):5.1f} %")
-    print(f"  total {tot / max(waves, 1) / ticks:.0f} cycles per wave per tick")
+        print(f"  {n:30s} {buf[base + i] / max(waves, 1) / ticks:10.0f} cyc/wave/tile  {100.0 * buf[base + i] / max(tot, 1):5.1f} %")
+    print(f"  total {tot / max(waves, 1) / ticks:.0f} cycles per wave per tile")
