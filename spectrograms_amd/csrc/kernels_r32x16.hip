@@ -697,11 +697,11 @@ hipError_t launch_variant(const StftArgs &a, hipStream_t s) {
             const char *v = getenv("SGX_KERNEL");
             return v && v[0] == 's';  // "single": two independent 256-thread workgroups per CU (round-1 first design)
         }();
-        static const bool want_direct = [] {
+        static const bool want_staged = [] {
             const char *v = getenv("SGX_LOADS");
-            return v && v[0] == 'd';  // "direct": per-lane float2 loads even when staging is possible
+            return v && v[0] == 's';  // "staged": coalesced 16-byte loads through LDS (measured slower so far: 192 vs 180 us)
         }();
-        const bool stage5 = !want_direct && aligned16 && chunks <= 5u * 256u;
+        const bool stage5 = want_staged && aligned16 && chunks <= 5u * 256u;
         if (want_single) {
             static bool done = false;
             if ((e = set_lds_once(k_r32x16<MODE, AMP, 1, 0>, lds, done)) != hipSuccess) return e;
