@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SGX_ABI_VERSION 1
+#define SGX_ABI_VERSION 2
 
 typedef struct sgx_plan sgx_plan; /* opaque */
 
@@ -78,7 +78,13 @@ typedef struct {
     int32_t has_log_params;       /* Option<&LogParams>: dB applied only when set (S6) */
     double floor_db;
     int32_t dtype;                /* SGX_F32 / SGX_F64 */
-    int32_t device;               /* HIP device ordinal; -1 = current device */
+    int32_t device;               /* HIP device ordinal; -1 = current device; -2 = host-only plan (no compute) */
+    /* MfccParams (src/mfcc.rs:20-90): n_mfcc > 0 turns the plan into mfcc_from_log_mel (:224-273) applied to its
+     * Mel-dB output — unnormalised DCT-II with an FMA chain in T (:278-292), sinusoidal lifter (:297-316), optional
+     * removal of C0.  Requires freq_scale = MEL and amp_scale = DECIBELS; n_mfcc <= n_mels. */
+    uint32_t n_mfcc;
+    int32_t mfcc_include_c0;
+    uint32_t mfcc_lifter;
 } sgx_params;
 
 /* Replaces StftPlan::new (:1204-1228), SpectrogramPlanner::{linear_plan :893-917, mel_plan :944-977}:

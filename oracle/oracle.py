@@ -69,6 +69,7 @@ def lib() -> C.CDLL:
             getattr(L, f"orc_spectrogram_{suf}").argtypes = [C.POINTER(_Params), p, sz, p]
             getattr(L, f"orc_spectrogram_batch_{suf}").argtypes = [C.POINTER(_Params), p, sz, sz, sz, p, C.c_int]
             getattr(L, f"orc_stft_batch_{suf}").argtypes = [C.POINTER(_Params), p, sz, sz, sz, p, C.c_int]
+            getattr(L, f"orc_mfcc_{suf}").argtypes = [C.POINTER(_Params), C.c_uint32, C.c_int, C.c_uint32, p, sz, p]
         _lib = L
     return _lib
 
@@ -247,6 +248,20 @@ def stft_batch(p: Params, x: np.ndarray, nthreads: int = 1) -> np.ndarray:
     if rc:
         raise OracleError(rc)
     return out.view(np.complex64 if suf == "f32" else np.complex128)[..., 0]
+
+
+def mfcc(p: Params, x: np.ndarray, n_mfcc: int = 13, include_c0: bool = True, lifter: int = 22) -> np.ndarray:
+    """src/mfcc.rs:224-316 over the Mel-dB spectrogram described by p (which must be Mel + dB)."""
+    x = np.ascontiguousarray(x)
+    suf = _suf(x.dtype)
+    nf = frame_count(x.size, p.n_fft, p.hop, p.centre)
+    rows = n_mfcc - (0 if include_c0 or n_mfcc <= 1 else 1)
+    out = np.empty((rows, nf), x.dtype)
+    cp = p.c()
+    rc = getattr(lib(), f"orc_mfcc_{suf}")(C.byref(cp), n_mfcc, int(include_c0), lifter, _ptr(x), x.size, _ptr(out))
+    if rc:
+        raise OracleError(rc)
+    return out
 
 
 def max_threads() -> int:

@@ -94,6 +94,10 @@ int orc_stft_batch_f32(const orc_params *p, const float *x, size_t batch, size_t
                        float *out, int nthreads);
 int orc_stft_batch_f64(const orc_params *p, const double *x, size_t batch, size_t n, size_t stride,
                        double *out, int nthreads);
+/* src/mfcc.rs:224-316 mfcc_from_log_mel over the plan's Mel-dB spectrogram (the plan must be Mel + dB);
+ * out[(coef * n_frames) + frame], rows = n_mfcc - (include_c0 ? 0 : (n_mfcc > 1)). */
+int orc_mfcc_f32(const orc_params *p, uint32_t n_mfcc, int include_c0, uint32_t lifter, const float *x, size_t n, float *out);
+int orc_mfcc_f64(const orc_params *p, uint32_t n_mfcc, int include_c0, uint32_t lifter, const double *x, size_t n, double *out);
 int orc_max_threads(void);
 
 #ifdef __cplusplus

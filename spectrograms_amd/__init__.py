@@ -8,9 +8,9 @@ compute calls raise FFTBackendError.
 from ._ffi import (DimensionMismatchError, FFTBackendError, InternalError, InvalidInputError, SpectrogramError)
 from .functions import (compute_linear_db_spectrogram, compute_linear_magnitude_spectrogram,
                         compute_linear_power_spectrogram, compute_mel_db_spectrogram,
-                        compute_mel_magnitude_spectrogram, compute_mel_power_spectrogram, compute_stft)
-from .params import LogParams, MelNorm, MelParams, SpectrogramParams, StftParams, WindowType
-from .planner import Plan, Spectrogram, SpectrogramPlanner, StftResult
+                        compute_mel_magnitude_spectrogram, compute_mel_power_spectrogram, compute_mfcc, compute_stft)
+from .params import LogParams, MelNorm, MelParams, MfccParams, SpectrogramParams, StftParams, WindowType
+from .planner import Mfcc, Plan, Spectrogram, SpectrogramPlanner, StftResult
 
 __all__ = [
     "SpectrogramError", "InvalidInputError", "DimensionMismatchError", "FFTBackendError", "InternalError",
@@ -18,5 +18,5 @@ __all__ = [
     "SpectrogramPlanner", "Plan", "Spectrogram", "StftResult",
     "compute_linear_power_spectrogram", "compute_linear_magnitude_spectrogram", "compute_linear_db_spectrogram",
     "compute_mel_power_spectrogram", "compute_mel_magnitude_spectrogram", "compute_mel_db_spectrogram",
-    "compute_stft",
+    "compute_stft", "compute_mfcc", "MfccParams", "Mfcc",
 ]

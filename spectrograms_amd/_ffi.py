@@ -36,6 +36,7 @@ class SgxParams(C.Structure):
         ("sample_rate_hz", C.c_double), ("freq_scale", C.c_int32), ("n_mels", C.c_uint32), ("f_min", C.c_double),
         ("f_max", C.c_double), ("mel_norm", C.c_int32), ("amp_scale", C.c_int32), ("has_log_params", C.c_int32),
         ("floor_db", C.c_double), ("dtype", C.c_int32), ("device", C.c_int32),
+        ("n_mfcc", C.c_uint32), ("mfcc_include_c0", C.c_int32), ("mfcc_lifter", C.c_uint32),
     ]
 
 

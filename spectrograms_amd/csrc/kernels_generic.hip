@@ -189,6 +189,26 @@ __global__ __launch_bounds__(256) void k_direct_dft(StftArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// MFCC epilogue (src/mfcc.rs:224-316): one thread per (signal, frame); lanes walk frames so every read of the Mel-dB
+// tensor and every write is frame-contiguous.  DCT-II as a sequential FMA chain in T over ascending mel index, exactly
+// `val.mul_add(basis, acc)` (:286-290); the basis is cos(pi k (i+0.5)/n) evaluated in f64 on the host and cast to T.
+template <typename T>
+__global__ __launch_bounds__(256) void k_mfcc(const T *mel, T *out, const T *basis, const T *lifter, unsigned batch,
+                                              unsigned n_mels, unsigned n_frames, unsigned n_mfcc, unsigned skip, int has_lifter) {
+    const unsigned long long gid = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (unsigned long long)batch * n_frames) return;
+    const unsigned b = (unsigned)(gid / n_frames), f = (unsigned)(gid - (unsigned long long)b * n_frames);
+    const T *m = mel + (size_t)b * n_mels * n_frames + f;
+    T *o = out + (size_t)b * (n_mfcc - skip) * n_frames + f;
+    for (unsigned k = skip; k < n_mfcc; ++k) {
+        T acc = T(0);
+        const T *bk = basis + (size_t)k * n_mels;
+        for (unsigned i = 0; i < n_mels; ++i) acc = fma(m[(size_t)i * n_frames], bk[i], acc);
+        if (has_lifter) acc *= lifter[k];
+        o[(size_t)(k - skip) * n_frames] = acc;
+    }
+}
+
 static const size_t kLdsBudget = 64 * 1024;
 
 static size_t elem_size(int dtype) { return dtype == SGX_F64 ? 8 : 4; }
@@ -245,6 +265,20 @@ hipError_t launch_direct_dft(const StftArgs &a, int dtype, hipStream_t s) {
         hipLaunchKernelGGL(k_direct_dft<double>, dim3((unsigned)g), dim3(256), lds, s, a);
     else
         hipLaunchKernelGGL(k_direct_dft<float>, dim3((unsigned)g), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_mfcc(const void *mel, void *out, const void *basis, const void *lifter, unsigned batch, unsigned n_mels,
+                       unsigned n_frames, unsigned n_mfcc, unsigned skip, int has_lifter, int dtype, hipStream_t s) {
+    const unsigned long long n = (unsigned long long)batch * n_frames;
+    const unsigned long long blocks = (n + 255) / 256;
+    if (blocks == 0 || blocks >= 0x7fffffffull) return hipErrorInvalidConfiguration;
+    if (dtype == SGX_F64)
+        hipLaunchKernelGGL(k_mfcc<double>, dim3((unsigned)blocks), dim3(256), 0, s, (const double *)mel, (double *)out,
+                           (const double *)basis, (const double *)lifter, batch, n_mels, n_frames, n_mfcc, skip, has_lifter);
+    else
+        hipLaunchKernelGGL(k_mfcc<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float *)mel, (float *)out,
+                           (const float *)basis, (const float *)lifter, batch, n_mels, n_frames, n_mfcc, skip, has_lifter);
     return hipGetLastError();
 }
 

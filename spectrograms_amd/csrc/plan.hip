@@ -191,6 +191,11 @@ sgx_status validate(const sgx_params &p, std::string &msg) {
         return bad("complex STFT output requires the linear frequency scale");
     if (p.has_log_params && !std::isfinite(p.floor_db)) return bad("floor_db must be finite");  // :4072-4074
     if (p.dtype != SGX_F32 && p.dtype != SGX_F64) return bad("dtype must be f32 or f64");
+    if (p.n_mfcc > 0) {
+        if (p.freq_scale != SGX_FREQ_MEL || p.amp_scale != SGX_AMP_DECIBELS)
+            return bad("MFCC requires a Mel / Decibels plan");
+        if (p.n_mfcc > p.n_mels) return bad("n_mfcc must be <= n_mels");  // src/mfcc.rs:231-233
+    }
     return SGX_OK;
 }
 
@@ -256,6 +261,17 @@ sgx_status build_device_tables(sgx_plan *pl) {
             if ((st = upload<uint32_t>(pl, &pl->d_mel_pcol, pcol)) != SGX_OK) return st;
             if ((st = upload<float>(pl, &pl->d_mel_pw, pw)) != SGX_OK) return st;
         }
+    }
+    if (pl->p.n_mfcc > 0) {
+        const unsigned nm = pl->p.n_mels, nc = pl->p.n_mfcc;
+        std::vector<double> basis(size_t(nc) * nm), lift(nc, 1.0);
+        for (unsigned k = 0; k < nc; ++k)
+            for (unsigned i = 0; i < nm; ++i) basis[size_t(k) * nm + i] = std::cos(kPi * double(k) * (double(i) + 0.5) / double(nm));
+        if (pl->p.mfcc_lifter > 0)
+            for (unsigned i = 0; i < nc; ++i)
+                lift[i] = std::fma(double(pl->p.mfcc_lifter) / 2.0, std::sin(kPi * double(i) / double(pl->p.mfcc_lifter)), 1.0);
+        if ((st = upload_cast<T>(pl, &pl->d_dct, basis)) != SGX_OK) return st;
+        if ((st = upload_cast<T>(pl, &pl->d_lifter, lift)) != SGX_OK) return st;
     }
     if (pl->kind == K_R32X16_F32) {
         // tw1[k1][n2] = W_512^(k1*n2) (pass-1 twiddles), tw2[j][k2] = W_1024^(j + 32*k2) (real-split twiddles)
@@ -361,7 +377,7 @@ sgx_status check_call(sgx_plan *pl, const void *samples, size_t batch, size_t n_
     if (batch > 0xffffffffull) return set_err(pl, SGX_INVALID_INPUT, "Invalid input: batch too large");
     const size_t nf = frame_count(pl->p, n_samples);
     if (nf > 0x7fffffffull) return set_err(pl, SGX_INVALID_INPUT, "Invalid input: too many frames");
-    const size_t expect = batch * size_t(pl->n_out) * nf * (pl->out_mode == OUT_COMPLEX ? 2 : 1);
+    const size_t expect = batch * size_t(pl->n_final) * nf * (pl->out_mode == OUT_COMPLEX ? 2 : 1);
     if (out_elems != expect)  // compute_into: DimensionMismatch{expected, got} (:423-434)
         return set_err(pl, SGX_DIM_MISMATCH, "Dimension mismatch: expected " + std::to_string(expect) + ", got " +
                                                  std::to_string(out_elems));
@@ -371,10 +387,20 @@ sgx_status check_call(sgx_plan *pl, const void *samples, size_t batch, size_t n_
     return SGX_OK;
 }
 
+sgx_status grow(sgx_plan *pl, void **buf, size_t *have, size_t need);
+
 sgx_status run_device(sgx_plan *pl, const void *x, size_t batch, size_t n_samples, size_t stride, void *out,
                       size_t n_frames, hipStream_t s, int iters, float *ms) {
     StftArgs a;
-    fill_args(pl, a, x, out, batch, n_samples, stride, n_frames);
+    void *stage_out = out;
+    const bool mfcc = pl->p.n_mfcc > 0;
+    if (mfcc) {  // Mel-dB goes to plan-owned scratch, the DCT/lifter epilogue writes the caller's buffer
+        SGX_HIP(pl, hipSetDevice(pl->device));
+        sgx_status st = grow(pl, &pl->d_melbuf, &pl->d_melbuf_bytes, batch * size_t(pl->n_out) * n_frames * pl->elem);
+        if (st != SGX_OK) return st;
+        stage_out = pl->d_melbuf;
+    }
+    fill_args(pl, a, x, stage_out, batch, n_samples, stride, n_frames);
     KernelKind kind = pick_kernel(pl, x, stride);
     if (!set_geometry(pl, a, kind)) {
         kind = (kind == K_R32X16_F32) ? K_LDS_RADIX2 : K_DIRECT_DFT;
@@ -384,7 +410,13 @@ sgx_status run_device(sgx_plan *pl, const void *x, size_t batch, size_t n_sample
     if (kind == K_R32X16_F32) a.window = pl->d_window_half;
     SGX_HIP(pl, hipSetDevice(pl->device));
     if (ms) SGX_HIP(pl, hipEventRecord(pl->ev0, s));
-    for (int i = 0; i < iters; ++i) SGX_HIP(pl, launch(pl, a, kind, s));
+    const unsigned skip = pl->p.n_mfcc - pl->n_final * (mfcc ? 1u : 0u);
+    for (int i = 0; i < iters; ++i) {
+        SGX_HIP(pl, launch(pl, a, kind, s));
+        if (mfcc)
+            SGX_HIP(pl, launch_mfcc(pl->d_melbuf, out, pl->d_dct, pl->d_lifter, unsigned(batch), pl->p.n_mels, unsigned(n_frames),
+                                    pl->p.n_mfcc, skip, pl->p.mfcc_lifter > 0, pl->dtype, s));
+    }
     if (ms) {
         SGX_HIP(pl, hipEventRecord(pl->ev1, s));
         SGX_HIP(pl, hipEventSynchronize(pl->ev1));
@@ -407,7 +439,7 @@ sgx_status grow(sgx_plan *pl, void **buf, size_t *have, size_t need) {
 
 void free_device(sgx_plan *pl) {
     void **bufs[] = {&pl->d_window, &pl->d_tw, &pl->d_tw1, &pl->d_tw2, &pl->d_mel_ptr, &pl->d_mel_col,
-                     &pl->d_mel_val, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half};
+                     &pl->d_mel_val, &pl->d_dct, &pl->d_lifter, &pl->d_melbuf, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half};
     for (void **b : bufs)
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
@@ -458,6 +490,8 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
     pl->out_mode = params->amp_scale == SGX_AMP_COMPLEX ? OUT_COMPLEX
                    : params->freq_scale == SGX_FREQ_MEL ? OUT_MEL : OUT_LINEAR;
     pl->n_out = pl->out_mode == OUT_MEL ? params->n_mels : pl->nb_fft;
+    const unsigned mfcc_skip = (params->n_mfcc > 1 && !params->mfcc_include_c0) ? 1u : 0u;  // src/mfcc.rs:262-268
+    pl->n_final = params->n_mfcc > 0 ? params->n_mfcc - mfcc_skip : pl->n_out;
     // S6: dB is applied only when LogParams were supplied; Decibels without them returns power
     pl->amp = params->amp_scale == SGX_AMP_MAGNITUDE ? AMP_MAGNITUDE
               : (params->amp_scale == SGX_AMP_DECIBELS && params->has_log_params) ? AMP_DB : AMP_POWER;
@@ -529,7 +563,7 @@ void sgx_plan_destroy(sgx_plan *plan) {
 sgx_status sgx_output_shape(const sgx_plan *plan, size_t n_samples, size_t *n_bins, size_t *n_frames) {
     if (!plan) return SGX_INVALID_INPUT;
     if (n_samples == 0) return set_err(plan, SGX_INVALID_INPUT, "Invalid input: signal length must be non-zero");
-    if (n_bins) *n_bins = plan->n_out;
+    if (n_bins) *n_bins = plan->n_final;
     if (n_frames) *n_frames = frame_count(plan->p, n_samples);
     return SGX_OK;
 }
@@ -574,7 +608,10 @@ sgx_status sgx_axes(const sgx_plan *plan, size_t n_frames, double *freqs, double
         const double dt = double(p.hop_size) / p.sample_rate_hz;
         for (size_t i = 0; i < n_frames; ++i) times[i] = double(i) * dt;
     }
-    if (freqs) {
+    if (freqs && plan->p.n_mfcc > 0) {  // Mfcc carries no frequency axis (src/mfcc.rs:130-133): report coefficient indices
+        const unsigned skip = plan->p.n_mfcc - plan->n_final;
+        for (unsigned i = 0; i < plan->n_final; ++i) freqs[i] = double(i + skip);
+    } else if (freqs) {
         if (plan->out_mode == OUT_MEL) {  // mel_band_centres_hz :2510-2530 — 0..Nyquist, ignores f_min/f_max
             const double lo = hz2mel(0.0), hi = hz2mel(p.sample_rate_hz * 0.5);
             const double step = (hi - lo) / double(p.n_mels + 1);

@@ -56,6 +56,9 @@ struct StftArgs {
 hipError_t launch_direct_dft(const StftArgs &a, int dtype, hipStream_t s);
 hipError_t launch_lds_radix2(const StftArgs &a, int dtype, hipStream_t s);
 hipError_t launch_r32x16_f32(const StftArgs &a, hipStream_t s);
+// MFCC epilogue over a Mel-dB tensor [batch][n_mels][n_frames] -> [batch][n_out][n_frames]; basis [n_mfcc][n_mels], lifter [n_mfcc]
+hipError_t launch_mfcc(const void *mel, void *out, const void *basis, const void *lifter, unsigned batch, unsigned n_mels,
+                       unsigned n_frames, unsigned n_mfcc, unsigned skip, int has_lifter, int dtype, hipStream_t s);
 // tile geometry chosen per kernel (fills a.ft / a.tiles); returns false if the kernel cannot run the shape
 bool plan_geometry_direct_dft(StftArgs &a, int dtype);
 bool plan_geometry_lds_radix2(StftArgs &a, int dtype);
@@ -85,6 +88,10 @@ struct sgx_plan {
     void *d_mel_ptr = nullptr, *d_mel_col = nullptr, *d_mel_val = nullptr, *d_mel_pptr = nullptr, *d_mel_pcol = nullptr, *d_mel_pw = nullptr;
     unsigned mel_pchunks = 0;
     void *d_ones = nullptr;  // rectangular window for sgx_r2c
+    // MFCC epilogue: DCT-II basis [n_mfcc][n_mels] and lifter [n_mfcc] in T; Mel-dB scratch (grown on demand)
+    void *d_dct = nullptr, *d_lifter = nullptr, *d_melbuf = nullptr;
+    size_t d_melbuf_bytes = 0;
+    unsigned n_final = 0;  // rows of the final output (n_out, or the MFCC row count)
     void *d_window_half = nullptr, *d_ones_half = nullptr;  // 0.5*window (exact) for the tuned kernel's real split
 
     // plan-owned staging for host-pointer execution

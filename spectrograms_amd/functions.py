@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 from . import _ffi
+from .params import LogParams, MelParams, SpectrogramParams
 from .planner import Plan
 
 
@@ -31,3 +32,10 @@ def compute_mel_db_spectrogram(samples, params, mel_params, db=None, dtype=None)
 
 def compute_stft(samples, params, dtype=None):
     return Plan(params, _ffi.AMP_COMPLEX, None, None, dtype).compute(samples)
+
+
+def compute_mfcc(samples, stft_params, sample_rate, n_mels, mfcc_params, dtype=None):
+    """src/python/functions.rs:606-640 -> mfcc() src/mfcc.rs:359-379."""
+    params = SpectrogramParams(stft_params, sample_rate)
+    return Plan(params, _ffi.AMP_DECIBELS, MelParams(n_mels, 0.0, sample_rate / 2.0), LogParams(-80.0), dtype,
+                mfcc=mfcc_params).compute(samples)

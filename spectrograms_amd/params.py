@@ -136,6 +136,25 @@ class MelParams:
         self.norm = norm if norm is not None else MelNorm.none
 
 
+class MfccParams:
+    """MfccParams(n_mfcc=13) — src/mfcc.rs:20-90 (defaults include_c0=True, lifter=22; `with_c0` / `with_lifter`)."""
+
+    def __init__(self, n_mfcc: int = 13, include_c0: bool = True, lifter: int = 22):
+        if int(n_mfcc) <= 0:
+            raise ValueError("n_mfcc must be > 0")
+        self.n_mfcc, self.include_c0, self.lifter = int(n_mfcc), bool(include_c0), int(lifter)
+
+    @classmethod
+    def speech_standard(cls) -> "MfccParams":
+        return cls(13)
+
+    def with_c0(self, include_c0: bool) -> "MfccParams":
+        return MfccParams(self.n_mfcc, include_c0, self.lifter)
+
+    def with_lifter(self, lifter: int) -> "MfccParams":
+        return MfccParams(self.n_mfcc, self.include_c0, lifter)
+
+
 def parse_dtype(dtype: Optional[str]) -> int:
     """src/python/dtype.rs:34-42."""
     d = "float64" if dtype is None else dtype

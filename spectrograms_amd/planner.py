@@ -8,7 +8,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 from . import _ffi
-from .params import LogParams, MelParams, SpectrogramParams, parse_dtype
+from .params import LogParams, MelParams, MfccParams, SpectrogramParams, parse_dtype
 
 
 class Spectrogram:
@@ -70,11 +70,28 @@ class StftResult:
         return self._data if dtype is None else self._data.astype(dtype)
 
 
+class Mfcc:
+    """Mfcc result (src/mfcc.rs:96-140): `.data` is (n_coefficients, n_frames)."""
+
+    def __init__(self, data: np.ndarray, params: MfccParams):
+        self._data, self.params = data, params
+
+    data = property(lambda s: s._data)
+    dtype = property(lambda s: "float32" if s._data.dtype == np.float32 else "float64")
+    n_bins = property(lambda s: s._data.shape[0])
+    n_frames = property(lambda s: s._data.shape[1])
+    shape = property(lambda s: s._data.shape)
+
+    def __array__(self, dtype=None, copy=None):
+        return self._data if dtype is None else self._data.astype(dtype)
+
+
 class Plan:
     """One sgx_plan.  Not thread-safe (mirrors `&mut self`; reference plan classes are `unsendable`)."""
 
     def __init__(self, params: SpectrogramParams, amp: int, mel: Optional[MelParams] = None,
-                 db: Optional[LogParams] = None, dtype: Optional[str] = None, device: int = _ffi.DEVICE_CURRENT):
+                 db: Optional[LogParams] = None, dtype: Optional[str] = None, device: int = _ffi.DEVICE_CURRENT,
+                 mfcc: Optional[MfccParams] = None):
         self._lib = _ffi.lib()
         self._params, self._mel, self._db = params, mel, db
         self._dt = parse_dtype(dtype)
@@ -97,6 +114,9 @@ class Plan:
         p.has_log_params = int(db is not None)
         p.floor_db = db.floor_db if db is not None else 0.0
         p.dtype, p.device = self._dt, device
+        self._mfcc = mfcc
+        if mfcc is not None:
+            p.n_mfcc, p.mfcc_include_c0, p.mfcc_lifter = mfcc.n_mfcc, int(mfcc.include_c0), mfcc.lifter
         h = C.c_void_p()
         _ffi.raise_status(self._lib.sgx_plan_create(C.byref(p), C.byref(h)))
         self._h = h
@@ -214,6 +234,8 @@ class Plan:
         freqs, times = self.axes(data.shape[1])
         if self.is_complex:
             return StftResult(data, freqs, self._params.sample_rate, self._params.stft)
+        if self._mfcc is not None:
+            return Mfcc(data, self._mfcc)
         return Spectrogram(data, freqs, times, self._params, self._db.floor_db if self._db else None)
 
     def compute_frame(self, samples, frame_idx: int) -> np.ndarray:
@@ -261,6 +283,12 @@ class SpectrogramPlanner:
 
     def mel_db_plan(self, params, mel_params, db_params, dtype=None):
         return Plan(params, _ffi.AMP_DECIBELS, mel_params, db_params, dtype, self._device)
+
+    def mfcc_plan(self, stft_params, sample_rate, n_mels, mfcc_params, dtype=None):
+        """Plan form of `mfcc()` (src/mfcc.rs:359-379): Mel 0..sr/2, floor -80 dB, then DCT-II + lifter."""
+        params = SpectrogramParams(stft_params, sample_rate)
+        return Plan(params, _ffi.AMP_DECIBELS, MelParams(n_mels, 0.0, sample_rate / 2.0), LogParams(-80.0), dtype,
+                    self._device, mfcc_params)
 
     def stft_plan(self, params, dtype=None):
         """StftPlan::new (src/spectrogram.rs:1204-1228)."""
