@@ -132,6 +132,29 @@ sgx_status sgx_mel_weights(const sgx_plan *plan, size_t *nnz, uint32_t *row_ptr 
  * the low ranks. */
 sgx_status sgx_shard_range(size_t batch, int32_t world_size, int32_t rank, size_t *start, size_t *count);
 
+/* ---- 2-D FFT path (BASELINE config 5): R2cPlan2d / C2rPlan2d (src/fft_backend.rs:169-246, 614-819), fft2d / ifft2d
+ * (src/fft2d.rs:77-185), convolve_fft and the radial filters (src/image_ops.rs:80-432).  Batched: `batch` images of
+ * nrows x ncols per call.  Real images are [batch][nrows][ncols] T; half spectra [batch][nrows][ncols/2+1] complex T
+ * (interleaved).  The plan owns every intermediate buffer. */
+typedef struct sgx_fft2d sgx_fft2d; /* opaque; same single-caller rule as sgx_plan */
+sgx_status sgx_fft2d_create(size_t nrows, size_t ncols, int32_t dtype, int32_t device, sgx_fft2d **out);
+void sgx_fft2d_destroy(sgx_fft2d *plan);
+/* fft2d: unnormalised forward (rows R2C, then columns C2C) */
+sgx_status sgx_fft2d_forward(sgx_fft2d *plan, const void *images, size_t batch, void *spectrum, int32_t mem_kind,
+                             void *hip_stream);
+/* ifft2d: columns inverse C2C, DC/Nyquist columns forced real, rows C2R, scale 1/(nrows*ncols) */
+sgx_status sgx_fft2d_inverse(sgx_fft2d *plan, const void *spectrum, size_t batch, void *images, int32_t mem_kind,
+                             void *hip_stream);
+/* convolve_fft(image, kernel): kernel (krows x kcols, host pointer, T) is wrapped so its centre sits at (0,0)
+ * (pad_kernel_for_fft, image_ops.rs:123-152), transformed once and multiplied into every image's spectrum */
+sgx_status sgx_fft2d_convolve(sgx_fft2d *plan, const void *images, size_t batch, const void *kernel_host, size_t krows,
+                              size_t kcols, void *out, int32_t mem_kind, void *hip_stream);
+/* lowpass (kind 0, cut_lo), highpass (1, cut_lo), bandpass (2, cut_lo..cut_hi): binary radial masks built on the HALF
+ * spectrum's own dimensions (image_ops.rs:236-267, 301-432 — the reference's quirk S14 is reproduced) */
+sgx_status sgx_fft2d_filter(sgx_fft2d *plan, const void *images, size_t batch, int32_t kind, double cut_lo, double cut_hi,
+                            void *out, int32_t mem_kind, void *hip_stream);
+const char *sgx_fft2d_last_error(const sgx_fft2d *plan);
+
 const char *sgx_last_error(const sgx_plan *plan);
 const char *sgx_last_create_error(void);
 /* Name of the kernel variant the plan dispatches to ("r32x16_f32", "lds_radix2", "direct_dft"). */

@@ -70,6 +70,13 @@ def lib() -> C.CDLL:
             getattr(L, f"orc_spectrogram_batch_{suf}").argtypes = [C.POINTER(_Params), p, sz, sz, sz, p, C.c_int]
             getattr(L, f"orc_stft_batch_{suf}").argtypes = [C.POINTER(_Params), p, sz, sz, sz, p, C.c_int]
             getattr(L, f"orc_mfcc_{suf}").argtypes = [C.POINTER(_Params), C.c_uint32, C.c_int, C.c_uint32, p, sz, p]
+            getattr(L, f"orc_fft2d_{suf}").argtypes = [p, sz, sz, p]
+            getattr(L, f"orc_ifft2d_{suf}").argtypes = [p, sz, sz, p]
+            getattr(L, f"orc_convolve_fft_{suf}").argtypes = [p, sz, sz, p, sz, sz, p]
+            getattr(L, f"orc_filter2d_{suf}").argtypes = [p, sz, sz, C.c_int, C.c_double, C.c_double, p]
+        L.orc_gaussian_kernel_2d.argtypes = [sz, C.c_double, dp]
+        L.orc_lowpass_mask.argtypes = [sz, sz, C.c_double, dp]
+        L.orc_lowpass_mask.restype = None
         _lib = L
     return _lib
 
@@ -261,6 +268,65 @@ def mfcc(p: Params, x: np.ndarray, n_mfcc: int = 13, include_c0: bool = True, li
     rc = getattr(lib(), f"orc_mfcc_{suf}")(C.byref(cp), n_mfcc, int(include_c0), lifter, _ptr(x), x.size, _ptr(out))
     if rc:
         raise OracleError(rc)
+    return out
+
+
+def fft2d(img: np.ndarray) -> np.ndarray:
+    img = np.ascontiguousarray(img)
+    suf = _suf(img.dtype)
+    r, c = img.shape
+    out = np.empty((r, c // 2 + 1, 2), img.dtype)
+    rc = getattr(lib(), f"orc_fft2d_{suf}")(_ptr(img), r, c, _ptr(out))
+    if rc:
+        raise OracleError(rc)
+    return out.view(np.complex64 if suf == "f32" else np.complex128)[..., 0]
+
+
+def ifft2d(spec: np.ndarray, ncols: int) -> np.ndarray:
+    spec = np.ascontiguousarray(spec)
+    rdt = np.float32 if spec.dtype == np.complex64 else np.float64
+    suf = _suf(rdt)
+    r = spec.shape[0]
+    assert spec.shape[1] == ncols // 2 + 1
+    out = np.empty((r, ncols), rdt)
+    rc = getattr(lib(), f"orc_ifft2d_{suf}")(_ptr(spec.view(rdt)), r, ncols, _ptr(out))
+    if rc:
+        raise OracleError(rc)
+    return out
+
+
+def convolve_fft(img: np.ndarray, ker: np.ndarray) -> np.ndarray:
+    img = np.ascontiguousarray(img)
+    ker = np.ascontiguousarray(ker, dtype=img.dtype)
+    suf = _suf(img.dtype)
+    out = np.empty_like(img)
+    rc = getattr(lib(), f"orc_convolve_fft_{suf}")(_ptr(img), img.shape[0], img.shape[1], _ptr(ker), ker.shape[0], ker.shape[1], _ptr(out))
+    if rc:
+        raise OracleError(rc)
+    return out
+
+
+def filter2d(img: np.ndarray, kind: int, lo: float, hi: float = 0.0) -> np.ndarray:
+    img = np.ascontiguousarray(img)
+    suf = _suf(img.dtype)
+    out = np.empty_like(img)
+    rc = getattr(lib(), f"orc_filter2d_{suf}")(_ptr(img), img.shape[0], img.shape[1], kind, float(lo), float(hi), _ptr(out))
+    if rc:
+        raise OracleError(rc)
+    return out
+
+
+def gaussian_kernel_2d(size: int, sigma: float) -> np.ndarray:
+    out = np.empty((size, size), np.float64)
+    rc = lib().orc_gaussian_kernel_2d(size, float(sigma), _ptr(out))
+    if rc:
+        raise OracleError(rc)
+    return out
+
+
+def lowpass_mask(nrows: int, ncols: int, cutoff: float) -> np.ndarray:
+    out = np.empty((nrows, ncols), np.float64)
+    lib().orc_lowpass_mask(nrows, ncols, float(cutoff), _ptr(out))
     return out
 
 

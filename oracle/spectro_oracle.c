@@ -251,6 +251,37 @@ int orc_axes(const orc_params *p, size_t n_frames, double *freqs, double *times)
     return ORC_OK;
 }
 
+/* gaussian_kernel_2d  src/image_ops.rs:188-220 (f64; caller casts v/sum to T) */
+int orc_gaussian_kernel_2d(size_t size, double sigma, double *out) {
+    if (size == 0 || size % 2 == 0) return ORC_INVALID_INPUT; /* "kernel size must be odd and > 0" */
+    if (sigma <= 0.0) return ORC_INVALID_INPUT;
+    double center = (double)(size / 2), variance = sigma * sigma;
+    double coeff = 1.0 / (2.0 * M_PI * variance), sum = 0.0;
+    for (size_t i = 0; i < size; i++)
+        for (size_t j = 0; j < size; j++) {
+            double x = (double)i - center, y = (double)j - center;
+            double e = -(x * x + y * y) / (2.0 * variance);
+            out[i * size + j] = coeff * exp(e);
+        }
+    for (size_t i = 0; i < size * size; i++) sum += out[i]; /* ndarray .sum(): sequential over the standard layout */
+    for (size_t i = 0; i < size * size; i++) out[i] = out[i] / sum;
+    return ORC_OK;
+}
+
+/* create_lowpass_mask  src/image_ops.rs:236-267 — called with the HALF spectrum's dims (quirk S14) */
+void orc_lowpass_mask(size_t nrows, size_t ncols, double cutoff, double *mask) {
+    double mr = (double)(nrows / 2), mc = (double)(ncols / 2);
+    double q = fmin(mr, mc) * cutoff;
+    double max_radius = q * q; /* powi(2) */
+    for (size_t i = 0; i < nrows; i++)
+        for (size_t j = 0; j < ncols; j++) {
+            double fr = i <= nrows / 2 ? (double)i : fabs((double)i - (double)nrows);
+            double fc = j <= ncols / 2 ? (double)j : fabs((double)j - (double)ncols);
+            double d = fma(fc, fc, fr * fr);
+            mask[i * ncols + j] = d <= max_radius ? 1.0 : 0.0;
+        }
+}
+
 int orc_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -98,6 +98,18 @@ int orc_stft_batch_f64(const orc_params *p, const double *x, size_t batch, size_
  * out[(coef * n_frames) + frame], rows = n_mfcc - (include_c0 ? 0 : (n_mfcc > 1)). */
 int orc_mfcc_f32(const orc_params *p, uint32_t n_mfcc, int include_c0, uint32_t lifter, const float *x, size_t n, float *out);
 int orc_mfcc_f64(const orc_params *p, uint32_t n_mfcc, int include_c0, uint32_t lifter, const double *x, size_t n, double *out);
+/* ---- 2-D path: src/fft_backend.rs:653-691 (forward), :744-818 (inverse); src/image_ops.rs:80-152,188-267,301-432 */
+int orc_fft2d_f32(const float *img, size_t nrows, size_t ncols, float *spec /*[nrows][ncols/2+1][2]*/);
+int orc_fft2d_f64(const double *img, size_t nrows, size_t ncols, double *spec);
+int orc_ifft2d_f32(const float *spec, size_t nrows, size_t ncols, float *img);
+int orc_ifft2d_f64(const double *spec, size_t nrows, size_t ncols, double *img);
+int orc_convolve_fft_f32(const float *img, size_t nrows, size_t ncols, const float *ker, size_t kr, size_t kc, float *out);
+int orc_convolve_fft_f64(const double *img, size_t nrows, size_t ncols, const double *ker, size_t kr, size_t kc, double *out);
+/* kind 0 lowpass(cut_lo), 1 highpass(cut_lo), 2 bandpass(cut_lo, cut_hi) */
+int orc_filter2d_f32(const float *img, size_t nrows, size_t ncols, int kind, double cut_lo, double cut_hi, float *out);
+int orc_filter2d_f64(const double *img, size_t nrows, size_t ncols, int kind, double cut_lo, double cut_hi, double *out);
+int orc_gaussian_kernel_2d(size_t size, double sigma, double *out /*size*size, normalised f64*/);
+void orc_lowpass_mask(size_t nrows, size_t ncols, double cutoff, double *mask);
 int orc_max_threads(void);
 
 #ifdef __cplusplus

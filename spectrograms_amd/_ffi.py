@@ -26,6 +26,8 @@ SYMBOLS = [
     "sgx_plan_create", "sgx_plan_destroy", "sgx_output_shape", "sgx_execute", "sgx_execute_timed", "sgx_axes",
     "sgx_r2c", "sgx_window", "sgx_mel_weights", "sgx_shard_range", "sgx_last_error", "sgx_last_create_error",
     "sgx_kernel_name", "sgx_abi_version", "sgx_device_count",
+    "sgx_fft2d_create", "sgx_fft2d_destroy", "sgx_fft2d_forward", "sgx_fft2d_inverse", "sgx_fft2d_convolve",
+    "sgx_fft2d_filter", "sgx_fft2d_last_error",
 ]
 
 
@@ -100,6 +102,15 @@ def lib() -> C.CDLL:
     L.sgx_kernel_name.restype = C.c_char_p
     L.sgx_abi_version.restype = C.c_int32
     L.sgx_device_count.restype = C.c_int32
+    L.sgx_fft2d_create.argtypes = [sz, sz, C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.sgx_fft2d_destroy.argtypes = [vp]
+    L.sgx_fft2d_destroy.restype = None
+    L.sgx_fft2d_forward.argtypes = [vp, vp, sz, vp, C.c_int32, vp]
+    L.sgx_fft2d_inverse.argtypes = [vp, vp, sz, vp, C.c_int32, vp]
+    L.sgx_fft2d_convolve.argtypes = [vp, vp, sz, vp, sz, sz, vp, C.c_int32, vp]
+    L.sgx_fft2d_filter.argtypes = [vp, vp, sz, C.c_int32, C.c_double, C.c_double, vp, C.c_int32, vp]
+    L.sgx_fft2d_last_error.argtypes = [vp]
+    L.sgx_fft2d_last_error.restype = C.c_char_p
     _lib = L
     return L
 

@@ -1,0 +1,306 @@
+// fft2d.hip — host side of the 2-D FFT path of libspectro_hip.so (C ABI: sgx_fft2d_* in include/spectro_hip.h).
+// Row R2C = the STFT engine (an internal sgx_plan with n_fft = hop = ncols, rectangular window, complex output), whose
+// frame-contiguous output is the transposed intermediate [k][r]; columns / inverse rows / pointwise = kernels_fft2d.hip.
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "sgx_internal.h"
+
+using namespace sgx;
+
+struct sgx_fft2d {
+    size_t nrows = 0, ncols = 0, cb = 0;
+    int dtype = SGX_F32, device = -1;
+    size_t elem = 4;
+    sgx_plan *rows = nullptr;              // row R2C through the STFT engine
+    void *d_tw_r = nullptr, *d_tw_c = nullptr;  // e^{-2 pi i k/nrows}, e^{-2 pi i k/ncols}
+    void *d_inter = nullptr, *d_spec = nullptr, *d_kspec = nullptr, *d_mask = nullptr, *d_in = nullptr, *d_out = nullptr, *d_kimg = nullptr;
+    size_t inter_bytes = 0, spec_bytes = 0, kspec_bytes = 0, mask_bytes = 0, in_bytes = 0, out_bytes = 0, kimg_bytes = 0;
+    unsigned log2r = 0, log2c = 0, tile_r = 0, tile_c = 0;
+    mutable std::string err;
+};
+
+namespace {
+
+thread_local std::string g_err2d;
+constexpr double kPi2 = 3.14159265358979323846264338327950288;
+
+sgx_status fail(const sgx_fft2d *p, sgx_status st, const std::string &m) {
+    if (p) p->err = m; else g_err2d = m;
+    return st;
+}
+#define F2_HIP(plan, call)                                                                                            \
+    do {                                                                                                              \
+        hipError_t e_ = (call);                                                                                       \
+        if (e_ != hipSuccess)                                                                                         \
+            return fail(plan, SGX_BACKEND, std::string("hip -- FFT backend error: ") + #call + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+sgx_status grow2(sgx_fft2d *p, void **buf, size_t *have, size_t need) {
+    if (*have >= need) return SGX_OK;
+    if (*buf) F2_HIP(p, hipFree(*buf));
+    *buf = nullptr;
+    *have = 0;
+    F2_HIP(p, hipMalloc(buf, need));
+    *have = need;
+    return SGX_OK;
+}
+
+unsigned ilog2_pow2(size_t n) {  // 0 unless n is a power of two >= 2
+    if (n < 2 || (n & (n - 1))) return 0;
+    unsigned l = 0;
+    while ((size_t(1) << l) < n) ++l;
+    return l;
+}
+
+template <typename T>
+sgx_status upload_tw(sgx_fft2d *p, void **dst, size_t n) {
+    std::vector<T> tw(2 * n);
+    for (size_t k = 0; k < n; ++k) {
+        const double a = -2.0 * kPi2 * double(k) / double(n);
+        tw[2 * k] = T(std::cos(a));
+        tw[2 * k + 1] = T(std::sin(a));
+    }
+    F2_HIP(p, hipMalloc(dst, tw.size() * sizeof(T)));
+    F2_HIP(p, hipMemcpy(*dst, tw.data(), tw.size() * sizeof(T), hipMemcpyHostToDevice));
+    return SGX_OK;
+}
+
+// device pointers in, device pointers out
+sgx_status forward_dev(sgx_fft2d *p, const void *img, size_t batch, void *spec, hipStream_t s) {
+    const size_t R = p->nrows, C = p->ncols, Cb = p->cb;
+    sgx_status st = grow2(p, &p->d_inter, &p->inter_bytes, batch * Cb * R * 2 * p->elem);
+    if (st != SGX_OK) return st;
+    // rows: every image is one "signal" of R*C samples, frames = rows -> inter[b][k][r]
+    st = sgx_execute(p->rows, img, batch, R * C, R * C, p->d_inter, batch * Cb * R * 2, SGX_MEM_DEVICE, s);
+    if (st != SGX_OK) return fail(p, st, sgx_last_error(p->rows));
+    C2cArgs a{};
+    a.in = p->d_inter; a.out = spec;
+    a.n = unsigned(R); a.log2n = p->log2r; a.nseq = unsigned(Cb); a.batch = unsigned(batch);
+    a.in_img = Cb * R; a.out_img = R * Cb;
+    a.in_ss = R; a.in_is = 1; a.out_ss = 1; a.out_is = Cb;
+    a.tile = p->tile_r; a.tiles = unsigned((Cb + a.tile - 1) / a.tile);
+    a.tw = p->d_tw_r; a.inverse = 0; a.in_seq_fast = 0; a.out_seq_fast = 1; a.scale = 1.0;
+    F2_HIP(p, launch_c2c_tile(a, p->dtype, s));
+    return SGX_OK;
+}
+
+sgx_status inverse_dev(sgx_fft2d *p, const void *spec, size_t batch, void *img, hipStream_t s) {
+    const size_t R = p->nrows, C = p->ncols, Cb = p->cb;
+    sgx_status st = grow2(p, &p->d_inter, &p->inter_bytes, batch * Cb * R * 2 * p->elem);
+    if (st != SGX_OK) return st;
+    C2cArgs a{};
+    a.in = spec; a.out = p->d_inter;
+    a.n = unsigned(R); a.log2n = p->log2r; a.nseq = unsigned(Cb); a.batch = unsigned(batch);
+    a.in_img = R * Cb; a.out_img = Cb * R;
+    a.in_ss = 1; a.in_is = Cb; a.out_ss = R; a.out_is = 1;
+    a.tile = p->tile_r; a.tiles = unsigned((Cb + a.tile - 1) / a.tile);
+    a.tw = p->d_tw_r; a.inverse = 1; a.in_seq_fast = 1; a.out_seq_fast = 0; a.scale = 1.0;
+    F2_HIP(p, launch_c2c_tile(a, p->dtype, s));
+    C2rArgs c{};
+    c.in = p->d_inter; c.out = img;
+    c.nrows = unsigned(R); c.ncols = unsigned(C); c.log2c = p->log2c; c.batch = unsigned(batch);
+    c.in_img = Cb * R; c.in_ks = R; c.in_rs = 1;
+    c.tile = p->tile_c; c.tiles = unsigned((R + c.tile - 1) / c.tile);
+    c.tw = p->d_tw_c; c.scale = 1.0 / (double(R) * double(C));
+    F2_HIP(p, launch_c2r_rows(c, p->dtype, s));
+    return SGX_OK;
+}
+
+// create_lowpass_mask (image_ops.rs:236-267) on the half spectrum's own dims (quirk S14), f64 logic
+void lowpass_mask(size_t nrows, size_t ncols, double cutoff, std::vector<double> &m) {
+    m.assign(nrows * ncols, 0.0);
+    const double mr = double(nrows / 2), mc = double(ncols / 2);
+    const double q = std::min(mr, mc) * cutoff;
+    const double max_radius = q * q;
+    for (size_t i = 0; i < nrows; ++i)
+        for (size_t j = 0; j < ncols; ++j) {
+            const double fr = i <= nrows / 2 ? double(i) : std::fabs(double(i) - double(nrows));
+            const double fc = j <= ncols / 2 ? double(j) : std::fabs(double(j) - double(ncols));
+            if (std::fma(fc, fc, fr * fr) <= max_radius) m[i * ncols + j] = 1.0;
+        }
+}
+
+template <typename F>
+sgx_status with_staging(sgx_fft2d *p, const void *in, size_t in_bytes, void *out, size_t out_bytes, int mem_kind,
+                        hipStream_t s, F body) {
+    F2_HIP(p, hipSetDevice(p->device));
+    if (mem_kind == SGX_MEM_DEVICE) return body(in, out);
+    if (mem_kind != SGX_MEM_HOST) return fail(p, SGX_INVALID_INPUT, "Invalid input: unknown mem_kind");
+    sgx_status st;
+    if ((st = grow2(p, &p->d_in, &p->in_bytes, in_bytes)) != SGX_OK) return st;
+    if ((st = grow2(p, &p->d_out, &p->out_bytes, out_bytes)) != SGX_OK) return st;
+    F2_HIP(p, hipMemcpyAsync(p->d_in, in, in_bytes, hipMemcpyHostToDevice, s));
+    if ((st = body(p->d_in, p->d_out)) != SGX_OK) return st;
+    F2_HIP(p, hipMemcpyAsync(out, p->d_out, out_bytes, hipMemcpyDeviceToHost, s));
+    F2_HIP(p, hipStreamSynchronize(s));
+    return SGX_OK;
+}
+
+sgx_status check(sgx_fft2d *p, const void *a, const void *b, size_t batch) {
+    if (!p) return SGX_INVALID_INPUT;
+    if (!a || !b) return fail(p, SGX_INVALID_INPUT, "Invalid input: null buffer");
+    if (batch == 0) return fail(p, SGX_INVALID_INPUT, "Invalid input: batch must be > 0");
+    if (!p->rows) return fail(p, SGX_BACKEND, "hip -- FFT backend error: plan has no HIP device (host-only plan)");
+    return SGX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *sgx_fft2d_last_error(const sgx_fft2d *plan) { return plan ? plan->err.c_str() : g_err2d.c_str(); }
+
+sgx_status sgx_fft2d_create(size_t nrows, size_t ncols, int32_t dtype, int32_t device, sgx_fft2d **out) {
+    if (out) *out = nullptr;
+    if (!out) return fail(nullptr, SGX_INVALID_INPUT, "Invalid input: null argument");
+    if (nrows == 0 || ncols == 0) return fail(nullptr, SGX_INVALID_INPUT, "Invalid input: array dimensions must be > 0");  // fft2d.rs:80-84
+    if (dtype != SGX_F32 && dtype != SGX_F64) return fail(nullptr, SGX_INVALID_INPUT, "Invalid input: dtype must be f32 or f64");
+    if (nrows > 0x7fffffffull || ncols > 0x7fffffffull) return fail(nullptr, SGX_INVALID_INPUT, "Invalid input: dimensions too large");
+    sgx_fft2d *p = new (std::nothrow) sgx_fft2d();
+    if (!p) return fail(nullptr, SGX_INTERNAL, "Internal error: out of memory");
+    p->nrows = nrows; p->ncols = ncols; p->cb = ncols / 2 + 1;
+    p->dtype = dtype; p->elem = dtype == SGX_F64 ? 8 : 4; p->device = device;
+    p->log2r = ilog2_pow2(nrows); p->log2c = ilog2_pow2(ncols);
+    p->tile_r = fft2d_tile_for(unsigned(nrows), dtype);
+    p->tile_c = fft2d_tile_for(unsigned(ncols), dtype);
+    if (p->tile_r == 0 || p->tile_c == 0) {
+        delete p;
+        return fail(nullptr, SGX_BACKEND, "hip -- FFT backend error: image dimension too large for the on-chip tile");
+    }
+    if (device == -2) { *out = p; return SGX_OK; }  // host-only: shapes / validation only
+    sgx_params sp{};
+    sp.n_fft = uint32_t(ncols); sp.hop_size = uint32_t(ncols); sp.centre = 0;
+    sp.window_kind = SGX_WIN_RECTANGULAR; sp.sample_rate_hz = 1.0;
+    sp.freq_scale = SGX_FREQ_LINEAR; sp.amp_scale = SGX_AMP_COMPLEX; sp.dtype = dtype; sp.device = device;
+    sgx_status st = sgx_plan_create(&sp, &p->rows);
+    if (st != SGX_OK) {
+        g_err2d = sgx_last_create_error();
+        delete p;
+        return st;
+    }
+    p->device = p->rows->device;
+    auto tables = [&]() -> sgx_status {
+        F2_HIP(p, hipSetDevice(p->device));
+        sgx_status s1 = dtype == SGX_F64 ? upload_tw<double>(p, &p->d_tw_r, nrows) : upload_tw<float>(p, &p->d_tw_r, nrows);
+        if (s1 != SGX_OK) return s1;
+        return dtype == SGX_F64 ? upload_tw<double>(p, &p->d_tw_c, ncols) : upload_tw<float>(p, &p->d_tw_c, ncols);
+    };
+    st = tables();
+    if (st != SGX_OK) {
+        g_err2d = p->err;
+        sgx_fft2d_destroy(p);
+        return st;
+    }
+    *out = p;
+    return SGX_OK;
+}
+
+void sgx_fft2d_destroy(sgx_fft2d *p) {
+    if (!p) return;
+    if (p->rows) {
+        (void)hipSetDevice(p->device);
+        void *bufs[] = {p->d_tw_r, p->d_tw_c, p->d_inter, p->d_spec, p->d_kspec, p->d_mask, p->d_in, p->d_out, p->d_kimg};
+        for (void *b : bufs)
+            if (b) (void)hipFree(b);
+        sgx_plan_destroy(p->rows);
+    }
+    delete p;
+}
+
+sgx_status sgx_fft2d_forward(sgx_fft2d *p, const void *images, size_t batch, void *spectrum, int32_t mem_kind, void *stream) {
+    sgx_status st = check(p, images, spectrum, batch);
+    if (st != SGX_OK) return st;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t inb = batch * p->nrows * p->ncols * p->elem, outb = batch * p->nrows * p->cb * 2 * p->elem;
+    return with_staging(p, images, inb, spectrum, outb, mem_kind, s,
+                        [&](const void *i, void *o) { return forward_dev(p, i, batch, o, s); });
+}
+
+sgx_status sgx_fft2d_inverse(sgx_fft2d *p, const void *spectrum, size_t batch, void *images, int32_t mem_kind, void *stream) {
+    sgx_status st = check(p, spectrum, images, batch);
+    if (st != SGX_OK) return st;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t inb = batch * p->nrows * p->cb * 2 * p->elem, outb = batch * p->nrows * p->ncols * p->elem;
+    return with_staging(p, spectrum, inb, images, outb, mem_kind, s,
+                        [&](const void *i, void *o) { return inverse_dev(p, i, batch, o, s); });
+}
+
+sgx_status sgx_fft2d_convolve(sgx_fft2d *p, const void *images, size_t batch, const void *kernel_host, size_t krows,
+                              size_t kcols, void *out, int32_t mem_kind, void *stream) {
+    sgx_status st = check(p, images, out, batch);
+    if (st != SGX_OK) return st;
+    if (!kernel_host) return fail(p, SGX_INVALID_INPUT, "Invalid input: null buffer");
+    if (krows > p->nrows || kcols > p->ncols)  // image_ops.rs:87-91
+        return fail(p, SGX_INVALID_INPUT, "Invalid input: kernel dimensions must not exceed image dimensions");
+    if (krows == 0 || kcols == 0) return fail(p, SGX_INVALID_INPUT, "Invalid input: kernel dimensions must be > 0");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t R = p->nrows, C = p->ncols, Cb = p->cb;
+    F2_HIP(p, hipSetDevice(p->device));
+    // pad_kernel_for_fft (image_ops.rs:123-152): kernel centre -> (0,0), wrapped
+    std::vector<unsigned char> padded(R * C * p->elem, 0);
+    const long cr = long(krows / 2), cc = long(kcols / 2);
+    for (size_t i = 0; i < krows; ++i)
+        for (size_t j = 0; j < kcols; ++j) {
+            const long tr = ((long(i) - cr) % long(R) + long(R)) % long(R), tc = ((long(j) - cc) % long(C) + long(C)) % long(C);
+            std::memcpy(&padded[(size_t(tr) * C + size_t(tc)) * p->elem], (const unsigned char *)kernel_host + (i * kcols + j) * p->elem, p->elem);
+        }
+    if ((st = grow2(p, &p->d_kimg, &p->kimg_bytes, padded.size())) != SGX_OK) return st;
+    if ((st = grow2(p, &p->d_kspec, &p->kspec_bytes, R * Cb * 2 * p->elem)) != SGX_OK) return st;
+    F2_HIP(p, hipMemcpyAsync(p->d_kimg, padded.data(), padded.size(), hipMemcpyHostToDevice, s));
+    F2_HIP(p, hipStreamSynchronize(s));  // `padded` goes out of scope
+    if ((st = forward_dev(p, p->d_kimg, 1, p->d_kspec, s)) != SGX_OK) return st;
+    const size_t imgb = batch * R * C * p->elem;
+    return with_staging(p, images, imgb, out, imgb, mem_kind, s, [&](const void *i, void *o) -> sgx_status {
+        sgx_status s2 = grow2(p, &p->d_spec, &p->spec_bytes, batch * R * Cb * 2 * p->elem);
+        if (s2 != SGX_OK) return s2;
+        if ((s2 = forward_dev(p, i, batch, p->d_spec, s)) != SGX_OK) return s2;
+        F2_HIP(p, launch_pointwise(p->d_spec, p->d_kspec, p->d_spec, batch * R * Cb, R * Cb, 0, p->dtype, s));
+        return inverse_dev(p, p->d_spec, batch, o, s);
+    });
+}
+
+sgx_status sgx_fft2d_filter(sgx_fft2d *p, const void *images, size_t batch, int32_t kind, double cut_lo, double cut_hi,
+                            void *out, int32_t mem_kind, void *stream) {
+    sgx_status st = check(p, images, out, batch);
+    if (st != SGX_OK) return st;
+    auto in01 = [](double v) { return v >= 0.0 && v <= 1.0; };
+    if (kind == 0 || kind == 1) {
+        if (!in01(cut_lo)) return fail(p, SGX_INVALID_INPUT, "Invalid input: cutoff_fraction must be between 0.0 and 1.0");
+    } else if (kind == 2) {
+        if (!in01(cut_lo) || !in01(cut_hi)) return fail(p, SGX_INVALID_INPUT, "Invalid input: cutoff fractions must be between 0.0 and 1.0");
+        if (cut_lo >= cut_hi) return fail(p, SGX_INVALID_INPUT, "Invalid input: high_cutoff must be greater than low_cutoff");
+    } else {
+        return fail(p, SGX_INVALID_INPUT, "Invalid input: unknown filter kind");
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t R = p->nrows, C = p->ncols, Cb = p->cb;
+    F2_HIP(p, hipSetDevice(p->device));
+    std::vector<double> m, m2;
+    lowpass_mask(R, Cb, cut_lo, m);  // spectrum.dim() = (nrows, ncols/2+1): S14
+    if (kind == 1) for (double &v : m) v = 1.0 - v;
+    if (kind == 2) {
+        lowpass_mask(R, Cb, cut_hi, m2);
+        for (size_t i = 0; i < m.size(); ++i) m[i] = m2[i] - m[i];
+    }
+    std::vector<unsigned char> mt(m.size() * p->elem);
+    for (size_t i = 0; i < m.size(); ++i) {
+        if (p->dtype == SGX_F64) ((double *)mt.data())[i] = m[i]; else ((float *)mt.data())[i] = float(m[i]);
+    }
+    if ((st = grow2(p, &p->d_mask, &p->mask_bytes, mt.size())) != SGX_OK) return st;
+    F2_HIP(p, hipMemcpyAsync(p->d_mask, mt.data(), mt.size(), hipMemcpyHostToDevice, s));
+    F2_HIP(p, hipStreamSynchronize(s));
+    const size_t imgb = batch * R * C * p->elem;
+    return with_staging(p, images, imgb, out, imgb, mem_kind, s, [&](const void *i, void *o) -> sgx_status {
+        sgx_status s2 = grow2(p, &p->d_spec, &p->spec_bytes, batch * R * Cb * 2 * p->elem);
+        if (s2 != SGX_OK) return s2;
+        if ((s2 = forward_dev(p, i, batch, p->d_spec, s)) != SGX_OK) return s2;
+        F2_HIP(p, launch_pointwise(p->d_spec, p->d_mask, p->d_spec, batch * R * Cb, R * Cb, 1, p->dtype, s));
+        return inverse_dev(p, p->d_spec, batch, o, s);
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,202 @@
+// kernels_fft2d.hip — shape-generic kernels of the 2-D FFT path (SURVEY.md §8 a17 / BASELINE config 5), f32 and f64.
+//
+// Reference algorithm (src/fft_backend.rs:653-691 forward, :744-818 inverse): row-column.  Forward = R2C along rows,
+// then C2C along the nrows-long columns of the (nrows, ncols/2+1) half spectrum.  Inverse = inverse C2C along columns,
+// force the DC / Nyquist columns real (:782-793), C2R along rows, scale by 1/(nrows*ncols) (:810-815).
+//
+// Here the row R2C is the STFT engine itself (n_fft = hop = ncols, rectangular window, no centring, complex output):
+// its frame-contiguous output layout [k][r] is exactly the transposed intermediate the column pass wants.  This file
+// holds the remaining pieces as LDS-tile kernels with transposing, coalesced loads/stores:
+//   k_c2c_tile   `tile` sequences of length n per workgroup in LDS; radix-2 (power-of-two n) or direct DFT; forward or
+//                inverse; arbitrary element strides on both sides, the thread mapping follows the unit stride
+//   k_c2r_rows   per row: Hermitian extension of the half spectrum into LDS (with the DC/Nyquist fix), inverse complex
+//                FFT, real part * scale -> contiguous image rows
+//   k_pointwise  spectrum x spectrum (convolve_fft, src/image_ops.rs:109) or spectrum x real mask (:315)
+#include "sgx_internal.h"
+
+namespace sgx {
+
+template <typename T>
+struct Cx2 {
+    T re, im;
+};
+
+template <typename T>
+__device__ inline Cx2<T> cmul2(Cx2<T> a, Cx2<T> b) {
+    return Cx2<T>{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+}
+
+// in-LDS radix-2 DIT over `nb` bit-reverse-ordered sequences of length n = 2^log2n, row stride fs; tw[k] = e^{-2 pi i k/n}
+template <typename T>
+__device__ inline void lds_fft_pow2(Cx2<T> *buf, unsigned nb, unsigned n, unsigned log2n, unsigned fs, const Cx2<T> *tw,
+                                    bool inverse) {
+    const unsigned half = n >> 1;
+    for (unsigned h = 1, lh = 0; h < n; h <<= 1, lh++) {
+        const unsigned twstep = n >> (lh + 1);
+        for (unsigned idx = threadIdx.x; idx < nb * half; idx += blockDim.x) {
+            const unsigned s = idx / half, q = idx - s * half;
+            const unsigned j = q & (h - 1), blk = q >> lh;
+            const unsigned p0 = s * fs + (blk << (lh + 1)) + j, p1 = p0 + h;
+            Cx2<T> w = tw[j * twstep];
+            if (inverse) w.im = -w.im;
+            const Cx2<T> u = buf[p0], v = cmul2(buf[p1], w);
+            buf[p0] = Cx2<T>{u.re + v.re, u.im + v.im};
+            buf[p1] = Cx2<T>{u.re - v.re, u.im - v.im};
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_c2c_tile(C2cArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Cx2<T> *buf = (Cx2<T> *)smem;
+    const unsigned n = a.n, fs = n + 1;
+    const unsigned t = blockIdx.x % a.tiles, b = blockIdx.x / a.tiles;
+    const unsigned s0 = t * a.tile;
+    const unsigned ns = min(a.tile, a.nseq - s0);
+    const Cx2<T> *in = (const Cx2<T> *)a.in + (size_t)b * a.in_img;
+    Cx2<T> *out = (Cx2<T> *)a.out + (size_t)b * a.out_img;
+    const Cx2<T> *tw = (const Cx2<T> *)a.tw;
+    const bool pow2 = a.log2n > 0;
+    for (unsigned idx = threadIdx.x; idx < ns * n; idx += 256) {
+        unsigned s, i;
+        if (a.in_seq_fast) { s = idx % ns; i = idx / ns; } else { i = idx % n; s = idx / n; }
+        const Cx2<T> v = in[(size_t)(s0 + s) * a.in_ss + (size_t)i * a.in_is];
+        const unsigned pos = pow2 ? (__brev(i) >> (32 - a.log2n)) : i;
+        buf[s * fs + pos] = v;
+    }
+    __syncthreads();
+    const T scale = (T)a.scale;
+    if (pow2) {
+        lds_fft_pow2<T>(buf, ns, n, a.log2n, fs, tw, a.inverse);
+        for (unsigned idx = threadIdx.x; idx < ns * n; idx += 256) {
+            unsigned s, o;
+            if (a.out_seq_fast) { s = idx % ns; o = idx / ns; } else { o = idx % n; s = idx / n; }
+            const Cx2<T> v = buf[s * fs + o];
+            out[(size_t)(s0 + s) * a.out_ss + (size_t)o * a.out_is] = Cx2<T>{v.re * scale, v.im * scale};
+        }
+    } else {  // direct sum (n == 1 lands here too)
+        for (unsigned idx = threadIdx.x; idx < ns * n; idx += 256) {
+            unsigned s, o;
+            if (a.out_seq_fast) { s = idx % ns; o = idx / ns; } else { o = idx % n; s = idx / n; }
+            T sr = T(0), si = T(0);
+            unsigned tt = 0;
+            for (unsigned i = 0; i < n; ++i) {
+                Cx2<T> w = tw[tt];
+                if (a.inverse) w.im = -w.im;
+                const Cx2<T> v = buf[s * fs + i];
+                sr += v.re * w.re - v.im * w.im;
+                si += v.re * w.im + v.im * w.re;
+                tt += o;
+                if (tt >= n) tt -= n;
+            }
+            out[(size_t)(s0 + s) * a.out_ss + (size_t)o * a.out_is] = Cx2<T>{sr * scale, si * scale};
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_c2r_rows(C2rArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Cx2<T> *buf = (Cx2<T> *)smem;
+    const unsigned C = a.ncols, Cb = C / 2 + 1, fs = C + 1;
+    const unsigned t = blockIdx.x % a.tiles, b = blockIdx.x / a.tiles;
+    const unsigned r0 = t * a.tile;
+    const unsigned nr = min(a.tile, a.nrows - r0);
+    const Cx2<T> *in = (const Cx2<T> *)a.in + (size_t)b * a.in_img;
+    T *out = (T *)a.out + (size_t)b * a.nrows * C;
+    const Cx2<T> *tw = (const Cx2<T> *)a.tw;
+    const bool pow2 = a.log2c > 0;
+    // Hermitian extension X[C-k] = conj(X[k]); DC and (even C) Nyquist columns forced real (fft_backend.rs:782-793)
+    for (unsigned idx = threadIdx.x; idx < nr * Cb; idx += 256) {
+        const unsigned r = idx % nr, k = idx / nr;  // rows fastest: the input is [k][r]-major
+        Cx2<T> v = in[(size_t)k * a.in_ks + (size_t)(r0 + r) * a.in_rs];
+        if (k == 0 || (!(C & 1u) && k == Cb - 1)) v.im = T(0);
+        const unsigned p = pow2 ? (__brev(k) >> (32 - a.log2c)) : k;
+        buf[r * fs + p] = v;
+        const unsigned km = C - k;
+        if (k != 0 && km != k) {
+            const unsigned pm = pow2 ? (__brev(km) >> (32 - a.log2c)) : km;
+            buf[r * fs + pm] = Cx2<T>{v.re, -v.im};
+        }
+    }
+    __syncthreads();
+    const T scale = (T)a.scale;
+    if (pow2) {
+        lds_fft_pow2<T>(buf, nr, C, a.log2c, fs, tw, true);
+        for (unsigned idx = threadIdx.x; idx < nr * C; idx += 256) {
+            const unsigned c = idx % C, r = idx / C;
+            out[(size_t)(r0 + r) * C + c] = buf[r * fs + c].re * scale;
+        }
+    } else {
+        for (unsigned idx = threadIdx.x; idx < nr * C; idx += 256) {
+            const unsigned c = idx % C, r = idx / C;
+            T sr = T(0);
+            unsigned tt = 0;
+            for (unsigned k = 0; k < C; ++k) {
+                const Cx2<T> w = tw[tt], v = buf[r * fs + k];  // e^{+i..} = conj(tw): re part = v.re*w.re + v.im*w.im
+                sr += v.re * w.re + v.im * w.im;
+                tt += c;
+                if (tt >= C) tt -= C;
+            }
+            out[(size_t)(r0 + r) * C + c] = sr * scale;
+        }
+    }
+}
+
+// mode 0: out = a * b[i % per] (complex x complex); mode 1: out = a * m[i % per] (complex x real mask)
+template <typename T>
+__global__ __launch_bounds__(256) void k_pointwise(const Cx2<T> *x, const void *y, Cx2<T> *out, unsigned long long n,
+                                                   unsigned long long per, int mode) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
+        const Cx2<T> v = x[i];
+        if (mode == 0) {
+            out[i] = cmul2(v, ((const Cx2<T> *)y)[i % per]);
+        } else {
+            const T m = ((const T *)y)[i % per];
+            out[i] = Cx2<T>{v.re * m, v.im * m};
+        }
+    }
+}
+
+static size_t esz(int dtype) { return dtype == SGX_F64 ? 8 : 4; }
+
+unsigned fft2d_tile_for(unsigned n, int dtype) {
+    const size_t per = (size_t)(n + 1) * 2 * esz(dtype);
+    unsigned tile = 16;
+    while (tile > 1 && per * tile > 64 * 1024) tile >>= 1;
+    return per * tile <= 64 * 1024 ? tile : 0;
+}
+
+hipError_t launch_c2c_tile(const C2cArgs &a, int dtype, hipStream_t s) {
+    const unsigned long long g = (unsigned long long)a.tiles * a.batch;
+    if (g == 0 || g >= 0x7fffffffull || a.tile == 0) return hipErrorInvalidConfiguration;
+    const size_t lds = (size_t)a.tile * (a.n + 1) * 2 * esz(dtype);
+    if (dtype == SGX_F64) hipLaunchKernelGGL(k_c2c_tile<double>, dim3((unsigned)g), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(k_c2c_tile<float>, dim3((unsigned)g), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_c2r_rows(const C2rArgs &a, int dtype, hipStream_t s) {
+    const unsigned long long g = (unsigned long long)a.tiles * a.batch;
+    if (g == 0 || g >= 0x7fffffffull || a.tile == 0) return hipErrorInvalidConfiguration;
+    const size_t lds = (size_t)a.tile * (a.ncols + 1) * 2 * esz(dtype);
+    if (dtype == SGX_F64) hipLaunchKernelGGL(k_c2r_rows<double>, dim3((unsigned)g), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(k_c2r_rows<float>, dim3((unsigned)g), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_pointwise(const void *x, const void *y, void *out, unsigned long long n, unsigned long long per, int mode,
+                            int dtype, hipStream_t s) {
+    unsigned long long blocks = (n + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    if (blocks == 0) return hipErrorInvalidConfiguration;
+    if (dtype == SGX_F64)
+        hipLaunchKernelGGL(k_pointwise<double>, dim3((unsigned)blocks), dim3(256), 0, s, (const Cx2<double> *)x, y, (Cx2<double> *)out, n, per, mode);
+    else
+        hipLaunchKernelGGL(k_pointwise<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const Cx2<float> *)x, y, (Cx2<float> *)out, n, per, mode);
+    return hipGetLastError();
+}
+
+}  // namespace sgx

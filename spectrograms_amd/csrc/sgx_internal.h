@@ -64,6 +64,35 @@ bool plan_geometry_direct_dft(StftArgs &a, int dtype);
 bool plan_geometry_lds_radix2(StftArgs &a, int dtype);
 bool plan_geometry_r32x16_f32(StftArgs &a);
 
+// ---- 2-D FFT path (kernels_fft2d.hip)
+struct C2cArgs {
+    const void *in;
+    void *out;
+    unsigned n, log2n;  // log2n == 0: not a power of two (direct DFT)
+    unsigned nseq, batch;
+    unsigned long long in_img, out_img;              // elements between images
+    unsigned long long in_ss, in_is, out_ss, out_is;  // sequence / index strides (elements)
+    unsigned tile, tiles;
+    const void *tw;  // e^{-2 pi i k / n}, n entries
+    int inverse;
+    int in_seq_fast, out_seq_fast;  // which of (sequence, index) is the unit-stride side: drives the thread mapping
+    double scale;
+};
+struct C2rArgs {
+    const void *in;  // half spectrum, element (row r, col k) at in[b*in_img + k*in_ks + r*in_rs]
+    void *out;       // real [batch][nrows][ncols]
+    unsigned nrows, ncols, log2c, batch;
+    unsigned long long in_img, in_ks, in_rs;
+    unsigned tile, tiles;
+    const void *tw;  // e^{-2 pi i k / ncols}, ncols entries
+    double scale;
+};
+unsigned fft2d_tile_for(unsigned n, int dtype);
+hipError_t launch_c2c_tile(const C2cArgs &a, int dtype, hipStream_t s);
+hipError_t launch_c2r_rows(const C2rArgs &a, int dtype, hipStream_t s);
+hipError_t launch_pointwise(const void *x, const void *y, void *out, unsigned long long n, unsigned long long per, int mode,
+                            int dtype, hipStream_t s);
+
 }  // namespace sgx
 
 struct sgx_plan {

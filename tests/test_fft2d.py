@@ -1,0 +1,162 @@
+"""2-D FFT path (BASELINE config 5).  CPU: the oracle against numpy's rfft2/irfft2 and the
+reference's known-answer tests (tests/fft2d_tests.rs, tests/images_ops_tests.rs, src/image_ops.rs:560-621).
+GPU: the HIP path through the C ABI against the oracle."""
+import numpy as np
+import pytest
+
+import spectrograms_amd as sg
+from oracle import oracle as orc
+from spectrograms_amd import _ffi
+
+SHAPES = [(1, 1), (2, 2), (3, 3), (4, 4), (5, 5), (8, 8), (16, 32), (10, 12), (7, 9), (64, 64), (33, 20), (100, 50), (128, 128)]
+
+
+def img(shape, seed=0, dtype=np.float64):
+    rng = np.random.default_rng(seed)
+    r, c = np.meshgrid(np.arange(shape[0]), np.arange(shape[1]), indexing="ij")
+    return (np.sin(0.01 * r) + np.cos(0.02 * c) + 0.05 * rng.standard_normal(shape)).astype(dtype)
+
+
+# ------------------------------------------------------------------ oracle pinned on CPU
+@pytest.mark.parametrize("shape", SHAPES)
+def test_oracle_fft2d_matches_numpy_and_roundtrips(shape):
+    x = img(shape)
+    S = orc.fft2d(x)
+    ref = np.fft.rfft2(x)
+    assert S.shape == (shape[0], shape[1] // 2 + 1)  # S13
+    assert np.max(np.abs(S - ref)) < 1e-10 * max(1.0, np.max(np.abs(ref)))
+    assert np.max(np.abs(orc.ifft2d(S, shape[1]) - x)) < 1e-10          # tests/fft2d_tests.rs:67-143 round trips
+    assert np.max(np.abs(orc.ifft2d(ref.copy(), shape[1]) - np.fft.irfft2(ref, s=shape))) < 1e-10
+    x32 = x.astype(np.float32)
+    assert np.max(np.abs(orc.fft2d(x32) - ref)) < 1e-5 * max(1.0, np.max(np.abs(ref)))
+
+
+def test_oracle_fft2d_kats():
+    # tests/fft2d_tests.rs:160-203: ones -> DC = rows*cols, rest < 1e-10; delta -> all 1+0i; Parseval; linearity
+    ones = np.ones((8, 12))
+    S = orc.fft2d(ones)
+    assert abs(S[0, 0] - 96.0) < 1e-10
+    S[0, 0] = 0
+    assert np.max(np.abs(S)) < 1e-10
+    d = np.zeros((8, 12))
+    d[0, 0] = 1.0
+    assert np.max(np.abs(orc.fft2d(d) - 1.0)) < 1e-12
+    a, b = img((16, 16), 1), img((16, 16), 2)
+    assert np.max(np.abs(orc.fft2d(2 * a + 3 * b) - (2 * orc.fft2d(a) + 3 * orc.fft2d(b)))) < 1e-10
+    S = orc.fft2d(a)
+    full = np.fft.fft2(a)
+    assert abs((np.abs(full) ** 2).sum() / a.size - (a ** 2).sum()) < 1e-6  # Parseval (full spectrum)
+    assert np.allclose(S, full[:, :9], atol=1e-10)
+
+
+def test_oracle_inverse_forces_dc_and_nyquist_real():
+    # src/fft_backend.rs:782-793: imag parts of the DC / Nyquist columns are dropped after the column IFFT
+    rng = np.random.default_rng(3)
+    S = rng.standard_normal((6, 5)) + 1j * rng.standard_normal((6, 5))  # ncols = 8 -> Nyquist column 4
+    cols = np.fft.ifft(S, axis=0) * 6
+    cols[:, 0] = cols[:, 0].real
+    cols[:, 4] = cols[:, 4].real
+    ref = np.fft.irfft(cols, n=8, axis=1) * 8 / 48.0
+    assert np.max(np.abs(orc.ifft2d(S, 8) - ref)) < 1e-12
+
+
+def test_oracle_image_ops_kats():
+    # src/image_ops.rs:560-621 and tests/images_ops_tests.rs
+    k = orc.gaussian_kernel_2d(5, 1.0)
+    assert abs(k.sum() - 1.0) < 1e-10 and np.allclose(k, k.T) and np.allclose(k, k[::-1, ::-1])
+    assert np.allclose(sg.gaussian_kernel_2d(5, 1.0), k, rtol=1e-15) and np.allclose(sg.gaussian_kernel_2d(9, 2.0), orc.gaussian_kernel_2d(9, 2.0), rtol=1e-15)
+    image = np.add.outer(np.arange(64.0), np.arange(64.0))
+    ident = np.zeros((3, 3))
+    ident[1, 1] = 1.0
+    res = orc.convolve_fft(image, ident)
+    assert np.max(np.abs(res[1:63, 1:63] - image[1:63, 1:63])) < 1e-6
+    wav = (np.sin(0.5 * np.arange(64))[:, None] + np.cos(0.5 * np.arange(64))[None, :]) * 50.0
+    lp = orc.filter2d(wav, 0, 0.2)
+    assert (lp ** 2).mean() < (wav ** 2).mean()
+    hp = orc.filter2d(np.full((32, 32), 7.0), 1, 0.1)
+    assert np.max(np.abs(hp)) < 1e-9  # highpass(const) ~ 0
+    with pytest.raises(orc.OracleError):
+        orc.filter2d(wav, 2, 0.5, 0.2)
+    # convolution against a direct circular sum
+    rng = np.random.default_rng(4)
+    a, kk = rng.standard_normal((12, 10)), rng.standard_normal((3, 5))
+    direct = np.zeros_like(a)
+    for i in range(3):
+        for j in range(5):
+            direct += kk[i, j] * np.roll(np.roll(a, i - 1, axis=0), j - 2, axis=1)
+    assert np.max(np.abs(orc.convolve_fft(a, kk) - direct)) < 1e-10
+
+
+def test_lowpass_mask_uses_half_spectrum_dims():
+    # S14: the radius / wrap use (nrows, ncols/2+1) as if it were the full width
+    m = orc.lowpass_mask(64, 33, 0.5)
+    assert m.shape == (64, 33) and m[0, 0] == 1.0
+    r = min(64 // 2, 33 // 2) * 0.5
+    assert m[0, int(r)] == 1.0 and m[0, int(r) + 1] == 0.0
+    assert m[0, 33 - int(r)] == 1.0  # "wrapped" on the half width — the quirk
+
+
+def test_host_validation():
+    with pytest.raises(sg.InvalidInputError):
+        sg.Fft2dPlan(0, 4, device=_ffi.DEVICE_HOST_ONLY)
+    with pytest.raises(sg.InvalidInputError):
+        sg.gaussian_kernel_2d(4, 1.0)
+    with pytest.raises(sg.InvalidInputError):
+        sg.gaussian_kernel_2d(5, 0.0)
+    pl = sg.Fft2dPlan(8, 8, "float32", device=_ffi.DEVICE_HOST_ONLY)
+    with pytest.raises(sg.FFTBackendError):
+        pl.forward(np.zeros((8, 8), np.float32))
+
+
+# ------------------------------------------------------------------ GPU parity
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("shape", SHAPES + [(256, 256), (1024, 1024), (512, 1024), (1024, 64)])
+def test_gpu_fft2d_matches_oracle(shape, dtype):
+    npdt = np.float32 if dtype == "float32" else np.float64
+    x = img(shape, 5, npdt)
+    S = sg.fft2d(x, dtype=dtype)
+    ref = orc.fft2d(x.astype(np.float64))
+    tol = 1e-10 if dtype == "float64" else 2e-5
+    assert S.shape == ref.shape and S.dtype == (np.complex64 if dtype == "float32" else np.complex128)
+    assert np.max(np.abs(S - ref)) <= tol * max(1.0, np.max(np.abs(ref)))
+    y = sg.ifft2d(S, shape[1], dtype=dtype)
+    assert np.max(np.abs(y - x)) <= (1e-10 if dtype == "float64" else 1e-5) * max(1.0, np.max(np.abs(x)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_gpu_image_ops_match_oracle(dtype):
+    npdt = np.float32 if dtype == "float32" else np.float64
+    tol = 1e-9 if dtype == "float64" else 2e-5
+    for shape, ksz in (((64, 64), 9), ((100, 50), 5), ((256, 128), 9)):
+        x = img(shape, 7, npdt)
+        k = sg.gaussian_kernel_2d(ksz, 2.0, dtype=dtype)
+        got = sg.convolve_fft(x, k, dtype=dtype)
+        ref = orc.convolve_fft(x.astype(np.float64), k.astype(np.float64))
+        assert np.max(np.abs(got - ref)) <= tol * max(1.0, np.max(np.abs(ref)))
+        for kind, fn, args in ((0, sg.lowpass_filter, (0.3,)), (1, sg.highpass_filter, (0.2,)), (2, sg.bandpass_filter, (0.1, 0.6))):
+            got = fn(x, *args, dtype=dtype)
+            ref = orc.filter2d(x.astype(np.float64), kind, *args)
+            assert np.max(np.abs(got - ref)) <= tol * max(1.0, np.max(np.abs(ref)))
+    with pytest.raises(sg.InvalidInputError, match="high_cutoff must be greater"):  # tests/images_ops_tests.rs:409-427
+        sg.bandpass_filter(np.zeros((16, 16)), 0.5, 0.2)
+    with pytest.raises(sg.InvalidInputError, match="must not exceed"):
+        sg.convolve_fft(np.zeros((4, 4)), np.zeros((5, 5)))
+    with pytest.raises(sg.DimensionMismatchError):
+        sg.ifft2d(np.zeros((8, 4), np.complex128), 8)  # 8 // 2 + 1 = 5 columns expected
+
+
+@pytest.mark.gpu
+def test_gpu_fft2d_batched_config5_subset():
+    # BASELINE config 5 shape, 4 of the 512 images: batched forward + Gaussian 9x9 convolve vs the oracle per image
+    imgs = np.stack([img((1024, 1024), 7 + k, np.float32) for k in range(4)])
+    plan = sg.Fft2dPlan(1024, 1024, "float32")
+    S = plan.forward(imgs)
+    k = sg.gaussian_kernel_2d(9, 2.0, dtype="float32")
+    Y = plan.convolve(imgs, k)
+    for i in range(4):
+        ref = orc.fft2d(imgs[i].astype(np.float64))
+        assert np.max(np.abs(S[i] - ref)) <= 2e-5 * np.max(np.abs(ref))
+        rc = orc.convolve_fft(imgs[i].astype(np.float64), k.astype(np.float64))
+        assert np.max(np.abs(Y[i] - rc)) <= 2e-5 * np.max(np.abs(rc))
