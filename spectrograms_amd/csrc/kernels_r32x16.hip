@@ -446,18 +446,15 @@ __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned
             const v2f *w2 = (const v2f *)(tabs + kWinOff) + n2;
 #pragma unroll
             for (int n1 = 0; n1 < 32; ++n1) wn[n1] = w2[16 * n1];
-            if constexpr (ROUNDS > 0) {
-                __syncthreads();  // every wave has read xs: pass 1 may overwrite it with ex
-                if (wid + slots * HALVES < hi) load_tile(wid + slots * HALVES);  // next tile's chunks: in flight all tile long
-            }
+            if constexpr (ROUNDS > 0) __syncthreads();  // every wave has read xs: pass 1 may overwrite it with ex
             SGX_STAMP(0);
             if (active) pass1_compute(xr, wn, twa, twb, smem + p1f * kFS + n2 * 8);
             SGX_STAMP(1);
         }
         const unsigned next = wid + slots * HALVES;
-        if constexpr (ROUNDS == 0) {
-            if (next < hi) load_tile(next);  // in flight during pass 2
-        }
+        // requested after pass 1 so the previous tile's store burst has had that long to drain: a vector load issued while
+        // the CU's store FIFO is backed up stalls its wave for thousands of cycles
+        if (next < hi) load_tile(next);  // in flight during pass 2
         SGX_STAMP(2);
         __syncthreads();
         SGX_STAMP(3);
