@@ -17,6 +17,8 @@ struct sgx_fft2d {
     size_t elem = 4;
     sgx_plan *rows = nullptr;              // row R2C through the STFT engine
     void *d_tw_r = nullptr, *d_tw_c = nullptr;  // e^{-2 pi i k/nrows}, e^{-2 pi i k/ncols}
+    void *d_tw1c = nullptr;                     // tuned column pass (f32, nrows == 1024): W_1024^(k1*n2), [32][32]
+    void *d_twr = nullptr, *d_tw1r = nullptr;   // tuned inverse row pass (f32, ncols == 1024): conj(W_1024^k) [32][16], W_512^(k1 n2) [32][16]
     void *d_inter = nullptr, *d_spec = nullptr, *d_kspec = nullptr, *d_mask = nullptr, *d_in = nullptr, *d_out = nullptr, *d_kimg = nullptr;
     size_t inter_bytes = 0, spec_bytes = 0, kspec_bytes = 0, mask_bytes = 0, in_bytes = 0, out_bytes = 0, kimg_bytes = 0;
     unsigned log2r = 0, log2c = 0, tile_r = 0, tile_c = 0;
@@ -84,7 +86,12 @@ sgx_status forward_dev(sgx_fft2d *p, const void *img, size_t batch, void *spec, 
     a.in_ss = R; a.in_is = 1; a.out_ss = 1; a.out_is = Cb;
     a.tile = p->tile_r; a.tiles = unsigned((Cb + a.tile - 1) / a.tile);
     a.tw = p->d_tw_r; a.inverse = 0; a.in_seq_fast = 0; a.out_seq_fast = 1; a.scale = 1.0;
-    F2_HIP(p, launch_c2c_tile(a, p->dtype, s));
+    if (p->d_tw1c) {
+        a.tile = 16; a.tiles = unsigned((Cb + 15) / 16);
+        F2_HIP(p, launch_c2c1024(a, p->d_tw1c, s));
+    } else {
+        F2_HIP(p, launch_c2c_tile(a, p->dtype, s));
+    }
     return SGX_OK;
 }
 
@@ -99,14 +106,27 @@ sgx_status inverse_dev(sgx_fft2d *p, const void *spec, size_t batch, void *img, 
     a.in_ss = 1; a.in_is = Cb; a.out_ss = R; a.out_is = 1;
     a.tile = p->tile_r; a.tiles = unsigned((Cb + a.tile - 1) / a.tile);
     a.tw = p->d_tw_r; a.inverse = 1; a.in_seq_fast = 1; a.out_seq_fast = 0; a.scale = 1.0;
-    F2_HIP(p, launch_c2c_tile(a, p->dtype, s));
     C2rArgs c{};
     c.in = p->d_inter; c.out = img;
     c.nrows = unsigned(R); c.ncols = unsigned(C); c.log2c = p->log2c; c.batch = unsigned(batch);
-    c.in_img = Cb * R; c.in_ks = R; c.in_rs = 1;
+    c.in_img = Cb * R;
+    if (p->d_tw1c) {  // tuned columns write [r][k] (sequence-contiguous stores); the row pass then reads rows contiguously
+        a.out_ss = 1; a.out_is = Cb; a.out_seq_fast = 1;
+        a.tile = 16; a.tiles = unsigned((Cb + 15) / 16);
+        F2_HIP(p, launch_c2c1024(a, p->d_tw1c, s));
+        c.in_ks = 1; c.in_rs = Cb; c.k_fast = 1;
+    } else {
+        F2_HIP(p, launch_c2c_tile(a, p->dtype, s));
+        c.in_ks = R; c.in_rs = 1; c.k_fast = 0;
+    }
     c.tile = p->tile_c; c.tiles = unsigned((R + c.tile - 1) / c.tile);
     c.tw = p->d_tw_c; c.scale = 1.0 / (double(R) * double(C));
-    F2_HIP(p, launch_c2r_rows(c, p->dtype, s));
+    if (p->d_twr && c.in_ks == 1) {
+        c.tile = 16; c.tiles = unsigned((R + 15) / 16);
+        F2_HIP(p, launch_c2r1024(c, p->d_twr, p->d_tw1r, s));
+    } else {
+        F2_HIP(p, launch_c2r_rows(c, p->dtype, s));
+    }
     return SGX_OK;
 }
 
@@ -187,7 +207,36 @@ sgx_status sgx_fft2d_create(size_t nrows, size_t ncols, int32_t dtype, int32_t d
         F2_HIP(p, hipSetDevice(p->device));
         sgx_status s1 = dtype == SGX_F64 ? upload_tw<double>(p, &p->d_tw_r, nrows) : upload_tw<float>(p, &p->d_tw_r, nrows);
         if (s1 != SGX_OK) return s1;
-        return dtype == SGX_F64 ? upload_tw<double>(p, &p->d_tw_c, ncols) : upload_tw<float>(p, &p->d_tw_c, ncols);
+        s1 = dtype == SGX_F64 ? upload_tw<double>(p, &p->d_tw_c, ncols) : upload_tw<float>(p, &p->d_tw_c, ncols);
+        if (s1 != SGX_OK) return s1;
+        if (dtype == SGX_F32 && nrows == 1024) {
+            std::vector<float> t(2 * 32 * 32);
+            for (unsigned k1 = 0; k1 < 32; ++k1)
+                for (unsigned n2 = 0; n2 < 32; ++n2) {
+                    const double a = -2.0 * kPi2 * double(k1 * n2) / 1024.0;
+                    t[2 * (k1 * 32 + n2)] = float(std::cos(a));
+                    t[2 * (k1 * 32 + n2) + 1] = float(std::sin(a));
+                }
+            F2_HIP(p, hipMalloc(&p->d_tw1c, t.size() * sizeof(float)));
+            F2_HIP(p, hipMemcpy(p->d_tw1c, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+        if (dtype == SGX_F32 && ncols == 1024 && p->d_tw1c) {  // the tuned row pass reads the [r][k] layout of the tuned columns
+            std::vector<float> tr(2 * 32 * 16), t1(2 * 32 * 16);
+            for (unsigned n1 = 0; n1 < 32; ++n1)
+                for (unsigned n2 = 0; n2 < 16; ++n2) {
+                    const double a = 2.0 * kPi2 * double(16 * n1 + n2) / 1024.0;  // conj(W_1024^k) = e^{+2 pi i k/1024}
+                    tr[2 * (n1 * 16 + n2)] = float(std::cos(a));
+                    tr[2 * (n1 * 16 + n2) + 1] = float(std::sin(a));
+                    const double b2 = -2.0 * kPi2 * double(n1 * n2) / 512.0;
+                    t1[2 * (n1 * 16 + n2)] = float(std::cos(b2));
+                    t1[2 * (n1 * 16 + n2) + 1] = float(std::sin(b2));
+                }
+            F2_HIP(p, hipMalloc(&p->d_twr, tr.size() * sizeof(float)));
+            F2_HIP(p, hipMemcpy(p->d_twr, tr.data(), tr.size() * sizeof(float), hipMemcpyHostToDevice));
+            F2_HIP(p, hipMalloc(&p->d_tw1r, t1.size() * sizeof(float)));
+            F2_HIP(p, hipMemcpy(p->d_tw1r, t1.data(), t1.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+        return SGX_OK;
     };
     st = tables();
     if (st != SGX_OK) {
@@ -203,7 +252,7 @@ void sgx_fft2d_destroy(sgx_fft2d *p) {
     if (!p) return;
     if (p->rows) {
         (void)hipSetDevice(p->device);
-        void *bufs[] = {p->d_tw_r, p->d_tw_c, p->d_inter, p->d_spec, p->d_kspec, p->d_mask, p->d_in, p->d_out, p->d_kimg};
+        void *bufs[] = {p->d_tw_r, p->d_tw_c, p->d_tw1c, p->d_twr, p->d_tw1r, p->d_inter, p->d_spec, p->d_kspec, p->d_mask, p->d_in, p->d_out, p->d_kimg};
         for (void *b : bufs)
             if (b) (void)hipFree(b);
         sgx_plan_destroy(p->rows);

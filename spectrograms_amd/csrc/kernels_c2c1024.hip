@@ -1,0 +1,188 @@
+// kernels_c2c1024.hip — tuned f32 1024-point complex FFT for the column passes of the 2-D path (BASELINE config 5:
+// 1024 x 1024 images).  Same construction as the STFT kernel: 1024 = 32 x 32, two 32-point FFTs entirely in registers
+// (fft_inreg.h, packed-f32 math) around ONE LDS exchange, 16 sequences per 512-thread workgroup.
+//
+//   pass 1  lane (s, n2) owns z[32*n1 + n2], n1 = 0..31, of sequence s; FFT32 over n1; twiddle W_1024^(k1*n2) from two
+//           short per-lane register tables; ds_write_b64 into ex[s][k1][n2] (sequence stride 8192+16 B)
+//   pass 2  lane (k1, s) reads row k1 of sequence s with 16 conflict-free ds_read_b128, FFT32 over n2 -> X[k1 + 32*k2];
+//           the 16 lanes of a row hold 16 consecutive sequences, so out[(k1+32*k2)][s0..s0+15] is one 128-byte segment
+//           when the output is sequence-contiguous ([r][k] layout: both column passes of the 2-D path).
+// The load side follows whichever input stride is 1 (IN_SEQ_FAST).  Inverse = conj(FFT(conj(.))).
+#include "fft_inreg.h"
+#include "sgx_internal.h"
+
+namespace sgx {
+namespace {
+
+using namespace inreg;
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int kCFS = 8192 + 16;     // LDS bytes per sequence (odd multiple of 16: conflict-free b128 row reads)
+constexpr int kCLds = 16 * kCFS;    // 131328 B -> one workgroup per CU
+
+template <bool IN_SEQ_FAST, bool INVERSE>
+__global__ __launch_bounds__(512, 2) void k_c2c1024(C2cArgs a, const v2f *tw1c) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned tid = threadIdx.x;
+    const unsigned t = blockIdx.x % a.tiles, b = blockIdx.x / a.tiles;
+    const unsigned s0 = t * 16u;
+    const v2f *in = (const v2f *)a.in + (size_t)b * a.in_img;
+    v2f *out = (v2f *)a.out + (size_t)b * a.out_img;
+    // ------------------------------------------------------------------ pass 1
+    {
+        const unsigned s = IN_SEQ_FAST ? (tid & 15u) : (tid >> 5), n2 = IN_SEQ_FAST ? (tid >> 4) : (tid & 31u);
+        const bool valid = s0 + s < a.nseq;
+        v2f v[32];
+        const v2f *p = in + (size_t)(s0 + s) * a.in_ss + (size_t)n2 * a.in_is;
+#pragma unroll
+        for (int n1 = 0; n1 < 32; ++n1) {
+            v2f x = valid ? p[(size_t)(32 * n1) * a.in_is] : (v2f){0.f, 0.f};
+            if (INVERSE) x.y = -x.y;
+            v[n1] = x;
+        }
+        Fft<32, false>::run(v, v);
+        v2f twa[4], twb[8];  // W_1024^(k1*n2) = twa[k1>>3] * twb[k1&7]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) twa[q] = tw1c[(8 * q) * 32 + n2];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) twb[q] = tw1c[q * 32 + n2];
+        unsigned char *dst = smem + s * kCFS + n2 * 8;
+#pragma unroll
+        for (int k1 = 0; k1 < 32; ++k1) {
+            const int qa = k1 >> 3, qb = k1 & 7;
+            v2f r = v[k1];
+            if (qb) r = cmulv(r, twb[qb]);
+            if (qa) r = cmulv(r, twa[qa]);
+            *(v2f *)(dst + k1 * 256) = r;
+        }
+    }
+    __syncthreads();
+    // ------------------------------------------------------------------ pass 2
+    {
+        const unsigned w = tid >> 6, l = tid & 63u, jq = l >> 4, s = l & 15u;
+        const unsigned k1 = w * 4u + jq;
+        v2f x[32];
+        const v4f *row = (const v4f *)(smem + s * kCFS + k1 * 256);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const v4f q = row[c];
+            x[2 * c] = (v2f){q.x, q.y};
+            x[2 * c + 1] = (v2f){q.z, q.w};
+        }
+        Fft<32, false>::run(x, x);
+        if (s0 + s < a.nseq) {
+            const float sc = (float)a.scale;
+            v2f *o = out + (size_t)(s0 + s) * a.out_ss + (size_t)k1 * a.out_is;
+#pragma unroll
+            for (int k2 = 0; k2 < 32; ++k2) {
+                v2f r = x[k2] * (v2f){sc, sc};
+                if (INVERSE) r.y = -r.y;
+                o[(size_t)(32 * k2) * a.out_is] = r;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_c2r1024: tuned f32 inverse row pass, half spectrum [r][k] (513 complex, k contiguous) -> 1024 real samples per row.
+// With z[n] = x[2n] + i x[2n+1] and Y = X[512-k]:  Z'[k] = (X[k] + conj Y) + i conj(W_1024^k) (X[k] - conj Y)  (= 2 Z[k]),
+// 1024 x = IDFT_512(Z') = conj(DFT_512(conj Z')).  The 512-point DFT is the STFT kernel's 32 x 16 split: lane (r, n2)
+// owns k = 16*n1 + n2 (both members X[k], X[512-k] of a pair are plain row loads), FFT32 over n1, twiddle W_512^(k1*n2),
+// LDS exchange (row stride 128+16 B), FFT16 over n2 -> sample index n = k1 + 32*k2; lanes walk k1, so every store is a
+// 256-byte contiguous run of the output row.  DC / Nyquist columns forced real on load (fft_backend.rs:782-793).
+constexpr int kRRS = 128 + 16;        // LDS bytes per k1-row (16 complex + pad: conflict-free b128 reads with lanes over k1)
+constexpr int kRSeq = 32 * kRRS;      // 4608 B per image row
+constexpr int kRLds = 16 * kRSeq;     // 73728 B -> two workgroups per CU
+
+__global__ __launch_bounds__(256, 2) void k_c2r1024(C2rArgs a, const v2f *twr /*[32][16] conj(W_1024^(16 n1 + n2))*/,
+                                                     const v2f *tw1 /*[32][16] W_512^(k1 n2)*/) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned tid = threadIdx.x;
+    const unsigned t = blockIdx.x % a.tiles, b = blockIdx.x / a.tiles;
+    const unsigned r0 = t * 16u;
+    const v2f *in = (const v2f *)a.in + (size_t)b * a.in_img;
+    float *out = (float *)a.out + (size_t)b * a.nrows * 1024u;
+    {
+        const unsigned r = tid >> 4, n2 = tid & 15u;
+        const bool valid = r0 + r < a.nrows;
+        const v2f *row = in + (size_t)(r0 + r) * a.in_rs;  // in_ks == 1
+        v2f v[32];
+#pragma unroll
+        for (int n1 = 0; n1 < 32; ++n1) {
+            const unsigned k = 16u * n1 + n2;
+            v2f A = valid ? row[k] : (v2f){0.f, 0.f};
+            v2f Y = valid ? row[512u - k] : (v2f){0.f, 0.f};
+            if (k == 0) { A.y = 0.f; Y.y = 0.f; }  // DC (k = 0) and Nyquist (512 - 0) columns are forced real
+            const v2f B = (v2f){Y.x, -Y.y};        // conj(X[512-k])
+            const v2f S = A + B, D = A - B;
+            const v2f T = cmulv(D, twr[16 * n1 + n2]);            // conj(W^k) (X[k] - conj Y)
+            const v2f Z = pfma(swp(T), (v2f){-1.f, 1.f}, S);      // S + i T
+            v[n1] = (v2f){Z.x, -Z.y};                             // conj for the forward-FFT inverse trick
+        }
+        Fft<32, false>::run(v, v);
+        unsigned char *dst = smem + r * kRSeq + n2 * 8;
+        *(v2f *)dst = v[0];
+#pragma unroll
+        for (int k1 = 1; k1 < 32; ++k1) *(v2f *)(dst + k1 * kRRS) = cmulv(v[k1], tw1[16 * k1 + n2]);
+    }
+    __syncthreads();
+    const float sc = (float)a.scale;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const unsigned r = (tid >> 5) + 8u * it, k1 = tid & 31u;
+        v2f x[16];
+        const v4f *rowp = (const v4f *)(smem + r * kRSeq + k1 * kRRS);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const v4f q = rowp[c];
+            x[2 * c] = (v2f){q.x, q.y};
+            x[2 * c + 1] = (v2f){q.z, q.w};
+        }
+        Fft<16, false>::run(x, x);
+        if (r0 + r < a.nrows) {
+            v2f *o = (v2f *)(out + (size_t)(r0 + r) * 1024u) + k1;
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) o[32 * k2] = x[k2] * (v2f){sc, -sc};  // conj, scale: (x[2n], x[2n+1])
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_c2r1024(const C2rArgs &a, const void *twr, const void *tw1, hipStream_t s) {
+    const unsigned long long g = (unsigned long long)a.tiles * a.batch;
+    if (g == 0 || g >= 0x7fffffffull || a.ncols != 1024 || a.in_ks != 1) return hipErrorInvalidConfiguration;
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_c2r1024, hipFuncAttributeMaxDynamicSharedMemorySize, kRLds);
+        if (e != hipSuccess) return e;
+        done = true;
+    }
+    hipLaunchKernelGGL(k_c2r1024, dim3((unsigned)g), dim3(256), kRLds, s, a, (const v2f *)twr, (const v2f *)tw1);
+    return hipGetLastError();
+}
+
+hipError_t launch_c2c1024(const C2cArgs &a, const void *tw1c, hipStream_t s) {
+    const unsigned long long g = (unsigned long long)a.tiles * a.batch;
+    if (g == 0 || g >= 0x7fffffffull || a.n != 1024) return hipErrorInvalidConfiguration;
+    static bool done = false;
+    if (!done) {
+        hipError_t e;
+        if ((e = hipFuncSetAttribute((const void *)k_c2c1024<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kCLds)) != hipSuccess) return e;
+        if ((e = hipFuncSetAttribute((const void *)k_c2c1024<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kCLds)) != hipSuccess) return e;
+        if ((e = hipFuncSetAttribute((const void *)k_c2c1024<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kCLds)) != hipSuccess) return e;
+        if ((e = hipFuncSetAttribute((const void *)k_c2c1024<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kCLds)) != hipSuccess) return e;
+        done = true;
+    }
+    const v2f *tw = (const v2f *)tw1c;
+    if (a.in_seq_fast) {
+        if (a.inverse) hipLaunchKernelGGL((k_c2c1024<true, true>), dim3((unsigned)g), dim3(512), kCLds, s, a, tw);
+        else hipLaunchKernelGGL((k_c2c1024<true, false>), dim3((unsigned)g), dim3(512), kCLds, s, a, tw);
+    } else {
+        if (a.inverse) hipLaunchKernelGGL((k_c2c1024<false, true>), dim3((unsigned)g), dim3(512), kCLds, s, a, tw);
+        else hipLaunchKernelGGL((k_c2c1024<false, false>), dim3((unsigned)g), dim3(512), kCLds, s, a, tw);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace sgx

@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256) void k_c2r_rows(C2rArgs a) {
     const bool pow2 = a.log2c > 0;
     // Hermitian extension X[C-k] = conj(X[k]); DC and (even C) Nyquist columns forced real (fft_backend.rs:782-793)
     for (unsigned idx = threadIdx.x; idx < nr * Cb; idx += 256) {
-        const unsigned r = idx % nr, k = idx / nr;  // rows fastest: the input is [k][r]-major
+        unsigned r, k;
+        if (a.k_fast) { k = idx % Cb; r = idx / Cb; } else { r = idx % nr; k = idx / nr; }  // follow the unit stride
         Cx2<T> v = in[(size_t)k * a.in_ks + (size_t)(r0 + r) * a.in_rs];
         if (k == 0 || (!(C & 1u) && k == Cb - 1)) v.im = T(0);
         const unsigned p = pow2 ? (__brev(k) >> (32 - a.log2c)) : k;

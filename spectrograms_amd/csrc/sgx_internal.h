@@ -83,6 +83,7 @@ struct C2rArgs {
     void *out;       // real [batch][nrows][ncols]
     unsigned nrows, ncols, log2c, batch;
     unsigned long long in_img, in_ks, in_rs;
+    int k_fast;  // input is [r][k]-major (in_ks == 1): map threads with k fastest
     unsigned tile, tiles;
     const void *tw;  // e^{-2 pi i k / ncols}, ncols entries
     double scale;
@@ -90,6 +91,11 @@ struct C2rArgs {
 unsigned fft2d_tile_for(unsigned n, int dtype);
 hipError_t launch_c2c_tile(const C2cArgs &a, int dtype, hipStream_t s);
 hipError_t launch_c2r_rows(const C2rArgs &a, int dtype, hipStream_t s);
+// tuned f32 1024-point C2C, 16 sequences per workgroup; tw1c = W_1024^(k1*n2), [32][32] complex f32; output must be
+// sequence-contiguous for coalesced stores (a.out_ss == 1)
+hipError_t launch_c2c1024(const C2cArgs &a, const void *tw1c, hipStream_t s);
+// tuned f32 inverse row pass for ncols == 1024 on a [r][k]-major half spectrum (a.in_ks == 1), 16 rows per workgroup
+hipError_t launch_c2r1024(const C2rArgs &a, const void *twr, const void *tw1, hipStream_t s);
 hipError_t launch_pointwise(const void *x, const void *y, void *out, unsigned long long n, unsigned long long per, int mode,
                             int dtype, hipStream_t s);
 
