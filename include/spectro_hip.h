@@ -49,8 +49,9 @@ typedef enum {
 /* src/window.rs:19-50 WindowType */
 enum { SGX_WIN_RECTANGULAR = 0, SGX_WIN_HANNING = 1, SGX_WIN_HAMMING = 2, SGX_WIN_BLACKMAN = 3,
        SGX_WIN_KAISER = 4, SGX_WIN_GAUSSIAN = 5, SGX_WIN_CUSTOM = 6 };
-/* src/spectrogram.rs:3374-3442 frequency-scale markers (LinearHz, Mel) */
-enum { SGX_FREQ_LINEAR = 0, SGX_FREQ_MEL = 1 };
+/* src/spectrogram.rs:3374-3442 frequency-scale markers (LinearHz, Mel, LogHz).  LogHz (LogHzParams :3935-3990, matrix
+ * build_loghz_matrix :2438-2508) reuses n_mels / f_min / f_max as n_bins / f_min / f_max. */
+enum { SGX_FREQ_LINEAR = 0, SGX_FREQ_MEL = 1, SGX_FREQ_LOGHZ = 2 };
 /* MelNorm src/spectrogram.rs:2385-2429 */
 enum { SGX_MELNORM_NONE = 0, SGX_MELNORM_SLANEY = 1, SGX_MELNORM_L1 = 2, SGX_MELNORM_L2 = 3 };
 /* AmpScaleSpec impls src/spectrogram.rs:1986-2037; COMPLEX = StftPlan::compute (:1424-1458) */

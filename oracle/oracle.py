@@ -97,6 +97,7 @@ class Params:
     centre: bool = True
     sample_rate: float = 16000.0
     n_mels: int = 0            # 0 -> linear
+    loghz: bool = False        # True: n_mels log-spaced bins between f_min and f_max (LogHzParams)
     f_min: float = 0.0
     f_max: float = 8000.0
     mel_norm: Optional[str] = None
@@ -114,7 +115,7 @@ class Params:
             self._keep.append(cw)
             p.custom_window = cw.ctypes.data_as(C.POINTER(C.c_double))
         p.sample_rate = float(self.sample_rate)
-        p.freq_scale = 1 if self.n_mels else 0
+        p.freq_scale = (2 if self.loghz else 1) if self.n_mels else 0
         p.n_mels = int(self.n_mels)
         p.f_min, p.f_max = float(self.f_min), float(self.f_max)
         p.mel_norm = MEL_NORMS[self.mel_norm]

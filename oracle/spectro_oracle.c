@@ -49,6 +49,12 @@ int orc_validate(const orc_params *p, char *err, size_t errlen) {
             return fail(err, errlen, ORC_INVALID_INPUT, "mel f_max must be <= Nyquist");
         if (p->n_mels > 10000) return fail(err, errlen, ORC_INVALID_INPUT, "n_mels is unreasonably large");
         if (isinf(p->f_min)) return fail(err, errlen, ORC_INVALID_INPUT, "f_min must be >= 0");
+    } else if (p->freq_scale == ORC_FREQ_LOGHZ) { /* LogHzParams::new :3960-3975; new_loghz :1726-1736; build_loghz_matrix :2445-2460 */
+        if (p->n_mels == 0) return fail(err, errlen, ORC_INVALID_INPUT, "n_bins must be > 0");
+        if (!(p->f_min > 0.0 && isfinite(p->f_min))) return fail(err, errlen, ORC_INVALID_INPUT, "f_min must be finite and > 0");
+        if (p->f_max <= p->f_min) return fail(err, errlen, ORC_INVALID_INPUT, "f_max must be > f_min");
+        if (p->n_mels > 10000) return fail(err, errlen, ORC_INVALID_INPUT, "n_bins is unreasonably large");
+        if (p->f_max > p->sample_rate * 0.5) return fail(err, errlen, ORC_INVALID_INPUT, "f_max must be <= Nyquist");
     } else if (p->freq_scale != ORC_FREQ_LINEAR) {
         return fail(err, errlen, ORC_INVALID_INPUT, "unknown frequency scale");
     }
@@ -70,7 +76,7 @@ size_t orc_frame_count(size_t n_samples, size_t n_fft, size_t hop, int centre) {
 
 size_t orc_n_bins(const orc_params *p) {
     /* FrequencyMapping::output_bins src/spectrogram.rs:1809-1820; r2c_output_size fft_backend.rs:16-18 */
-    return p->freq_scale == ORC_FREQ_MEL ? (size_t)p->n_mels : (size_t)p->n_fft / 2 + 1;
+    return p->freq_scale != ORC_FREQ_LINEAR ? (size_t)p->n_mels : (size_t)p->n_fft / 2 + 1;
 }
 
 /* modified_bessel_i0  src/spectrogram.rs:2237-2259 (Abramowitz-Stegun polynomial, not exact I0) */
@@ -227,6 +233,50 @@ done:
     return rc;
 }
 
+static size_t sat_usize(double v) { /* Rust `as usize` */
+    if (!(v == v) || v <= 0.0) return 0;
+    if (v >= 1.8446744073709552e19) return (size_t)-1;
+    return (size_t)v;
+}
+
+/* build_loghz_matrix  src/spectrogram.rs:2438-2508 */
+long orc_loghz_matrix(double sr, size_t n_fft, size_t n_bins, double f_min, double f_max, size_t *row_ptr, uint32_t *cols,
+                      double *vals, size_t cap, double *freqs) {
+    if (sr <= 0.0 || !isfinite(sr)) return -ORC_INVALID_INPUT;
+    if (f_min <= 0.0 || isinf(f_min)) return -ORC_INVALID_INPUT;
+    if (f_max <= f_min) return -ORC_INVALID_INPUT;
+    if (f_max > sr * 0.5) return -ORC_INVALID_INPUT;
+    size_t out_len = n_fft / 2 + 1;
+    double df = sr / (double)n_fft;
+    double log_f_min = log(f_min), log_f_max = log(f_max);
+    double log_step = (log_f_max - log_f_min) / (double)(n_bins - 1);
+    size_t nnz = 0;
+    for (size_t b = 0; b < n_bins; b++) {
+        double target = exp(fma((double)b, log_step, log_f_min));
+        if (freqs) freqs[b] = target;
+        row_ptr[b] = nnz;
+        double exact = target / df;
+        size_t lower = sat_usize(floor(exact));
+        size_t upper = sat_usize(ceil(exact));
+        if (upper > out_len - 1) upper = out_len - 1;
+        if (lower >= out_len) continue;
+        double w[2]; size_t c[2]; int cnt = 0;
+        if (lower == upper) { c[cnt] = lower; w[cnt++] = 1.0; }
+        else {
+            double frac = exact - (double)lower;
+            c[cnt] = lower; w[cnt++] = 1.0 - frac;
+            if (upper < out_len) { c[cnt] = upper; w[cnt++] = frac; }
+        }
+        for (int i = 0; i < cnt; i++)
+            if (c[i] < out_len && fabs(w[i]) > 1e-10) { /* SparseMatrix::set :69-87 */
+                if (nnz >= cap) return -ORC_DIM_MISMATCH;
+                cols[nnz] = (uint32_t)c[i]; vals[nnz] = w[i]; nnz++;
+            }
+    }
+    row_ptr[n_bins] = nnz;
+    return (long)nnz;
+}
+
 /* axes: build_time_axis_seconds :2128-2139; frequencies_hz :1909-1931;
  * mel_band_centres_hz :2510-2530 (ignores MelParams f_min/f_max — S10) */
 int orc_axes(const orc_params *p, size_t n_frames, double *freqs, double *times) {
@@ -236,7 +286,10 @@ int orc_axes(const orc_params *p, size_t n_frames, double *freqs, double *times)
         for (size_t i = 0; i < n_frames; i++) times[i] = (double)i * dt;
     }
     if (freqs) {
-        if (p->freq_scale == ORC_FREQ_MEL) {
+        if (p->freq_scale == ORC_FREQ_LOGHZ) { /* stored log frequencies :1932-1935 */
+            double l0 = log(p->f_min), st = (log(p->f_max) - l0) / (double)(p->n_mels - 1);
+            for (size_t i = 0; i < p->n_mels; i++) freqs[i] = exp(fma((double)i, st, l0));
+        } else if (p->freq_scale == ORC_FREQ_MEL) {
             double nyq = p->sample_rate * 0.5;
             double f_max = fmin(nyq, p->sample_rate * 0.5);
             double mel_min = orc_hz_to_mel(0.0), mel_max = orc_hz_to_mel(f_max);

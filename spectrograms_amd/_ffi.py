@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SGX_LIB_PATH") or os.path.join(_PKG, "libspectro_hip.
 
 SGX_OK, SGX_INVALID_INPUT, SGX_DIM_MISMATCH, SGX_BACKEND, SGX_INTERNAL = range(5)
 WIN_RECTANGULAR, WIN_HANNING, WIN_HAMMING, WIN_BLACKMAN, WIN_KAISER, WIN_GAUSSIAN, WIN_CUSTOM = range(7)
-FREQ_LINEAR, FREQ_MEL = 0, 1
+FREQ_LINEAR, FREQ_MEL, FREQ_LOGHZ = 0, 1, 2
 MELNORM_NONE, MELNORM_SLANEY, MELNORM_L1, MELNORM_L2 = range(4)
 AMP_POWER, AMP_MAGNITUDE, AMP_DECIBELS, AMP_COMPLEX = range(4)
 F32, F64 = 0, 1

@@ -162,6 +162,45 @@ void build_mel_csr(const sgx_params &p, std::vector<uint32_t> &ptr, std::vector<
     }
 }
 
+// ---- log-frequency interpolation matrix (build_loghz_matrix, src/spectrogram.rs:2438-2508) as CSR -----------------
+size_t sat_usize(double v) {  // Rust `as usize`: NaN -> 0, negative -> 0, saturating
+    if (!(v == v) || v <= 0.0) return 0;
+    if (v >= 1.8446744073709552e19) return ~size_t(0);
+    return size_t(v);
+}
+
+void build_loghz_csr(const sgx_params &p, std::vector<uint32_t> &ptr, std::vector<uint32_t> &col, std::vector<double> &val,
+                     std::vector<double> &freqs) {
+    const size_t nb = p.n_mels, out_len = p.n_fft / 2 + 1;
+    const double df = p.sample_rate_hz / double(p.n_fft);
+    const double lo = std::log(p.f_min), hi = std::log(p.f_max);
+    const double step = (hi - lo) / double(nb - 1);
+    freqs.resize(nb);
+    for (size_t i = 0; i < nb; ++i) freqs[i] = std::exp(std::fma(double(i), step, lo));
+    ptr.assign(nb + 1, 0);
+    col.clear();
+    val.clear();
+    auto set = [&](size_t c, double v) {  // SparseMatrix::set (:69-87): bounds + |v| > 1e-10
+        if (c >= out_len) return;
+        if (std::fabs(v) > 1e-10) { col.push_back(uint32_t(c)); val.push_back(v); }
+    };
+    for (size_t b = 0; b < nb; ++b) {
+        ptr[b] = uint32_t(col.size());
+        const double exact = freqs[b] / df;
+        const size_t lower = sat_usize(std::floor(exact));
+        const size_t upper = std::min(sat_usize(std::ceil(exact)), out_len - 1);
+        if (lower >= out_len) continue;
+        if (lower == upper) {
+            set(lower, 1.0);
+        } else {
+            const double frac = exact - double(lower);
+            set(lower, 1.0 - frac);
+            if (upper < out_len) set(upper, frac);
+        }
+    }
+    ptr[nb] = uint32_t(col.size());
+}
+
 // ---- validation (same conditions and texts as the reference constructors) ------------------------
 sgx_status validate(const sgx_params &p, std::string &msg) {
     auto bad = [&](const char *m) { msg = std::string("Invalid input: ") + m; return SGX_INVALID_INPUT; };
@@ -183,6 +222,12 @@ sgx_status validate(const sgx_params &p, std::string &msg) {
         if (p.f_max > p.sample_rate_hz * 0.5) return bad("mel f_max must be <= Nyquist");  // :954-959
         if (p.n_mels > 10000) return bad("n_mels is unreasonably large");                  // :1696-1700
         if (std::isinf(p.f_min)) return bad("f_min must be >= 0");                         // :2315
+    } else if (p.freq_scale == SGX_FREQ_LOGHZ) {
+        if (p.n_mels == 0) return bad("n_bins must be > 0");
+        if (!(p.f_min > 0.0 && std::isfinite(p.f_min))) return bad("f_min must be finite and > 0");  // :3961-3965
+        if (p.f_max <= p.f_min) return bad("f_max must be > f_min");                                  // :3967-3969
+        if (p.n_mels > 10000) return bad("n_bins is unreasonably large");                             // :1732-1736
+        if (p.f_max > p.sample_rate_hz * 0.5) return bad("f_max must be <= Nyquist");                 // :2458-2460
     } else if (p.freq_scale != SGX_FREQ_LINEAR) {
         return bad("unknown frequency scale");
     }
@@ -487,8 +532,9 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
     pl->dtype = params->dtype;
     pl->elem = params->dtype == SGX_F64 ? 8 : 4;
     pl->nb_fft = params->n_fft / 2 + 1;
+    // Mel and LogHz are both sparse row mappings of the power spectrum (MappingKind::{Mel, LogHz}, :1845-1865): one path
     pl->out_mode = params->amp_scale == SGX_AMP_COMPLEX ? OUT_COMPLEX
-                   : params->freq_scale == SGX_FREQ_MEL ? OUT_MEL : OUT_LINEAR;
+                   : params->freq_scale != SGX_FREQ_LINEAR ? OUT_MEL : OUT_LINEAR;
     pl->n_out = pl->out_mode == OUT_MEL ? params->n_mels : pl->nb_fft;
     const unsigned mfcc_skip = (params->n_mfcc > 1 && !params->mfcc_include_c0) ? 1u : 0u;  // src/mfcc.rs:262-268
     pl->n_final = params->n_mfcc > 0 ? params->n_mfcc - mfcc_skip : pl->n_out;
@@ -497,7 +543,8 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
               : (params->amp_scale == SGX_AMP_DECIBELS && params->has_log_params) ? AMP_DB : AMP_POWER;
     pl->eps = pl->amp == AMP_DB ? std::pow(10.0, params->floor_db / 10.0) : 0.0;
     build_window(pl->p, pl->custom_window, pl->window);
-    if (pl->out_mode == OUT_MEL) build_mel_csr(pl->p, pl->mel_ptr, pl->mel_col, pl->mel_val);
+    if (params->freq_scale == SGX_FREQ_MEL) build_mel_csr(pl->p, pl->mel_ptr, pl->mel_col, pl->mel_val);
+    if (params->freq_scale == SGX_FREQ_LOGHZ) build_loghz_csr(pl->p, pl->mel_ptr, pl->mel_col, pl->mel_val, pl->loghz_freqs);
 
     const bool pow2 = params->n_fft >= 4 && (params->n_fft & (params->n_fft - 1)) == 0;
     pl->kind = pow2 ? K_LDS_RADIX2 : K_DIRECT_DFT;
@@ -612,7 +659,9 @@ sgx_status sgx_axes(const sgx_plan *plan, size_t n_frames, double *freqs, double
         const unsigned skip = plan->p.n_mfcc - plan->n_final;
         for (unsigned i = 0; i < plan->n_final; ++i) freqs[i] = double(i + skip);
     } else if (freqs) {
-        if (plan->out_mode == OUT_MEL) {  // mel_band_centres_hz :2510-2530 — 0..Nyquist, ignores f_min/f_max
+        if (p.freq_scale == SGX_FREQ_LOGHZ) {  // the frequencies stored when the mapping was built (:1932-1935)
+            for (size_t i = 0; i < plan->loghz_freqs.size(); ++i) freqs[i] = plan->loghz_freqs[i];
+        } else if (plan->out_mode == OUT_MEL) {  // mel_band_centres_hz :2510-2530 — 0..Nyquist, ignores f_min/f_max
             const double lo = hz2mel(0.0), hi = hz2mel(p.sample_rate_hz * 0.5);
             const double step = (hi - lo) / double(p.n_mels + 1);
             for (size_t i = 0; i < p.n_mels; ++i) freqs[i] = mel2hz(std::fma(double(i) + 1.0, step, lo));

@@ -39,3 +39,15 @@ def compute_mfcc(samples, stft_params, sample_rate, n_mels, mfcc_params, dtype=N
     params = SpectrogramParams(stft_params, sample_rate)
     return Plan(params, _ffi.AMP_DECIBELS, MelParams(n_mels, 0.0, sample_rate / 2.0), LogParams(-80.0), dtype,
                 mfcc=mfcc_params).compute(samples)
+
+
+def compute_loghz_power_spectrogram(samples, params, loghz_params, db=None, dtype=None):
+    return Plan(params, _ffi.AMP_POWER, loghz_params, db, dtype).compute(samples)
+
+
+def compute_loghz_magnitude_spectrogram(samples, params, loghz_params, db=None, dtype=None):
+    return Plan(params, _ffi.AMP_MAGNITUDE, loghz_params, db, dtype).compute(samples)
+
+
+def compute_loghz_db_spectrogram(samples, params, loghz_params, db=None, dtype=None):
+    return Plan(params, _ffi.AMP_DECIBELS, loghz_params, db, dtype).compute(samples)

@@ -136,6 +136,19 @@ class MelParams:
         self.norm = norm if norm is not None else MelNorm.none
 
 
+class LogHzParams:
+    """LogHzParams(n_bins, f_min, f_max) — src/spectrogram.rs:3935-3990."""
+
+    def __init__(self, n_bins: int, f_min: float, f_max: float):
+        if int(n_bins) <= 0:
+            raise ValueError("n_bins must be > 0")
+        if not (f_min > 0.0 and math.isfinite(f_min)):
+            raise _ffi.InvalidInputError("Invalid input: f_min must be finite and > 0")
+        if f_max <= f_min:
+            raise _ffi.InvalidInputError("Invalid input: f_max must be > f_min")
+        self.n_bins, self.f_min, self.f_max = int(n_bins), float(f_min), float(f_max)
+
+
 class MfccParams:
     """MfccParams(n_mfcc=13) — src/mfcc.rs:20-90 (defaults include_c0=True, lifter=22; `with_c0` / `with_lifter`)."""
 

@@ -8,7 +8,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 from . import _ffi
-from .params import LogParams, MelParams, MfccParams, SpectrogramParams, parse_dtype
+from .params import LogHzParams, LogParams, MelParams, MfccParams, SpectrogramParams, parse_dtype
 
 
 class Spectrogram:
@@ -107,9 +107,14 @@ class Plan:
             p.custom_window = self._cw.ctypes.data_as(C.POINTER(C.c_double))
             p.custom_window_len = self._cw.size
         p.sample_rate_hz = params.sample_rate
-        p.freq_scale = _ffi.FREQ_MEL if mel is not None else _ffi.FREQ_LINEAR
-        if mel is not None:
+        if isinstance(mel, LogHzParams):
+            p.freq_scale = _ffi.FREQ_LOGHZ
+            p.n_mels, p.f_min, p.f_max = mel.n_bins, mel.f_min, mel.f_max
+        elif mel is not None:
+            p.freq_scale = _ffi.FREQ_MEL
             p.n_mels, p.f_min, p.f_max, p.mel_norm = mel.n_mels, mel.f_min, mel.f_max, mel.norm.code
+        else:
+            p.freq_scale = _ffi.FREQ_LINEAR
         p.amp_scale = amp
         p.has_log_params = int(db is not None)
         p.floor_db = db.floor_db if db is not None else 0.0
@@ -163,7 +168,7 @@ class Plan:
     def mel_weights(self):
         nnz = C.c_size_t()
         _ffi.raise_status(self._lib.sgx_mel_weights(self._h, C.byref(nnz), None, None, None), self._h)
-        ptr = np.empty(self._mel.n_mels + 1, np.uint32)
+        ptr = np.empty((self._mel.n_bins if isinstance(self._mel, LogHzParams) else self._mel.n_mels) + 1, np.uint32)
         col = np.empty(nnz.value, np.uint32)
         val = np.empty(nnz.value, np.float64)
         _ffi.raise_status(self._lib.sgx_mel_weights(self._h, None, ptr.ctypes.data_as(C.POINTER(C.c_uint32)),
@@ -283,6 +288,15 @@ class SpectrogramPlanner:
 
     def mel_db_plan(self, params, mel_params, db_params, dtype=None):
         return Plan(params, _ffi.AMP_DECIBELS, mel_params, db_params, dtype, self._device)
+
+    def loghz_power_plan(self, params, loghz_params, dtype=None):
+        return Plan(params, _ffi.AMP_POWER, loghz_params, None, dtype, self._device)
+
+    def loghz_magnitude_plan(self, params, loghz_params, dtype=None):
+        return Plan(params, _ffi.AMP_MAGNITUDE, loghz_params, None, dtype, self._device)
+
+    def loghz_db_plan(self, params, loghz_params, db_params, dtype=None):
+        return Plan(params, _ffi.AMP_DECIBELS, loghz_params, db_params, dtype, self._device)
 
     def mfcc_plan(self, stft_params, sample_rate, n_mels, mfcc_params, dtype=None):
         """Plan form of `mfcc()` (src/mfcc.rs:359-379): Mel 0..sr/2, floor -80 dB, then DCT-II + lifter."""
