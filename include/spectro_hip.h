@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SGX_ABI_VERSION 2
+#define SGX_ABI_VERSION 3
 
 typedef struct sgx_plan sgx_plan; /* opaque */
 
@@ -49,9 +49,13 @@ typedef enum {
 /* src/window.rs:19-50 WindowType */
 enum { SGX_WIN_RECTANGULAR = 0, SGX_WIN_HANNING = 1, SGX_WIN_HAMMING = 2, SGX_WIN_BLACKMAN = 3,
        SGX_WIN_KAISER = 4, SGX_WIN_GAUSSIAN = 5, SGX_WIN_CUSTOM = 6 };
-/* src/spectrogram.rs:3374-3442 frequency-scale markers (LinearHz, Mel, LogHz).  LogHz (LogHzParams :3935-3990, matrix
- * build_loghz_matrix :2438-2508) reuses n_mels / f_min / f_max as n_bins / f_min / f_max. */
-enum { SGX_FREQ_LINEAR = 0, SGX_FREQ_MEL = 1, SGX_FREQ_LOGHZ = 2 };
+/* src/spectrogram.rs:3374-3442 frequency-scale markers (LinearHz, Mel, LogHz, Erb).  LogHz (LogHzParams :3935-3990,
+ * matrix build_loghz_matrix :2438-2508) reuses n_mels / f_min / f_max as n_bins / f_min / f_max.  Erb (ErbParams
+ * src/erb.rs:27-92, frequency-domain gammatone bank ErbFilterbank::generate :266-335, applied as a DENSE
+ * n_filters x (n_fft/2+1) product with the power spectrum :374-401) reuses them as n_filters / f_min / f_max. */
+enum { SGX_FREQ_LINEAR = 0, SGX_FREQ_MEL = 1, SGX_FREQ_LOGHZ = 2, SGX_FREQ_ERB = 3 };
+/* ErbSpacing src/erb.rs:14-25 */
+enum { SGX_ERB_LINEAR = 0, SGX_ERB_APPLE_TR35 = 1 };
 /* MelNorm src/spectrogram.rs:2385-2429 */
 enum { SGX_MELNORM_NONE = 0, SGX_MELNORM_SLANEY = 1, SGX_MELNORM_L1 = 2, SGX_MELNORM_L2 = 3 };
 /* AmpScaleSpec impls src/spectrogram.rs:1986-2037; COMPLEX = StftPlan::compute (:1424-1458) */
@@ -86,6 +90,7 @@ typedef struct {
     uint32_t n_mfcc;
     int32_t mfcc_include_c0;
     uint32_t mfcc_lifter;
+    int32_t erb_spacing;          /* SGX_ERB_* (only read when freq_scale = SGX_FREQ_ERB) */
 } sgx_params;
 
 /* Replaces StftPlan::new (:1204-1228), SpectrogramPlanner::{linear_plan :893-917, mel_plan :944-977}:

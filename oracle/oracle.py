@@ -98,6 +98,8 @@ class Params:
     sample_rate: float = 16000.0
     n_mels: int = 0            # 0 -> linear
     loghz: bool = False        # True: n_mels log-spaced bins between f_min and f_max (LogHzParams)
+    erb: bool = False          # True: n_mels frequency-domain gammatone filters (ErbParams)
+    erb_spacing: int = 0       # 0 linear on the ERB scale, 1 Apple TR #35
     f_min: float = 0.0
     f_max: float = 8000.0
     mel_norm: Optional[str] = None
@@ -115,10 +117,10 @@ class Params:
             self._keep.append(cw)
             p.custom_window = cw.ctypes.data_as(C.POINTER(C.c_double))
         p.sample_rate = float(self.sample_rate)
-        p.freq_scale = (2 if self.loghz else 1) if self.n_mels else 0
+        p.freq_scale = (3 if self.erb else 2 if self.loghz else 1) if self.n_mels else 0
         p.n_mels = int(self.n_mels)
         p.f_min, p.f_max = float(self.f_min), float(self.f_max)
-        p.mel_norm = MEL_NORMS[self.mel_norm]
+        p.mel_norm = int(self.erb_spacing) if self.erb else MEL_NORMS[self.mel_norm]
         p.amp_scale = AMPS[self.amp]
         p.has_db = int(self.floor_db is not None)
         p.floor_db = float(self.floor_db) if self.floor_db is not None else 0.0

@@ -8,6 +8,7 @@
  */
 #include "spectro_oracle.h"
 
+#include <complex.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -55,6 +56,12 @@ int orc_validate(const orc_params *p, char *err, size_t errlen) {
         if (p->f_max <= p->f_min) return fail(err, errlen, ORC_INVALID_INPUT, "f_max must be > f_min");
         if (p->n_mels > 10000) return fail(err, errlen, ORC_INVALID_INPUT, "n_bins is unreasonably large");
         if (p->f_max > p->sample_rate * 0.5) return fail(err, errlen, ORC_INVALID_INPUT, "f_max must be <= Nyquist");
+    } else if (p->freq_scale == ORC_FREQ_ERB) { /* ErbParams::new erb.rs:66-80; erb_plan spectrogram.rs:1014-1022; new_erb :1768-1773 */
+        if (p->n_mels < 2) return fail(err, errlen, ORC_INVALID_INPUT, "n_filters must be >= 2 (single filter would cause division by zero)");
+        if (p->f_min < 0.0 || isinf(p->f_min)) return fail(err, errlen, ORC_INVALID_INPUT, "f_min must be finite and >= 0");
+        if (p->f_max <= p->f_min) return fail(err, errlen, ORC_INVALID_INPUT, "f_max must be > f_min");
+        if (p->f_max > p->sample_rate * 0.5) return fail(err, errlen, ORC_INVALID_INPUT, "f_max exceeds Nyquist");
+        if (p->n_mels > 10000) return fail(err, errlen, ORC_INVALID_INPUT, "n_filters is unreasonably large");
     } else if (p->freq_scale != ORC_FREQ_LINEAR) {
         return fail(err, errlen, ORC_INVALID_INPUT, "unknown frequency scale");
     }
@@ -277,6 +284,42 @@ long orc_loghz_matrix(double sr, size_t n_fft, size_t n_bins, double f_min, doub
     return (long)nnz;
 }
 
+static void erb_centres(size_t n, double f_min, double f_max, int spacing, double *cf) {
+    if (spacing == 1) { /* apple_tr35_center_freqs erb.rs:221-238 */
+        double shift = 9.26449 * 24.7, a = -shift, d = f_max + shift;
+        double e = (log(f_min + shift) - log(f_max + shift)) / (double)n;
+        for (size_t i = 0; i < n; i++) cf[n - 1 - i] = a + exp(((double)i + 1.0) * e) * d;
+    } else { /* erb.rs:276-284 with hz_to_erb :208, erb_to_hz :249 */
+        double emin = 24.7 * (4.37 * f_min / 1000.0 + 1.0), emax = 24.7 * (4.37 * f_max / 1000.0 + 1.0);
+        double step = (emax - emin) / (double)(n - 1);
+        for (size_t i = 0; i < n; i++) cf[i] = (fma((double)i, step, emin) / 24.7 - 1.0) * 1000.0 / 4.37;
+    }
+}
+
+long orc_erb_matrix(double sr, size_t n_fft, size_t nf, double f_min, double f_max, int spacing, size_t *row_ptr,
+                    uint32_t *cols, double *vals, size_t cap, double *centres) {
+    if (sr <= 0.0) return -ORC_INVALID_INPUT;
+    size_t nb = n_fft / 2 + 1;
+    if (cap < nf * nb) return -ORC_DIM_MISMATCH;
+    double *cf = centres ? centres : (double *)malloc(nf * sizeof(double));
+    erb_centres(nf, f_min, f_max, spacing, cf);
+    double df = sr / (double)n_fft;
+    for (size_t m = 0; m < nf; m++) {
+        double bw = 1.019 * (24.7 * (4.37 * cf[m] / 1000.0 + 1.0)); /* erb.rs:296-297 */
+        row_ptr[m] = m * nb;
+        for (size_t k = 0; k < nb; k++) {
+            double freq = (double)k * df;
+            double complex den = 1.0 + I * ((freq - cf[m]) / bw); /* :306-309 */
+            double complex d2 = den * den, d4 = d2 * d2;
+            cols[m * nb + k] = (uint32_t)k;
+            vals[m * nb + k] = 1.0 / (creal(d4) * creal(d4) + cimag(d4) * cimag(d4)); /* norm_sqr :312 */
+        }
+    }
+    row_ptr[nf] = nf * nb;
+    if (!centres) free(cf);
+    return (long)(nf * nb);
+}
+
 /* axes: build_time_axis_seconds :2128-2139; frequencies_hz :1909-1931;
  * mel_band_centres_hz :2510-2530 (ignores MelParams f_min/f_max — S10) */
 int orc_axes(const orc_params *p, size_t n_frames, double *freqs, double *times) {
@@ -286,7 +329,9 @@ int orc_axes(const orc_params *p, size_t n_frames, double *freqs, double *times)
         for (size_t i = 0; i < n_frames; i++) times[i] = (double)i * dt;
     }
     if (freqs) {
-        if (p->freq_scale == ORC_FREQ_LOGHZ) { /* stored log frequencies :1932-1935 */
+        if (p->freq_scale == ORC_FREQ_ERB) { /* centre frequencies :1936-1939 */
+            erb_centres(p->n_mels, p->f_min, p->f_max, p->mel_norm, freqs);
+        } else if (p->freq_scale == ORC_FREQ_LOGHZ) { /* stored log frequencies :1932-1935 */
             double l0 = log(p->f_min), st = (log(p->f_max) - l0) / (double)(p->n_mels - 1);
             for (size_t i = 0; i < p->n_mels; i++) freqs[i] = exp(fma((double)i, st, l0));
         } else if (p->freq_scale == ORC_FREQ_MEL) {

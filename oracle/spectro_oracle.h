@@ -37,7 +37,8 @@ enum { ORC_OK = 0, ORC_INVALID_INPUT = 1, ORC_DIM_MISMATCH = 2, ORC_BACKEND = 3,
 
 enum { ORC_WIN_RECT = 0, ORC_WIN_HANNING = 1, ORC_WIN_HAMMING = 2, ORC_WIN_BLACKMAN = 3,
        ORC_WIN_KAISER = 4, ORC_WIN_GAUSSIAN = 5, ORC_WIN_CUSTOM = 6 };
-enum { ORC_FREQ_LINEAR = 0, ORC_FREQ_MEL = 1, ORC_FREQ_LOGHZ = 2 /* n_mels = n_bins */ };
+enum { ORC_FREQ_LINEAR = 0, ORC_FREQ_MEL = 1, ORC_FREQ_LOGHZ = 2 /* n_mels = n_bins */,
+       ORC_FREQ_ERB = 3 /* n_mels = n_filters, mel_norm = spacing (0 linear, 1 Apple TR35) */ };
 enum { ORC_MELNORM_NONE = 0, ORC_MELNORM_SLANEY = 1, ORC_MELNORM_L1 = 2, ORC_MELNORM_L2 = 3 };
 enum { ORC_AMP_POWER = 0, ORC_AMP_MAGNITUDE = 1, ORC_AMP_DECIBELS = 2 };
 
@@ -71,6 +72,9 @@ long orc_mel_filterbank(double sample_rate, size_t n_fft, size_t n_mels, double 
 /* spectrogram.rs:2438-2508; CSR + centre frequencies. returns nnz (>=0) or -status. */
 long orc_loghz_matrix(double sample_rate, size_t n_fft, size_t n_bins, double f_min, double f_max, size_t *row_ptr,
                       uint32_t *cols, double *vals, size_t cap, double *freqs);
+/* src/erb.rs:266-335 (ErbFilterbank::generate): dense n_filters x (n_fft/2+1) |H|^2 rows as CSR + centre freqs */
+long orc_erb_matrix(double sample_rate, size_t n_fft, size_t n_filters, double f_min, double f_max, int spacing,
+                    size_t *row_ptr, uint32_t *cols, double *vals, size_t cap, double *centres);
 double orc_hz_to_mel(double hz);
 double orc_mel_to_hz(double mel);
 /* spectrogram.rs:2128-2139,1909-1931,2510-2530 */

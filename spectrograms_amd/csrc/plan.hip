@@ -201,6 +201,40 @@ void build_loghz_csr(const sgx_params &p, std::vector<uint32_t> &ptr, std::vecto
     ptr[nb] = uint32_t(col.size());
 }
 
+// ---- ERB / gammatone bank (ErbFilterbank::generate, src/erb.rs:266-335): DENSE rows of |H(f)|^2, no threshold --------
+void build_erb_dense(const sgx_params &p, std::vector<uint32_t> &ptr, std::vector<uint32_t> &col, std::vector<double> &val,
+                     std::vector<double> &centres) {
+    const size_t nf = p.n_mels, nb = p.n_fft / 2 + 1;
+    centres.resize(nf);
+    if (p.erb_spacing == SGX_ERB_APPLE_TR35) {  // apple_tr35_center_freqs :221-238 (computed high->low, stored low->high)
+        const double shift = 9.26449 * 24.7;
+        const double d = p.f_max + shift;
+        const double e = (std::log(p.f_min + shift) - std::log(p.f_max + shift)) / double(nf);
+        for (size_t i = 0; i < nf; ++i) centres[nf - 1 - i] = -shift + std::exp((double(i) + 1.0) * e) * d;
+    } else {  // uniform on hz_to_erb :208-210, back through erb_to_hz :249-251
+        const double lo = 24.7 * (4.37 * p.f_min / 1000.0 + 1.0), hi = 24.7 * (4.37 * p.f_max / 1000.0 + 1.0);
+        const double step = (hi - lo) / double(nf - 1);
+        for (size_t i = 0; i < nf; ++i) centres[i] = (std::fma(double(i), step, lo) / 24.7 - 1.0) * 1000.0 / 4.37;
+    }
+    const double df = p.sample_rate_hz / double(p.n_fft);
+    ptr.resize(nf + 1);
+    col.resize(nf * nb);
+    val.resize(nf * nb);
+    for (size_t m = 0; m < nf; ++m) {
+        ptr[m] = uint32_t(m * nb);
+        const double bw = 1.019 * (24.7 * (4.37 * centres[m] / 1000.0 + 1.0));
+        for (size_t k = 0; k < nb; ++k) {
+            // |1/(1 + j x)^4|^2 through the same complex products as the reference (:306-312)
+            const double x = (double(k) * df - centres[m]) / bw;
+            const double r2 = 1.0 * 1.0 - x * x, i2 = 1.0 * x + x * 1.0;  // (1 + jx)^2
+            const double r4 = r2 * r2 - i2 * i2, i4 = r2 * i2 + i2 * r2;  // ^4
+            col[m * nb + k] = uint32_t(k);
+            val[m * nb + k] = 1.0 / (r4 * r4 + i4 * i4);
+        }
+    }
+    ptr[nf] = uint32_t(nf * nb);
+}
+
 // ---- validation (same conditions and texts as the reference constructors) ------------------------
 sgx_status validate(const sgx_params &p, std::string &msg) {
     auto bad = [&](const char *m) { msg = std::string("Invalid input: ") + m; return SGX_INVALID_INPUT; };
@@ -228,6 +262,18 @@ sgx_status validate(const sgx_params &p, std::string &msg) {
         if (p.f_max <= p.f_min) return bad("f_max must be > f_min");                                  // :3967-3969
         if (p.n_mels > 10000) return bad("n_bins is unreasonably large");                             // :1732-1736
         if (p.f_max > p.sample_rate_hz * 0.5) return bad("f_max must be <= Nyquist");                 // :2458-2460
+    } else if (p.freq_scale == SGX_FREQ_ERB) {
+        // ErbParams::new src/erb.rs:66-80; erb_plan src/spectrogram.rs:1014-1022; new_erb :1768-1773
+        if (p.n_mels < 2) return bad("n_filters must be >= 2 (single filter would cause division by zero)");
+        if (p.f_min < 0.0 || !std::isfinite(p.f_min)) return bad("f_min must be finite and >= 0");
+        if (p.f_max <= p.f_min) return bad("f_max must be > f_min");
+        if (p.f_max > p.sample_rate_hz * 0.5) {
+            char b[128];
+            snprintf(b, sizeof b, "f_max=%g exceeds Nyquist=%g", p.f_max, p.sample_rate_hz * 0.5);
+            return bad(b);
+        }
+        if (p.n_mels > 10000) return bad("n_filters is unreasonably large");
+        if (p.erb_spacing != SGX_ERB_LINEAR && p.erb_spacing != SGX_ERB_APPLE_TR35) return bad("unknown ERB spacing");
     } else if (p.freq_scale != SGX_FREQ_LINEAR) {
         return bad("unknown frequency scale");
     }
@@ -545,6 +591,7 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
     build_window(pl->p, pl->custom_window, pl->window);
     if (params->freq_scale == SGX_FREQ_MEL) build_mel_csr(pl->p, pl->mel_ptr, pl->mel_col, pl->mel_val);
     if (params->freq_scale == SGX_FREQ_LOGHZ) build_loghz_csr(pl->p, pl->mel_ptr, pl->mel_col, pl->mel_val, pl->loghz_freqs);
+    if (params->freq_scale == SGX_FREQ_ERB) build_erb_dense(pl->p, pl->mel_ptr, pl->mel_col, pl->mel_val, pl->loghz_freqs);
 
     const bool pow2 = params->n_fft >= 4 && (params->n_fft & (params->n_fft - 1)) == 0;
     pl->kind = pow2 ? K_LDS_RADIX2 : K_DIRECT_DFT;
@@ -659,7 +706,7 @@ sgx_status sgx_axes(const sgx_plan *plan, size_t n_frames, double *freqs, double
         const unsigned skip = plan->p.n_mfcc - plan->n_final;
         for (unsigned i = 0; i < plan->n_final; ++i) freqs[i] = double(i + skip);
     } else if (freqs) {
-        if (p.freq_scale == SGX_FREQ_LOGHZ) {  // the frequencies stored when the mapping was built (:1932-1935)
+        if (p.freq_scale == SGX_FREQ_LOGHZ || p.freq_scale == SGX_FREQ_ERB) {  // frequencies stored with the mapping (:1932-1939)
             for (size_t i = 0; i < plan->loghz_freqs.size(); ++i) freqs[i] = plan->loghz_freqs[i];
         } else if (plan->out_mode == OUT_MEL) {  // mel_band_centres_hz :2510-2530 — 0..Nyquist, ignores f_min/f_max
             const double lo = hz2mel(0.0), hi = hz2mel(p.sample_rate_hz * 0.5);

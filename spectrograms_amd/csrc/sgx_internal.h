@@ -117,7 +117,7 @@ struct sgx_plan {
     std::vector<double> window;
     std::vector<uint32_t> mel_ptr, mel_col;
     std::vector<double> mel_val;
-    std::vector<double> loghz_freqs;  // LogHz axis (centre frequencies), empty otherwise
+    std::vector<double> loghz_freqs;  // LogHz / ERB axis (centre frequencies), empty otherwise
 
     // device tables
     void *d_window = nullptr, *d_tw = nullptr, *d_tw1 = nullptr, *d_tw2 = nullptr;

@@ -51,3 +51,15 @@ def compute_loghz_magnitude_spectrogram(samples, params, loghz_params, db=None, 
 
 def compute_loghz_db_spectrogram(samples, params, loghz_params, db=None, dtype=None):
     return Plan(params, _ffi.AMP_DECIBELS, loghz_params, db, dtype).compute(samples)
+
+
+def compute_erb_power_spectrogram(samples, params, erb_params, db=None, dtype=None):  # src/python/functions.rs:274-300
+    return Plan(params, _ffi.AMP_POWER, erb_params, db, dtype).compute(samples)
+
+
+def compute_erb_magnitude_spectrogram(samples, params, erb_params, db=None, dtype=None):
+    return Plan(params, _ffi.AMP_MAGNITUDE, erb_params, db, dtype).compute(samples)
+
+
+def compute_erb_db_spectrogram(samples, params, erb_params, db=None, dtype=None):
+    return Plan(params, _ffi.AMP_DECIBELS, erb_params, db, dtype).compute(samples)

@@ -149,6 +149,41 @@ class LogHzParams:
         self.n_bins, self.f_min, self.f_max = int(n_bins), float(f_min), float(f_max)
 
 
+class ErbParams:
+    """ErbParams(n_filters, f_min, f_max) — src/erb.rs:27-92, Python class src/python/params.rs:910-980.
+
+    `spacing`: "linear" (uniform on the Glasberg & Moore ERB scale, default) or "apple_tr35" (ErbSpacing, erb.rs:14-25).
+    """
+
+    def __init__(self, n_filters: int, f_min: float, f_max: float, spacing: str = "linear"):
+        if int(n_filters) < 2:
+            raise _ffi.InvalidInputError("Invalid input: n_filters must be >= 2 (single filter would cause division by zero)")
+        if f_min < 0.0 or math.isinf(f_min):
+            raise _ffi.InvalidInputError("Invalid input: f_min must be finite and >= 0")
+        if f_max <= f_min:
+            raise _ffi.InvalidInputError("Invalid input: f_max must be > f_min")
+        if spacing not in ("linear", "apple_tr35"):
+            raise ValueError("spacing must be 'linear' or 'apple_tr35'")
+        self.n_filters, self.f_min, self.f_max, self.spacing = int(n_filters), float(f_min), float(f_max), spacing
+
+    def with_spacing(self, spacing: str) -> "ErbParams":
+        return ErbParams(self.n_filters, self.f_min, self.f_max, spacing)
+
+    @staticmethod
+    def speech_standard() -> "ErbParams":  # erb.rs:170-173
+        return ErbParams(40, 0.0, 8000.0)
+
+    @staticmethod
+    def music_standard(sample_rate: float) -> "ErbParams":  # erb.rs:190-192
+        return ErbParams(64, 0.0, sample_rate / 2.0)
+
+    def __repr__(self):
+        return f"ErbParams(n_filters={self.n_filters}, f_min={self.f_min}, f_max={self.f_max})"
+
+
+GammatoneParams = ErbParams
+
+
 class MfccParams:
     """MfccParams(n_mfcc=13) — src/mfcc.rs:20-90 (defaults include_c0=True, lifter=22; `with_c0` / `with_lifter`)."""
 

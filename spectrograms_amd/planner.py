@@ -8,7 +8,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 from . import _ffi
-from .params import LogHzParams, LogParams, MelParams, MfccParams, SpectrogramParams, parse_dtype
+from .params import ErbParams, LogHzParams, LogParams, MelParams, MfccParams, SpectrogramParams, parse_dtype
 
 
 class Spectrogram:
@@ -107,7 +107,11 @@ class Plan:
             p.custom_window = self._cw.ctypes.data_as(C.POINTER(C.c_double))
             p.custom_window_len = self._cw.size
         p.sample_rate_hz = params.sample_rate
-        if isinstance(mel, LogHzParams):
+        if isinstance(mel, ErbParams):
+            p.freq_scale = _ffi.FREQ_ERB
+            p.n_mels, p.f_min, p.f_max = mel.n_filters, mel.f_min, mel.f_max
+            p.erb_spacing = 1 if mel.spacing == "apple_tr35" else 0
+        elif isinstance(mel, LogHzParams):
             p.freq_scale = _ffi.FREQ_LOGHZ
             p.n_mels, p.f_min, p.f_max = mel.n_bins, mel.f_min, mel.f_max
         elif mel is not None:
@@ -168,7 +172,8 @@ class Plan:
     def mel_weights(self):
         nnz = C.c_size_t()
         _ffi.raise_status(self._lib.sgx_mel_weights(self._h, C.byref(nnz), None, None, None), self._h)
-        ptr = np.empty((self._mel.n_bins if isinstance(self._mel, LogHzParams) else self._mel.n_mels) + 1, np.uint32)
+        rows = getattr(self._mel, "n_mels", None) or getattr(self._mel, "n_bins", None) or self._mel.n_filters
+        ptr = np.empty(rows + 1, np.uint32)
         col = np.empty(nnz.value, np.uint32)
         val = np.empty(nnz.value, np.float64)
         _ffi.raise_status(self._lib.sgx_mel_weights(self._h, None, ptr.ctypes.data_as(C.POINTER(C.c_uint32)),
@@ -297,6 +302,15 @@ class SpectrogramPlanner:
 
     def loghz_db_plan(self, params, loghz_params, db_params, dtype=None):
         return Plan(params, _ffi.AMP_DECIBELS, loghz_params, db_params, dtype, self._device)
+
+    def erb_power_plan(self, params, erb_params, dtype=None):  # src/python/planner.rs:343-365
+        return Plan(params, _ffi.AMP_POWER, erb_params, None, dtype, self._device)
+
+    def erb_magnitude_plan(self, params, erb_params, dtype=None):
+        return Plan(params, _ffi.AMP_MAGNITUDE, erb_params, None, dtype, self._device)
+
+    def erb_db_plan(self, params, erb_params, db_params, dtype=None):
+        return Plan(params, _ffi.AMP_DECIBELS, erb_params, db_params, dtype, self._device)
 
     def mfcc_plan(self, stft_params, sample_rate, n_mels, mfcc_params, dtype=None):
         """Plan form of `mfcc()` (src/mfcc.rs:359-379): Mel 0..sr/2, floor -80 dB, then DCT-II + lifter."""
