@@ -224,6 +224,49 @@ __device__ __forceinline__ void mel_tile_lds(const StftArgs &a, const float *pwa
     }
 }
 
+// Dense bank (ERB / gammatone, src/erb.rs:374-401: every filter weighs every bin) on the matrix cores.  Per tile the
+// product is [n_filters x 516] x [516 x 16 frames]; v_mfma_f32_16x16x4_f32 is an exact-f32 fmaf chain at the packed VALU
+// rate that does the operand broadcast a per-lane loop cannot.  Wave w owns the 16-filter blocks w, w+4, ...; lane
+// (i = l & 15, q = l >> 4) feeds A = weight[16 blk + i][k] and B = pw[frame i][k] with k = 16 c + 4 q + s for step s of chunk c —
+// the k order inside a chunk is permuted identically on both operands, so each lane fetches its 4 steps with ONE 16-byte
+// load (weights: fragment-ordered table, 1 KiB per wave-load, L2 resident) and ONE ds_read_b128 (pw rows are 516 floats:
+// the 16 lanes of a q group cover all 64 banks).  D[4 q + r][frame i] lands frame-contiguous across lanes: 64-byte stores.
+// The sum runs over k < 516: weights and pw are zero for k = 513..515.
+typedef float v4acc __attribute__((ext_vector_type(4)));
+template <int AMP>
+__device__ __forceinline__ void dense_tile_mfma(const StftArgs &a, const float *pwall, unsigned b, unsigned f0, unsigned nf,
+                                                float eps, unsigned t) {
+    const unsigned wave = t >> 6, lane = t & 63u, fi = lane & 15u, q = lane >> 4;
+    const unsigned nblk = (a.n_mels + 15u) >> 4;
+    float *o = (float *)a.out + ((size_t)b * a.n_out) * a.n_frames + f0 + fi;
+    const v4f *pp = (const v4f *)(pwall + fi * kPS + 4u * q);
+    for (unsigned blk = wave; blk < nblk; blk += 4u) {
+        const v4f *wf = (const v4f *)a.dense_w + (size_t)blk * 33u * 64u + lane;
+        v4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};  // two chains: the dependent latency is 40 cycles
+        v4f wq[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wq[c] = wf[c * 64];
+#pragma unroll 4
+        for (int c = 0; c < 32; ++c) {
+            const v4f w = wq[c & 3], p = pp[c * 4];
+            if (c + 4 < 33) wq[c & 3] = wf[(c + 4) * 64];
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, p.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, p.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, p.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, p.w, acc1, 0, 0, 0);
+        }
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[0].x, pwall[fi * kPS + 512u + q], acc0, 0, 0, 0);  // k = 512..515
+        const v4acc acc = acc0 + acc1;
+        if (fi < nf) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned m = 16u * blk + 4u * q + r;
+                if (m < a.n_mels) o[(size_t)m * a.n_frames] = amp_f32<AMP>(acc[r], eps);
+            }
+        }
+    }
+}
+
 #ifdef SGX_STAMPS  // diagnostic build only (tools/stamps.py): share of a wave's cycles per phase, per role
 __device__ unsigned long long g_stamps[32];
 #define SGX_STAMP(i)                                                                        \
@@ -387,6 +430,9 @@ __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned
         SGX_STAMP(4);
         __syncthreads();  // ex consumed: the next pass 1 (or the pw overlay) may overwrite it
         SGX_STAMP(5);
+        if constexpr (MODE == OUT_MEL) {  // pw rows are 516 floats wide: bins 513..515 are read with zero weights
+            if (tid < 48u) ((float *)smem)[(tid / 3u) * kPS + 513u + tid % 3u] = 0.0f;
+        }
         if (active && p2f < nf) {
             const v4f *t2 = (const v4f *)(tabs + kTw2Off);
             auto tw = [&](int i) {  // read from LDS where consumed (this kernel has no registers to keep them)
@@ -398,7 +444,8 @@ __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned
             __syncthreads();
 #ifndef SGX_ABL_NOMELTILE
             if (active) {
-                if (mel_lds) mel_tile_lds<AMP>(a, (const float *)smem, lw4, lptr, lcol, b, f0, nf, eps, tid, 256u);
+                if (a.dense_w) dense_tile_mfma<AMP>(a, (const float *)smem, b, f0, nf, eps, tid);
+                else if (mel_lds) mel_tile_lds<AMP>(a, (const float *)smem, lw4, lptr, lcol, b, f0, nf, eps, tid, 256u);
                 else mel_tile<AMP>(a, (const float *)smem, b, f0, nf, eps, tid, 256u);
             }
 #endif

@@ -352,6 +352,21 @@ sgx_status build_device_tables(sgx_plan *pl) {
             if ((st = upload<uint32_t>(pl, &pl->d_mel_pcol, pcol)) != SGX_OK) return st;
             if ((st = upload<float>(pl, &pl->d_mel_pw, pw)) != SGX_OK) return st;
         }
+        // dense bank (ERB): weights in v_mfma_f32_16x16x4_f32 A-fragment order for the tuned kernel's matrix-core epilogue
+        if (pl->p.freq_scale == SGX_FREQ_ERB && std::is_same<T, float>::value && pl->p.n_fft == 1024) {
+            const unsigned nm = pl->p.n_mels, nblk = (nm + 15) / 16, nb = 513;
+            std::vector<float> frag(size_t(nblk) * 33 * 64 * 4, 0.0f);
+            auto wt = [&](unsigned m, unsigned k) { return m < nm && k < nb ? float(pl->mel_val[size_t(m) * nb + k]) : 0.0f; };
+            for (unsigned blk = 0; blk < nblk; ++blk)
+                for (unsigned c = 0; c < 33; ++c)
+                    for (unsigned l = 0; l < 64; ++l)
+                        for (unsigned e = 0; e < 4; ++e) {
+                            const unsigned m = 16 * blk + (l & 15u);
+                            const unsigned k = c < 32 ? 16 * c + 4 * (l >> 4) + e : (e == 0 ? 512 + (l >> 4) : 0xffffffffu);
+                            frag[((size_t(blk) * 33 + c) * 64 + l) * 4 + e] = wt(m, k);
+                        }
+            if ((st = upload<float>(pl, &pl->d_dense_w, frag)) != SGX_OK) return st;
+        }
     }
     if (pl->p.n_mfcc > 0) {
         const unsigned nm = pl->p.n_mels, nc = pl->p.n_mfcc;
@@ -423,6 +438,7 @@ void fill_args(const sgx_plan *pl, StftArgs &a, const void *x, void *out, size_t
     a.mel_pcol = (const unsigned *)pl->d_mel_pcol;
     a.mel_pw = pl->d_mel_pw;
     a.mel_pchunks = pl->mel_pchunks;
+    a.dense_w = pl->d_dense_w;
     a.n_mels = p.n_mels;
     a.mel_nnz = unsigned(pl->mel_col.size());
     a.out_mode = pl->out_mode;
@@ -530,7 +546,7 @@ sgx_status grow(sgx_plan *pl, void **buf, size_t *have, size_t need) {
 
 void free_device(sgx_plan *pl) {
     void **bufs[] = {&pl->d_window, &pl->d_tw, &pl->d_tw1, &pl->d_tw2, &pl->d_mel_ptr, &pl->d_mel_col,
-                     &pl->d_mel_val, &pl->d_dct, &pl->d_lifter, &pl->d_melbuf, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half};
+                     &pl->d_mel_val, &pl->d_dct, &pl->d_lifter, &pl->d_melbuf, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_dense_w, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half};
     for (void **b : bufs)
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);

@@ -42,6 +42,9 @@ struct StftArgs {
     const unsigned *mel_pcol;
     const void *mel_pw;
     unsigned mel_pchunks;
+    // dense bank in MFMA fragment order (tuned f32 kernel, ERB): float4 dense_w[block][33][64]; block = 16 filters; chunk
+    // c < 32, lane l, element s = weight[16*block + (l & 15)][16 c + 4 (l >> 4) + s]; chunk 32: .x = weight[..][512 + (l >> 4)]
+    const void *dense_w;
     unsigned n_mels;
     unsigned mel_nnz;
     int out_mode;
@@ -121,7 +124,7 @@ struct sgx_plan {
 
     // device tables
     void *d_window = nullptr, *d_tw = nullptr, *d_tw1 = nullptr, *d_tw2 = nullptr;
-    void *d_mel_ptr = nullptr, *d_mel_col = nullptr, *d_mel_val = nullptr, *d_mel_pptr = nullptr, *d_mel_pcol = nullptr, *d_mel_pw = nullptr;
+    void *d_mel_ptr = nullptr, *d_mel_col = nullptr, *d_mel_val = nullptr, *d_mel_pptr = nullptr, *d_mel_pcol = nullptr, *d_mel_pw = nullptr, *d_dense_w = nullptr;
     unsigned mel_pchunks = 0;
     void *d_ones = nullptr;  // rectangular window for sgx_r2c
     // MFCC epilogue: DCT-II basis [n_mfcc][n_mels] and lifter [n_mfcc] in T; Mel-dB scratch (grown on demand)
