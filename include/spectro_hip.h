@@ -128,6 +128,21 @@ sgx_status sgx_axes(const sgx_plan *plan, size_t n_frames, double *freqs /*n_bin
  * in_len must be n_fft and out_len n_fft/2+1 complex values else SGX_DIM_MISMATCH (:264-282). */
 sgx_status sgx_r2c(sgx_plan *plan, const void *in, size_t in_len, void *out, size_t out_len);
 
+/* ---- inverse 1-D path ------------------------------------------------------------------------------------------
+ * Conforming per-call C2rPlan::process (src/fft_backend.rs:526-565) = irfft (src/spectrogram.rs:4789-4811): host pointers,
+ * in_len must be n_fft/2+1 complex values and out_len n_fft else SGX_DIM_MISMATCH; output scaled by 1/n_fft in T.  A
+ * non-zero imaginary part in the DC (or, even n_fft, Nyquist) bin is ignored in the arithmetic and reported as
+ * SGX_BACKEND after the output has been written — realfft's FftError::InputValues, mapped at :555-557. */
+sgx_status sgx_c2r(sgx_plan *plan, const void *in, size_t in_len, void *out, size_t out_len);
+/* istft (src/spectrogram.rs:4860-4946), batched over `batch` STFT matrices laid out [batch][n_bins][n_frames] complex T
+ * (what sgx_execute writes for SGX_AMP_COMPLEX): per frame C2R, * window, overlap-add in ascending frame order,
+ * / sum(w*w) where that exceeds T(1e-10), centre trim.  Uses the plan's n_fft / hop_size / window / centre.
+ *   n_bins != n_fft/2+1 or out_elems != batch * sgx_istft_length  ->  SGX_DIM_MISMATCH
+ *   mem_kind as sgx_execute; the DC/Nyquist check above is only reported for SGX_MEM_HOST (it needs a synchronisation). */
+sgx_status sgx_istft_length(const sgx_plan *plan, size_t n_frames, size_t *n_samples);
+sgx_status sgx_istft(sgx_plan *plan, const void *stft, size_t batch, size_t n_bins, size_t n_frames, void *out,
+                     size_t out_elems, int32_t mem_kind, void *hip_stream);
+
 /* make_window (:2159-2235): the plan's window coefficients as built (f64, before the cast to T). */
 sgx_status sgx_window(const sgx_plan *plan, double *out /*n_fft*/);
 /* build_mel_filterbank_matrix (:2302-2432) as CSR; pass NULL arrays to query nnz only. */

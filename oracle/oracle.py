@@ -54,6 +54,8 @@ def lib() -> C.CDLL:
         L.orc_validate.argtypes = [C.POINTER(_Params), C.c_char_p, sz]
         L.orc_frame_count.restype = sz
         L.orc_frame_count.argtypes = [sz, sz, sz, C.c_int]
+        L.orc_istft_length.restype = sz
+        L.orc_istft_length.argtypes = [sz, sz, sz, C.c_int]
         L.orc_make_window.argtypes = [C.c_int, C.c_double, dp, sz, dp]
         L.orc_mel_filterbank.restype = C.c_long
         L.orc_mel_filterbank.argtypes = [C.c_double, sz, sz, C.c_double, C.c_double, C.c_int,
@@ -70,6 +72,8 @@ def lib() -> C.CDLL:
             getattr(L, f"orc_spectrogram_batch_{suf}").argtypes = [C.POINTER(_Params), p, sz, sz, sz, p, C.c_int]
             getattr(L, f"orc_stft_batch_{suf}").argtypes = [C.POINTER(_Params), p, sz, sz, sz, p, C.c_int]
             getattr(L, f"orc_mfcc_{suf}").argtypes = [C.POINTER(_Params), C.c_uint32, C.c_int, C.c_uint32, p, sz, p]
+            getattr(L, f"orc_irfft_{suf}").argtypes = [p, sz, sz, p]
+            getattr(L, f"orc_istft_{suf}").argtypes = [p, sz, sz, sz, sz, C.c_int, C.c_double, dp, C.c_int, p]
             getattr(L, f"orc_fft2d_{suf}").argtypes = [p, sz, sz, p]
             getattr(L, f"orc_ifft2d_{suf}").argtypes = [p, sz, sz, p]
             getattr(L, f"orc_convolve_fft_{suf}").argtypes = [p, sz, sz, p, sz, sz, p]
@@ -271,6 +275,41 @@ def mfcc(p: Params, x: np.ndarray, n_mfcc: int = 13, include_c0: bool = True, li
     rc = getattr(lib(), f"orc_mfcc_{suf}")(C.byref(cp), n_mfcc, int(include_c0), lifter, _ptr(x), x.size, _ptr(out))
     if rc:
         raise OracleError(rc)
+    return out
+
+
+def irfft(spec: np.ndarray, n_fft: int) -> np.ndarray:
+    """irfft (spectrogram.rs:4789-4811) in spec's precision (complex64 -> f32, complex128 -> f64)."""
+    spec = np.ascontiguousarray(spec)
+    rdt = np.float32 if spec.dtype == np.complex64 else np.float64
+    spec = spec.astype(np.complex64 if rdt == np.float32 else np.complex128)
+    out = np.empty(n_fft, rdt)
+    rc = getattr(lib(), f"orc_irfft_{_suf(rdt)}")(_ptr(spec.view(rdt)), spec.shape[0], n_fft, _ptr(out))
+    if rc != 0:
+        raise OracleError(rc, "irfft")
+    return out
+
+
+def istft_length(n_frames: int, n_fft: int, hop: int, centre: bool) -> int:
+    return int(lib().orc_istft_length(n_frames, n_fft, hop, int(centre)))
+
+
+def istft(stft_matrix: np.ndarray, n_fft: int, hop: int, window: str = "hanning", centre: bool = True,
+          window_param: float = 0.0, custom=None) -> np.ndarray:
+    """istft (spectrogram.rs:4860-4946) of one (n_bins, n_frames) complex matrix, in its precision."""
+    m = np.ascontiguousarray(stft_matrix)
+    rdt = np.float32 if m.dtype == np.complex64 else np.float64
+    m = m.astype(np.complex64 if rdt == np.float32 else np.complex128)
+    nb, nf = m.shape
+    out = np.empty(istft_length(nf, n_fft, hop, centre), rdt)
+    cw = None
+    if custom is not None:
+        cw = np.ascontiguousarray(custom, dtype=np.float64)
+    rc = getattr(lib(), f"orc_istft_{_suf(rdt)}")(_ptr(m.view(rdt)), nb, nf, n_fft, hop, WINDOWS[window], float(window_param),
+                                                   cw.ctypes.data_as(C.POINTER(C.c_double)) if cw is not None else None,
+                                                   int(centre), _ptr(out))
+    if rc != 0:
+        raise OracleError(rc, "istft")
     return out
 
 

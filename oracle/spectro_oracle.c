@@ -240,6 +240,13 @@ done:
     return rc;
 }
 
+size_t orc_istft_length(size_t n_frames, size_t n_fft, size_t hop, int centre) {
+    size_t pad = centre ? n_fft / 2 : 0;
+    size_t out_len = (n_frames - 1) * hop + n_fft;
+    size_t unpadded = out_len > 2 * pad ? out_len - 2 * pad : 0;
+    return (centre && unpadded > 0) ? unpadded : out_len;
+}
+
 static size_t sat_usize(double v) { /* Rust `as usize` */
     if (!(v == v) || v <= 0.0) return 0;
     if (v >= 1.8446744073709552e19) return (size_t)-1;

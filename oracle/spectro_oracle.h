@@ -60,6 +60,8 @@ typedef struct {
 
 /* spectrogram.rs:3479-3506, 4129-4140, 3793-3813, 4071-4077, 944-959 */
 int orc_validate(const orc_params *p, char *err, size_t errlen);
+/* istft output length (spectrogram.rs:4888-4893, 4933-4941): (n_frames-1)*hop + n_fft, minus 2*pad when centred and > 0 */
+size_t orc_istft_length(size_t n_frames, size_t n_fft, size_t hop, int centre);
 /* spectrogram.rs:1230-1250 */
 size_t orc_frame_count(size_t n_samples, size_t n_fft, size_t hop, int centre);
 size_t orc_n_bins(const orc_params *p);
@@ -108,6 +110,13 @@ int orc_mfcc_f64(const orc_params *p, uint32_t n_mfcc, int include_c0, uint32_t 
 /* ---- 2-D path: src/fft_backend.rs:653-691 (forward), :744-818 (inverse); src/image_ops.rs:80-152,188-267,301-432 */
 int orc_fft2d_f32(const float *img, size_t nrows, size_t ncols, float *spec /*[nrows][ncols/2+1][2]*/);
 int orc_fft2d_f64(const double *img, size_t nrows, size_t ncols, double *spec);
+/* irfft spectrogram.rs:4789-4811 (C2rPlan::process fft_backend.rs:526-565); istft spectrogram.rs:4860-4946 */
+int orc_irfft_f32(const float *spec, size_t n_bins, size_t n_fft, float *out);
+int orc_irfft_f64(const double *spec, size_t n_bins, size_t n_fft, double *out);
+int orc_istft_f32(const float *stft, size_t n_bins, size_t n_frames, size_t n_fft, size_t hop, int window_kind,
+                  double window_param, const double *custom, int centre, float *out);
+int orc_istft_f64(const double *stft, size_t n_bins, size_t n_frames, size_t n_fft, size_t hop, int window_kind,
+                  double window_param, const double *custom, int centre, double *out);
 int orc_ifft2d_f32(const float *spec, size_t nrows, size_t ncols, float *img);
 int orc_ifft2d_f64(const double *spec, size_t nrows, size_t ncols, double *img);
 int orc_convolve_fft_f32(const float *img, size_t nrows, size_t ncols, const float *ker, size_t kr, size_t kc, float *out);

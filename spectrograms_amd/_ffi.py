@@ -24,7 +24,7 @@ DEVICE_CURRENT, DEVICE_HOST_ONLY = -1, -2
 # every symbol include/spectro_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "sgx_plan_create", "sgx_plan_destroy", "sgx_output_shape", "sgx_execute", "sgx_execute_timed", "sgx_axes",
-    "sgx_r2c", "sgx_window", "sgx_mel_weights", "sgx_shard_range", "sgx_last_error", "sgx_last_create_error",
+    "sgx_r2c", "sgx_c2r", "sgx_istft", "sgx_istft_length", "sgx_window", "sgx_mel_weights", "sgx_shard_range", "sgx_last_error", "sgx_last_create_error",
     "sgx_kernel_name", "sgx_abi_version", "sgx_device_count",
     "sgx_fft2d_create", "sgx_fft2d_destroy", "sgx_fft2d_forward", "sgx_fft2d_inverse", "sgx_fft2d_convolve",
     "sgx_fft2d_filter", "sgx_fft2d_last_error",
@@ -92,6 +92,9 @@ def lib() -> C.CDLL:
     L.sgx_execute_timed.argtypes = [vp, vp, sz, sz, sz, vp, sz, vp, C.c_int32, C.POINTER(C.c_float)]
     L.sgx_axes.argtypes = [vp, sz, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.sgx_r2c.argtypes = [vp, vp, sz, vp, sz]
+    L.sgx_c2r.argtypes = [vp, vp, sz, vp, sz]
+    L.sgx_istft_length.argtypes = [vp, sz, C.POINTER(sz)]
+    L.sgx_istft.argtypes = [vp, vp, sz, sz, sz, vp, sz, C.c_int32, vp]
     L.sgx_window.argtypes = [vp, C.POINTER(C.c_double)]
     L.sgx_mel_weights.argtypes = [vp, C.POINTER(sz), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
     L.sgx_shard_range.argtypes = [sz, C.c_int32, C.c_int32, C.POINTER(sz), C.POINTER(sz)]

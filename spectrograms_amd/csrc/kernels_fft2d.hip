@@ -113,7 +113,10 @@ __global__ __launch_bounds__(256) void k_c2r_rows(C2rArgs a) {
         unsigned r, k;
         if (a.k_fast) { k = idx % Cb; r = idx / Cb; } else { r = idx % nr; k = idx / nr; }  // follow the unit stride
         Cx2<T> v = in[(size_t)k * a.in_ks + (size_t)(r0 + r) * a.in_rs];
-        if (k == 0 || (!(C & 1u) && k == Cb - 1)) v.im = T(0);
+        if (k == 0 || (!(C & 1u) && k == Cb - 1)) {
+            if (a.bad_flag && v.im != T(0)) atomicOr(a.bad_flag, 1u);
+            v.im = T(0);
+        }
         const unsigned p = pow2 ? (__brev(k) >> (32 - a.log2c)) : k;
         buf[r * fs + p] = v;
         const unsigned km = C - k;
@@ -124,11 +127,14 @@ __global__ __launch_bounds__(256) void k_c2r_rows(C2rArgs a) {
     }
     __syncthreads();
     const T scale = (T)a.scale;
+    const T *win = (const T *)a.win;
     if (pow2) {
         lds_fft_pow2<T>(buf, nr, C, a.log2c, fs, tw, true);
         for (unsigned idx = threadIdx.x; idx < nr * C; idx += 256) {
             const unsigned c = idx % C, r = idx / C;
-            out[(size_t)(r0 + r) * C + c] = buf[r * fs + c].re * scale;
+            T v = buf[r * fs + c].re * scale;
+            if (win) v *= win[c];
+            out[(size_t)(r0 + r) * C + c] = v;
         }
     } else {
         for (unsigned idx = threadIdx.x; idx < nr * C; idx += 256) {
@@ -141,9 +147,36 @@ __global__ __launch_bounds__(256) void k_c2r_rows(C2rArgs a) {
                 tt += c;
                 if (tt >= C) tt -= C;
             }
-            out[(size_t)(r0 + r) * C + c] = sr * scale;
+            T v = sr * scale;
+            if (win) v *= win[c];
+            out[(size_t)(r0 + r) * C + c] = v;
         }
     }
+}
+
+// istft overlap-add (src/spectrogram.rs:4911-4930) as a gather: sample `pos` of the padded signal sums, in ascending frame
+// order, the windowed frame values covering it; norm = sum of w*w (each product rounded, then added — no contraction);
+// divide where norm > T(1e-10).  One thread per output sample; out[b][i] = padded[start + i].
+template <typename T>
+__global__ __launch_bounds__(256) void k_istft_ola(const T *frames, const T *win, T *out, unsigned n, unsigned hop,
+                                                   unsigned n_frames, unsigned long long start, unsigned long long out_len) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= out_len) return;
+    const unsigned b = blockIdx.y;
+    const unsigned long long pos = start + i;
+    const unsigned long long f_hi = min(pos / hop, (unsigned long long)n_frames - 1);
+    const unsigned long long f_lo = pos >= n ? (pos - n) / hop + 1 : 0;
+    const T *fr = frames + (size_t)b * n_frames * n;
+    T acc = T(0), nrm = T(0);
+    for (unsigned long long f = f_lo; f <= f_hi; ++f) {
+        const unsigned j = (unsigned)(pos - f * hop);
+        acc += fr[f * n + j];
+        const T w = win[j];
+        if constexpr (sizeof(T) == 4) nrm = __fadd_rn(nrm, __fmul_rn(w, w));
+        else nrm = __dadd_rn(nrm, __dmul_rn(w, w));
+    }
+    if (nrm > T(1e-10)) acc /= nrm;
+    out[(size_t)b * out_len + i] = acc;
 }
 
 // mode 0: out = a * b[i % per] (complex x complex); mode 1: out = a * m[i % per] (complex x real mask)
@@ -179,10 +212,34 @@ hipError_t launch_c2c_tile(const C2cArgs &a, int dtype, hipStream_t s) {
     return hipGetLastError();
 }
 
+unsigned c2r_tile_for(unsigned n, int dtype, size_t lds_budget) {
+    const size_t per = (size_t)(n + 1) * 2 * esz(dtype);
+    unsigned tile = 16;
+    while (tile > 1 && per * tile > lds_budget) tile >>= 1;
+    return per * tile <= lds_budget ? tile : 0;
+}
+
+hipError_t launch_istft_ola(const void *frames, const void *win, void *out, unsigned n, unsigned hop, unsigned n_frames,
+                            unsigned long long start, unsigned long long out_len, unsigned batch, int dtype, hipStream_t s) {
+    const unsigned long long gx = (out_len + 255) / 256;
+    if (gx == 0 || gx >= 0x7fffffffull || batch == 0 || batch > 65535u) return hipErrorInvalidConfiguration;
+    const dim3 grid((unsigned)gx, batch);
+    if (dtype == SGX_F64)
+        hipLaunchKernelGGL(k_istft_ola<double>, grid, dim3(256), 0, s, (const double *)frames, (const double *)win, (double *)out, n, hop, n_frames, start, out_len);
+    else
+        hipLaunchKernelGGL(k_istft_ola<float>, grid, dim3(256), 0, s, (const float *)frames, (const float *)win, (float *)out, n, hop, n_frames, start, out_len);
+    return hipGetLastError();
+}
+
 hipError_t launch_c2r_rows(const C2rArgs &a, int dtype, hipStream_t s) {
     const unsigned long long g = (unsigned long long)a.tiles * a.batch;
     if (g == 0 || g >= 0x7fffffffull || a.tile == 0) return hipErrorInvalidConfiguration;
     const size_t lds = (size_t)a.tile * (a.ncols + 1) * 2 * esz(dtype);
+    if (lds > 64 * 1024) {  // opt in to the large LDS window (160 KiB per CU on gfx950)
+        hipError_t e = dtype == SGX_F64 ? hipFuncSetAttribute((const void *)k_c2r_rows<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                        : hipFuncSetAttribute((const void *)k_c2r_rows<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     if (dtype == SGX_F64) hipLaunchKernelGGL(k_c2r_rows<double>, dim3((unsigned)g), dim3(256), lds, s, a);
     else hipLaunchKernelGGL(k_c2r_rows<float>, dim3((unsigned)g), dim3(256), lds, s, a);
     return hipGetLastError();

@@ -180,6 +180,7 @@ __global__ __launch_bounds__(256) void k_direct_dft(StftArgs a) {
             t += k;
             if (t >= n) t -= n;
         }
+        if (k == 0 || (!(n & 1u) && k == a.nb_fft - 1)) si = T(0);  // realfft: DC / Nyquist bins are exactly real
         emit_bin<T>(a, b, f0 + f, f, k, sr, si, pw, eps);
     }
     if (a.out_mode == OUT_MEL) {

@@ -546,12 +546,87 @@ sgx_status grow(sgx_plan *pl, void **buf, size_t *have, size_t need) {
 
 void free_device(sgx_plan *pl) {
     void **bufs[] = {&pl->d_window, &pl->d_tw, &pl->d_tw1, &pl->d_tw2, &pl->d_mel_ptr, &pl->d_mel_col,
-                     &pl->d_mel_val, &pl->d_dct, &pl->d_lifter, &pl->d_melbuf, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_dense_w, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half};
+                     &pl->d_mel_val, &pl->d_dct, &pl->d_lifter, &pl->d_melbuf, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_dense_w, &pl->d_itw, &pl->d_frames, &pl->d_flag, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half};
     for (void **b : bufs)
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
     if (pl->ev1) (void)hipEventDestroy(pl->ev1);
     pl->ev0 = pl->ev1 = nullptr;
+}
+
+}  // namespace
+
+// ---- inverse path: C2rPlan::process / irfft / istft ------------------------------------------------------------------
+namespace {
+
+size_t istft_length(const sgx_params &p, size_t n_frames) {  // spectrogram.rs:4888-4893, 4933-4941
+    const size_t pad = p.centre ? p.n_fft / 2 : 0;
+    const size_t out_len = (n_frames - 1) * size_t(p.hop_size) + p.n_fft;
+    const size_t unpadded = out_len > 2 * pad ? out_len - 2 * pad : 0;
+    return (p.centre && unpadded > 0) ? unpadded : out_len;
+}
+
+template <typename T>
+sgx_status inverse_tables(sgx_plan *pl) {
+    if (pl->d_itw) return SGX_OK;
+    const size_t n = pl->p.n_fft;
+    std::vector<T> tw(2 * n);
+    for (size_t k = 0; k < n; ++k) {
+        const double a = -2.0 * kPi * double(k) / double(n);
+        tw[2 * k] = T(std::cos(a));
+        tw[2 * k + 1] = T(std::sin(a));
+    }
+    sgx_status st = upload<T>(pl, &pl->d_itw, tw);
+    if (st != SGX_OK) return st;
+    SGX_HIP(pl, hipMalloc(&pl->d_flag, sizeof(unsigned)));
+    return SGX_OK;
+}
+
+// frames (rows) of `spec` -> real rows of n_fft samples: inverse real FFT, * 1/n in T (fft_backend.rs:559-563), optional window
+sgx_status launch_c2r_frames(sgx_plan *pl, const void *spec, void *frames, size_t batch, size_t n_frames, bool frame_fast,
+                             const void *win, hipStream_t s) {
+    const unsigned n = pl->p.n_fft;
+    C2rArgs c{};
+    c.in = spec; c.out = frames;
+    c.nrows = unsigned(n_frames); c.ncols = n; c.batch = unsigned(batch);
+    c.log2c = 0;
+    if (n >= 2 && !(n & (n - 1))) while ((1u << c.log2c) < n) ++c.log2c;
+    c.in_img = (unsigned long long)pl->nb_fft * n_frames;
+    if (frame_fast) { c.in_ks = n_frames; c.in_rs = 1; c.k_fast = 0; }  // [bin][frame] (StftResult layout, S9)
+    else { c.in_ks = 1; c.in_rs = pl->nb_fft; c.k_fast = 1; }
+    c.tile = c2r_tile_for(n, pl->dtype, 144 * 1024);
+    if (c.tile == 0) return set_err(pl, SGX_BACKEND, "hip -- FFT backend error: n_fft too large for the on-chip frame tile");
+    c.tiles = unsigned((n_frames + c.tile - 1) / c.tile);
+    c.tw = pl->d_itw;
+    c.scale = pl->dtype == SGX_F64 ? 1.0 / double(n) : double(1.0f / float(n));  // T::one() / T::from_usize(n_fft)
+    c.win = win;
+    c.bad_flag = (unsigned *)pl->d_flag;
+    SGX_HIP(pl, launch_c2r_rows(c, pl->dtype, s));
+    return SGX_OK;
+}
+
+sgx_status run_istft(sgx_plan *pl, const void *spec, size_t batch, size_t n_frames, void *out, size_t out_len, hipStream_t s) {
+    sgx_status st = pl->dtype == SGX_F64 ? inverse_tables<double>(pl) : inverse_tables<float>(pl);
+    if (st != SGX_OK) return st;
+    const size_t n = pl->p.n_fft;
+    if ((st = grow(pl, &pl->d_frames, &pl->d_frames_bytes, batch * n_frames * n * pl->elem)) != SGX_OK) return st;
+    SGX_HIP(pl, hipMemsetAsync(pl->d_flag, 0, sizeof(unsigned), s));
+    if ((st = launch_c2r_frames(pl, spec, pl->d_frames, batch, n_frames, true, pl->d_window, s)) != SGX_OK) return st;
+    const size_t pad = pl->p.centre ? n / 2 : 0;
+    const size_t full = (n_frames - 1) * size_t(pl->p.hop_size) + n;
+    const size_t start = out_len == full ? 0 : pad;  // untrimmed when the centred signal would be empty (:4933)
+    SGX_HIP(pl, launch_istft_ola(pl->d_frames, pl->d_window, out, unsigned(n), pl->p.hop_size, unsigned(n_frames), start, out_len,
+                                 unsigned(batch), pl->dtype, s));
+    return SGX_OK;
+}
+
+sgx_status check_flag(sgx_plan *pl, hipStream_t s) {
+    unsigned flag = 0;
+    SGX_HIP(pl, hipMemcpyAsync(&flag, pl->d_flag, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    SGX_HIP(pl, hipStreamSynchronize(s));
+    if (flag)  // realfft: FftError::InputValues, mapped at fft_backend.rs:555-557
+        return set_err(pl, SGX_BACKEND, "hip -- FFT backend error: imaginary part of the DC or Nyquist bin is non-zero");
+    return SGX_OK;
 }
 
 }  // namespace
@@ -773,6 +848,63 @@ sgx_status sgx_r2c(sgx_plan *plan, const void *in, size_t in_len, void *out, siz
     SGX_HIP(plan, launch(plan, a, kind, nullptr));
     SGX_HIP(plan, hipMemcpy(out, plan->d_out, 2 * nb * plan->elem, hipMemcpyDeviceToHost));
     return SGX_OK;
+}
+
+// ---- inverse path entry points (helpers above the extern "C" block)
+sgx_status sgx_istft_length(const sgx_plan *plan, size_t n_frames, size_t *n_samples) {
+    if (!plan || !n_samples) return SGX_INVALID_INPUT;
+    if (n_frames == 0) return set_err(const_cast<sgx_plan *>(plan), SGX_INVALID_INPUT, "Invalid input: stft matrix must be non-empty");
+    *n_samples = istft_length(plan->p, n_frames);
+    return SGX_OK;
+}
+
+sgx_status sgx_istft(sgx_plan *plan, const void *stft, size_t batch, size_t n_bins, size_t n_frames, void *out,
+                     size_t out_elems, int32_t mem_kind, void *hip_stream) {
+    if (!plan) return SGX_INVALID_INPUT;
+    if (!stft || !out) return set_err(plan, SGX_INVALID_INPUT, "Invalid input: null buffer");
+    if (batch == 0 || n_frames == 0) return set_err(plan, SGX_INVALID_INPUT, "Invalid input: stft matrix must be non-empty");
+    if (n_bins != plan->nb_fft)  // :4876-4879
+        return set_err(plan, SGX_DIM_MISMATCH, "Dimension mismatch: expected " + std::to_string(plan->nb_fft) + ", got " + std::to_string(n_bins));
+    if (batch > 65535 || n_frames > 0x7fffffffull) return set_err(plan, SGX_INVALID_INPUT, "Invalid input: batch or frame count too large");
+    const size_t len = istft_length(plan->p, n_frames);
+    if (out_elems != batch * len)
+        return set_err(plan, SGX_DIM_MISMATCH, "Dimension mismatch: expected " + std::to_string(batch * len) + ", got " + std::to_string(out_elems));
+    if (!plan->device_ready)
+        return set_err(plan, SGX_BACKEND, "hip -- FFT backend error: plan has no HIP device (host-only plan)");
+    SGX_HIP(plan, hipSetDevice(plan->device));
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if (mem_kind == SGX_MEM_DEVICE) return run_istft(plan, stft, batch, n_frames, out, len, s);
+    if (mem_kind != SGX_MEM_HOST) return set_err(plan, SGX_INVALID_INPUT, "Invalid input: unknown mem_kind");
+    const size_t in_bytes = batch * n_bins * n_frames * 2 * plan->elem, out_bytes = out_elems * plan->elem;
+    sgx_status st;
+    if ((st = grow(plan, &plan->d_in, &plan->d_in_bytes, in_bytes)) != SGX_OK) return st;
+    if ((st = grow(plan, &plan->d_out, &plan->d_out_bytes, out_bytes)) != SGX_OK) return st;
+    SGX_HIP(plan, hipMemcpyAsync(plan->d_in, stft, in_bytes, hipMemcpyHostToDevice, s));
+    if ((st = run_istft(plan, plan->d_in, batch, n_frames, plan->d_out, len, s)) != SGX_OK) return st;
+    SGX_HIP(plan, hipMemcpyAsync(out, plan->d_out, out_bytes, hipMemcpyDeviceToHost, s));
+    return check_flag(plan, s);  // synchronises
+}
+
+sgx_status sgx_c2r(sgx_plan *plan, const void *in, size_t in_len, void *out, size_t out_len) {
+    if (!plan) return SGX_INVALID_INPUT;
+    if (!in || !out) return set_err(plan, SGX_INVALID_INPUT, "Invalid input: null buffer");
+    const size_t n = plan->p.n_fft, nb = plan->nb_fft;
+    if (in_len != nb)  // fft_backend.rs:538-544
+        return set_err(plan, SGX_DIM_MISMATCH, "Dimension mismatch: expected " + std::to_string(nb) + ", got " + std::to_string(in_len));
+    if (out_len != n)  // :545-550
+        return set_err(plan, SGX_DIM_MISMATCH, "Dimension mismatch: expected " + std::to_string(n) + ", got " + std::to_string(out_len));
+    if (!plan->device_ready)
+        return set_err(plan, SGX_BACKEND, "hip -- FFT backend error: plan has no HIP device (host-only plan)");
+    SGX_HIP(plan, hipSetDevice(plan->device));
+    sgx_status st = plan->dtype == SGX_F64 ? inverse_tables<double>(plan) : inverse_tables<float>(plan);
+    if (st != SGX_OK) return st;
+    if ((st = grow(plan, &plan->d_in, &plan->d_in_bytes, 2 * nb * plan->elem)) != SGX_OK) return st;
+    if ((st = grow(plan, &plan->d_out, &plan->d_out_bytes, n * plan->elem)) != SGX_OK) return st;
+    SGX_HIP(plan, hipMemcpy(plan->d_in, in, 2 * nb * plan->elem, hipMemcpyHostToDevice));
+    SGX_HIP(plan, hipMemsetAsync(plan->d_flag, 0, sizeof(unsigned), nullptr));
+    if ((st = launch_c2r_frames(plan, plan->d_in, plan->d_out, 1, 1, false, nullptr, nullptr)) != SGX_OK) return st;
+    SGX_HIP(plan, hipMemcpy(out, plan->d_out, n * plan->elem, hipMemcpyDeviceToHost));
+    return check_flag(plan, nullptr);
 }
 
 sgx_status sgx_window(const sgx_plan *plan, double *out) {

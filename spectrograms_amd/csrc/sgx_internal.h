@@ -90,8 +90,16 @@ struct C2rArgs {
     unsigned tile, tiles;
     const void *tw;  // e^{-2 pi i k / ncols}, ncols entries
     double scale;
+    // ISTFT use (rows = frames): optional synthesis window applied after the scale, and a flag word set when a DC /
+    // Nyquist bin carries a non-zero imaginary part (realfft's C2R reports FftError::InputValues for that)
+    const void *win;
+    unsigned *bad_flag;
 };
 unsigned fft2d_tile_for(unsigned n, int dtype);
+unsigned c2r_tile_for(unsigned n, int dtype, size_t lds_budget);
+// overlap-add + normalisation of windowed frames [batch][n_frames][n] into out[batch][out_len] (istft, spectrogram.rs:4911-4930)
+hipError_t launch_istft_ola(const void *frames, const void *win, void *out, unsigned n, unsigned hop, unsigned n_frames,
+                            unsigned long long start, unsigned long long out_len, unsigned batch, int dtype, hipStream_t s);
 hipError_t launch_c2c_tile(const C2cArgs &a, int dtype, hipStream_t s);
 hipError_t launch_c2r_rows(const C2rArgs &a, int dtype, hipStream_t s);
 // tuned f32 1024-point C2C, 16 sequences per workgroup; tw1c = W_1024^(k1*n2), [32][32] complex f32; output must be
@@ -132,6 +140,9 @@ struct sgx_plan {
     size_t d_melbuf_bytes = 0;
     unsigned n_final = 0;  // rows of the final output (n_out, or the MFCC row count)
     void *d_window_half = nullptr, *d_ones_half = nullptr;  // 0.5*window (exact) for the tuned kernel's real split
+    // inverse path (sgx_istft / sgx_c2r), created on first use: full twiddle table e^{-2 pi i k/n}, frame scratch, flag
+    void *d_itw = nullptr, *d_frames = nullptr, *d_flag = nullptr;
+    size_t d_frames_bytes = 0;
 
     // plan-owned staging for host-pointer execution
     void *d_in = nullptr, *d_out = nullptr;

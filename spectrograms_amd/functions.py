@@ -1,6 +1,8 @@
 """One-shot functions with the reference's names and argument order (src/python/functions.rs:92-266, 757-773)."""
 from __future__ import annotations
 
+import numpy as np
+
 from . import _ffi
 from .params import LogParams, MelParams, SpectrogramParams
 from .planner import Plan
@@ -63,3 +65,24 @@ def compute_erb_magnitude_spectrogram(samples, params, erb_params, db=None, dtyp
 
 def compute_erb_db_spectrogram(samples, params, erb_params, db=None, dtype=None):
     return Plan(params, _ffi.AMP_DECIBELS, erb_params, db, dtype).compute(samples)
+
+
+def compute_irfft(spectrum, n_fft, dtype=None):
+    """irfft (src/spectrogram.rs:4789-4811; Python src/python/functions.rs:970-983): n_fft/2+1 bins -> n_fft samples."""
+    from .params import StftParams, WindowType
+    if int(n_fft) <= 0:
+        raise ValueError("n_fft must be > 0")
+    params = SpectrogramParams(StftParams(int(n_fft), int(n_fft), WindowType.rectangular, False), 1.0)
+    return Plan(params, _ffi.AMP_COMPLEX, None, None, dtype).c2r(spectrum)
+
+
+def compute_istft(stft_matrix, n_fft, hop_size, window, center=True, dtype=None):
+    """istft (src/spectrogram.rs:4860-4946; Python src/python/functions.rs:1018-1038)."""
+    from .params import StftParams
+    if int(n_fft) <= 0 or int(hop_size) <= 0:
+        raise ValueError("n_fft and hop_size must be > 0")
+    m = np.asarray(getattr(stft_matrix, "data", stft_matrix))
+    if m.ndim == 2 and m.shape[0] != int(n_fft) // 2 + 1:  # checked before hop_size (:4876-4882)
+        raise _ffi.DimensionMismatchError(f"Dimension mismatch: expected {int(n_fft) // 2 + 1}, got {m.shape[0]}")
+    params = SpectrogramParams(StftParams(int(n_fft), int(hop_size), window, bool(center)), 1.0)
+    return Plan(params, _ffi.AMP_COMPLEX, None, None, dtype).istft(m)

@@ -270,6 +270,58 @@ class Plan:
         return out
 
 
+    def c2r(self, spectrum) -> np.ndarray:
+        """Conforming C2rPlan::process (src/fft_backend.rs:526-565): n_fft/2+1 complex bins -> n_fft reals, scaled 1/n_fft."""
+        cdt = np.complex64 if self._dt == _ffi.F32 else np.complex128
+        x = np.ascontiguousarray(spectrum, dtype=cdt)
+        out = np.empty(self.n_fft, self._np)
+        _ffi.raise_status(self._lib.sgx_c2r(self._h, x.ctypes.data, x.size, out.ctypes.data, out.size), self._h)
+        return out
+
+    def istft_length(self, n_frames: int) -> int:
+        n = C.c_size_t()
+        _ffi.raise_status(self._lib.sgx_istft_length(self._h, n_frames, C.byref(n)), self._h)
+        return n.value
+
+    def istft_batch(self, stft, out=None, stream: int = 0):
+        """Batched istft (src/spectrogram.rs:4860-4946) of [batch][n_bins][n_frames] complex matrices with this plan's
+        n_fft / hop / window / centre.  numpy in -> numpy out (plan-owned staging); torch device tensor in -> device tensor
+        out, asynchronous on the current (or given) stream."""
+        cdt = np.complex64 if self._dt == _ffi.F32 else np.complex128
+        if isinstance(stft, np.ndarray) or not hasattr(stft, "data_ptr"):
+            m = np.ascontiguousarray(stft, dtype=cdt)
+            if m.ndim != 3:
+                raise ValueError("stft must be a 3-D array (batch, n_bins, n_frames)")
+            b, nb, nf = m.shape
+            if b == 0 or nf == 0:
+                raise ValueError("stft must be non-empty")
+            if out is None and nb == self.n_fft // 2 + 1:
+                out = np.empty((b, self.istft_length(nf)), self._np)
+            elif out is None:
+                out = np.empty((b, 0), self._np)
+            _ffi.raise_status(self._lib.sgx_istft(self._h, m.ctypes.data, b, nb, nf, out.ctypes.data, out.size, _ffi.MEM_HOST,
+                                                  C.c_void_p(stream)), self._h)
+            return out
+        import torch
+        want = torch.complex64 if self._dt == _ffi.F32 else torch.complex128
+        if stft.dtype != want or not stft.is_contiguous() or stft.dim() != 3:
+            raise ValueError("stft must be a contiguous 3-D tensor of the plan's complex dtype")
+        b, nb, nf = stft.shape
+        if out is None:
+            n_out = self.istft_length(nf) if nb == self.n_fft // 2 + 1 else 0
+            out = torch.empty((b, n_out), dtype=torch.float32 if self._dt == _ffi.F32 else torch.float64, device=stft.device)
+        s = stream or torch.cuda.current_stream(stft.device).cuda_stream
+        _ffi.raise_status(self._lib.sgx_istft(self._h, stft.data_ptr(), b, nb, nf, out.data_ptr(), out.numel(), _ffi.MEM_DEVICE,
+                                              C.c_void_p(s)), self._h)
+        return out
+
+    def istft(self, stft_matrix) -> np.ndarray:
+        m = np.asarray(stft_matrix.data if isinstance(stft_matrix, StftResult) else stft_matrix)
+        if m.ndim != 2:
+            raise ValueError("stft_matrix must be a 2-D array (n_bins, n_frames)")
+        return self.istft_batch(m[None])[0]
+
+
 class SpectrogramPlanner:
     """src/python/planner.rs:107-350 — same method names and argument order."""
 

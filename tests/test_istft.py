@@ -1,0 +1,138 @@
+"""Inverse 1-D path: irfft / C2rPlan::process (src/fft_backend.rs:526-565, src/spectrogram.rs:4789-4811)
+and batched istft (src/spectrogram.rs:4860-4946).  CPU tests pin the oracle; GPU tests compare the HIP path with it."""
+import numpy as np
+import pytest
+
+import spectrograms_amd as sg
+from oracle import oracle as orc
+from spectrograms_amd import _ffi
+from tests import helpers as H
+
+
+def np_istft(S, n_fft, hop, w, centre):
+    nb, nf = S.shape
+    out_len = (nf - 1) * hop + n_fft
+    acc, nrm = np.zeros(out_len), np.zeros(out_len)
+    for f in range(nf):
+        col = S[:, f].copy()
+        col[0] = col[0].real
+        if n_fft % 2 == 0:
+            col[-1] = col[-1].real
+        acc[f * hop:f * hop + n_fft] += np.fft.irfft(col, n_fft) * w
+        nrm[f * hop:f * hop + n_fft] += w * w
+    ok = nrm > 1e-10
+    acc[ok] /= nrm[ok]
+    pad = n_fft // 2 if centre else 0
+    unp = max(out_len - 2 * pad, 0)
+    return acc[pad:pad + unp] if centre and unp > 0 else acc
+
+
+CASES = [(512, 128, True, "hanning"), (512, 256, True, "hanning"), (400, 100, False, "hamming"), (1024, 256, True, "hanning"),
+         (400, 160, True, "blackman"), (256, 256, False, "rectangular"), (8, 3, True, "hanning"), (15, 4, True, "hamming")]
+
+
+@pytest.mark.parametrize("n_fft,hop,centre,window", CASES)
+def test_oracle_istft_matches_numpy(n_fft, hop, centre, window):
+    x = np.random.default_rng(3).standard_normal(3000)
+    S = orc.stft(orc.Params(n_fft=n_fft, hop=hop, centre=centre, window=window), x)
+    got = orc.istft(S, n_fft, hop, window, centre)
+    ref = np_istft(S, n_fft, hop, orc.make_window(window, n_fft), centre)
+    assert got.shape == ref.shape and np.max(np.abs(got - ref)) < 1e-11
+    assert len(got) == orc.istft_length(S.shape[1], n_fft, hop, centre)
+
+
+def test_oracle_istft_roundtrip_and_edge_lengths():
+    x = np.sin(0.02 * np.arange(2048))  # tests/f32_smoke_tests.rs:66-76
+    for dt, tol in ((np.float64, 1e-12), (np.float32, 2e-6)):
+        S = orc.stft(orc.Params(n_fft=256, hop=128), x.astype(dt))
+        y = orc.istft(S, 256, 128, "hanning", True)
+        assert y.dtype == dt and np.all(np.isfinite(y))
+        n = min(len(y), len(x))
+        assert np.max(np.abs(y[128:n - 128] - x[128:n - 128])) < tol
+    # one centred frame of even n_fft: the trimmed length would be 0, so the untrimmed n_fft samples come back (:4933)
+    assert orc.istft_length(1, 512, 128, True) == 512 and orc.istft_length(1, 15, 4, True) == 1
+    assert orc.istft_length(3, 512, 128, True) == 256 and orc.istft_length(3, 512, 128, False) == 768
+    with pytest.raises(orc.OracleError):  # n_bins mismatch (:4876-4879)
+        orc.istft(np.zeros((100, 4), np.complex128), 512, 128)
+    with pytest.raises(orc.OracleError):  # tests/fft_padding_tests.rs:133-138
+        orc.irfft(np.ones(4, np.complex128), 8)
+    with pytest.raises(orc.OracleError):  # realfft rejects a complex DC bin
+        orc.irfft(np.array([1 + 1j, 0, 0, 0, 0]), 8)
+    z = np.random.default_rng(0).standard_normal(100)
+    assert np.max(np.abs(orc.irfft(np.fft.rfft(z), 100) - z)) < 1e-12
+
+
+def test_host_istft_validation():
+    params = sg.SpectrogramParams(sg.StftParams(512, 128, sg.WindowType.hanning, True), 16000.0)
+    pl = sg.Plan(params, _ffi.AMP_COMPLEX, None, None, "float64", device=_ffi.DEVICE_HOST_ONLY)
+    assert pl.istft_length(3) == 256 and pl.istft_length(1) == 512
+    with pytest.raises(sg.DimensionMismatchError, match="expected 257, got 100"):
+        pl.istft_batch(np.zeros((1, 100, 4), np.complex128))
+    with pytest.raises(sg.DimensionMismatchError):
+        pl.istft_batch(np.zeros((1, 257, 4), np.complex128), out=np.zeros((1, 5)))
+    with pytest.raises(sg.SpectrogramError, match="no HIP device"):  # no CPU fallback
+        pl.istft_batch(np.zeros((1, 257, 4), np.complex128))
+    with pytest.raises(sg.DimensionMismatchError, match="expected 5, got 4"):
+        pl8 = sg.Plan(sg.SpectrogramParams(sg.StftParams(8, 8, sg.WindowType.rectangular, False), 1.0), _ffi.AMP_COMPLEX, None, None,
+                      "float64", device=_ffi.DEVICE_HOST_ONLY)
+        pl8.c2r(np.ones(4, np.complex128))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("n_fft,hop,centre,window", CASES + [(4096, 1024, True, "hanning"), (8192, 2048, True, "hanning")])
+def test_gpu_istft_matches_oracle(n_fft, hop, centre, window, dtype):
+    rdt, cdt = (np.float32, np.complex64) if dtype == "float32" else (np.float64, np.complex128)
+    n = max(3000, 3 * n_fft)
+    x = np.random.default_rng(5).standard_normal((3, n)).astype(rdt)
+    wt = getattr(sg.WindowType, window)
+    params = sg.SpectrogramParams(sg.StftParams(n_fft, hop, wt, centre), 16000.0)
+    plan = sg.Plan(params, _ffi.AMP_COMPLEX, None, None, dtype)
+    S = np.stack([orc.stft(orc.Params(n_fft=n_fft, hop=hop, centre=centre, window=window), r) for r in x]).astype(cdt)
+    got = plan.istft_batch(S)
+    ref = np.stack([orc.istft(s, n_fft, hop, window, centre) for s in S])
+    assert got.dtype == rdt and got.shape == ref.shape
+    assert np.max(np.abs(got - ref)) < (1e-11 if dtype == "float64" else 2e-5 * max(1.0, np.max(np.abs(ref))))
+    one = sg.compute_istft(S[1], n_fft, hop, wt, centre, dtype=dtype)
+    assert np.array_equal(one, got[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [("float32", 3e-6), ("float64", 1e-12)])
+def test_gpu_stft_istft_roundtrip_device(dtype, tol):
+    """forward on the GPU, inverse on the GPU, device-resident end to end (config-2 shaped rows)."""
+    import torch
+    x = H.cfg2_batch(4).astype(np.float32 if dtype == "float32" else np.float64)
+    params = sg.SpectrogramParams(sg.StftParams(1024, 256, sg.WindowType.hanning, True), 16000.0)
+    plan = sg.Plan(params, _ffi.AMP_COMPLEX, None, None, dtype)
+    xd = torch.from_numpy(x).cuda()
+    S = plan.compute_batch(xd)
+    Sc = torch.view_as_complex(S.reshape(S.shape[0], 513, -1, 2)) if not S.is_complex() else S
+    y = plan.istft_batch(Sc.contiguous())
+    torch.cuda.synchronize()
+    y = y.cpu().numpy()
+    n = min(y.shape[1], x.shape[1])
+    assert y.shape[1] == plan.istft_length(Sc.shape[2])
+    assert np.max(np.abs(y[:, 512:n - 512] - x[:, 512:n - 512])) < tol
+
+
+@pytest.mark.gpu
+def test_gpu_irfft_and_dc_check():
+    z = np.random.default_rng(0).standard_normal(2048)
+    spec = np.fft.rfft(z)
+    o64 = sg.compute_irfft(spec, 2048, dtype="float64")  # python/tests/test_dtype_ops.py:81-88
+    o32 = sg.compute_irfft(spec, 2048, dtype="float32")
+    assert o64.dtype == np.float64 and o32.dtype == np.float32
+    np.testing.assert_allclose(o64, z, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(o32, z, rtol=1e-3, atol=1e-3)
+    assert np.max(np.abs(o64 - orc.irfft(spec, 2048))) < 1e-12
+    z100 = z[:100]
+    assert np.max(np.abs(sg.compute_irfft(np.fft.rfft(z100), 100) - z100)) < 1e-12
+    with pytest.raises(sg.DimensionMismatchError):  # tests/fft_padding_tests.rs:133-138
+        sg.compute_irfft(np.ones(4, np.complex128), 8)
+    with pytest.raises(sg.SpectrogramError, match="DC or Nyquist"):
+        sg.compute_irfft(np.array([1 + 1j, 0, 0, 0, 0]), 8)
+    with pytest.raises(sg.SpectrogramError, match="DC or Nyquist"):
+        bad = np.zeros((257, 4), np.complex128)
+        bad[256, 2] = 1j
+        sg.compute_istft(bad, 512, 128, sg.WindowType.hanning, True)
