@@ -147,7 +147,148 @@ __global__ __launch_bounds__(256, 2) void k_c2r1024(C2rArgs a, const v2f *twr /*
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_istft1024: fused f32 inverse STFT for n_fft = 1024 (src/spectrogram.rs:4860-4946).  A workgroup owns `nbk` consecutive
+// hop blocks of one signal's padded output and the 16 = nbk + ov frames that touch them (ov = floor(1023/hop) halo
+// frames are recomputed by the neighbouring workgroup instead of exchanging partial sums through HBM or atomics).
+//   load    [bin][frame] input (frame axis contiguous, S9): lane (r = tid & 15, n2 = tid >> 4) -> 128-byte segments
+//   C2R     exactly k_c2r1024's construction (32 x 16 split of the 512-point complex transform, one LDS exchange)
+//   frames  (x * 1/n) * w written as real rows fr[16][1024] over the dead exchange buffer
+//   OLA     one thread per output sample: ascending-frame sum, norm = sum of w*w (unfused), divide where norm > 1e-10,
+//           centre trim by index shift; stores are contiguous runs of the output signal.
+struct IstftArgs {
+    const void *spec;  // [batch][513][n_frames] complex f32
+    void *out;         // [batch][out_len] f32
+    const void *win;   // [1024] f32
+    unsigned n_frames, hop, batch, tiles, ov, nbk;
+    unsigned long long start, out_len;
+    float scale;
+    unsigned *bad_flag;
+};
+constexpr int kISeq = kRSeq + 32;     // row stride of the exchange buffer: lanes walk r in pass 1 -> spread rows over banks
+constexpr int kILds = 16 * kISeq;     // 74240 B -> two workgroups per CU (the real frames, 64 KiB, overlay it)
+
+__global__ __launch_bounds__(256, 2) void k_istft1024(IstftArgs a, const v2f *twr, const v2f *tw1) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned tid = threadIdx.x;
+    const unsigned t = blockIdx.x % a.tiles, b = blockIdx.x / a.tiles;
+    const long long h0 = (long long)t * a.nbk;      // first hop block of this tile
+    const long long fbase = h0 - (long long)a.ov;   // frame held in row 0
+    const v2f *in = (const v2f *)a.spec + (size_t)b * 513u * a.n_frames;
+    {
+        const unsigned r = tid & 15u, n2 = tid >> 4;
+        const long long f = fbase + r;
+        const bool valid = f >= 0 && f < (long long)a.n_frames;
+        const v2f *col = in + (valid ? f : 0);
+        v2f v[32];
+#pragma unroll
+        for (int n1 = 0; n1 < 32; ++n1) {
+            const unsigned k = 16u * n1 + n2;
+            v2f A = valid ? col[(size_t)k * a.n_frames] : (v2f){0.f, 0.f};
+            v2f Y = valid ? col[(size_t)(512u - k) * a.n_frames] : (v2f){0.f, 0.f};
+            if (k == 0) {  // DC and Nyquist bins: realfft ignores (and reports) their imaginary parts
+                if (a.bad_flag && (A.y != 0.f || Y.y != 0.f)) atomicOr(a.bad_flag, 1u);
+                A.y = 0.f;
+                Y.y = 0.f;
+            }
+            const v2f B = (v2f){Y.x, -Y.y};
+            const v2f S = A + B, D = A - B;
+            const v2f T = cmulv(D, twr[16 * n1 + n2]);
+            const v2f Z = pfma(swp(T), (v2f){-1.f, 1.f}, S);
+            v[n1] = (v2f){Z.x, -Z.y};
+        }
+        Fft<32, false>::run(v, v);
+        unsigned char *dst = smem + r * kISeq + n2 * 8;
+        *(v2f *)dst = v[0];
+#pragma unroll
+        for (int k1 = 1; k1 < 32; ++k1) *(v2f *)(dst + k1 * kRRS) = cmulv(v[k1], tw1[16 * k1 + n2]);
+    }
+    __syncthreads();
+    v2f y[2][16];
+    const unsigned k1 = tid & 31u;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const unsigned r = (tid >> 5) + 8u * it;
+        v2f x[16];
+        const v4f *rowp = (const v4f *)(smem + r * kISeq + k1 * kRRS);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const v4f q = rowp[c];
+            x[2 * c] = (v2f){q.x, q.y};
+            x[2 * c + 1] = (v2f){q.z, q.w};
+        }
+        Fft<16, false>::run(x, x);
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) y[it][k2] = x[k2];
+    }
+    __syncthreads();  // exchange buffer consumed: overlay the real frames
+    {
+        const v2f *w2 = (const v2f *)a.win + k1;
+        float *fr = (float *)smem;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+            const v2f w = w2[32 * k2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const unsigned r = (tid >> 5) + 8u * it;
+                const v2f sc = y[it][k2] * (v2f){a.scale, -a.scale};  // conj + 1/n: (x[2n], x[2n+1]), n = k1 + 32 k2
+                *(v2f *)(fr + r * 1024u + 2u * (k1 + 32u * k2)) = (v2f){__fmul_rn(sc.x, w.x), __fmul_rn(sc.y, w.y)};
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const float *fr = (const float *)smem;
+        const float *w = (const float *)a.win;
+        float *o = (float *)a.out + (size_t)b * a.out_len;
+        const unsigned span = a.nbk * a.hop;
+        const unsigned long long p0 = (unsigned long long)h0 * a.hop;
+        for (unsigned idx = tid; idx < span; idx += 256u) {
+            const unsigned long long pos = p0 + idx;
+            if (pos < a.start || pos - a.start >= a.out_len) continue;
+            const long long f_hi = min((long long)(pos / a.hop), (long long)a.n_frames - 1);
+            const long long f_lo = pos >= 1024ull ? (long long)((pos - 1024ull) / a.hop) + 1 : 0;
+            float acc = 0.f, nrm = 0.f;
+            for (long long f = f_lo; f <= f_hi; ++f) {
+                const unsigned j = (unsigned)(pos - (unsigned long long)f * a.hop);
+                acc += fr[(unsigned)(f - fbase) * 1024u + j];
+                const float wj = w[j];
+                nrm = __fadd_rn(nrm, __fmul_rn(wj, wj));
+            }
+            if (nrm > 1e-10f) acc /= nrm;
+            o[pos - a.start] = acc;
+        }
+    }
+}
+
 }  // namespace
+
+hipError_t launch_istft1024(const void *spec, void *out, const void *win, unsigned n_frames, unsigned hop, unsigned batch,
+                            unsigned long long start, unsigned long long out_len, float scale, unsigned *bad_flag,
+                            const void *twr, const void *tw1, hipStream_t s) {
+    if (hop == 0 || hop > 1024) return hipErrorInvalidConfiguration;
+    IstftArgs a{};
+    a.spec = spec; a.out = out; a.win = win;
+    a.n_frames = n_frames; a.hop = hop; a.batch = batch;
+    a.ov = 1023u / hop;
+    if (a.ov >= 16) return hipErrorInvalidConfiguration;
+    a.nbk = 16u - a.ov;
+    const unsigned long long full = (unsigned long long)(n_frames - 1) * hop + 1024ull;
+    const unsigned long long blocks = (full + hop - 1) / hop;
+    a.tiles = (unsigned)((blocks + a.nbk - 1) / a.nbk);
+    a.start = start; a.out_len = out_len; a.scale = scale; a.bad_flag = bad_flag;
+    const unsigned long long g = (unsigned long long)a.tiles * batch;
+    if (g == 0 || g >= 0x7fffffffull) return hipErrorInvalidConfiguration;
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_istft1024, hipFuncAttributeMaxDynamicSharedMemorySize, kILds);
+        if (e != hipSuccess) return e;
+        done = true;
+    }
+    hipLaunchKernelGGL(k_istft1024, dim3((unsigned)g), dim3(256), kILds, s, a, (const v2f *)twr, (const v2f *)tw1);
+    return hipGetLastError();
+}
 
 hipError_t launch_c2r1024(const C2rArgs &a, const void *twr, const void *tw1, hipStream_t s) {
     const unsigned long long g = (unsigned long long)a.tiles * a.batch;

@@ -546,7 +546,7 @@ sgx_status grow(sgx_plan *pl, void **buf, size_t *have, size_t need) {
 
 void free_device(sgx_plan *pl) {
     void **bufs[] = {&pl->d_window, &pl->d_tw, &pl->d_tw1, &pl->d_tw2, &pl->d_mel_ptr, &pl->d_mel_col,
-                     &pl->d_mel_val, &pl->d_dct, &pl->d_lifter, &pl->d_melbuf, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_dense_w, &pl->d_itw, &pl->d_frames, &pl->d_flag, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half};
+                     &pl->d_mel_val, &pl->d_dct, &pl->d_lifter, &pl->d_melbuf, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_dense_w, &pl->d_itw, &pl->d_itwr, &pl->d_itw1, &pl->d_frames, &pl->d_flag, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half};
     for (void **b : bufs)
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
@@ -578,6 +578,20 @@ sgx_status inverse_tables(sgx_plan *pl) {
     }
     sgx_status st = upload<T>(pl, &pl->d_itw, tw);
     if (st != SGX_OK) return st;
+    if (std::is_same<T, float>::value && n == 1024 && pl->p.hop_size >= 64) {  // tables of the fused tuned kernel
+        std::vector<float> tr(2 * 32 * 16), t1(2 * 32 * 16);
+        for (unsigned n1 = 0; n1 < 32; ++n1)
+            for (unsigned n2 = 0; n2 < 16; ++n2) {
+                const double a = 2.0 * kPi * double(16 * n1 + n2) / 1024.0;  // conj(W_1024^k)
+                tr[2 * (n1 * 16 + n2)] = float(std::cos(a));
+                tr[2 * (n1 * 16 + n2) + 1] = float(std::sin(a));
+                const double b2 = -2.0 * kPi * double(n1 * n2) / 512.0;     // W_512^(k1 n2)
+                t1[2 * (n1 * 16 + n2)] = float(std::cos(b2));
+                t1[2 * (n1 * 16 + n2) + 1] = float(std::sin(b2));
+            }
+        if ((st = upload<float>(pl, &pl->d_itwr, tr)) != SGX_OK) return st;
+        if ((st = upload<float>(pl, &pl->d_itw1, t1)) != SGX_OK) return st;
+    }
     SGX_HIP(pl, hipMalloc(&pl->d_flag, sizeof(unsigned)));
     return SGX_OK;
 }
@@ -609,8 +623,16 @@ sgx_status run_istft(sgx_plan *pl, const void *spec, size_t batch, size_t n_fram
     sgx_status st = pl->dtype == SGX_F64 ? inverse_tables<double>(pl) : inverse_tables<float>(pl);
     if (st != SGX_OK) return st;
     const size_t n = pl->p.n_fft;
-    if ((st = grow(pl, &pl->d_frames, &pl->d_frames_bytes, batch * n_frames * n * pl->elem)) != SGX_OK) return st;
     SGX_HIP(pl, hipMemsetAsync(pl->d_flag, 0, sizeof(unsigned), s));
+    if (pl->d_itwr && !std::getenv("SGX_ISTFT_GENERIC")) {  // fused tuned kernel: no frame scratch in HBM
+        const size_t pad0 = pl->p.centre ? n / 2 : 0;
+        const size_t full0 = (n_frames - 1) * size_t(pl->p.hop_size) + n;
+        SGX_HIP(pl, launch_istft1024(spec, out, pl->d_window, unsigned(n_frames), pl->p.hop_size, unsigned(batch),
+                                     out_len == full0 ? 0 : pad0, out_len, 1.0f / 1024.0f, (unsigned *)pl->d_flag, pl->d_itwr,
+                                     pl->d_itw1, s));
+        return SGX_OK;
+    }
+    if ((st = grow(pl, &pl->d_frames, &pl->d_frames_bytes, batch * n_frames * n * pl->elem)) != SGX_OK) return st;
     if ((st = launch_c2r_frames(pl, spec, pl->d_frames, batch, n_frames, true, pl->d_window, s)) != SGX_OK) return st;
     const size_t pad = pl->p.centre ? n / 2 : 0;
     const size_t full = (n_frames - 1) * size_t(pl->p.hop_size) + n;

@@ -107,6 +107,10 @@ hipError_t launch_c2r_rows(const C2rArgs &a, int dtype, hipStream_t s);
 hipError_t launch_c2c1024(const C2cArgs &a, const void *tw1c, hipStream_t s);
 // tuned f32 inverse row pass for ncols == 1024 on a [r][k]-major half spectrum (a.in_ks == 1), 16 rows per workgroup
 hipError_t launch_c2r1024(const C2rArgs &a, const void *twr, const void *tw1, hipStream_t s);
+// fused f32 n_fft = 1024 inverse STFT (C2R + window + overlap-add + normalise + trim); hop >= 64; twr/tw1 as launch_c2r1024
+hipError_t launch_istft1024(const void *spec, void *out, const void *win, unsigned n_frames, unsigned hop, unsigned batch,
+                            unsigned long long start, unsigned long long out_len, float scale, unsigned *bad_flag,
+                            const void *twr, const void *tw1, hipStream_t s);
 hipError_t launch_pointwise(const void *x, const void *y, void *out, unsigned long long n, unsigned long long per, int mode,
                             int dtype, hipStream_t s);
 
@@ -142,6 +146,7 @@ struct sgx_plan {
     void *d_window_half = nullptr, *d_ones_half = nullptr;  // 0.5*window (exact) for the tuned kernel's real split
     // inverse path (sgx_istft / sgx_c2r), created on first use: full twiddle table e^{-2 pi i k/n}, frame scratch, flag
     void *d_itw = nullptr, *d_frames = nullptr, *d_flag = nullptr;
+    void *d_itwr = nullptr, *d_itw1 = nullptr;  // tuned f32 n_fft = 1024 inverse: conj(W_1024^k) [32][16], W_512^(k1 n2) [32][16]
     size_t d_frames_bytes = 0;
 
     // plan-owned staging for host-pointer execution

@@ -98,6 +98,32 @@ def test_gpu_istft_matches_oracle(n_fft, hop, centre, window, dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("hop,centre,window,n", [(64, True, "hanning", 9000), (100, True, "hamming", 9000), (256, False, "hanning", 20000),
+                                                 (300, True, "blackman", 20000), (512, True, "hanning", 20000),
+                                                 (1024, True, "rectangular", 20000), (256, True, "hanning", 700)])
+def test_gpu_istft_fused_1024_kernel(hop, centre, window, n):
+    """f32, n_fft = 1024: the fused tuned kernel (halo frames recomputed per tile) for hops that do and do not divide n_fft,
+    with tile edges, a single-tile signal and the untrimmed / trimmed output windows."""
+    x = np.random.default_rng(11).standard_normal((5, n)).astype(np.float32)
+    wt = getattr(sg.WindowType, window)
+    plan = sg.Plan(sg.SpectrogramParams(sg.StftParams(1024, hop, wt, centre), 16000.0), _ffi.AMP_COMPLEX, None, None, "float32")
+    S = np.stack([orc.stft(orc.Params(n_fft=1024, hop=hop, centre=centre, window=window), r) for r in x])
+    got = plan.istft_batch(S)
+    ref = np.stack([orc.istft(s, 1024, hop, window, centre) for s in S])
+    assert got.shape == ref.shape
+    # out = sum(y w) / sum(w w): where the window sum is tiny (the first / last samples of an uncentred Hann frame) the
+    # division amplifies the f32 rounding of y by 1/w in ANY implementation, so the error is weighed by sqrt(norm) there
+    w = orc.make_window(window, 1024)
+    nf = S.shape[2]
+    nrm = np.zeros((nf - 1) * hop + 1024)
+    for f in range(nf):
+        nrm[f * hop:f * hop + 1024] += w * w
+    nrm = nrm[512:512 + ref.shape[1]] if centre and ref.shape[1] != nrm.size else nrm
+    scale = np.minimum(1.0, np.sqrt(nrm))[None, :]
+    assert np.max(np.abs(got - ref) * scale) < 2e-5 * max(1.0, np.max(np.abs(ref)))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype,tol", [("float32", 3e-6), ("float64", 1e-12)])
 def test_gpu_stft_istft_roundtrip_device(dtype, tol):
     """forward on the GPU, inverse on the GPU, device-resident end to end (config-2 shaped rows)."""
