@@ -224,38 +224,65 @@ __device__ __forceinline__ void mel_tile_lds(const StftArgs &a, const float *pwa
     }
 }
 
-// Dense bank (ERB / gammatone, src/erb.rs:374-401: every filter weighs every bin) on the matrix cores.  Per tile the
-// product is [n_filters x 516] x [516 x 16 frames]; v_mfma_f32_16x16x4_f32 is an exact-f32 fmaf chain at the packed VALU
-// rate that does the operand broadcast a per-lane loop cannot.  Wave w owns the 16-filter blocks w, w+4, ...; lane
-// (i = l & 15, q = l >> 4) feeds A = weight[16 blk + i][k] and B = pw[frame i][k] with k = 16 c + 4 q + s for step s of chunk c —
-// the k order inside a chunk is permuted identically on both operands, so each lane fetches its 4 steps with ONE 16-byte
-// load (weights: fragment-ordered table, 1 KiB per wave-load, L2 resident) and ONE ds_read_b128 (pw rows are 516 floats:
-// the 16 lanes of a q group cover all 64 banks).  D[4 q + r][frame i] lands frame-contiguous across lanes: 64-byte stores.
-// The sum runs over k < 516: weights and pw are zero for k = 513..515.
+// Bank rows with wide supports (Mel bands, the dense ERB / gammatone bank of src/erb.rs:374-401) on the matrix cores.
+// Per tile and 16-row block the product is [16 rows x K] x [K x 16 frames] with K = the block's own bin range;
+// v_mfma_f32_16x16x4_f32 is an exact-f32 fmaf chain at the packed VALU rate that does the operand broadcast a per-lane
+// loop cannot.  A wave owns whole blocks (host-balanced); lane (i = l & 15, q = l >> 4) feeds A = weight[16 blk + i][k] and
+// B = pw[frame i][k] with k = lo + 16 c + 4 q + s for step s of chunk c — the k order inside a chunk is permuted
+// identically on both operands, so each lane fetches its 4 steps with ONE 16-byte load (weights: fragment-ordered table,
+// 1 KiB per wave-load, L2 resident, prefetched 4 chunks ahead) and ONE ds_read_b128 (pw rows are 516 floats: the 16 lanes
+// of a q group cover all 64 banks).  D[4 q + r][frame i] lands frame-contiguous across lanes: 64-byte stores.
+// Two accumulator chains hide the 40-cycle dependent latency.  pw[f][513..515] are zero (the cover is a multiple of 4).
 typedef float v4acc __attribute__((ext_vector_type(4)));
 template <int AMP>
-__device__ __forceinline__ void dense_tile_mfma(const StftArgs &a, const float *pwall, unsigned b, unsigned f0, unsigned nf,
-                                                float eps, unsigned t) {
-    const unsigned wave = t >> 6, lane = t & 63u, fi = lane & 15u, q = lane >> 4;
-    const unsigned nblk = (a.n_mels + 15u) >> 4;
+__device__ __forceinline__ void map_tile_mfma(const StftArgs &a, const float *pwall, unsigned b, unsigned f0, unsigned nf,
+                                              float eps, unsigned t, unsigned rot) {
+    const unsigned wave = ((t >> 6) + rot) & 3u, lane = t & 63u, fi = lane & 15u, q = lane >> 4;
     float *o = (float *)a.out + ((size_t)b * a.n_out) * a.n_frames + f0 + fi;
-    const v4f *pp = (const v4f *)(pwall + fi * kPS + 4u * q);
-    for (unsigned blk = wave; blk < nblk; blk += 4u) {
-        const v4f *wf = (const v4f *)a.dense_w + (size_t)blk * 33u * 64u + lane;
-        v4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};  // two chains: the dependent latency is 40 cycles
+    for (unsigned blk = 0; blk < a.mm_nblk; ++blk) {
+        const uint4 d = a.mm_blk[blk];  // uniform: scalar loads
+        if (((d.w >> 8) & 3u) != wave) continue;
+        const unsigned lo = d.y, n16 = d.z, n4 = d.w & 3u;
+        const v4f *wf = (const v4f *)a.mm_frag + (size_t)d.x * 64u + lane;
+        const float *prow = pwall + fi * kPS + lo;
+        const v4f *pp = (const v4f *)(prow + 4u * q);
+        v4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        // fragment ring, 4 deep.  The table is padded by 4 fragments, so the prefetch never needs a guard: guards would put
+        // the loads behind scalar branches and force a full vmcnt(0) wait per chunk.
         v4f wq[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) wq[c] = wf[c * 64];
-#pragma unroll 4
-        for (int c = 0; c < 32; ++c) {
-            const v4f w = wq[c & 3], p = pp[c * 4];
-            if (c + 4 < 33) wq[c & 3] = wf[(c + 4) * 64];
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, p.x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, p.y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, p.z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, p.w, acc1, 0, 0, 0);
+        for (int u = 0; u < 4; ++u) wq[u] = wf[u * 64];
+        const unsigned nmain = n16 & ~3u;
+        for (unsigned c0 = 0; c0 < nmain; c0 += 4u) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned c = c0 + u;
+                const v4f w = wq[u], p = pp[c * 4u];
+                wq[u] = wf[(c + 4u) * 64u];
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, p.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, p.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, p.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, p.w, acc1, 0, 0, 0);
+            }
         }
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[0].x, pwall[fi * kPS + 512u + q], acc0, 0, 0, 0);  // k = 512..515
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {  // n16 % 4 remaining chunks: their fragments are already in the ring
+            if (nmain + u < n16) {
+                const v4f w = wq[u], p = pp[(nmain + u) * 4u];
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, p.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, p.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, p.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, p.w, acc1, 0, 0, 0);
+            }
+        }
+        if (n4) {  // trailing 4-wide steps: k = lo + 16 n16 + 4 s + q
+            const unsigned u = n16 & 3u;
+            const v4f w = u == 0 ? wq[0] : u == 1 ? wq[1] : u == 2 ? wq[2] : wq[3];
+            const float *pt = prow + 16u * n16 + q;
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, pt[0], acc0, 0, 0, 0);
+            if (n4 > 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, pt[4], acc1, 0, 0, 0);
+            if (n4 > 2) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, pt[8], acc0, 0, 0, 0);
+        }
         const v4acc acc = acc0 + acc1;
         if (fi < nf) {
 #pragma unroll
@@ -444,7 +471,7 @@ __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned
             __syncthreads();
 #ifndef SGX_ABL_NOMELTILE
             if (active) {
-                if (a.dense_w) dense_tile_mfma<AMP>(a, (const float *)smem, b, f0, nf, eps, tid);
+                if (a.mm_frag) map_tile_mfma<AMP>(a, (const float *)smem, b, f0, nf, eps, tid, 2u * half);
                 else if (mel_lds) mel_tile_lds<AMP>(a, (const float *)smem, lw4, lptr, lcol, b, f0, nf, eps, tid, 256u);
                 else mel_tile<AMP>(a, (const float *)smem, b, f0, nf, eps, tid, 256u);
             }

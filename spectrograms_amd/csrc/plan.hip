@@ -352,20 +352,61 @@ sgx_status build_device_tables(sgx_plan *pl) {
             if ((st = upload<uint32_t>(pl, &pl->d_mel_pcol, pcol)) != SGX_OK) return st;
             if ((st = upload<float>(pl, &pl->d_mel_pw, pw)) != SGX_OK) return st;
         }
-        // dense bank (ERB): weights in v_mfma_f32_16x16x4_f32 A-fragment order for the tuned kernel's matrix-core epilogue
-        if (pl->p.freq_scale == SGX_FREQ_ERB && std::is_same<T, float>::value && pl->p.n_fft == 1024) {
+        // Matrix-core epilogue of the tuned kernel (f32, n_fft = 1024): banks with wide rows (the dense ERB bank, very coarse
+        // Mel banks) are applied as [16 rows x K] x [K x 16 frames] products on v_mfma_f32_16x16x4_f32, K restricted to the
+        // block's own bin range.  Measured on MI355X (256 x 10 s): ERB-64 266 us vs 4.3 ms on the CSR loop; Mel-80 (12.5
+        // non-zeros per row) 183 us on the matrix cores vs 169 us on the LDS band table — so ordinary Mel banks and log-Hz
+        // (<= 2 non-zeros) stay on the band table above.  SGX_MEL=mfma|lds overrides the choice for experiments.
+        const char *force = std::getenv("SGX_MEL");
+        const bool wide = pl->mel_val.size() >= size_t(48) * pl->p.n_mels;
+        const bool want_mm = force ? std::string(force) == "mfma" : wide;
+        if (std::is_same<T, float>::value && pl->p.n_fft == 1024 && want_mm) {
             const unsigned nm = pl->p.n_mels, nblk = (nm + 15) / 16, nb = 513;
-            std::vector<float> frag(size_t(nblk) * 33 * 64 * 4, 0.0f);
-            auto wt = [&](unsigned m, unsigned k) { return m < nm && k < nb ? float(pl->mel_val[size_t(m) * nb + k]) : 0.0f; };
-            for (unsigned blk = 0; blk < nblk; ++blk)
-                for (unsigned c = 0; c < 33; ++c)
+            std::vector<uint32_t> blk(size_t(nblk) * 4, 0);
+            std::vector<float> frag;
+            std::vector<std::pair<unsigned, unsigned>> load;  // (chunk-equivalents, block) for the wave assignment
+            for (unsigned bk = 0; bk < nblk; ++bk) {
+                unsigned lo = nb, hi = 0;
+                for (unsigned m = 16 * bk; m < std::min(nm, 16 * bk + 16); ++m)
+                    for (uint32_t i = pl->mel_ptr[m]; i < pl->mel_ptr[m + 1]; ++i) {
+                        lo = std::min(lo, pl->mel_col[i]);
+                        hi = std::max(hi, pl->mel_col[i] + 1);
+                    }
+                if (hi <= lo) { lo = 0; hi = 0; }
+                lo &= ~3u;
+                const unsigned len4 = (hi - lo + 3) / 4, n16 = len4 / 4, n4 = len4 % 4;
+                // dense lookup of this block's weights
+                std::vector<float> w(size_t(16) * 516, 0.0f);
+                for (unsigned m = 16 * bk; m < std::min(nm, 16 * bk + 16); ++m)
+                    for (uint32_t i = pl->mel_ptr[m]; i < pl->mel_ptr[m + 1]; ++i)
+                        w[size_t(m - 16 * bk) * 516 + pl->mel_col[i]] = float(pl->mel_val[i]);
+                blk[4 * bk + 0] = uint32_t(frag.size() / 256);
+                blk[4 * bk + 1] = lo;
+                blk[4 * bk + 2] = n16;
+                blk[4 * bk + 3] = n4;
+                for (unsigned c = 0; c < n16; ++c)
                     for (unsigned l = 0; l < 64; ++l)
-                        for (unsigned e = 0; e < 4; ++e) {
-                            const unsigned m = 16 * blk + (l & 15u);
-                            const unsigned k = c < 32 ? 16 * c + 4 * (l >> 4) + e : (e == 0 ? 512 + (l >> 4) : 0xffffffffu);
-                            frag[((size_t(blk) * 33 + c) * 64 + l) * 4 + e] = wt(m, k);
-                        }
-            if ((st = upload<float>(pl, &pl->d_dense_w, frag)) != SGX_OK) return st;
+                        for (unsigned e = 0; e < 4; ++e) frag.push_back(w[size_t(l & 15u) * 516 + lo + 16 * c + 4 * (l >> 4) + e]);
+                if (n4)
+                    for (unsigned l = 0; l < 64; ++l)
+                        for (unsigned e = 0; e < 4; ++e)
+                            frag.push_back(e < n4 ? w[size_t(l & 15u) * 516 + lo + 16 * n16 + 4 * e + (l >> 4)] : 0.0f);
+                load.push_back({4 * n16 + n4, bk});
+            }
+            // longest-first assignment of blocks to the 4 waves of a half (the second half rotates the owners by 2 so the two
+            // waves sharing a SIMD do not both hold the widest block)
+            std::sort(load.begin(), load.end(), [](auto &x, auto &y) { return x.first > y.first; });
+            unsigned sum[4] = {0, 0, 0, 0};
+            for (auto &lb : load) {
+                unsigned best = 0;
+                for (unsigned w = 1; w < 4; ++w) if (sum[w] < sum[best]) best = w;
+                sum[best] += lb.first;
+                blk[4 * lb.second + 3] |= best << 8;
+            }
+            frag.resize(frag.size() + 4 * 256, 0.0f);  // the kernel's 4-deep fragment ring prefetches unguarded
+            pl->mm_nblk = nblk;
+            if ((st = upload<float>(pl, &pl->d_mm_frag, frag)) != SGX_OK) return st;
+            if ((st = upload<uint32_t>(pl, &pl->d_mm_blk, blk)) != SGX_OK) return st;
         }
     }
     if (pl->p.n_mfcc > 0) {
@@ -438,7 +479,9 @@ void fill_args(const sgx_plan *pl, StftArgs &a, const void *x, void *out, size_t
     a.mel_pcol = (const unsigned *)pl->d_mel_pcol;
     a.mel_pw = pl->d_mel_pw;
     a.mel_pchunks = pl->mel_pchunks;
-    a.dense_w = pl->d_dense_w;
+    a.mm_frag = pl->d_mm_frag;
+    a.mm_blk = (const uint4 *)pl->d_mm_blk;
+    a.mm_nblk = pl->mm_nblk;
     a.n_mels = p.n_mels;
     a.mel_nnz = unsigned(pl->mel_col.size());
     a.out_mode = pl->out_mode;
@@ -546,7 +589,7 @@ sgx_status grow(sgx_plan *pl, void **buf, size_t *have, size_t need) {
 
 void free_device(sgx_plan *pl) {
     void **bufs[] = {&pl->d_window, &pl->d_tw, &pl->d_tw1, &pl->d_tw2, &pl->d_mel_ptr, &pl->d_mel_col,
-                     &pl->d_mel_val, &pl->d_dct, &pl->d_lifter, &pl->d_melbuf, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_dense_w, &pl->d_itw, &pl->d_itwr, &pl->d_itw1, &pl->d_frames, &pl->d_flag, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half};
+                     &pl->d_mel_val, &pl->d_dct, &pl->d_lifter, &pl->d_melbuf, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_mm_frag, &pl->d_mm_blk, &pl->d_itw, &pl->d_itwr, &pl->d_itw1, &pl->d_frames, &pl->d_flag, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half};
     for (void **b : bufs)
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);

@@ -42,9 +42,14 @@ struct StftArgs {
     const unsigned *mel_pcol;
     const void *mel_pw;
     unsigned mel_pchunks;
-    // dense bank in MFMA fragment order (tuned f32 kernel, ERB): float4 dense_w[block][33][64]; block = 16 filters; chunk
-    // c < 32, lane l, element s = weight[16*block + (l & 15)][16 c + 4 (l >> 4) + s]; chunk 32: .x = weight[..][512 + (l >> 4)]
-    const void *dense_w;
+    // banded / dense bank for the tuned f32 kernel's matrix-core epilogue (Mel with wide bands, ERB).  Block = 16 rows of
+    // the bank; its support [lo, lo + 16 n16 + 4 n4) is a multiple-of-4 cover of the rows' non-zero bins (<= 516).
+    //   mm_blk[blk]  = {fragment offset, lo, n16, n4 | owner wave << 8}
+    //   mm_frag      float4 [fragment][64 lanes]: chunk c < n16: element s = weight[16 blk + (l & 15)][lo + 16 c + 4 (l >> 4) + s];
+    //                tail fragment (if n4 > 0): element s < n4 = weight[..][lo + 16 n16 + 4 s + (l >> 4)]
+    const void *mm_frag;
+    const uint4 *mm_blk;
+    unsigned mm_nblk;
     unsigned n_mels;
     unsigned mel_nnz;
     int out_mode;
@@ -136,7 +141,8 @@ struct sgx_plan {
 
     // device tables
     void *d_window = nullptr, *d_tw = nullptr, *d_tw1 = nullptr, *d_tw2 = nullptr;
-    void *d_mel_ptr = nullptr, *d_mel_col = nullptr, *d_mel_val = nullptr, *d_mel_pptr = nullptr, *d_mel_pcol = nullptr, *d_mel_pw = nullptr, *d_dense_w = nullptr;
+    void *d_mel_ptr = nullptr, *d_mel_col = nullptr, *d_mel_val = nullptr, *d_mel_pptr = nullptr, *d_mel_pcol = nullptr, *d_mel_pw = nullptr, *d_mm_frag = nullptr, *d_mm_blk = nullptr;
+    unsigned mm_nblk = 0;
     unsigned mel_pchunks = 0;
     void *d_ones = nullptr;  // rectangular window for sgx_r2c
     // MFCC epilogue: DCT-II basis [n_mfcc][n_mels] and lifter [n_mfcc] in T; Mel-dB scratch (grown on demand)

@@ -47,6 +47,7 @@ int main() {
     run<16, 2>(d, n_frames, batch);
     run<32, 1>(d, n_frames, batch);
     run<32, 2>(d, n_frames, batch);
+    run<64, 1>(d, n_frames, batch);
     // aligned variant: 640 frames per row (rows 16-B aligned, tiles never straddle)
     return 0;
     printf("-- n_frames = 640 (aligned rows)\n");
