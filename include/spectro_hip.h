@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SGX_ABI_VERSION 3
+#define SGX_ABI_VERSION 4
 
 typedef struct sgx_plan sgx_plan; /* opaque */
 
@@ -53,7 +53,13 @@ enum { SGX_WIN_RECTANGULAR = 0, SGX_WIN_HANNING = 1, SGX_WIN_HAMMING = 2, SGX_WI
  * matrix build_loghz_matrix :2438-2508) reuses n_mels / f_min / f_max as n_bins / f_min / f_max.  Erb (ErbParams
  * src/erb.rs:27-92, frequency-domain gammatone bank ErbFilterbank::generate :266-335, applied as a DENSE
  * n_filters x (n_fft/2+1) product with the power spectrum :374-401) reuses them as n_filters / f_min / f_max. */
-enum { SGX_FREQ_LINEAR = 0, SGX_FREQ_MEL = 1, SGX_FREQ_LOGHZ = 2, SGX_FREQ_ERB = 3 };
+enum { SGX_FREQ_LINEAR = 0, SGX_FREQ_MEL = 1, SGX_FREQ_LOGHZ = 2, SGX_FREQ_ERB = 3, SGX_FREQ_CHROMA = 4 };
+/* Chroma (src/chroma.rs): chromagram() :470-505 = linear MAGNITUDE spectrogram -> dense 12 x (n_fft/2+1) pitch-class bank
+ * (build_chroma_filterbank :262-345, bins inside [f_min, f_max], Gaussian over the circular semitone distance, rows
+ * normalised to unit sum) applied with sequential accumulation (:378-392) -> per-frame normalisation over the 12 rows
+ * (apply_chroma_normalization :403-445).  Requires amp_scale = SGX_AMP_MAGNITUDE and no LogParams; f_min / f_max reused;
+ * output has 12 rows.  ChromaNorm :24-31: */
+enum { SGX_CHROMA_NORM_NONE = 0, SGX_CHROMA_NORM_L1 = 1, SGX_CHROMA_NORM_L2 = 2, SGX_CHROMA_NORM_MAX = 3 };
 /* ErbSpacing src/erb.rs:14-25 */
 enum { SGX_ERB_LINEAR = 0, SGX_ERB_APPLE_TR35 = 1 };
 /* MelNorm src/spectrogram.rs:2385-2429 */
@@ -91,6 +97,8 @@ typedef struct {
     int32_t mfcc_include_c0;
     uint32_t mfcc_lifter;
     int32_t erb_spacing;          /* SGX_ERB_* (only read when freq_scale = SGX_FREQ_ERB) */
+    double chroma_tuning;         /* A4 in Hz (ChromaParams::tuning); only read when freq_scale = SGX_FREQ_CHROMA */
+    int32_t chroma_norm;          /* SGX_CHROMA_NORM_* */
 } sgx_params;
 
 /* Replaces StftPlan::new (:1204-1228), SpectrogramPlanner::{linear_plan :893-917, mel_plan :944-977}:

@@ -72,6 +72,7 @@ def lib() -> C.CDLL:
             getattr(L, f"orc_spectrogram_batch_{suf}").argtypes = [C.POINTER(_Params), p, sz, sz, sz, p, C.c_int]
             getattr(L, f"orc_stft_batch_{suf}").argtypes = [C.POINTER(_Params), p, sz, sz, sz, p, C.c_int]
             getattr(L, f"orc_mfcc_{suf}").argtypes = [C.POINTER(_Params), C.c_uint32, C.c_int, C.c_uint32, p, sz, p]
+            getattr(L, f"orc_chromagram_{suf}").argtypes = [C.POINTER(_Params), C.c_double, C.c_double, C.c_double, C.c_int, p, sz, p]
             getattr(L, f"orc_irfft_{suf}").argtypes = [p, sz, sz, p]
             getattr(L, f"orc_istft_{suf}").argtypes = [p, sz, sz, sz, sz, C.c_int, C.c_double, dp, C.c_int, p]
             getattr(L, f"orc_fft2d_{suf}").argtypes = [p, sz, sz, p]
@@ -275,6 +276,31 @@ def mfcc(p: Params, x: np.ndarray, n_mfcc: int = 13, include_c0: bool = True, li
     rc = getattr(lib(), f"orc_mfcc_{suf}")(C.byref(cp), n_mfcc, int(include_c0), lifter, _ptr(x), x.size, _ptr(out))
     if rc:
         raise OracleError(rc)
+    return out
+
+
+CHROMA_NORMS = {None: 0, "none": 0, "l1": 1, "l2": 2, "max": 3}
+
+
+def chroma_filterbank(sr: float, n_fft: int, tuning: float = 440.0, f_min: float = 32.7, f_max: float = 4186.0) -> np.ndarray:
+    fb = np.empty((12, n_fft // 2 + 1), np.float64)
+    L = lib()
+    L.orc_chroma_filterbank.argtypes = [C.c_double, C.c_size_t, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double)]
+    rc = L.orc_chroma_filterbank(sr, n_fft, tuning, f_min, f_max, fb.ctypes.data_as(C.POINTER(C.c_double)))
+    if rc != 0:
+        raise OracleError(rc, "chroma_filterbank")
+    return fb
+
+
+def chromagram(p: Params, x: np.ndarray, tuning: float = 440.0, f_min: float = 32.7, f_max: float = 4186.0, norm="l2") -> np.ndarray:
+    """chromagram() (src/chroma.rs:470-505) of one signal in x's precision; p carries the STFT parameters."""
+    x = np.ascontiguousarray(x)
+    rdt = np.float32 if x.dtype == np.float32 else np.float64
+    x = x.astype(rdt)
+    out = np.empty((12, frame_count(x.size, p.n_fft, p.hop, p.centre)), rdt)
+    rc = getattr(lib(), f"orc_chromagram_{_suf(rdt)}")(C.byref(p.c()), tuning, f_min, f_max, CHROMA_NORMS[norm], _ptr(x), x.size, _ptr(out))
+    if rc != 0:
+        raise OracleError(rc, "chromagram")
     return out
 
 

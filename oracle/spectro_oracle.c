@@ -291,6 +291,36 @@ long orc_loghz_matrix(double sr, size_t n_fft, size_t n_bins, double f_min, doub
     return (long)nnz;
 }
 
+/* build_chroma_filterbank  src/chroma.rs:262-345 (ChromaParams::new :64-90 for the checks) */
+int orc_chroma_filterbank(double sr, size_t n_fft, double tuning, double f_min, double f_max, double *fb) {
+    if (sr <= 0.0 || !isfinite(sr)) return ORC_INVALID_INPUT;
+    if (!(tuning > 0.0 && isfinite(tuning))) return ORC_INVALID_INPUT;
+    if (!(f_min > 0.0 && isfinite(f_min))) return ORC_INVALID_INPUT;
+    if (f_max <= f_min) return ORC_INVALID_INPUT;
+    size_t nb = n_fft / 2 + 1;
+    double df = sr / (double)n_fft;
+    memset(fb, 0, 12 * nb * sizeof(double));
+    for (size_t k = 0; k < nb; k++) {
+        double freq = (double)k * df;
+        if (freq < f_min || freq > f_max || freq <= 0.0) continue;
+        double midi = 69.0 + 12.0 * log(freq / tuning) / 0.6931471805599453; /* std::f64::consts::LN_2 */
+        double pc = fmod(midi, 12.0);
+        if (pc < 0.0) pc += 12.0; /* rem_euclid */
+        for (size_t c = 0; c < 12; c++) {
+            double dist = fabs(pc - (double)c);
+            double circ = dist < 12.0 - dist ? dist : 12.0 - dist;
+            double q = circ / 1.0;
+            fb[c * nb + k] = exp(-0.5 * (q * q));
+        }
+    }
+    for (size_t c = 0; c < 12; c++) {
+        double row = 0.0;
+        for (size_t k = 0; k < nb; k++) row += fb[c * nb + k];
+        if (row > 0.0) for (size_t k = 0; k < nb; k++) fb[c * nb + k] /= row;
+    }
+    return ORC_OK;
+}
+
 static void erb_centres(size_t n, double f_min, double f_max, int spacing, double *cf) {
     if (spacing == 1) { /* apple_tr35_center_freqs erb.rs:221-238 */
         double shift = 9.26449 * 24.7, a = -shift, d = f_max + shift;

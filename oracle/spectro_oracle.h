@@ -77,6 +77,10 @@ long orc_loghz_matrix(double sample_rate, size_t n_fft, size_t n_bins, double f_
 /* src/erb.rs:266-335 (ErbFilterbank::generate): dense n_filters x (n_fft/2+1) |H|^2 rows as CSR + centre freqs */
 long orc_erb_matrix(double sample_rate, size_t n_fft, size_t n_filters, double f_min, double f_max, int spacing,
                     size_t *row_ptr, uint32_t *cols, double *vals, size_t cap, double *centres);
+/* build_chroma_filterbank src/chroma.rs:262-345: dense fb[12][n_fft/2+1], rows normalised to unit sum */
+int orc_chroma_filterbank(double sample_rate, size_t n_fft, double tuning, double f_min, double f_max, double *fb);
+int orc_chromagram_f32(const orc_params *stft_p, double tuning, double f_min, double f_max, int norm, const float *x, size_t n, float *out);
+int orc_chromagram_f64(const orc_params *stft_p, double tuning, double f_min, double f_max, int norm, const double *x, size_t n, double *out);
 double orc_hz_to_mel(double hz);
 double orc_mel_to_hz(double mel);
 /* spectrogram.rs:2128-2139,1909-1931,2510-2530 */

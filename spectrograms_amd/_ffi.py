@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SGX_LIB_PATH") or os.path.join(_PKG, "libspectro_hip.
 
 SGX_OK, SGX_INVALID_INPUT, SGX_DIM_MISMATCH, SGX_BACKEND, SGX_INTERNAL = range(5)
 WIN_RECTANGULAR, WIN_HANNING, WIN_HAMMING, WIN_BLACKMAN, WIN_KAISER, WIN_GAUSSIAN, WIN_CUSTOM = range(7)
-FREQ_LINEAR, FREQ_MEL, FREQ_LOGHZ, FREQ_ERB = 0, 1, 2, 3
+FREQ_LINEAR, FREQ_MEL, FREQ_LOGHZ, FREQ_ERB, FREQ_CHROMA = 0, 1, 2, 3, 4
 MELNORM_NONE, MELNORM_SLANEY, MELNORM_L1, MELNORM_L2 = range(4)
 AMP_POWER, AMP_MAGNITUDE, AMP_DECIBELS, AMP_COMPLEX = range(4)
 F32, F64 = 0, 1
@@ -39,6 +39,7 @@ class SgxParams(C.Structure):
         ("f_max", C.c_double), ("mel_norm", C.c_int32), ("amp_scale", C.c_int32), ("has_log_params", C.c_int32),
         ("floor_db", C.c_double), ("dtype", C.c_int32), ("device", C.c_int32),
         ("n_mfcc", C.c_uint32), ("mfcc_include_c0", C.c_int32), ("mfcc_lifter", C.c_uint32), ("erb_spacing", C.c_int32),
+        ("chroma_tuning", C.c_double), ("chroma_norm", C.c_int32),
     ]
 
 

@@ -55,7 +55,7 @@ __device__ inline void emit_bin(const StftArgs &a, unsigned b, unsigned frame, u
     } else {
         T p = re * re + im * im;
         if (a.out_mode == OUT_MEL) {
-            pw[(size_t)f * a.nb_fft + k] = p;
+            pw[(size_t)f * a.nb_fft + k] = a.amp == AMP_MAG_IN ? t_sqrt(p) : p;
         } else {
             T *o = (T *)a.out;
             o[((size_t)b * a.n_out + k) * a.n_frames + frame] = amp_apply(p, a.amp, eps);
@@ -208,6 +208,37 @@ __global__ __launch_bounds__(256) void k_mfcc(const T *mel, T *out, const T *bas
         if (has_lifter) acc *= lifter[k];
         o[(size_t)(k - skip) * n_frames] = acc;
     }
+}
+
+// chroma: out[b][12][n_frames] normalised per frame over the 12 rows, sums / squares accumulated in row order, unfused
+template <typename T>
+__global__ __launch_bounds__(256) void k_chroma_norm(T *data, unsigned n_frames, unsigned long long total, int norm) {
+    const unsigned long long gid = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const unsigned b = (unsigned)(gid / n_frames), f = (unsigned)(gid - (unsigned long long)b * n_frames);
+    T *col = data + (size_t)b * 12 * n_frames + f;
+    T v[12];
+    for (int i = 0; i < 12; ++i) v[i] = col[(size_t)i * n_frames];
+    T d = T(0);
+    if (norm == 1) {
+        for (int i = 0; i < 12; ++i) d = t_mul_add_unfused(T(1), v[i], d);
+    } else if (norm == 2) {
+        for (int i = 0; i < 12; ++i) d = t_mul_add_unfused(v[i], v[i], d);
+        d = t_sqrt(d);
+    } else {
+        for (int i = 0; i < 12; ++i) d = t_max(d, v[i]);
+    }
+    if (d > T(0))
+        for (int i = 0; i < 12; ++i) col[(size_t)i * n_frames] = v[i] / d;
+}
+
+hipError_t launch_chroma_norm(void *data, unsigned batch, unsigned n_frames, int norm, int dtype, hipStream_t s) {
+    if (norm == 0) return hipSuccess;
+    const unsigned long long total = (unsigned long long)batch * n_frames, blocks = (total + 255) / 256;
+    if (blocks == 0 || blocks >= 0x7fffffffull) return hipErrorInvalidConfiguration;
+    if (dtype == SGX_F64) hipLaunchKernelGGL(k_chroma_norm<double>, dim3((unsigned)blocks), dim3(256), 0, s, (double *)data, n_frames, total, norm);
+    else hipLaunchKernelGGL(k_chroma_norm<float>, dim3((unsigned)blocks), dim3(256), 0, s, (float *)data, n_frames, total, norm);
+    return hipGetLastError();
 }
 
 static const size_t kLdsBudget = 64 * 1024;

@@ -81,14 +81,22 @@ __device__ __forceinline__ void load_tw1(const StftArgs &a, unsigned n2, v2f (&t
 // pass 1 arithmetic of one lane: raw column xr (consumed), window column from LDS, result rows -> ex
 __device__ __forceinline__ void pass1_compute(v2f (&xr)[32], const v2f (&wn)[32], const v2f (&twa)[4],
                                               const v2f (&twb)[8], unsigned char *dst) {
+#ifndef SGX_ABL_NOFFT32
     Fft<32, true>::run(xr, wn);
+#endif
 #pragma unroll
     for (int k1 = 0; k1 < 32; ++k1) {
         const int qa = k1 >> 3, qb = k1 & 7;
         v2f r = xr[k1];
+#ifndef SGX_ABL_NOP1TW
         if (qb) r = cmulv(r, twb[qb]);
         if (qa) r = cmulv(r, twa[qa]);
+#endif
+#ifdef SGX_ABL_NOEXW
+        asm volatile("" ::"v"(r));
+#else
         *(v2f *)(dst + k1 * 128) = r;
+#endif
     }
 }
 
@@ -152,7 +160,7 @@ __device__ __forceinline__ void pass2_compute(const StftArgs &a, v2f (&A)[16], v
 #ifdef SGX_ABL_NOPW
             asm volatile("" ::"v"(X), "v"(k));
 #else
-            pw[k] = power_of(X);
+            pw[k] = AMP == AMP_MAG_IN ? sqrtf(power_of(X)) : power_of(X);
 #endif
         } else {
             *(float *)(ob + off) = amp_f32<AMP>(power_of(X), eps);
@@ -388,6 +396,12 @@ __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned
             }
         } else {
             const long long s0 = (long long)(f0 + p1f) * a.hop - (long long)a.pad + 2 * n2;
+#ifdef SGX_ABL_NOLOAD
+            if (true) {
+#pragma unroll
+                for (int n1 = 0; n1 < 32; ++n1) xr[n1] = (v2f){(float)(s0 + n1), 1.0f};
+            } else
+#endif
             if (interior) {
                 const v2f *xp = (const v2f *)(xb + s0);
 #pragma unroll
@@ -747,6 +761,7 @@ hipError_t launch_r32x16_f32(const StftArgs &a, hipStream_t s) {
     if (a.out_mode == OUT_MEL) {
         if (a.amp == AMP_MAGNITUDE) return launch_variant<OUT_MEL, AMP_MAGNITUDE>(a, s);
         if (a.amp == AMP_DB) return launch_variant<OUT_MEL, AMP_DB>(a, s);
+        if (a.amp == AMP_MAG_IN) return launch_variant<OUT_MEL, AMP_MAG_IN>(a, s);
         return launch_variant<OUT_MEL, AMP_POWER>(a, s);
     }
     if (a.amp == AMP_MAGNITUDE) return launch_variant<OUT_LINEAR, AMP_MAGNITUDE>(a, s);

@@ -235,6 +235,43 @@ void build_erb_dense(const sgx_params &p, std::vector<uint32_t> &ptr, std::vecto
     ptr[nf] = uint32_t(nf * nb);
 }
 
+// ---- chroma pitch-class bank (build_chroma_filterbank, src/chroma.rs:262-345): 12 rows, non-zero inside [f_min, f_max] -----
+void build_chroma_csr(const sgx_params &p, std::vector<uint32_t> &ptr, std::vector<uint32_t> &col, std::vector<double> &val) {
+    const size_t nb = p.n_fft / 2 + 1;
+    const double df = p.sample_rate_hz / double(p.n_fft);
+    std::vector<double> fb(12 * nb, 0.0);
+    for (size_t k = 0; k < nb; ++k) {
+        const double freq = double(k) * df;
+        if (freq < p.f_min || freq > p.f_max || freq <= 0.0) continue;
+        const double midi = 69.0 + 12.0 * std::log(freq / p.chroma_tuning) / 0.6931471805599453;  // LN_2
+        double pc = std::fmod(midi, 12.0);  // rem_euclid(12.0)
+        if (pc < 0.0) pc += 12.0;
+        for (size_t c = 0; c < 12; ++c) {
+            const double dist = std::fabs(pc - double(c));
+            const double circ = std::min(dist, 12.0 - dist);
+            const double q = circ / 1.0;
+            fb[c * nb + k] = std::exp(-0.5 * (q * q));
+        }
+    }
+    ptr.assign(13, 0);
+    col.clear();
+    val.clear();
+    for (size_t c = 0; c < 12; ++c) {
+        double row_sum = 0.0;
+        for (size_t k = 0; k < nb; ++k) row_sum += fb[c * nb + k];
+        ptr[c] = uint32_t(col.size());
+        for (size_t k = 0; k < nb; ++k) {
+            double w = fb[c * nb + k];
+            if (row_sum > 0.0) w /= row_sum;
+            if (w != 0.0) {  // the reference multiplies every bin; an exactly-zero weight adds +0
+                col.push_back(uint32_t(k));
+                val.push_back(w);
+            }
+        }
+    }
+    ptr[12] = uint32_t(col.size());
+}
+
 // ---- validation (same conditions and texts as the reference constructors) ------------------------
 sgx_status validate(const sgx_params &p, std::string &msg) {
     auto bad = [&](const char *m) { msg = std::string("Invalid input: ") + m; return SGX_INVALID_INPUT; };
@@ -274,6 +311,13 @@ sgx_status validate(const sgx_params &p, std::string &msg) {
         }
         if (p.n_mels > 10000) return bad("n_filters is unreasonably large");
         if (p.erb_spacing != SGX_ERB_LINEAR && p.erb_spacing != SGX_ERB_APPLE_TR35) return bad("unknown ERB spacing");
+    } else if (p.freq_scale == SGX_FREQ_CHROMA) {  // ChromaParams::new src/chroma.rs:64-90
+        if (!(p.chroma_tuning > 0.0 && std::isfinite(p.chroma_tuning))) return bad("tuning must be finite and > 0");
+        if (!(p.f_min > 0.0 && std::isfinite(p.f_min))) return bad("f_min must be finite and > 0");
+        if (p.f_max <= p.f_min) return bad("f_max must be > f_min");
+        if (p.chroma_norm < SGX_CHROMA_NORM_NONE || p.chroma_norm > SGX_CHROMA_NORM_MAX) return bad("unknown chroma normalisation");
+        if (p.amp_scale != SGX_AMP_MAGNITUDE || p.has_log_params || p.n_mfcc > 0)
+            return bad("chromagram is computed from the magnitude spectrogram (amp_scale = magnitude, no LogParams, no MFCC)");
     } else if (p.freq_scale != SGX_FREQ_LINEAR) {
         return bad("unknown frequency scale");
     }
@@ -563,6 +607,8 @@ sgx_status run_device(sgx_plan *pl, const void *x, size_t batch, size_t n_sample
     const unsigned skip = pl->p.n_mfcc - pl->n_final * (mfcc ? 1u : 0u);
     for (int i = 0; i < iters; ++i) {
         SGX_HIP(pl, launch(pl, a, kind, s));
+        if (pl->p.freq_scale == SGX_FREQ_CHROMA)
+            SGX_HIP(pl, launch_chroma_norm(out, unsigned(batch), unsigned(n_frames), pl->p.chroma_norm, pl->dtype, s));
         if (mfcc)
             SGX_HIP(pl, launch_mfcc(pl->d_melbuf, out, pl->d_dct, pl->d_lifter, unsigned(batch), pl->p.n_mels, unsigned(n_frames),
                                     pl->p.n_mfcc, skip, pl->p.mfcc_lifter > 0, pl->dtype, s));
@@ -734,19 +780,22 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
     pl->dtype = params->dtype;
     pl->elem = params->dtype == SGX_F64 ? 8 : 4;
     pl->nb_fft = params->n_fft / 2 + 1;
+    if (params->freq_scale == SGX_FREQ_CHROMA) pl->p.n_mels = 12;  // N_CHROMA rows go through the mapping slot
     // Mel and LogHz are both sparse row mappings of the power spectrum (MappingKind::{Mel, LogHz}, :1845-1865): one path
     pl->out_mode = params->amp_scale == SGX_AMP_COMPLEX ? OUT_COMPLEX
                    : params->freq_scale != SGX_FREQ_LINEAR ? OUT_MEL : OUT_LINEAR;
-    pl->n_out = pl->out_mode == OUT_MEL ? params->n_mels : pl->nb_fft;
+    pl->n_out = pl->out_mode == OUT_MEL ? pl->p.n_mels : pl->nb_fft;
     const unsigned mfcc_skip = (params->n_mfcc > 1 && !params->mfcc_include_c0) ? 1u : 0u;  // src/mfcc.rs:262-268
     pl->n_final = params->n_mfcc > 0 ? params->n_mfcc - mfcc_skip : pl->n_out;
     // S6: dB is applied only when LogParams were supplied; Decibels without them returns power
     pl->amp = params->amp_scale == SGX_AMP_MAGNITUDE ? AMP_MAGNITUDE
               : (params->amp_scale == SGX_AMP_DECIBELS && params->has_log_params) ? AMP_DB : AMP_POWER;
+    if (params->freq_scale == SGX_FREQ_CHROMA) pl->amp = AMP_MAG_IN;  // the bank weighs magnitudes; nothing after it
     pl->eps = pl->amp == AMP_DB ? std::pow(10.0, params->floor_db / 10.0) : 0.0;
     build_window(pl->p, pl->custom_window, pl->window);
     if (params->freq_scale == SGX_FREQ_MEL) build_mel_csr(pl->p, pl->mel_ptr, pl->mel_col, pl->mel_val);
     if (params->freq_scale == SGX_FREQ_LOGHZ) build_loghz_csr(pl->p, pl->mel_ptr, pl->mel_col, pl->mel_val, pl->loghz_freqs);
+    if (params->freq_scale == SGX_FREQ_CHROMA) build_chroma_csr(pl->p, pl->mel_ptr, pl->mel_col, pl->mel_val);
     if (params->freq_scale == SGX_FREQ_ERB) build_erb_dense(pl->p, pl->mel_ptr, pl->mel_col, pl->mel_val, pl->loghz_freqs);
 
     const bool pow2 = params->n_fft >= 4 && (params->n_fft & (params->n_fft - 1)) == 0;
@@ -861,6 +910,8 @@ sgx_status sgx_axes(const sgx_plan *plan, size_t n_frames, double *freqs, double
     if (freqs && plan->p.n_mfcc > 0) {  // Mfcc carries no frequency axis (src/mfcc.rs:130-133): report coefficient indices
         const unsigned skip = plan->p.n_mfcc - plan->n_final;
         for (unsigned i = 0; i < plan->n_final; ++i) freqs[i] = double(i + skip);
+    } else if (freqs && p.freq_scale == SGX_FREQ_CHROMA) {  // pitch classes C..B carry no Hz axis: report their indices
+        for (unsigned i = 0; i < 12; ++i) freqs[i] = double(i);
     } else if (freqs) {
         if (p.freq_scale == SGX_FREQ_LOGHZ || p.freq_scale == SGX_FREQ_ERB) {  // frequencies stored with the mapping (:1932-1939)
             for (size_t i = 0; i < plan->loghz_freqs.size(); ++i) freqs[i] = plan->loghz_freqs[i];

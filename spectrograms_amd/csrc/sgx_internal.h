@@ -14,7 +14,8 @@
 namespace sgx {
 
 enum OutMode : int { OUT_LINEAR = 0, OUT_MEL = 1, OUT_COMPLEX = 2 };
-enum AmpMode : int { AMP_POWER = 0, AMP_MAGNITUDE = 1, AMP_DB = 2 };
+// AMP_MAG_IN: the mapping consumes sqrt(power) and its output is final (chromagram: bank applied to magnitudes)
+enum AmpMode : int { AMP_POWER = 0, AMP_MAGNITUDE = 1, AMP_DB = 2, AMP_MAG_IN = 3 };
 enum KernelKind : int { K_DIRECT_DFT = 0, K_LDS_RADIX2 = 1, K_R32X16_F32 = 2 };
 
 // Kernel arguments (POD, passed by value).  Layouts in HBM:
@@ -116,6 +117,8 @@ hipError_t launch_c2r1024(const C2rArgs &a, const void *twr, const void *tw1, hi
 hipError_t launch_istft1024(const void *spec, void *out, const void *win, unsigned n_frames, unsigned hop, unsigned batch,
                             unsigned long long start, unsigned long long out_len, float scale, unsigned *bad_flag,
                             const void *twr, const void *tw1, hipStream_t s);
+// per-frame normalisation over the 12 chroma rows, in place (apply_chroma_normalization, src/chroma.rs:403-445)
+hipError_t launch_chroma_norm(void *data, unsigned batch, unsigned n_frames, int norm, int dtype, hipStream_t s);
 hipError_t launch_pointwise(const void *x, const void *y, void *out, unsigned long long n, unsigned long long per, int mode,
                             int dtype, hipStream_t s);
 

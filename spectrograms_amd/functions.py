@@ -86,3 +86,8 @@ def compute_istft(stft_matrix, n_fft, hop_size, window, center=True, dtype=None)
         raise _ffi.DimensionMismatchError(f"Dimension mismatch: expected {int(n_fft) // 2 + 1}, got {m.shape[0]}")
     params = SpectrogramParams(StftParams(int(n_fft), int(hop_size), window, bool(center)), 1.0)
     return Plan(params, _ffi.AMP_COMPLEX, None, None, dtype).istft(m)
+
+
+def compute_chromagram(samples, stft_params, sample_rate, chroma_params, dtype=None):
+    """chromagram() (src/chroma.rs:470-505; Python src/python/functions.rs:551-567): 12 pitch classes x n_frames."""
+    return Plan(SpectrogramParams(stft_params, sample_rate), _ffi.AMP_MAGNITUDE, chroma_params, None, dtype).compute(samples)

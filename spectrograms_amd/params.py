@@ -184,6 +184,56 @@ class ErbParams:
 GammatoneParams = ErbParams
 
 
+class ChromaNorm:
+    """ChromaNorm (src/chroma.rs:24-31; Python class src/python/params.rs:1101-1158): `ChromaNorm.none/l1/l2/max`."""
+
+    def __init__(self, name: str, code: int):
+        self.name, self.code = name, code
+
+    def __repr__(self):
+        return f"ChromaNorm.{self.name}"
+
+    def __eq__(self, other):
+        return isinstance(other, ChromaNorm) and other.code == self.code
+
+    def __hash__(self):
+        return hash(self.code)
+
+
+ChromaNorm.none = ChromaNorm("none", 0)
+ChromaNorm.l1 = ChromaNorm("l1", 1)
+ChromaNorm.l2 = ChromaNorm("l2", 2)
+ChromaNorm.max = ChromaNorm("max", 3)
+
+
+class ChromaParams:
+    """ChromaParams(tuning=440.0, f_min=32.7, f_max=4186.0, norm=None) — src/chroma.rs:12-130, src/python/params.rs:1161-1240.
+    `norm=None` is the enum default, L2 (`#[default] L2`, chroma.rs:28)."""
+
+    def __init__(self, tuning: float = 440.0, f_min: float = 32.7, f_max: float = 4186.0, norm: "ChromaNorm" = None):
+        if not (tuning > 0.0 and math.isfinite(tuning)):
+            raise _ffi.InvalidInputError("Invalid input: tuning must be finite and > 0")
+        if not (f_min > 0.0 and math.isfinite(f_min)):
+            raise _ffi.InvalidInputError("Invalid input: f_min must be finite and > 0")
+        if f_max <= f_min:
+            raise _ffi.InvalidInputError("Invalid input: f_max must be > f_min")
+        self.tuning, self.f_min, self.f_max = float(tuning), float(f_min), float(f_max)
+        self.norm = norm if norm is not None else ChromaNorm.l2
+        self.n_octaves = max(int(math.ceil(math.log2(f_max / f_min))), 1)
+
+    @classmethod
+    def music_standard(cls) -> "ChromaParams":
+        p = cls(440.0, 32.7, 4186.0, ChromaNorm.l2)
+        p.n_octaves = 7
+        return p
+
+    def with_norm(self, norm: "ChromaNorm") -> "ChromaParams":
+        return ChromaParams(self.tuning, self.f_min, self.f_max, norm)
+
+    def __repr__(self):
+        return f"ChromaParams(tuning={self.tuning}, f_min={self.f_min}, f_max={self.f_max})"
+
+
 class MfccParams:
     """MfccParams(n_mfcc=13) — src/mfcc.rs:20-90 (defaults include_c0=True, lifter=22; `with_c0` / `with_lifter`)."""
 

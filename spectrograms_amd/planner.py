@@ -8,7 +8,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 from . import _ffi
-from .params import ErbParams, LogHzParams, LogParams, MelParams, MfccParams, SpectrogramParams, parse_dtype
+from .params import ChromaParams, ErbParams, LogHzParams, LogParams, MelParams, MfccParams, SpectrogramParams, parse_dtype
 
 
 class Spectrogram:
@@ -49,6 +49,48 @@ class Spectrogram:
     def astype(self, dtype):
         return self._data.astype(dtype)
 
+    # DLPack protocol (src/python/dlpack.rs, spectrogram.rs `real_dlpack`): zero-copy export of the host array
+    def __dlpack__(self, **kwargs):
+        return self._data.__dlpack__(**kwargs)
+
+    def __dlpack_device__(self):
+        return self._data.__dlpack_device__()
+
+
+class SpectrogramBatch:
+    """Device-resident batch of spectrograms: what `Plan.compute_batch_resident` returns.
+
+    `tensor` is a torch tensor [batch, n_bins, n_frames] living where the kernel wrote it (frame axis contiguous, S9).  The
+    DLPack export hands that memory to any consumer without a copy (device type kDLROCM), which is what makes the
+    reference's `spectrograms.torch.batch` (python/spectrograms/torch.py:200-285: torch.stack over per-signal host arrays,
+    then `.to(device)`) a zero-copy view here.
+    """
+
+    def __init__(self, tensor, frequencies: np.ndarray, times: np.ndarray, params, db_floor):
+        self.tensor, self._freqs, self._times, self._params, self._db_floor = tensor, frequencies, times, params, db_floor
+
+    frequencies = property(lambda s: s._freqs.tolist())
+    times = property(lambda s: s._times.tolist())
+    params = property(lambda s: s._params)
+    shape = property(lambda s: tuple(s.tensor.shape))
+    batch_size = property(lambda s: s.tensor.shape[0])
+    n_bins = property(lambda s: s.tensor.shape[1])
+    n_frames = property(lambda s: s.tensor.shape[2])
+    dtype = property(lambda s: str(s.tensor.dtype).replace("torch.", ""))
+
+    def __len__(self) -> int:
+        return self.tensor.shape[0]
+
+    def __getitem__(self, i):
+        """One signal's spectrogram as a host `Spectrogram` (copies that slice to the host)."""
+        return Spectrogram(self.tensor[i].cpu().numpy(), self._freqs, self._times, self._params, self._db_floor)
+
+    def __dlpack__(self, **kwargs):
+        return self.tensor.__dlpack__(**kwargs)
+
+    def __dlpack_device__(self):
+        return self.tensor.__dlpack_device__()
+
 
 class StftResult:
     """StftResult (src/spectrogram.rs:534-630)."""
@@ -68,6 +110,34 @@ class StftResult:
 
     def __array__(self, dtype=None, copy=None):
         return self._data if dtype is None else self._data.astype(dtype)
+
+
+class Chromagram:
+    """Chromagram result (src/chroma.rs:132-190): `.data` is (12, n_frames)."""
+
+    LABELS = ["C", "C#", "D", "D#", "E", "F", "F#", "G", "G#", "A", "A#", "B"]
+
+    def __init__(self, data: np.ndarray, params: "ChromaParams"):
+        self._data, self.params = data, params
+
+    data = property(lambda s: s._data)
+    dtype = property(lambda s: "float32" if s._data.dtype == np.float32 else "float64")
+    n_bins = property(lambda s: s._data.shape[0])
+    n_frames = property(lambda s: s._data.shape[1])
+    shape = property(lambda s: s._data.shape)
+
+    @staticmethod
+    def labels():
+        return list(Chromagram.LABELS)
+
+    def __array__(self, dtype=None, copy=None):
+        return self._data if dtype is None else self._data.astype(dtype)
+
+    def __dlpack__(self, **kwargs):
+        return self._data.__dlpack__(**kwargs)
+
+    def __dlpack_device__(self):
+        return self._data.__dlpack_device__()
 
 
 class Mfcc:
@@ -107,7 +177,10 @@ class Plan:
             p.custom_window = self._cw.ctypes.data_as(C.POINTER(C.c_double))
             p.custom_window_len = self._cw.size
         p.sample_rate_hz = params.sample_rate
-        if isinstance(mel, ErbParams):
+        if isinstance(mel, ChromaParams):
+            p.freq_scale = _ffi.FREQ_CHROMA
+            p.f_min, p.f_max, p.chroma_tuning, p.chroma_norm = mel.f_min, mel.f_max, mel.tuning, mel.norm.code
+        elif isinstance(mel, ErbParams):
             p.freq_scale = _ffi.FREQ_ERB
             p.n_mels, p.f_min, p.f_max = mel.n_filters, mel.f_min, mel.f_max
             p.erb_spacing = 1 if mel.spacing == "apple_tr35" else 0
@@ -172,7 +245,8 @@ class Plan:
     def mel_weights(self):
         nnz = C.c_size_t()
         _ffi.raise_status(self._lib.sgx_mel_weights(self._h, C.byref(nnz), None, None, None), self._h)
-        rows = getattr(self._mel, "n_mels", None) or getattr(self._mel, "n_bins", None) or self._mel.n_filters
+        rows = 12 if isinstance(self._mel, ChromaParams) else (getattr(self._mel, "n_mels", None) or getattr(self._mel, "n_bins", None)
+                                                                 or self._mel.n_filters)
         ptr = np.empty(rows + 1, np.uint32)
         col = np.empty(nnz.value, np.uint32)
         val = np.empty(nnz.value, np.float64)
@@ -227,6 +301,17 @@ class Plan:
                                                 _ffi.MEM_DEVICE, C.c_void_p(s)), self._h)
         return torch.view_as_complex(out) if self.is_complex else out
 
+    def compute_batch_resident(self, samples, stream: int = 0) -> "SpectrogramBatch":
+        """[B, N] signals (torch device tensor, or a numpy array that is uploaded once) -> a device-resident
+        `SpectrogramBatch` with axes and DLPack export; nothing comes back to the host."""
+        import torch
+        if not type(samples).__module__.startswith("torch"):
+            dev = torch.device("cuda", torch.cuda.current_device())
+            samples = torch.from_numpy(self._host_samples(samples, 2)).to(dev)
+        t = self._compute_batch_torch(samples, None, stream)
+        freqs, times = self.axes(t.shape[2])
+        return SpectrogramBatch(t, freqs, times, self._params, self._db.floor_db if self._db else None)
+
     def time_batch_torch(self, x, out, iters: int, stream: int = 0) -> float:
         """Mean device milliseconds per launch over `iters` back-to-back launches (hipEvents on the launch stream)."""
         import torch
@@ -246,6 +331,8 @@ class Plan:
             return StftResult(data, freqs, self._params.sample_rate, self._params.stft)
         if self._mfcc is not None:
             return Mfcc(data, self._mfcc)
+        if isinstance(self._mel, ChromaParams):
+            return Chromagram(data, self._mel)
         return Spectrogram(data, freqs, times, self._params, self._db.floor_db if self._db else None)
 
     def compute_frame(self, samples, frame_idx: int) -> np.ndarray:
@@ -363,6 +450,10 @@ class SpectrogramPlanner:
 
     def erb_db_plan(self, params, erb_params, db_params, dtype=None):
         return Plan(params, _ffi.AMP_DECIBELS, erb_params, db_params, dtype, self._device)
+
+    def chroma_plan(self, stft_params, sample_rate, chroma_params, dtype=None):
+        """Plan for chromagram() (src/chroma.rs:470-505): reusable, with `compute_batch`."""
+        return Plan(SpectrogramParams(stft_params, sample_rate), _ffi.AMP_MAGNITUDE, chroma_params, None, dtype, self._device)
 
     def mfcc_plan(self, stft_params, sample_rate, n_mels, mfcc_params, dtype=None):
         """Plan form of `mfcc()` (src/mfcc.rs:359-379): Mel 0..sr/2, floor -80 dB, then DCT-II + lifter."""

@@ -1,0 +1,60 @@
+"""PyTorch interop layer (python/spectrograms/torch.py): DLPack export, to_torch, batch, and the device-resident batch."""
+import numpy as np
+import pytest
+import torch
+
+import spectrograms_amd as sg
+import spectrograms_amd.torch as sgt
+from oracle import oracle as orc
+from spectrograms_amd import _ffi
+from spectrograms_amd.planner import Spectrogram
+from tests import helpers as H
+
+
+def _spec(n_frames, seed=0):
+    rng = np.random.default_rng(seed)
+    data = rng.random((5, n_frames))
+    params = sg.SpectrogramParams(sg.StftParams(8, 4, sg.WindowType.hanning, True), 16000.0)
+    return Spectrogram(data, np.arange(5.0), np.arange(n_frames) * 0.1, params, None)
+
+
+def test_dlpack_and_to_torch_are_zero_copy_on_host():
+    s = _spec(7)
+    t = torch.from_dlpack(s)
+    assert t.shape == (5, 7) and t.dtype == torch.float64 and t.data_ptr() == s.data.ctypes.data
+    r = s.to_torch(with_metadata=True)
+    assert isinstance(r, sgt.TorchSpectrogram) and r.shape == (5, 7) and r.times.shape == (7,) and r.db_range is None
+    assert s.to_torch(dtype=torch.float32).dtype == torch.float32
+
+
+def test_batch_semantics_match_reference():
+    a, b, c = _spec(7, 1), _spec(7, 2), _spec(9, 3)
+    out = sgt.batch([a, b])
+    assert out.shape == (2, 5, 7) and torch.equal(out[1], torch.from_numpy(b.data))
+    with pytest.raises(ValueError, match="same shape"):
+        sgt.batch([a, c])
+    with pytest.raises(ValueError, match="empty"):
+        sgt.batch([])
+    p = sgt.batch([a, c], pad=True)
+    assert p.shape == (2, 5, 9) and torch.all(p[0, :, 7:] == 0)
+    t, meta = sgt.batch_with_metadata([a, b], dtype=torch.float32)
+    assert t.dtype == torch.float32 and len(meta) == 2 and meta[0]["shape"] == (5, 7)
+
+
+@pytest.mark.gpu
+def test_resident_batch_is_zero_copy_and_matches_oracle():
+    x = H.cfg2_batch(4)
+    params = sg.SpectrogramParams(sg.StftParams(1024, 256, sg.WindowType.hanning, True), 16000.0)
+    plan = sg.SpectrogramPlanner().mel_db_plan(params, sg.MelParams(80, 0.0, 8000.0), sg.LogParams(-80.0), dtype="float32")
+    sb = sgt.batch_signals(plan, x)
+    assert sb.shape == (4, 80, 626) and sb.__dlpack_device__()[0] == 10  # kDLROCM
+    t = sgt.batch(sb, device="cuda")
+    assert t.data_ptr() == sb.tensor.data_ptr() and t.is_cuda
+    assert np.array_equal(t.cpu().numpy(), plan.compute_batch(x))  # same launch as the host-pointer path
+    ref = orc.spectrogram_batch(orc.Params(n_fft=1024, hop=256, n_mels=80, amp="db", floor_db=-80.0), x.astype(np.float64))
+    near = ref > ref.max() - 40.0  # tolerance tiers of tests/test_gpu_parity.py: 1e-3 dB within 40 dB of the peak
+    assert np.max(np.abs(t.cpu().numpy() - ref)[near]) < 1e-3
+    one = sb[2]
+    assert one.shape == (80, 626) and len(one.times) == 626 and one.db_range() is not None
+    host, meta = sgt.batch_with_metadata(sb)
+    assert not host.is_cuda and len(meta) == 4
