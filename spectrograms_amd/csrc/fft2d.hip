@@ -2,6 +2,7 @@
 // Row R2C = the STFT engine (an internal sgx_plan with n_fft = hop = ncols, rectangular window, complex output), whose
 // frame-contiguous output is the transposed intermediate [k][r]; columns / inverse rows / pointwise = kernels_fft2d.hip.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -128,6 +129,42 @@ sgx_status inverse_dev(sgx_fft2d *p, const void *spec, size_t batch, void *img, 
         F2_HIP(p, launch_c2r_rows(c, p->dtype, s));
     }
     return SGX_OK;
+}
+
+// convolve_fft / filters with the fused column stage (f32, 1024 rows): rows R2C -> k_colconv1024 -> rows C2R.  `mul` is the
+// kernel's half spectrum (complex) or a real mask, both [row][col].
+sgx_status fused_product_dev(sgx_fft2d *p, const void *img, size_t batch, const void *mul, bool real_mask, void *out, hipStream_t s) {
+    const size_t R = p->nrows, C = p->ncols, Cb = p->cb;
+    sgx_status st = grow2(p, &p->d_inter, &p->inter_bytes, batch * Cb * R * 2 * p->elem);
+    if (st != SGX_OK) return st;
+    if ((st = grow2(p, &p->d_spec, &p->spec_bytes, batch * R * Cb * 2 * p->elem)) != SGX_OK) return st;
+    st = sgx_execute(p->rows, img, batch, R * C, R * C, p->d_inter, batch * Cb * R * 2, SGX_MEM_DEVICE, s);
+    if (st != SGX_OK) return fail(p, st, sgx_last_error(p->rows));
+    C2cArgs a{};
+    a.in = p->d_inter; a.out = p->d_spec;
+    a.n = unsigned(R); a.log2n = p->log2r; a.nseq = unsigned(Cb); a.batch = unsigned(batch);
+    a.in_img = Cb * R; a.out_img = R * Cb;
+    a.in_ss = R; a.in_is = 1; a.out_ss = 1; a.out_is = Cb;
+    a.tile = 16; a.tiles = unsigned((Cb + 15) / 16);
+    F2_HIP(p, launch_colconv1024(a, p->d_tw1c, mul, Cb, real_mask, s));
+    C2rArgs c{};
+    c.in = p->d_spec; c.out = out;
+    c.nrows = unsigned(R); c.ncols = unsigned(C); c.log2c = p->log2c; c.batch = unsigned(batch);
+    c.in_img = Cb * R; c.in_ks = 1; c.in_rs = Cb; c.k_fast = 1;
+    c.tw = p->d_tw_c; c.scale = 1.0 / (double(R) * double(C));
+    if (p->d_twr) {
+        c.tile = 16; c.tiles = unsigned((R + 15) / 16);
+        F2_HIP(p, launch_c2r1024(c, p->d_twr, p->d_tw1r, s));
+    } else {
+        c.tile = p->tile_c; c.tiles = unsigned((R + c.tile - 1) / c.tile);
+        F2_HIP(p, launch_c2r_rows(c, p->dtype, s));
+    }
+    return SGX_OK;
+}
+
+bool use_fused(const sgx_fft2d *p) {
+    static const bool off = [] { const char *v = std::getenv("SGX_FFT2D_FUSED"); return v && v[0] == '0'; }();
+    return p->d_tw1c && !off;
 }
 
 // create_lowpass_mask (image_ops.rs:236-267) on the half spectrum's own dims (quirk S14), f64 logic
@@ -304,6 +341,7 @@ sgx_status sgx_fft2d_convolve(sgx_fft2d *p, const void *images, size_t batch, co
     if ((st = forward_dev(p, p->d_kimg, 1, p->d_kspec, s)) != SGX_OK) return st;
     const size_t imgb = batch * R * C * p->elem;
     return with_staging(p, images, imgb, out, imgb, mem_kind, s, [&](const void *i, void *o) -> sgx_status {
+        if (use_fused(p)) return fused_product_dev(p, i, batch, p->d_kspec, false, o, s);
         sgx_status s2 = grow2(p, &p->d_spec, &p->spec_bytes, batch * R * Cb * 2 * p->elem);
         if (s2 != SGX_OK) return s2;
         if ((s2 = forward_dev(p, i, batch, p->d_spec, s)) != SGX_OK) return s2;
@@ -344,6 +382,7 @@ sgx_status sgx_fft2d_filter(sgx_fft2d *p, const void *images, size_t batch, int3
     F2_HIP(p, hipStreamSynchronize(s));
     const size_t imgb = batch * R * C * p->elem;
     return with_staging(p, images, imgb, out, imgb, mem_kind, s, [&](const void *i, void *o) -> sgx_status {
+        if (use_fused(p)) return fused_product_dev(p, i, batch, p->d_mask, true, o, s);
         sgx_status s2 = grow2(p, &p->d_spec, &p->spec_bytes, batch * R * Cb * 2 * p->elem);
         if (s2 != SGX_OK) return s2;
         if ((s2 = forward_dev(p, i, batch, p->d_spec, s)) != SGX_OK) return s2;

@@ -84,6 +84,111 @@ __global__ __launch_bounds__(512, 2) void k_c2c1024(C2cArgs a, const v2f *tw1c) 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// k_colconv1024: the whole column stage of convolve_fft / the radial filters (src/image_ops.rs:80-115, 301-432) for 1024
+// rows in ONE pass over the half spectrum: forward 1024-point FFT of 16 columns, product with the kernel spectrum (or a real
+// mask), inverse 1024-point FFT — the spectrum never goes back to HBM between the three steps (3 launches and 25 MB per
+// image before; 8.4 MB now).
+//   forward   as k_c2c1024: k = k1 + 32 k2 ends up in registers of thread (k1, s), k2 = 0..31
+//   product   X[k] *= K[k][col] (lanes walk the 16 columns: 128-byte segments of the [row][col] kernel spectrum / mask)
+//   inverse   y = conj(FFT(conj(X))) with the index split mirrored: FFT32 over k2 IN REGISTERS -> n_b, twiddle
+//             W_1024^(k1 n_b), second LDS exchange (same buffer), FFT32 over k1 -> n = 32 n_a + n_b
+//   store     out[n][col] (the [row][col] layout k_c2r1024 reads), 128-byte segments; unnormalised (C2R applies 1/(R C))
+template <bool REAL_MASK>
+__global__ __launch_bounds__(512, 2) void k_colconv1024(C2cArgs a, const v2f *tw1c, const void *mul, unsigned long long mul_row) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned tid = threadIdx.x;
+    const unsigned t = blockIdx.x % a.tiles, b = blockIdx.x / a.tiles;
+    const unsigned s0 = t * 16u;
+    const v2f *in = (const v2f *)a.in + (size_t)b * a.in_img;
+    v2f *out = (v2f *)a.out + (size_t)b * a.out_img;
+    {   // forward pass 1: lane (s, n2), element index contiguous in memory
+        const unsigned s = tid >> 5, n2 = tid & 31u;
+        const bool valid = s0 + s < a.nseq;
+        v2f v[32];
+        const v2f *p = in + (size_t)(s0 + s) * a.in_ss + (size_t)n2 * a.in_is;
+#pragma unroll
+        for (int n1 = 0; n1 < 32; ++n1) v[n1] = valid ? p[(size_t)(32 * n1) * a.in_is] : (v2f){0.f, 0.f};
+        Fft<32, false>::run(v, v);
+        v2f twa[4], twb[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) twa[q] = tw1c[(8 * q) * 32 + n2];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) twb[q] = tw1c[q * 32 + n2];
+        unsigned char *dst = smem + s * kCFS + n2 * 8;
+#pragma unroll
+        for (int k1 = 0; k1 < 32; ++k1) {
+            const int qa = k1 >> 3, qb = k1 & 7;
+            v2f r = v[k1];
+            if (qb) r = cmulv(r, twb[qb]);
+            if (qa) r = cmulv(r, twa[qa]);
+            *(v2f *)(dst + k1 * 256) = r;
+        }
+    }
+    __syncthreads();
+    const unsigned w = tid >> 6, l = tid & 63u, jq = l >> 4, s = l & 15u;
+    const unsigned k1 = w * 4u + jq;  // forward: row k1; inverse step B: row n_b
+    const bool valid = s0 + s < a.nseq;
+    v2f x[32];
+    {
+        const v4f *row = (const v4f *)(smem + s * kCFS + k1 * 256);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const v4f q = row[c];
+            x[2 * c] = (v2f){q.x, q.y};
+            x[2 * c + 1] = (v2f){q.z, q.w};
+        }
+    }
+    __syncthreads();  // every row has been read: the buffer is free for the second exchange
+    Fft<32, false>::run(x, x);  // X[k1 + 32 k2]
+    if (valid) {
+#pragma unroll
+        for (int k2 = 0; k2 < 32; ++k2) {
+            const size_t mi = (size_t)(k1 + 32u * k2) * mul_row + s0 + s;
+            if constexpr (REAL_MASK) {
+                const float m = ((const float *)mul)[mi];
+                x[k2] = x[k2] * (v2f){m, -m};  // product, then conj for the forward-FFT inverse trick
+            } else {
+                const v2f r = cmulv(x[k2], ((const v2f *)mul)[mi]);
+                x[k2] = (v2f){r.x, -r.y};
+            }
+        }
+    }
+    Fft<32, false>::run(x, x);  // over k2 -> n_b
+    {
+        v2f twa[4], twb[8];  // W_1024^(k1 n_b) = twa[n_b >> 3] * twb[n_b & 7] (the table is symmetric in its two indices)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) twa[q] = tw1c[(8 * q) * 32 + k1];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) twb[q] = tw1c[q * 32 + k1];
+        unsigned char *dst = smem + s * kCFS + k1 * 8;
+#pragma unroll
+        for (int nb = 0; nb < 32; ++nb) {
+            const int qa = nb >> 3, qb = nb & 7;
+            v2f r = x[nb];
+            if (qb) r = cmulv(r, twb[qb]);
+            if (qa) r = cmulv(r, twa[qa]);
+            *(v2f *)(dst + nb * 256) = r;
+        }
+    }
+    __syncthreads();
+    {
+        const v4f *row = (const v4f *)(smem + s * kCFS + k1 * 256);  // row n_b = k1 of this thread: 32 values over the old k1
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const v4f q = row[c];
+            x[2 * c] = (v2f){q.x, q.y};
+            x[2 * c + 1] = (v2f){q.z, q.w};
+        }
+        Fft<32, false>::run(x, x);  // over k1 -> n_a: Y[32 n_a + n_b]
+        if (valid) {
+            v2f *o = out + (size_t)(s0 + s) * a.out_ss + (size_t)k1 * a.out_is;
+#pragma unroll
+            for (int na = 0; na < 32; ++na) o[(size_t)(32 * na) * a.out_is] = (v2f){x[na].x, -x[na].y};
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // k_c2r1024: tuned f32 inverse row pass, half spectrum [r][k] (513 complex, k contiguous) -> 1024 real samples per row.
 // With z[n] = x[2n] + i x[2n+1] and Y = X[512-k]:  Z'[k] = (X[k] + conj Y) + i conj(W_1024^k) (X[k] - conj Y)  (= 2 Z[k]),
 // 1024 x = IDFT_512(Z') = conj(DFT_512(conj Z')).  The 512-point DFT is the STFT kernel's 32 x 16 split: lane (r, n2)
@@ -287,6 +392,22 @@ hipError_t launch_istft1024(const void *spec, void *out, const void *win, unsign
         done = true;
     }
     hipLaunchKernelGGL(k_istft1024, dim3((unsigned)g), dim3(256), kILds, s, a, (const v2f *)twr, (const v2f *)tw1);
+    return hipGetLastError();
+}
+
+hipError_t launch_colconv1024(const C2cArgs &a, const void *tw1c, const void *mul, unsigned long long mul_row, bool real_mask,
+                              hipStream_t s) {
+    const unsigned long long g = (unsigned long long)a.tiles * a.batch;
+    if (g == 0 || g >= 0x7fffffffull || a.n != 1024) return hipErrorInvalidConfiguration;
+    static bool done = false;
+    if (!done) {
+        hipError_t e;
+        if ((e = hipFuncSetAttribute((const void *)k_colconv1024<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kCLds)) != hipSuccess) return e;
+        if ((e = hipFuncSetAttribute((const void *)k_colconv1024<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kCLds)) != hipSuccess) return e;
+        done = true;
+    }
+    if (real_mask) hipLaunchKernelGGL((k_colconv1024<true>), dim3((unsigned)g), dim3(512), kCLds, s, a, (const v2f *)tw1c, mul, mul_row);
+    else hipLaunchKernelGGL((k_colconv1024<false>), dim3((unsigned)g), dim3(512), kCLds, s, a, (const v2f *)tw1c, mul, mul_row);
     return hipGetLastError();
 }
 

@@ -111,6 +111,11 @@ hipError_t launch_c2r_rows(const C2rArgs &a, int dtype, hipStream_t s);
 // tuned f32 1024-point C2C, 16 sequences per workgroup; tw1c = W_1024^(k1*n2), [32][32] complex f32; output must be
 // sequence-contiguous for coalesced stores (a.out_ss == 1)
 hipError_t launch_c2c1024(const C2cArgs &a, const void *tw1c, hipStream_t s);
+// fused column stage of the 2-D convolution / filters for 1024 rows, f32: forward FFT, product with `mul` (complex kernel
+// spectrum or real mask, [row][col] with row stride mul_row), inverse FFT; in = [col][row] (a.in_ss = rows, a.in_is = 1),
+// out = [row][col] (a.out_ss = 1, a.out_is = cols)
+hipError_t launch_colconv1024(const C2cArgs &a, const void *tw1c, const void *mul, unsigned long long mul_row, bool real_mask,
+                              hipStream_t s);
 // tuned f32 inverse row pass for ncols == 1024 on a [r][k]-major half spectrum (a.in_ks == 1), 16 rows per workgroup
 hipError_t launch_c2r1024(const C2rArgs &a, const void *twr, const void *tw1, hipStream_t s);
 // fused f32 n_fft = 1024 inverse STFT (C2R + window + overlap-add + normalise + trim); hop >= 64; twr/tw1 as launch_c2r1024

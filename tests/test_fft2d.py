@@ -160,3 +160,23 @@ def test_gpu_fft2d_batched_config5_subset():
         assert np.max(np.abs(S[i] - ref)) <= 2e-5 * np.max(np.abs(ref))
         rc = orc.convolve_fft(imgs[i].astype(np.float64), k.astype(np.float64))
         assert np.max(np.abs(Y[i] - rc)) <= 2e-5 * np.max(np.abs(rc))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1024, 1024), (1024, 64), (1024, 100), (1024, 7)])
+def test_gpu_fused_column_stage_1024_rows(shape):
+    """f32 images with 1024 rows take the fused column kernel (forward FFT x kernel spectrum / mask x inverse FFT in one
+    pass) for convolve_fft and the radial filters; the column count is free (tuned or generic row kernels)."""
+    x = np.stack([img(shape, 11 + k, np.float32) for k in range(3)])
+    plan = sg.Fft2dPlan(shape[0], shape[1], "float32")
+    ksz = 9 if shape[1] >= 9 else 5
+    k = sg.gaussian_kernel_2d(ksz, 2.0, dtype="float32")
+    got = plan.convolve(x, k)
+    for i in range(3):
+        ref = orc.convolve_fft(x[i].astype(np.float64), k.astype(np.float64))
+        assert np.max(np.abs(got[i] - ref)) <= 2e-5 * max(1.0, np.max(np.abs(ref)))
+    for kind, args in ((0, (0.3, 0.0)), (1, (0.2, 0.0)), (2, (0.1, 0.6))):
+        got = plan.filter(x, kind, *args)
+        for i in range(3):
+            ref = orc.filter2d(x[i].astype(np.float64), kind, *args)
+            assert np.max(np.abs(got[i] - ref)) <= 2e-5 * max(1.0, np.max(np.abs(ref)))
