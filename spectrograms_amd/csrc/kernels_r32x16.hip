@@ -706,10 +706,17 @@ hipError_t launch_variant(const StftArgs &a, hipStream_t s) {
             const char *v = getenv("SGX_KERNEL");
             return v && v[0] == 's';  // "single": two independent 256-thread workgroups per CU (round-1 first design)
         }();
-        static const bool want_staged = [] {
+        // Sample loads: "direct" = per-lane float2 loads (4 x 128-byte segments per wave-instruction, every line requested ~4
+        // times because frames overlap by 75 %); "staged" = the tile's samples fetched once with coalesced 16-byte loads,
+        // staged in LDS and re-read per frame from there.  Measured on MI355X (256 x 10 s): Mel-dB 162 us staged vs 186 us
+        // direct; linear power 189 us staged vs 171 us direct (there the coalesced loads queue right behind the tile's
+        // 33 KB store burst in the CU's in-order vector-memory pipe).  So Mel-type outputs stage, the others load directly;
+        // SGX_LOADS=staged|direct overrides.
+        static const int loads_mode = [] {
             const char *v = getenv("SGX_LOADS");
-            return v && v[0] == 's';  // "staged": coalesced 16-byte loads through LDS (measured slower so far: 192 vs 180 us)
+            return !v ? 0 : v[0] == 's' ? 1 : v[0] == 'd' ? 2 : 0;
         }();
+        const bool want_staged = loads_mode == 1 || (loads_mode == 0 && MODE == OUT_MEL);
         const bool stage5 = want_staged && aligned16 && chunks <= 5u * 256u;
         if (want_single) {
             static bool done = false;
