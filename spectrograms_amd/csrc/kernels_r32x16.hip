@@ -402,11 +402,7 @@ __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned
                 for (int n1 = 0; n1 < 32; ++n1) xr[n1] = (v2f){(float)(s0 + n1), 1.0f};
             } else
 #endif
-            if (interior) {
-                const v2f *xp = (const v2f *)(xb + s0);
-#pragma unroll
-                for (int n1 = 0; n1 < 32; ++n1) xr[n1] = xp[16 * n1];
-            } else {
+            if (!interior) {  // edge tile: zero padding (S1) by predication
                 const long long n = (long long)a.n_samples;
 #pragma unroll
                 for (int n1 = 0; n1 < 32; ++n1) {
@@ -414,11 +410,31 @@ __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned
                     xr[n1].x = (sx >= 0 && sx < n) ? xb[sx] : 0.0f;
                     xr[n1].y = (sx + 1 >= 0 && sx + 1 < n) ? xb[sx + 1] : 0.0f;
                 }
+                if constexpr (MODE != OUT_MEL) {
+                    // consume the edge tile's samples here (2 tiles in 40): with these predicated loads still pending at the
+                    // join, the compiler protects the interior path's loads into the same registers with s_waitcnt vmcnt(0),
+                    // i.e. a full drain of the previous tile's stores on EVERY tile
+#pragma unroll
+                    for (int n1 = 0; n1 < 32; ++n1) asm volatile("" : "+v"(xr[n1]));
+                }
+            } else {
+                const v2f *xp = (const v2f *)(xb + s0);
+#pragma unroll
+                for (int n1 = 0; n1 < 32; ++n1) xr[n1] = xp[16 * n1];
             }
         }
     };
 
     if (wid < hi) load_tile(wid);
+    if constexpr (ROUNDS == 0 && MODE != OUT_MEL) {
+        // "use" the first tile's samples here: the compiler then waits for these loads in the prologue, and inside the
+        // loop every sample load is followed by this half's >= 32 unconditional output stores — which lets it emit
+        // s_waitcnt vmcnt(32) at the top of the loop instead of vmcnt(0).  gfx9-family hardware counts loads and stores
+        // with ONE in-order counter: with vmcnt(0) every wave waited for all of its stores to be acknowledged by a
+        // write-saturated memory system before it began the next tile.
+#pragma unroll
+        for (int n1 = 0; n1 < 32; ++n1) asm volatile("" : "+v"(xr[n1]));
+    }
     __syncthreads();  // tables visible
 #ifdef SGX_STAMPS
     unsigned long long st_acc[8] = {0}, st_prev;
@@ -466,20 +482,26 @@ __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned
         SGX_STAMP(2);
         __syncthreads();
         SGX_STAMP(3);
+        // Linear / complex outputs: every lane runs pass 2 and stores, so the compiler can count the stores behind the next
+        // tile's loads (see the prologue).  A lane whose frame does not exist (last tile of a signal) mirrors the tile's last
+        // frame, an idle second half (odd tile count) mirrors the first half's tile: same values to the same addresses.
+        constexpr bool ALLSTORE = MODE != OUT_MEL;
+        const unsigned p2f_eff = ALLSTORE ? min(p2f, nf - 1u) : p2f;
+        const unsigned char *ex_src = (ALLSTORE && !active) ? smem_all : smem;
         v2f A[16], B[16];
-        read_rows(smem + p2f * kFS, ra, rb, A, B);
+        read_rows(ex_src + p2f_eff * kFS, ra, rb, A, B);
         SGX_STAMP(4);
         __syncthreads();  // ex consumed: the next pass 1 (or the pw overlay) may overwrite it
         SGX_STAMP(5);
         if constexpr (MODE == OUT_MEL) {  // pw rows are 516 floats wide: bins 513..515 are read with zero weights
             if (tid < 48u) ((float *)smem)[(tid / 3u) * kPS + 513u + tid % 3u] = 0.0f;
         }
-        if (active && p2f < nf) {
+        if (ALLSTORE || (active && p2f < nf)) {
             const v4f *t2 = (const v4f *)(tabs + kTw2Off);
             auto tw = [&](int i) {  // read from LDS where consumed (this kernel has no registers to keep them)
                 return i < 8 ? t2[(j == 0 ? 16u : j) * kTw2Stride + i] : t2[j == 0 ? (unsigned)(i - 8) : j * kTw2Stride + i];
             };
-            pass2_compute<MODE, AMP>(a, A, B, b, f0, p2f, j, eps, tw, jo, (float *)smem + p2f * kPS);
+            pass2_compute<MODE, AMP>(a, A, B, b, f0, p2f_eff, j, eps, tw, jo, (float *)smem + p2f * kPS);
         }
         if constexpr (MODE == OUT_MEL) {
             __syncthreads();
