@@ -101,6 +101,10 @@ __device__ __forceinline__ void pass1_compute(v2f (&xr)[32], const v2f (&wn)[32]
 }
 
 __device__ __forceinline__ void read_rows(const unsigned char *exf, unsigned ra, unsigned rb, v2f (&A)[16], v2f (&B)[16]) {
+#ifdef SGX_ABL_NOROWS
+    for (int c = 0; c < 16; ++c) { A[c] = (v2f){(float)ra, 1.f}; B[c] = (v2f){(float)rb, 2.f}; }
+    return;
+#endif
     const v4f *pa = (const v4f *)(exf + ra * 128);
     const v4f *pb = (const v4f *)(exf + rb * 128);
 #pragma unroll
@@ -469,7 +473,11 @@ __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned
             v2f wn[32];
             const v2f *w2 = (const v2f *)(tabs + kWinOff) + n2;
 #pragma unroll
+#ifdef SGX_ABL_NOWIN
+            for (int n1 = 0; n1 < 32; ++n1) wn[n1] = (v2f){0.5f, 0.25f};
+#else
             for (int n1 = 0; n1 < 32; ++n1) wn[n1] = w2[16 * n1];
+#endif
             if constexpr (ROUNDS > 0) __syncthreads();  // every wave has read xs: pass 1 may overwrite it with ex
             SGX_STAMP(0);
             if (active) pass1_compute(xr, wn, twa, twb, smem + p1f * kFS + n2 * 8);
@@ -499,6 +507,9 @@ __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned
         if (ALLSTORE || (active && p2f < nf)) {
             const v4f *t2 = (const v4f *)(tabs + kTw2Off);
             auto tw = [&](int i) {  // read from LDS where consumed (this kernel has no registers to keep them)
+#ifdef SGX_ABL_NOTW2
+                return (v4f){1.f, 0.5f, 0.5f, -1.f};
+#endif
                 return i < 8 ? t2[(j == 0 ? 16u : j) * kTw2Stride + i] : t2[j == 0 ? (unsigned)(i - 8) : j * kTw2Stride + i];
             };
             pass2_compute<MODE, AMP>(a, A, B, b, f0, p2f_eff, j, eps, tw, jo, (float *)smem + p2f * kPS);
