@@ -111,7 +111,7 @@ def test_host_validation():
 # ------------------------------------------------------------------ GPU parity
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
-@pytest.mark.parametrize("shape", SHAPES + [(256, 256), (1024, 1024), (512, 1024), (1024, 64)])
+@pytest.mark.parametrize("shape", SHAPES + [(256, 256), (1024, 1024), (512, 1024), (1024, 64), (100, 1024), (37, 1024)])
 def test_gpu_fft2d_matches_oracle(shape, dtype):
     npdt = np.float32 if dtype == "float32" else np.float64
     x = img(shape, 5, npdt)
