@@ -17,6 +17,15 @@ namespace {
 using namespace inreg;
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// Workgroups are dispatched round-robin over the 8 XCDs, each with its own L2.  Neighbouring tiles share cache lines (a
+// 16-sequence store segment is 128 bytes at a 4104-byte row pitch, an inverse-STFT tile re-reads 3 halo frames), so XCD x
+// takes the contiguous range [x * per, (x + 1) * per) of the logical tile space; the grid is rounded up to a multiple of 8.
+__device__ __forceinline__ unsigned xcd_logical_block(unsigned nblocks) {
+    const unsigned per = (nblocks + 7u) >> 3;
+    return (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+}
+static inline unsigned xcd_grid(unsigned long long nblocks) { return (unsigned)(((nblocks + 7ull) >> 3) << 3); }
+
 constexpr int kCFS = 8192 + 16;     // LDS bytes per sequence (odd multiple of 16: conflict-free b128 row reads)
 constexpr int kCLds = 16 * kCFS;    // 131328 B -> one workgroup per CU
 
@@ -24,7 +33,9 @@ template <bool IN_SEQ_FAST, bool INVERSE>
 __global__ __launch_bounds__(512, 2) void k_c2c1024(C2cArgs a, const v2f *tw1c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned tid = threadIdx.x;
-    const unsigned t = blockIdx.x % a.tiles, b = blockIdx.x / a.tiles;
+    const unsigned lb = xcd_logical_block(a.tiles * a.batch);
+    if (lb >= a.tiles * a.batch) return;
+    const unsigned t = lb % a.tiles, b = lb / a.tiles;
     const unsigned s0 = t * 16u;
     const v2f *in = (const v2f *)a.in + (size_t)b * a.in_img;
     v2f *out = (v2f *)a.out + (size_t)b * a.out_img;
@@ -97,7 +108,9 @@ template <bool REAL_MASK>
 __global__ __launch_bounds__(512, 2) void k_colconv1024(C2cArgs a, const v2f *tw1c, const void *mul, unsigned long long mul_row) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned tid = threadIdx.x;
-    const unsigned t = blockIdx.x % a.tiles, b = blockIdx.x / a.tiles;
+    const unsigned lb = xcd_logical_block(a.tiles * a.batch);
+    if (lb >= a.tiles * a.batch) return;
+    const unsigned t = lb % a.tiles, b = lb / a.tiles;
     const unsigned s0 = t * 16u;
     const v2f *in = (const v2f *)a.in + (size_t)b * a.in_img;
     v2f *out = (v2f *)a.out + (size_t)b * a.out_img;
@@ -277,7 +290,9 @@ constexpr int kILds = 16 * kISeq;     // 74240 B -> two workgroups per CU (the r
 __global__ __launch_bounds__(256, 2) void k_istft1024(IstftArgs a, const v2f *twr, const v2f *tw1) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned tid = threadIdx.x;
-    const unsigned t = blockIdx.x % a.tiles, b = blockIdx.x / a.tiles;
+    const unsigned lb = xcd_logical_block(a.tiles * a.batch);
+    if (lb >= a.tiles * a.batch) return;
+    const unsigned t = lb % a.tiles, b = lb / a.tiles;
     const long long h0 = (long long)t * a.nbk;      // first hop block of this tile
     const long long fbase = h0 - (long long)a.ov;   // frame held in row 0
     const v2f *in = (const v2f *)a.spec + (size_t)b * 513u * a.n_frames;
@@ -391,7 +406,7 @@ hipError_t launch_istft1024(const void *spec, void *out, const void *win, unsign
         if (e != hipSuccess) return e;
         done = true;
     }
-    hipLaunchKernelGGL(k_istft1024, dim3((unsigned)g), dim3(256), kILds, s, a, (const v2f *)twr, (const v2f *)tw1);
+    hipLaunchKernelGGL(k_istft1024, dim3(xcd_grid(g)), dim3(256), kILds, s, a, (const v2f *)twr, (const v2f *)tw1);
     return hipGetLastError();
 }
 
@@ -406,8 +421,8 @@ hipError_t launch_colconv1024(const C2cArgs &a, const void *tw1c, const void *mu
         if ((e = hipFuncSetAttribute((const void *)k_colconv1024<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kCLds)) != hipSuccess) return e;
         done = true;
     }
-    if (real_mask) hipLaunchKernelGGL((k_colconv1024<true>), dim3((unsigned)g), dim3(512), kCLds, s, a, (const v2f *)tw1c, mul, mul_row);
-    else hipLaunchKernelGGL((k_colconv1024<false>), dim3((unsigned)g), dim3(512), kCLds, s, a, (const v2f *)tw1c, mul, mul_row);
+    if (real_mask) hipLaunchKernelGGL((k_colconv1024<true>), dim3(xcd_grid(g)), dim3(512), kCLds, s, a, (const v2f *)tw1c, mul, mul_row);
+    else hipLaunchKernelGGL((k_colconv1024<false>), dim3(xcd_grid(g)), dim3(512), kCLds, s, a, (const v2f *)tw1c, mul, mul_row);
     return hipGetLastError();
 }
 
@@ -438,11 +453,11 @@ hipError_t launch_c2c1024(const C2cArgs &a, const void *tw1c, hipStream_t s) {
     }
     const v2f *tw = (const v2f *)tw1c;
     if (a.in_seq_fast) {
-        if (a.inverse) hipLaunchKernelGGL((k_c2c1024<true, true>), dim3((unsigned)g), dim3(512), kCLds, s, a, tw);
-        else hipLaunchKernelGGL((k_c2c1024<true, false>), dim3((unsigned)g), dim3(512), kCLds, s, a, tw);
+        if (a.inverse) hipLaunchKernelGGL((k_c2c1024<true, true>), dim3(xcd_grid(g)), dim3(512), kCLds, s, a, tw);
+        else hipLaunchKernelGGL((k_c2c1024<true, false>), dim3(xcd_grid(g)), dim3(512), kCLds, s, a, tw);
     } else {
-        if (a.inverse) hipLaunchKernelGGL((k_c2c1024<false, true>), dim3((unsigned)g), dim3(512), kCLds, s, a, tw);
-        else hipLaunchKernelGGL((k_c2c1024<false, false>), dim3((unsigned)g), dim3(512), kCLds, s, a, tw);
+        if (a.inverse) hipLaunchKernelGGL((k_c2c1024<false, true>), dim3(xcd_grid(g)), dim3(512), kCLds, s, a, tw);
+        else hipLaunchKernelGGL((k_c2c1024<false, false>), dim3(xcd_grid(g)), dim3(512), kCLds, s, a, tw);
     }
     return hipGetLastError();
 }
