@@ -400,11 +400,9 @@ hipError_t launch_istft1024(const void *spec, void *out, const void *win, unsign
     a.start = start; a.out_len = out_len; a.scale = scale; a.bad_flag = bad_flag;
     const unsigned long long g = (unsigned long long)a.tiles * batch;
     if (g == 0 || g >= 0x7fffffffull) return hipErrorInvalidConfiguration;
-    static bool done = false;
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_istft1024, hipFuncAttributeMaxDynamicSharedMemorySize, kILds);
+    {
+        hipError_t e = set_max_dynamic_lds((const void *)k_istft1024, kILds);
         if (e != hipSuccess) return e;
-        done = true;
     }
     hipLaunchKernelGGL(k_istft1024, dim3(xcd_grid(g)), dim3(256), kILds, s, a, (const v2f *)twr, (const v2f *)tw1);
     return hipGetLastError();
@@ -414,12 +412,10 @@ hipError_t launch_colconv1024(const C2cArgs &a, const void *tw1c, const void *mu
                               hipStream_t s) {
     const unsigned long long g = (unsigned long long)a.tiles * a.batch;
     if (g == 0 || g >= 0x7fffffffull || a.n != 1024) return hipErrorInvalidConfiguration;
-    static bool done = false;
-    if (!done) {
+    {
         hipError_t e;
-        if ((e = hipFuncSetAttribute((const void *)k_colconv1024<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kCLds)) != hipSuccess) return e;
-        if ((e = hipFuncSetAttribute((const void *)k_colconv1024<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kCLds)) != hipSuccess) return e;
-        done = true;
+        if ((e = set_max_dynamic_lds((const void *)k_colconv1024<false>, kCLds)) != hipSuccess) return e;
+        if ((e = set_max_dynamic_lds((const void *)k_colconv1024<true>, kCLds)) != hipSuccess) return e;
     }
     if (real_mask) hipLaunchKernelGGL((k_colconv1024<true>), dim3(xcd_grid(g)), dim3(512), kCLds, s, a, (const v2f *)tw1c, mul, mul_row);
     else hipLaunchKernelGGL((k_colconv1024<false>), dim3(xcd_grid(g)), dim3(512), kCLds, s, a, (const v2f *)tw1c, mul, mul_row);
@@ -429,11 +425,9 @@ hipError_t launch_colconv1024(const C2cArgs &a, const void *tw1c, const void *mu
 hipError_t launch_c2r1024(const C2rArgs &a, const void *twr, const void *tw1, hipStream_t s) {
     const unsigned long long g = (unsigned long long)a.tiles * a.batch;
     if (g == 0 || g >= 0x7fffffffull || a.ncols != 1024 || a.in_ks != 1) return hipErrorInvalidConfiguration;
-    static bool done = false;
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_c2r1024, hipFuncAttributeMaxDynamicSharedMemorySize, kRLds);
+    {
+        hipError_t e = set_max_dynamic_lds((const void *)k_c2r1024, kRLds);
         if (e != hipSuccess) return e;
-        done = true;
     }
     hipLaunchKernelGGL(k_c2r1024, dim3((unsigned)g), dim3(256), kRLds, s, a, (const v2f *)twr, (const v2f *)tw1);
     return hipGetLastError();
@@ -442,14 +436,12 @@ hipError_t launch_c2r1024(const C2rArgs &a, const void *twr, const void *tw1, hi
 hipError_t launch_c2c1024(const C2cArgs &a, const void *tw1c, hipStream_t s) {
     const unsigned long long g = (unsigned long long)a.tiles * a.batch;
     if (g == 0 || g >= 0x7fffffffull || a.n != 1024) return hipErrorInvalidConfiguration;
-    static bool done = false;
-    if (!done) {
+    {
         hipError_t e;
-        if ((e = hipFuncSetAttribute((const void *)k_c2c1024<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kCLds)) != hipSuccess) return e;
-        if ((e = hipFuncSetAttribute((const void *)k_c2c1024<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kCLds)) != hipSuccess) return e;
-        if ((e = hipFuncSetAttribute((const void *)k_c2c1024<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kCLds)) != hipSuccess) return e;
-        if ((e = hipFuncSetAttribute((const void *)k_c2c1024<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kCLds)) != hipSuccess) return e;
-        done = true;
+        if ((e = set_max_dynamic_lds((const void *)k_c2c1024<false, false>, kCLds)) != hipSuccess) return e;
+        if ((e = set_max_dynamic_lds((const void *)k_c2c1024<false, true>, kCLds)) != hipSuccess) return e;
+        if ((e = set_max_dynamic_lds((const void *)k_c2c1024<true, false>, kCLds)) != hipSuccess) return e;
+        if ((e = set_max_dynamic_lds((const void *)k_c2c1024<true, true>, kCLds)) != hipSuccess) return e;
     }
     const v2f *tw = (const v2f *)tw1c;
     if (a.in_seq_fast) {

@@ -703,14 +703,7 @@ __global__ __launch_bounds__(512, 2) void k_ws(StftArgs a, unsigned per_xcd, uns
 }
 
 template <typename K>
-hipError_t set_lds_once(K kernel, int bytes, bool &done) {
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        if (e != hipSuccess) return e;
-        done = true;
-    }
-    return hipSuccess;
-}
+hipError_t set_lds_once(K kernel, int bytes, bool &) { return set_max_dynamic_lds((const void *)kernel, bytes); }
 
 template <int MODE, int AMP>
 hipError_t launch_variant(const StftArgs &a, hipStream_t s) {

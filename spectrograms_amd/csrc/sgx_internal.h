@@ -6,7 +6,10 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <mutex>
+#include <set>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "spectro_hip.h"
@@ -126,6 +129,21 @@ hipError_t launch_istft1024(const void *spec, void *out, const void *win, unsign
 hipError_t launch_chroma_norm(void *data, unsigned batch, unsigned n_frames, int norm, int dtype, hipStream_t s);
 hipError_t launch_pointwise(const void *x, const void *y, void *out, unsigned long long n, unsigned long long per, int mode,
                             int dtype, hipStream_t s);
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device setting: remember which (kernel, device) pairs have been
+// configured, so a process that drives several GPUs (sgx_params.device) gets the large-LDS opt-in on each of them.
+inline hipError_t set_max_dynamic_lds(const void *fn, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> guard(mu);
+    if (done.count({fn, dev})) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.insert({fn, dev});
+    return e;
+}
 
 }  // namespace sgx
 
