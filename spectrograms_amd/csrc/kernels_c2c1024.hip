@@ -225,6 +225,7 @@ __global__ __launch_bounds__(256, 2) void k_c2r1024(C2rArgs a, const v2f *twr /*
         const bool valid = r0 + r < a.nrows;
         const v2f *row = in + (size_t)(r0 + r) * a.in_rs;  // in_ks == 1
         v2f v[32];
+        const v2f wl = twr[n2];  // conj(W_1024^(16 n1 + n2)) = e^{+2 pi i n1 / 64} (constant) * conj(W_1024^n2) (this load)
 #pragma unroll
         for (int n1 = 0; n1 < 32; ++n1) {
             const unsigned k = 16u * n1 + n2;
@@ -233,15 +234,27 @@ __global__ __launch_bounds__(256, 2) void k_c2r1024(C2rArgs a, const v2f *twr /*
             if (k == 0) { A.y = 0.f; Y.y = 0.f; }  // DC (k = 0) and Nyquist (512 - 0) columns are forced real
             const v2f B = (v2f){Y.x, -Y.y};        // conj(X[512-k])
             const v2f S = A + B, D = A - B;
-            const v2f T = cmulv(D, twr[16 * n1 + n2]);            // conj(W^k) (X[k] - conj Y)
+            const v2f cw = n1 == 0 ? wl : cmulv(wl, (v2f){(float)kCos64[n1], (float)kSin64[n1]});
+            const v2f T = cmulv(D, cw);                           // conj(W^k) (X[k] - conj Y)
             const v2f Z = pfma(swp(T), (v2f){-1.f, 1.f}, S);      // S + i T
             v[n1] = (v2f){Z.x, -Z.y};                             // conj for the forward-FFT inverse trick
         }
         Fft<32, false>::run(v, v);
         unsigned char *dst = smem + r * kRSeq + n2 * 8;
         *(v2f *)dst = v[0];
+        v2f twa[4], twb[8];  // W_512^(k1 n2) = twa[k1 >> 3] * twb[k1 & 7]
 #pragma unroll
-        for (int k1 = 1; k1 < 32; ++k1) *(v2f *)(dst + k1 * kRRS) = cmulv(v[k1], tw1[16 * k1 + n2]);
+        for (int q = 0; q < 4; ++q) twa[q] = tw1[16 * 8 * q + n2];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) twb[q] = tw1[16 * q + n2];
+#pragma unroll
+        for (int k1 = 1; k1 < 32; ++k1) {
+            const int qa = k1 >> 3, qb = k1 & 7;
+            v2f r2 = v[k1];
+            if (qb) r2 = cmulv(r2, twb[qb]);
+            if (qa) r2 = cmulv(r2, twa[qa]);
+            *(v2f *)(dst + k1 * kRRS) = r2;
+        }
     }
     __syncthreads();
     const float sc = (float)a.scale;
@@ -302,6 +315,9 @@ __global__ __launch_bounds__(256, 2) void k_istft1024(IstftArgs a, const v2f *tw
         const bool valid = f >= 0 && f < (long long)a.n_frames;
         const v2f *col = in + (valid ? f : 0);
         v2f v[32];
+        // conj(W_1024^(16 n1 + n2)) = e^{+2 pi i n1 / 64} (compile-time constant) * conj(W_1024^n2) (one load per lane): the
+        // table loads (L1 hits, but 63 more instructions through the same in-order vector-memory pipe as the data) drop to 13
+        const v2f wl = twr[n2];
 #pragma unroll
         for (int n1 = 0; n1 < 32; ++n1) {
             const unsigned k = 16u * n1 + n2;
@@ -314,15 +330,27 @@ __global__ __launch_bounds__(256, 2) void k_istft1024(IstftArgs a, const v2f *tw
             }
             const v2f B = (v2f){Y.x, -Y.y};
             const v2f S = A + B, D = A - B;
-            const v2f T = cmulv(D, twr[16 * n1 + n2]);
+            const v2f cw = n1 == 0 ? wl : cmulv(wl, (v2f){(float)kCos64[n1], (float)kSin64[n1]});
+            const v2f T = cmulv(D, cw);
             const v2f Z = pfma(swp(T), (v2f){-1.f, 1.f}, S);
             v[n1] = (v2f){Z.x, -Z.y};
         }
         Fft<32, false>::run(v, v);
         unsigned char *dst = smem + r * kISeq + n2 * 8;
         *(v2f *)dst = v[0];
+        v2f twa[4], twb[8];  // W_512^(k1 n2) = twa[k1 >> 3] * twb[k1 & 7]
 #pragma unroll
-        for (int k1 = 1; k1 < 32; ++k1) *(v2f *)(dst + k1 * kRRS) = cmulv(v[k1], tw1[16 * k1 + n2]);
+        for (int q = 0; q < 4; ++q) twa[q] = tw1[16 * 8 * q + n2];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) twb[q] = tw1[16 * q + n2];
+#pragma unroll
+        for (int k1 = 1; k1 < 32; ++k1) {
+            const int qa = k1 >> 3, qb = k1 & 7;
+            v2f r2 = v[k1];
+            if (qb) r2 = cmulv(r2, twb[qb]);
+            if (qa) r2 = cmulv(r2, twa[qa]);
+            *(v2f *)(dst + k1 * kRRS) = r2;
+        }
     }
     __syncthreads();
     v2f y[2][16];
