@@ -210,6 +210,45 @@ __global__ __launch_bounds__(256) void k_mfcc(const T *mel, T *out, const T *bas
     }
 }
 
+// Same arithmetic with the loops swapped: a lane keeps NC accumulators (one per coefficient) and walks the mel bands once,
+// so every Mel value is read from memory ONCE (coalesced across the lanes' frames) instead of once per coefficient, and the
+// basis sits in LDS as [band][coefficient] (16-byte broadcast reads).  Each accumulator still sees its own FMA chain in
+// ascending band order, so the results are bit-identical to k_mfcc / the reference.  Measured (256 x 10 s, 13 of 80):
+// 300 us -> see DESIGN.md.
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void k_mfcc_acc(const T *mel, T *out, const T *basis, const T *lifter, unsigned batch,
+                                                  unsigned n_mels, unsigned n_frames, unsigned n_mfcc, unsigned skip, int has_lifter) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T *sb = (T *)smem;  // [n_mels][NC], zero beyond n_mfcc
+    for (unsigned idx = threadIdx.x; idx < n_mels * NC; idx += 256) {
+        const unsigned i = idx / NC, k = idx % NC;
+        sb[idx] = k < n_mfcc ? basis[(size_t)k * n_mels + i] : T(0);
+    }
+    __syncthreads();
+    const unsigned long long gid = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (unsigned long long)batch * n_frames) return;
+    const unsigned b = (unsigned)(gid / n_frames), f = (unsigned)(gid - (unsigned long long)b * n_frames);
+    const T *m = mel + (size_t)b * n_mels * n_frames + f;
+    T *o = out + (size_t)b * (n_mfcc - skip) * n_frames + f;
+    T acc[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) acc[k] = T(0);
+    for (unsigned i = 0; i < n_mels; ++i) {
+        const T v = m[(size_t)i * n_frames];
+        const T *bi = sb + i * NC;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) acc[k] = fma(v, bi[k], acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        if ((unsigned)k >= skip && (unsigned)k < n_mfcc) {
+            T r = acc[k];
+            if (has_lifter) r *= lifter[k];
+            o[(size_t)(k - skip) * n_frames] = r;
+        }
+    }
+}
+
 // chroma: out[b][12][n_frames] normalised per frame over the 12 rows, sums / squares accumulated in row order, unfused
 template <typename T>
 __global__ __launch_bounds__(256) void k_chroma_norm(T *data, unsigned n_frames, unsigned long long total, int norm) {
@@ -305,6 +344,20 @@ hipError_t launch_mfcc(const void *mel, void *out, const void *basis, const void
     const unsigned long long n = (unsigned long long)batch * n_frames;
     const unsigned long long blocks = (n + 255) / 256;
     if (blocks == 0 || blocks >= 0x7fffffffull) return hipErrorInvalidConfiguration;
+    const size_t es = dtype == SGX_F64 ? 8 : 4;
+#define SGX_MFCC_ACC(T, NC)                                                                                                    \
+    hipLaunchKernelGGL((k_mfcc_acc<T, NC>), dim3((unsigned)blocks), dim3(256), (size_t)n_mels * NC * es, s, (const T *)mel,    \
+                       (T *)out, (const T *)basis, (const T *)lifter, batch, n_mels, n_frames, n_mfcc, skip, has_lifter)
+    const int nc = n_mfcc <= 16 ? 16 : n_mfcc <= 32 ? 32 : n_mfcc <= 64 ? 64 : 0;
+    if (nc && (size_t)n_mels * nc * es <= 48 * 1024) {
+        if (dtype == SGX_F64) {
+            if (nc == 16) SGX_MFCC_ACC(double, 16); else if (nc == 32) SGX_MFCC_ACC(double, 32); else SGX_MFCC_ACC(double, 64);
+        } else {
+            if (nc == 16) SGX_MFCC_ACC(float, 16); else if (nc == 32) SGX_MFCC_ACC(float, 32); else SGX_MFCC_ACC(float, 64);
+        }
+        return hipGetLastError();
+    }
+#undef SGX_MFCC_ACC
     if (dtype == SGX_F64)
         hipLaunchKernelGGL(k_mfcc<double>, dim3((unsigned)blocks), dim3(256), 0, s, (const double *)mel, (double *)out,
                            (const double *)basis, (const double *)lifter, batch, n_mels, n_frames, n_mfcc, skip, has_lifter);
