@@ -190,6 +190,74 @@ __global__ __launch_bounds__(256) void k_direct_dft(StftArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_two_factor: composite n_fft that is not a power of two (400 = 20 x 20, the classic 25 ms speech frame; 480, 1000, ...).
+// n = A * B, A the largest divisor <= sqrt(n).  With input index i = B n1 + n2 and output index k = k1 + A k2:
+//   pass 1  Y[n2][k1] = W_n^(n2 k1) * sum_{n1 < A} x[B n1 + n2] W_A^(n1 k1)          (n outputs of A real x complex MACs)
+//   pass 2  X[k1 + A k2] = sum_{n2 < B} Y[n2][k1] W_B^(n2 k2), only for k <= n/2      (n/2+1 outputs of B complex MACs)
+// i.e. n (A + B/2)-ish MACs per frame instead of the direct sum's n^2/2 (400: 12 k vs 80 k), every twiddle taken from the
+// same n-entry table W_n^m with the exponent reduced mod n incrementally.  Sums are shorter than the direct kernel's, so the
+// result is at least as accurate; DC / Nyquist bins are forced real like realfft does.
+template <typename T>
+__global__ __launch_bounds__(256) void k_two_factor(StftArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned n = a.n_fft, A = a.fac_a, B = a.fac_b;
+    T *fr = (T *)smem;                                   // [ft][n] windowed frames
+    Cx<T> *Y = (Cx<T> *)(fr + (size_t)a.ft * n);         // [ft][n]  (n2 * A + k1)
+    T *pw = (T *)(Y + (size_t)a.ft * n);                 // [ft][nb_fft] (Mel only)
+    const unsigned tile = blockIdx.x % a.tiles, b = blockIdx.x / a.tiles;
+    const unsigned f0 = tile * a.ft;
+    const unsigned nf = min(a.ft, a.n_frames - f0);
+    const T *xb = (const T *)a.x + (size_t)b * a.sample_stride;
+    const T *w = (const T *)a.window;
+    const Cx<T> *tw = (const Cx<T> *)a.tw;
+    const T eps = (T)a.eps;
+    for (unsigned idx = threadIdx.x; idx < nf * n; idx += 256) {
+        const unsigned f = idx / n, i = idx % n;
+        const long long s = (long long)(f0 + f) * a.hop + (long long)i - (long long)a.pad;
+        fr[(size_t)f * n + i] = load_sample(xb, s, a.n_samples) * w[i];
+    }
+    __syncthreads();
+    for (unsigned idx = threadIdx.x; idx < nf * n; idx += 256) {
+        const unsigned f = idx / n, r = idx % n, n2 = r / A, k1 = r % A;
+        const T *x = fr + (size_t)f * n + n2;
+        const unsigned step = (unsigned)(((unsigned long long)B * k1) % n);
+        T sr = T(0), si = T(0);
+        unsigned t = 0;
+        for (unsigned n1 = 0; n1 < A; ++n1) {
+            const Cx<T> c = tw[t];
+            const T v = x[(size_t)B * n1];
+            sr += v * c.re;
+            si += v * c.im;
+            t += step;
+            if (t >= n) t -= n;
+        }
+        const Cx<T> g = tw[(unsigned)(((unsigned long long)n2 * k1) % n)];
+        Y[(size_t)f * n + r] = Cx<T>{sr * g.re - si * g.im, sr * g.im + si * g.re};
+    }
+    __syncthreads();
+    for (unsigned idx = threadIdx.x; idx < nf * a.nb_fft; idx += 256) {
+        const unsigned f = idx % nf, k = idx / nf, k1 = k % A, k2 = k / A;
+        const Cx<T> *y = Y + (size_t)f * n + k1;
+        const unsigned step = (unsigned)(((unsigned long long)A * k2) % n);
+        T sr = T(0), si = T(0);
+        unsigned t = 0;
+        for (unsigned n2 = 0; n2 < B; ++n2) {
+            const Cx<T> c = tw[t], v = y[(size_t)A * n2];
+            sr += v.re * c.re - v.im * c.im;
+            si += v.re * c.im + v.im * c.re;
+            t += step;
+            if (t >= n) t -= n;
+        }
+        if (k == 0 || (!(n & 1u) && k == a.nb_fft - 1)) si = T(0);  // realfft: DC / Nyquist bins are exactly real
+        emit_bin<T>(a, b, f0 + f, f, k, sr, si, pw, eps);
+    }
+    if (a.out_mode == OUT_MEL) {
+        __syncthreads();
+        mel_stage<T>(a, b, f0, nf, pw, eps);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // MFCC epilogue (src/mfcc.rs:224-316): one thread per (signal, frame); lanes walk frames so every read of the Mel-dB
 // tensor and every write is frame-contiguous.  DCT-II as a sequential FMA chain in T over ascending mel index, exactly
 // `val.mul_add(basis, acc)` (:286-290); the basis is cos(pi k (i+0.5)/n) evaluated in f64 on the host and cast to T.
@@ -309,6 +377,26 @@ bool plan_geometry_direct_dft(StftArgs &a, int dtype) {
     return false;
 }
 
+static size_t two_factor_bytes(const StftArgs &a, unsigned ft, size_t es) {
+    return (size_t)ft * a.n_fft * 3 * es + (a.out_mode == OUT_MEL ? (size_t)ft * a.nb_fft * es : 0);
+}
+
+bool plan_geometry_two_factor(StftArgs &a, int dtype) {
+    unsigned best = 1;
+    for (unsigned d = 2; (unsigned long long)d * d <= a.n_fft; ++d)
+        if (a.n_fft % d == 0) best = d;
+    if (best < 2) return false;  // prime (or tiny) length: the direct sum is all there is
+    a.fac_a = best;
+    a.fac_b = a.n_fft / best;
+    const size_t es = elem_size(dtype);
+    for (unsigned ft = 16; ft >= 1; ft >>= 1)
+        if (two_factor_bytes(a, ft, es) <= kLdsBudget) {
+            a.ft = ft;
+            return true;
+        }
+    return false;
+}
+
 static bool grid_ok(const StftArgs &a, unsigned long long *blocks) {
     unsigned long long g = (unsigned long long)a.tiles * a.batch;
     *blocks = g;
@@ -336,6 +424,17 @@ hipError_t launch_direct_dft(const StftArgs &a, int dtype, hipStream_t s) {
         hipLaunchKernelGGL(k_direct_dft<double>, dim3((unsigned)g), dim3(256), lds, s, a);
     else
         hipLaunchKernelGGL(k_direct_dft<float>, dim3((unsigned)g), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_two_factor(const StftArgs &a, int dtype, hipStream_t s) {
+    unsigned long long g;
+    if (!grid_ok(a, &g) || a.fac_a < 2 || a.fac_a * a.fac_b != a.n_fft) return hipErrorInvalidConfiguration;
+    const size_t lds = two_factor_bytes(a, a.ft, elem_size(dtype));
+    if (dtype == SGX_F64)
+        hipLaunchKernelGGL(k_two_factor<double>, dim3((unsigned)g), dim3(256), lds, s, a);
+    else
+        hipLaunchKernelGGL(k_two_factor<float>, dim3((unsigned)g), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 

@@ -539,6 +539,7 @@ bool set_geometry(const sgx_plan *pl, StftArgs &a, KernelKind kind) {
     case K_R32X16_F32: ok = plan_geometry_r32x16_f32(a); break;
     case K_LDS_RADIX2: ok = plan_geometry_lds_radix2(a, pl->dtype); break;
     case K_DIRECT_DFT: ok = plan_geometry_direct_dft(a, pl->dtype); break;
+    case K_TWO_FACTOR: ok = plan_geometry_two_factor(a, pl->dtype); break;
     }
     if (ok) a.tiles = (a.n_frames + a.ft - 1) / a.ft;
     return ok;
@@ -548,6 +549,7 @@ hipError_t launch(const sgx_plan *pl, const StftArgs &a, KernelKind kind, hipStr
     switch (kind) {
     case K_R32X16_F32: return launch_r32x16_f32(a, s);
     case K_LDS_RADIX2: return launch_lds_radix2(a, pl->dtype, s);
+    case K_TWO_FACTOR: return launch_two_factor(a, pl->dtype, s);
     default: return launch_direct_dft(a, pl->dtype, s);
     }
 }
@@ -597,7 +599,7 @@ sgx_status run_device(sgx_plan *pl, const void *x, size_t batch, size_t n_sample
     fill_args(pl, a, x, stage_out, batch, n_samples, stride, n_frames);
     KernelKind kind = pick_kernel(pl, x, stride);
     if (!set_geometry(pl, a, kind)) {
-        kind = (kind == K_R32X16_F32) ? K_LDS_RADIX2 : K_DIRECT_DFT;
+        kind = (kind == K_R32X16_F32) ? K_LDS_RADIX2 : K_DIRECT_DFT;  // (a two-factor plan that no longer fits falls to the direct sum)
         if (!set_geometry(pl, a, kind))
             return set_err(pl, SGX_BACKEND, "hip -- FFT backend error: n_fft too large for the on-chip frame tile");
     }
@@ -760,6 +762,7 @@ const char *sgx_kernel_name(const sgx_plan *plan) {
     switch (plan->kind) {
     case K_R32X16_F32: return "r32x16_f32";
     case K_LDS_RADIX2: return "lds_radix2";
+    case K_TWO_FACTOR: return "two_factor_dft";
     default: return "direct_dft";
     }
 }
@@ -799,7 +802,7 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
     if (params->freq_scale == SGX_FREQ_ERB) build_erb_dense(pl->p, pl->mel_ptr, pl->mel_col, pl->mel_val, pl->loghz_freqs);
 
     const bool pow2 = params->n_fft >= 4 && (params->n_fft & (params->n_fft - 1)) == 0;
-    pl->kind = pow2 ? K_LDS_RADIX2 : K_DIRECT_DFT;
+    pl->kind = pow2 ? K_LDS_RADIX2 : K_TWO_FACTOR;  // composite lengths: two-factor DFT; primes fall through to the direct sum
     if (params->dtype == SGX_F32 && params->n_fft == 1024 && params->hop_size % 2 == 0) pl->kind = K_R32X16_F32;
     {
         StftArgs probe;

@@ -19,7 +19,7 @@ namespace sgx {
 enum OutMode : int { OUT_LINEAR = 0, OUT_MEL = 1, OUT_COMPLEX = 2 };
 // AMP_MAG_IN: the mapping consumes sqrt(power) and its output is final (chromagram: bank applied to magnitudes)
 enum AmpMode : int { AMP_POWER = 0, AMP_MAGNITUDE = 1, AMP_DB = 2, AMP_MAG_IN = 3 };
-enum KernelKind : int { K_DIRECT_DFT = 0, K_LDS_RADIX2 = 1, K_R32X16_F32 = 2 };
+enum KernelKind : int { K_DIRECT_DFT = 0, K_LDS_RADIX2 = 1, K_R32X16_F32 = 2, K_TWO_FACTOR = 3 };
 
 // Kernel arguments (POD, passed by value).  Layouts in HBM:
 //   x      : [batch][sample_stride] T, row b valid for n_samples elements
@@ -35,6 +35,7 @@ struct StftArgs {
     unsigned n_fft, m, log2m, hop, pad;
     unsigned n_frames, nb_fft, n_out;
     unsigned ft, tiles;  // frames per workgroup tile, tiles per signal
+    unsigned fac_a, fac_b;  // K_TWO_FACTOR: n_fft = fac_a * fac_b, fac_a = largest divisor <= sqrt(n_fft)
     const void *window;
     const void *tw;
     const unsigned *mel_ptr;
@@ -73,6 +74,8 @@ hipError_t launch_mfcc(const void *mel, void *out, const void *basis, const void
                        unsigned n_frames, unsigned n_mfcc, unsigned skip, int has_lifter, int dtype, hipStream_t s);
 // tile geometry chosen per kernel (fills a.ft / a.tiles); returns false if the kernel cannot run the shape
 bool plan_geometry_direct_dft(StftArgs &a, int dtype);
+bool plan_geometry_two_factor(StftArgs &a, int dtype);
+hipError_t launch_two_factor(const StftArgs &a, int dtype, hipStream_t s);
 bool plan_geometry_lds_radix2(StftArgs &a, int dtype);
 bool plan_geometry_r32x16_f32(StftArgs &a);
 

@@ -134,7 +134,7 @@ def test_pow2_sizes(n_fft, hop, amp, dtype):
 
 # ------------------------------------------------------------------ arbitrary sizes (reference accepts any n_fft)
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
-@pytest.mark.parametrize("n_fft,hop", [(1, 1), (2, 1), (3, 2), (7, 3), (10, 10), (100, 33), (400, 160), (1000, 250)])
+@pytest.mark.parametrize("n_fft,hop", [(1, 1), (2, 1), (3, 2), (7, 3), (10, 10), (100, 33), (400, 160), (1000, 250), (251, 100), (480, 160), (15, 4), (2 * 3 * 5 * 7 * 11, 500)])
 def test_non_pow2_sizes(n_fft, hop, dtype):
     window = "rectangular" if n_fft == 1 else "hanning"  # symmetric Hann of length 1 is 0/0 = NaN in the reference too
     run_case(n=3000, n_fft=n_fft, hop=hop, amp="complex", dtype=dtype, window=window)
