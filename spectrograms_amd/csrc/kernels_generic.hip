@@ -104,20 +104,46 @@ __global__ __launch_bounds__(256) void k_lds_radix2(StftArgs a) {
     }
     __syncthreads();
 
-    // 2. radix-2 DIT stages; W_{2h}^j = tw[j * n_fft / (2h)]
-    const unsigned halfm = m >> 1, lhm = a.log2m - 1;
-    for (unsigned h = 1, lh = 0; h < m; h <<= 1, lh++) {
-        const unsigned twstep = a.n_fft >> (lh + 1);
+    // 2. DIT stages on the bit-reversed data, W_{2h}^j = tw[j * n_fft / (2h)].  Two consecutive radix-2 stages are fused
+    //    into one pass (radix-2^2: identical arithmetic and ordering, half the LDS round trips and barriers); an odd
+    //    stage count starts with one plain radix-2 stage.
+    unsigned h = 1, lh = 0;
+    if (a.log2m & 1u) {
+        const unsigned halfm = m >> 1, lhm = a.log2m - 1;
         for (unsigned idx = tid; idx < nf * halfm; idx += 256) {
-            unsigned f = idx >> lhm, q = idx & (halfm - 1);
-            unsigned j = q & (h - 1), blk = q >> lh;
-            unsigned p0 = f * fs + (blk << (lh + 1)) + j, p1 = p0 + h;
-            Cx<T> wv = tw[j * twstep];
-            Cx<T> u = buf[p0], v = buf[p1];
-            T tr = v.re * wv.re - v.im * wv.im;
-            T ti = v.re * wv.im + v.im * wv.re;
-            buf[p0] = Cx<T>{u.re + tr, u.im + ti};
-            buf[p1] = Cx<T>{u.re - tr, u.im - ti};
+            const unsigned f = idx >> lhm, q = idx & (halfm - 1);
+            const unsigned p0 = f * fs + (q << 1), p1 = p0 + 1;  // h = 1: twiddle W_2^0 = 1
+            const Cx<T> u = buf[p0], v = buf[p1];
+            buf[p0] = Cx<T>{u.re + v.re, u.im + v.im};
+            buf[p1] = Cx<T>{u.re - v.re, u.im - v.im};
+        }
+        __syncthreads();
+        h = 2;
+        lh = 1;
+    }
+    const unsigned quarter = m >> 2, lq = a.log2m - 2;
+    for (; h < m; h <<= 2, lh += 2) {
+        const unsigned st2 = a.n_fft >> (lh + 2);  // exponent step of W_{4h}
+        for (unsigned idx = tid; idx < nf * quarter; idx += 256) {
+            const unsigned f = idx >> lq, q = idx & (quarter - 1);
+            const unsigned j = q & (h - 1), blk = q >> lh;
+            const unsigned p = f * fs + (blk << (lh + 2)) + j;
+            const Cx<T> t0 = tw[j * st2];            // W_{4h}^j
+            const Cx<T> w = tw[2 * j * st2];         // W_{2h}^j = W_{4h}^{2j}
+            const Cx<T> e0 = buf[p], e1 = buf[p + h], e2 = buf[p + 2 * h], e3 = buf[p + 3 * h];
+            // stage h: pairs (e0, e1) and (e2, e3), twiddle w
+            const T v1r = e1.re * w.re - e1.im * w.im, v1i = e1.re * w.im + e1.im * w.re;
+            const T v3r = e3.re * w.re - e3.im * w.im, v3i = e3.re * w.im + e3.im * w.re;
+            const Cx<T> a0{e0.re + v1r, e0.im + v1i}, a1{e0.re - v1r, e0.im - v1i};
+            const Cx<T> a2{e2.re + v3r, e2.im + v3i}, a3{e2.re - v3r, e2.im - v3i};
+            // stage 2h: pairs (a0, a2) with W_{4h}^j and (a1, a3) with W_{4h}^{j+h} = tw[(j + h) * st2]
+            const Cx<T> t1 = tw[(j + h) * st2];
+            const T c2r = a2.re * t0.re - a2.im * t0.im, c2i = a2.re * t0.im + a2.im * t0.re;
+            const T c3r = a3.re * t1.re - a3.im * t1.im, c3i = a3.re * t1.im + a3.im * t1.re;
+            buf[p] = Cx<T>{a0.re + c2r, a0.im + c2i};
+            buf[p + 2 * h] = Cx<T>{a0.re - c2r, a0.im - c2i};
+            buf[p + h] = Cx<T>{a1.re + c3r, a1.im + c3i};
+            buf[p + 3 * h] = Cx<T>{a1.re - c3r, a1.im - c3i};
         }
         __syncthreads();
     }
