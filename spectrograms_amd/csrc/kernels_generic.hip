@@ -14,6 +14,8 @@
 // accumulation in T in ascending-bin order (:102-117) -> Power / sqrt / 10*log10(max(p, eps))
 // (:1986-2036, :2068-2080) -> out[b][bin][frame] with the frame axis contiguous (S9).  Threads are
 // mapped (bin, frame) with frame fastest so global stores are contiguous along frames.
+#include <cstdlib>
+
 #include "sgx_internal.h"
 
 namespace sgx {
@@ -63,16 +65,30 @@ __device__ inline void emit_bin(const StftArgs &a, unsigned b, unsigned frame, u
     }
 }
 
-// Mel stage: pw[f][k] holds the power spectrum of the tile's frames.
+// Mel stage: pw[f][k] holds the power spectrum of the tile's frames.  `scratch` is LDS the transform no longer needs
+// (scratch_bytes of it): when the bank's CSR arrays fit they are staged there once per tile — otherwise every (band, frame)
+// thread streams its band's values and columns from global memory, ft times redundantly.
 template <typename T>
-__device__ inline void mel_stage(const StftArgs &a, unsigned b, unsigned f0, unsigned nf, const T *pw, T eps) {
+__device__ inline void mel_stage(const StftArgs &a, unsigned b, unsigned f0, unsigned nf, const T *pw, T eps,
+                                 unsigned char *scratch, size_t scratch_bytes) {
     const T *val = (const T *)a.mel_val;
+    const unsigned *col = a.mel_col;
+    const unsigned *ptr = a.mel_ptr;
+    const size_t need = (size_t)a.mel_nnz * (sizeof(T) + 4) + (size_t)(a.n_mels + 1) * 4;
+    if (need <= scratch_bytes) {  // uniform
+        T *sval = (T *)scratch;
+        unsigned *scol = (unsigned *)(sval + a.mel_nnz), *sptr = scol + a.mel_nnz;
+        for (unsigned i = threadIdx.x; i < a.mel_nnz; i += blockDim.x) { sval[i] = val[i]; scol[i] = col[i]; }
+        for (unsigned i = threadIdx.x; i <= a.n_mels; i += blockDim.x) sptr[i] = ptr[i];
+        __syncthreads();
+        val = sval; col = scol; ptr = sptr;
+    }
     T *o = (T *)a.out;
     for (unsigned idx = threadIdx.x; idx < nf * a.n_mels; idx += blockDim.x) {
         unsigned f = idx % nf, mm = idx / nf;
         T acc = T(0);
-        unsigned i0 = a.mel_ptr[mm], i1 = a.mel_ptr[mm + 1];
-        for (unsigned i = i0; i < i1; i++) acc = t_mul_add_unfused(val[i], pw[(size_t)f * a.nb_fft + a.mel_col[i]], acc);
+        unsigned i0 = ptr[mm], i1 = ptr[mm + 1];
+        for (unsigned i = i0; i < i1; i++) acc = t_mul_add_unfused(val[i], pw[(size_t)f * a.nb_fft + col[i]], acc);
         o[((size_t)b * a.n_out + mm) * a.n_frames + f0 + f] = amp_apply(acc, a.amp, eps);
     }
 }
@@ -169,7 +185,7 @@ __global__ __launch_bounds__(256) void k_lds_radix2(StftArgs a) {
     }
     if (a.out_mode == OUT_MEL) {
         __syncthreads();
-        mel_stage<T>(a, b, f0, nf, pw, eps);
+        mel_stage<T>(a, b, f0, nf, pw, eps, smem, (size_t)a.ft * fs * sizeof(Cx<T>));
     }
 }
 
@@ -211,7 +227,7 @@ __global__ __launch_bounds__(256) void k_direct_dft(StftArgs a) {
     }
     if (a.out_mode == OUT_MEL) {
         __syncthreads();
-        mel_stage<T>(a, b, f0, nf, pw, eps);
+        mel_stage<T>(a, b, f0, nf, pw, eps, smem, (size_t)a.ft * n * sizeof(T));
     }
 }
 
@@ -279,7 +295,7 @@ __global__ __launch_bounds__(256) void k_two_factor(StftArgs a) {
     }
     if (a.out_mode == OUT_MEL) {
         __syncthreads();
-        mel_stage<T>(a, b, f0, nf, pw, eps);
+        mel_stage<T>(a, b, f0, nf, pw, eps, smem, (size_t)a.ft * n * 3 * sizeof(T));
     }
 }
 
@@ -374,7 +390,13 @@ hipError_t launch_chroma_norm(void *data, unsigned batch, unsigned n_frames, int
     return hipGetLastError();
 }
 
-static const size_t kLdsBudget = 64 * 1024;
+static const size_t kLdsBudget = [] {
+    // frames per tile are chosen to fill this much LDS.  32 KB (4-5 workgroups per CU) measured 5-20 % faster than 64 KB for
+    // the sizes in tools/time_generic.py: shorter store segments, but more waves to hide the LDS / barrier latency
+    const char *v = getenv("SGX_GENERIC_LDS_KB");
+    const long kb = v ? atol(v) : 32;
+    return (size_t)(kb >= 4 && kb <= 64 ? kb : 32) * 1024;
+}();
 
 static size_t elem_size(int dtype) { return dtype == SGX_F64 ? 8 : 4; }
 
