@@ -398,31 +398,38 @@ static const size_t kLdsBudget = [] {
     return (size_t)(kb >= 4 && kb <= 64 ? kb : 32) * 1024;
 }();
 
+static const size_t kLdsHardLimit = 64 * 1024;  // static + dynamic LDS a kernel gets without the large-LDS opt-in
+
 static size_t elem_size(int dtype) { return dtype == SGX_F64 ? 8 : 4; }
 
-bool plan_geometry_lds_radix2(StftArgs &a, int dtype) {
-    if (a.n_fft < 4 || (a.n_fft & (a.n_fft - 1))) return false;
-    size_t es = elem_size(dtype);
-    for (unsigned ft = 16; ft >= 1; ft >>= 1) {
-        size_t bytes = (size_t)ft * (a.m + 1) * 2 * es + (a.out_mode == OUT_MEL ? (size_t)ft * a.nb_fft * es : 0);
-        if (bytes <= kLdsBudget) {
+// frames per tile: the largest power of two <= 16 whose tile fits the preferred budget; a single frame may use the hard limit
+template <typename F>
+static bool pick_frames_per_tile(StftArgs &a, F bytes_for) {
+    for (unsigned ft = 16; ft >= 1; ft >>= 1)
+        if (bytes_for(ft) <= kLdsBudget) {
             a.ft = ft;
             return true;
         }
+    if (bytes_for(1) <= kLdsHardLimit) {
+        a.ft = 1;
+        return true;
     }
     return false;
 }
 
+bool plan_geometry_lds_radix2(StftArgs &a, int dtype) {
+    if (a.n_fft < 4 || (a.n_fft & (a.n_fft - 1))) return false;
+    const size_t es = elem_size(dtype);
+    return pick_frames_per_tile(a, [&](unsigned ft) {
+        return (size_t)ft * (a.m + 1) * 2 * es + (a.out_mode == OUT_MEL ? (size_t)ft * a.nb_fft * es : 0);
+    });
+}
+
 bool plan_geometry_direct_dft(StftArgs &a, int dtype) {
-    size_t es = elem_size(dtype);
-    for (unsigned ft = 16; ft >= 1; ft >>= 1) {
-        size_t bytes = (size_t)ft * a.n_fft * es + (a.out_mode == OUT_MEL ? (size_t)ft * a.nb_fft * es : 0);
-        if (bytes <= kLdsBudget) {
-            a.ft = ft;
-            return true;
-        }
-    }
-    return false;
+    const size_t es = elem_size(dtype);
+    return pick_frames_per_tile(a, [&](unsigned ft) {
+        return (size_t)ft * a.n_fft * es + (a.out_mode == OUT_MEL ? (size_t)ft * a.nb_fft * es : 0);
+    });
 }
 
 static size_t two_factor_bytes(const StftArgs &a, unsigned ft, size_t es) {
@@ -437,12 +444,7 @@ bool plan_geometry_two_factor(StftArgs &a, int dtype) {
     a.fac_a = best;
     a.fac_b = a.n_fft / best;
     const size_t es = elem_size(dtype);
-    for (unsigned ft = 16; ft >= 1; ft >>= 1)
-        if (two_factor_bytes(a, ft, es) <= kLdsBudget) {
-            a.ft = ft;
-            return true;
-        }
-    return false;
+    return pick_frames_per_tile(a, [&](unsigned ft) { return two_factor_bytes(a, ft, es); });
 }
 
 static bool grid_ok(const StftArgs &a, unsigned long long *blocks) {
