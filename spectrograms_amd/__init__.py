@@ -8,7 +8,8 @@ compute calls raise FFTBackendError.
 from ._ffi import (DimensionMismatchError, FFTBackendError, InternalError, InvalidInputError, SpectrogramError)
 from .functions import (compute_linear_db_spectrogram, compute_linear_magnitude_spectrogram,
                         compute_linear_power_spectrogram, compute_mel_db_spectrogram,
-                        compute_chromagram, compute_erb_db_spectrogram, compute_irfft, compute_istft, compute_erb_magnitude_spectrogram, compute_erb_power_spectrogram,
+                        compute_chromagram, compute_erb_db_spectrogram, compute_fft, compute_rfft, compute_power_spectrum,
+                        compute_magnitude_spectrum, compute_irfft, compute_istft, compute_erb_magnitude_spectrogram, compute_erb_power_spectrogram,
                         compute_loghz_db_spectrogram, compute_loghz_magnitude_spectrogram,
                         compute_loghz_power_spectrogram, compute_mel_magnitude_spectrogram, compute_mel_power_spectrogram,
                         compute_mfcc, compute_stft)
@@ -25,7 +26,7 @@ __all__ = [
     "compute_linear_power_spectrogram", "compute_linear_magnitude_spectrogram", "compute_linear_db_spectrogram",
     "compute_mel_power_spectrogram", "compute_mel_magnitude_spectrogram", "compute_mel_db_spectrogram",
     "compute_stft", "compute_mfcc", "MfccParams", "Mfcc",
-    "compute_chromagram", "ChromaParams", "ChromaNorm", "Chromagram", "SpectrogramBatch", "compute_irfft", "compute_istft", "ErbParams", "GammatoneParams", "compute_erb_power_spectrogram", "compute_erb_magnitude_spectrogram", "compute_erb_db_spectrogram",
+    "compute_fft", "compute_rfft", "compute_power_spectrum", "compute_magnitude_spectrum", "compute_chromagram", "ChromaParams", "ChromaNorm", "Chromagram", "SpectrogramBatch", "compute_irfft", "compute_istft", "ErbParams", "GammatoneParams", "compute_erb_power_spectrogram", "compute_erb_magnitude_spectrogram", "compute_erb_db_spectrogram",
     "LogHzParams", "compute_loghz_power_spectrogram", "compute_loghz_magnitude_spectrogram", "compute_loghz_db_spectrogram",
     "fft2d", "ifft2d", "Fft2dPlan", "Fft2dPlanner", "convolve_fft", "gaussian_kernel_2d", "lowpass_filter", "highpass_filter",
     "bandpass_filter", "detect_edges_fft", "sharpen_fft", "power_spectrum_2d", "magnitude_spectrum_2d", "fftshift",

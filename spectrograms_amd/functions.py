@@ -91,3 +91,43 @@ def compute_istft(stft_matrix, n_fft, hop_size, window, center=True, dtype=None)
 def compute_chromagram(samples, stft_params, sample_rate, chroma_params, dtype=None):
     """chromagram() (src/chroma.rs:470-505; Python src/python/functions.rs:551-567): 12 pitch classes x n_frames."""
     return Plan(SpectrogramParams(stft_params, sample_rate), _ffi.AMP_MAGNITUDE, chroma_params, None, dtype).compute(samples)
+
+
+# ---- single-frame transforms sharing the backend (SURVEY.md §8 a14; src/spectrogram.rs:4490-4693) -----------------------
+def _one_frame(samples, n_fft, window, amp, dtype):
+    """Zero-pad `samples` to n_fft (`fft` :4479-4503 / `power_spectrum` :4611-4633), optional window, one R2C on the GPU."""
+    from .params import StftParams, WindowType
+    n_fft = int(n_fft)
+    if n_fft <= 0:
+        raise ValueError("n_fft must be non-zero positive integer")
+    x = np.ascontiguousarray(samples).reshape(-1)
+    if x.size == 0:
+        raise ValueError("samples must be non-empty")
+    if x.size > n_fft:
+        raise _ffi.InvalidInputError(f"Invalid input: Input length ({x.size}) exceeds FFT size ({n_fft})")
+    params = SpectrogramParams(StftParams(n_fft, n_fft, window if window is not None else WindowType.rectangular, False), 1.0)
+    plan = Plan(params, amp, None, None, dtype)
+    padded = np.zeros(n_fft, plan._np)
+    padded[:x.size] = x
+    return plan.compute_batch(padded[None, :])[0][:, 0]
+
+
+def compute_fft(samples, n_fft=None, dtype=None):
+    """fft (src/spectrogram.rs:4475-4506; Python src/python/functions.rs:787-805): n_fft/2+1 complex bins of the zero-padded input."""
+    n = np.size(samples) if n_fft is None else n_fft
+    return _one_frame(samples, n, None, _ffi.AMP_COMPLEX, dtype)
+
+
+def compute_rfft(samples, n_fft, dtype=None):
+    """rfft (:4535-4541): |fft|."""
+    return np.abs(_one_frame(samples, n_fft, None, _ffi.AMP_COMPLEX, dtype))
+
+
+def compute_power_spectrum(samples, n_fft, window=None, dtype=None):
+    """power_spectrum (:4611-4643): |X|^2 of the zero-padded, optionally windowed frame."""
+    return _one_frame(samples, n_fft, window, _ffi.AMP_POWER, dtype)
+
+
+def compute_magnitude_spectrum(samples, n_fft, window=None, dtype=None):
+    """magnitude_spectrum (:4684-4693): sqrt of the power spectrum."""
+    return _one_frame(samples, n_fft, window, _ffi.AMP_MAGNITUDE, dtype)

@@ -162,3 +162,29 @@ def test_gpu_irfft_and_dc_check():
         bad = np.zeros((257, 4), np.complex128)
         bad[256, 2] = 1j
         sg.compute_istft(bad, 512, 128, sg.WindowType.hanning, True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [("float32", 2e-5), ("float64", 1e-10)])
+def test_gpu_single_frame_helpers(dtype, tol):
+    """fft / rfft / power_spectrum / magnitude_spectrum (src/spectrogram.rs:4475-4693): zero padding to n_fft, optional window;
+    known answers from tests/fft_padding_tests.rs."""
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal(300)
+    for n_fft in (512, 400, 300):
+        ref = np.fft.rfft(np.concatenate([x, np.zeros(n_fft - 300)]))
+        got = sg.compute_fft(x, n_fft, dtype=dtype)
+        assert got.shape == (n_fft // 2 + 1,) and got.dtype == (np.complex64 if dtype == "float32" else np.complex128)
+        assert np.max(np.abs(got - ref)) < tol * np.max(np.abs(ref))
+        assert np.max(np.abs(sg.compute_rfft(x, n_fft, dtype=dtype) - np.abs(ref))) < tol * np.max(np.abs(ref))
+        w = orc.make_window("hanning", n_fft)
+        refw = np.abs(np.fft.rfft(np.concatenate([x, np.zeros(n_fft - 300)]) * w)) ** 2
+        p = sg.compute_power_spectrum(x, n_fft, sg.WindowType.hanning, dtype=dtype)
+        assert np.max(np.abs(p - refw)) < 2 * tol * np.max(refw)
+        m = sg.compute_magnitude_spectrum(x, n_fft, sg.WindowType.hanning, dtype=dtype)
+        assert np.max(np.abs(m - np.sqrt(refw))) < 2 * tol * np.max(np.sqrt(refw))
+    assert np.size(sg.compute_fft(x, dtype=dtype)) == 151  # n_fft defaults to len(samples)
+    dc = sg.compute_fft(np.array([1.0, 1.0, 1.0]), 8, dtype=dtype)  # tests/fft_padding_tests.rs:149-158: DC of zero-padded ones = 3
+    assert abs(dc[0] - 3.0) < 1e-6 and sg.compute_magnitude_spectrum(np.array([1.0, 2.0, 3.0]), 8, sg.WindowType.hanning).shape == (5,)
+    with pytest.raises(sg.InvalidInputError, match="exceeds FFT size"):
+        sg.compute_fft(np.zeros(10), 8)
