@@ -209,6 +209,21 @@ def ifftshift(arr, dtype=None):
     return np.fft.ifftshift(np.asarray(arr, dtype=np.float32 if parse_dtype(dtype) == _ffi.F32 else np.float64))
 
 
+def fftshift_1d(arr, dtype=None):
+    """1-D fftshift (src/fft2d.rs fftshift_1d): DC to the centre."""
+    a = np.asarray(arr, dtype=np.float32 if parse_dtype(dtype) == _ffi.F32 else np.float64)
+    if a.ndim != 1:
+        raise ValueError("fftshift_1d expects a 1-D array")
+    return np.fft.fftshift(a)
+
+
+def ifftshift_1d(arr, dtype=None):
+    a = np.asarray(arr, dtype=np.float32 if parse_dtype(dtype) == _ffi.F32 else np.float64)
+    if a.ndim != 1:
+        raise ValueError("ifftshift_1d expects a 1-D array")
+    return np.fft.ifftshift(a)
+
+
 def fftfreq(n: int, d: float = 1.0, dtype=None):
     return np.fft.fftfreq(n, d).astype(np.float32 if parse_dtype(dtype) == _ffi.F32 else np.float64)
 

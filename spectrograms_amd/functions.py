@@ -5,7 +5,52 @@ import numpy as np
 
 from . import _ffi
 from .params import LogParams, MelParams, SpectrogramParams
-from .planner import Plan
+from .planner import Plan as _Plan
+
+# ---- plan cache for the one-shot functions ------------------------------------------------------------------------------
+# The reference caches FFT plans process-wide (src/fft_backend.rs:946-1076; clear_fft_plan_cache / fft_plan_cache_info in the
+# Python module).  Here a "plan" also owns its device tables (window, twiddles, filterbank), so a one-shot compute_* call that
+# repeats earlier parameters reuses the whole plan instead of rebuilding and re-uploading them.  Least-recently-used, bounded.
+_PLAN_CACHE = {}
+_PLAN_CACHE_MAX = 32
+
+
+def _key(obj):
+    if obj is None or isinstance(obj, (int, float, str, bool)):
+        return obj
+    if isinstance(obj, np.ndarray):
+        return (obj.dtype.str, obj.shape, obj.tobytes())
+    if isinstance(obj, (list, tuple)):
+        return tuple(_key(v) for v in obj)
+    if hasattr(obj, "__dict__"):
+        return (type(obj).__name__,) + tuple((k, _key(v)) for k, v in sorted(vars(obj).items()))
+    return repr(obj)
+
+
+def Plan(params, amp, mapping, db, dtype, mfcc=None, inverse=False):
+    """Cached constructor used by every one-shot function below (same arguments as planner.Plan)."""
+    from .params import parse_dtype
+    import torch
+    dev = torch.cuda.current_device() if torch.cuda.is_available() else -1
+    key = (_key(params), amp, _key(mapping), _key(db), parse_dtype(dtype), _key(mfcc), bool(inverse), dev)
+    plan = _PLAN_CACHE.pop(key, None)
+    if plan is None:
+        plan = _Plan(params, amp, mapping, db, dtype, mfcc=mfcc)
+        while len(_PLAN_CACHE) >= _PLAN_CACHE_MAX:
+            _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
+    _PLAN_CACHE[key] = plan  # most recently used last
+    return plan
+
+
+def clear_fft_plan_cache() -> None:
+    """Drop every cached plan (and its device tables)."""
+    _PLAN_CACHE.clear()
+
+
+def fft_plan_cache_info():
+    """(n_forward_plans, n_inverse_plans) currently cached."""
+    inv = sum(1 for k in _PLAN_CACHE if k[6])
+    return len(_PLAN_CACHE) - inv, inv
 
 
 def compute_linear_power_spectrogram(samples, params, db=None, dtype=None):
@@ -73,7 +118,7 @@ def compute_irfft(spectrum, n_fft, dtype=None):
     if int(n_fft) <= 0:
         raise ValueError("n_fft must be > 0")
     params = SpectrogramParams(StftParams(int(n_fft), int(n_fft), WindowType.rectangular, False), 1.0)
-    return Plan(params, _ffi.AMP_COMPLEX, None, None, dtype).c2r(spectrum)
+    return Plan(params, _ffi.AMP_COMPLEX, None, None, dtype, inverse=True).c2r(spectrum)
 
 
 def compute_istft(stft_matrix, n_fft, hop_size, window, center=True, dtype=None):
@@ -85,7 +130,7 @@ def compute_istft(stft_matrix, n_fft, hop_size, window, center=True, dtype=None)
     if m.ndim == 2 and m.shape[0] != int(n_fft) // 2 + 1:  # checked before hop_size (:4876-4882)
         raise _ffi.DimensionMismatchError(f"Dimension mismatch: expected {int(n_fft) // 2 + 1}, got {m.shape[0]}")
     params = SpectrogramParams(StftParams(int(n_fft), int(hop_size), window, bool(center)), 1.0)
-    return Plan(params, _ffi.AMP_COMPLEX, None, None, dtype).istft(m)
+    return Plan(params, _ffi.AMP_COMPLEX, None, None, dtype, inverse=True).istft(m)
 
 
 def compute_chromagram(samples, stft_params, sample_rate, chroma_params, dtype=None):

@@ -58,3 +58,30 @@ def test_resident_batch_is_zero_copy_and_matches_oracle():
     assert one.shape == (80, 626) and len(one.times) == 626 and one.db_range() is not None
     host, meta = sgt.batch_with_metadata(sb)
     assert not host.is_cuda and len(meta) == 4
+
+
+def test_shift_helpers_and_plan_aliases():
+    a = np.arange(7.0)
+    assert np.array_equal(sg.fftshift_1d(a), np.fft.fftshift(a)) and np.array_equal(sg.ifftshift_1d(sg.fftshift_1d(a)), a)
+    assert sg.fftshift_1d(a, dtype="float32").dtype == np.float32
+    with pytest.raises(ValueError):
+        sg.fftshift_1d(np.zeros((2, 2)))
+    assert sg.MelDbPlan is sg.Plan and sg.LogHzPowerPlan is sg.Plan
+
+
+@pytest.mark.gpu
+def test_one_shot_functions_reuse_cached_plans():
+    sg.clear_fft_plan_cache()
+    assert sg.fft_plan_cache_info() == (0, 0)
+    x = np.random.default_rng(0).standard_normal(4000)
+    params = sg.SpectrogramParams(sg.StftParams(512, 128, sg.WindowType.hanning, True), 16000.0)
+    a = sg.compute_mel_power_spectrogram(x, params, sg.MelParams(40, 0.0, 8000.0))
+    b = sg.compute_mel_power_spectrogram(2 * x, sg.SpectrogramParams(sg.StftParams(512, 128, sg.WindowType.hanning, True), 16000.0),
+                                         sg.MelParams(40, 0.0, 8000.0))
+    assert sg.fft_plan_cache_info() == (1, 0) and np.allclose(b.data, 4 * a.data, rtol=1e-12)
+    sg.compute_mel_power_spectrogram(x, params, sg.MelParams(40, 0.0, 8000.0), dtype="float32")  # another dtype: another plan
+    S = sg.compute_stft(x, params)
+    y = sg.compute_istft(S.data, 512, 128, sg.WindowType.hanning, True)
+    assert sg.fft_plan_cache_info() == (3, 1) and np.max(np.abs(y[256:3500] - x[256:3500])) < 1e-10
+    sg.clear_fft_plan_cache()
+    assert sg.fft_plan_cache_info() == (0, 0)
