@@ -22,13 +22,15 @@
 // (tools/ubench/valu_rate.hip), and the 64 KiB exchange buffer caps occupancy at 2 waves per SIMD.
 //
 // Two kernels:
-//   k_ws      (default, hop <= 272, 16-byte aligned rows) wave-specialised, 512 threads = 4 producer + 4 consumer
-//             waves, one persistent workgroup per CU, ex double-buffered.  Producers run pass 1 of tile t while
-//             consumers run pass 2 + stores of tile t-1, so the store stream (HBM-bound: 2 KiB per frame) and the
-//             loads overlap the FFT arithmetic instead of serialising with it inside one wave.  Producers also fetch
-//             the samples two tiles ahead with coalesced 16-byte loads and stage them in LDS (xs); they issue no
-//             stores, so those loads never queue behind the HBM-bound store stream of the consumers.
-//   k_r32x16  (any even hop / 8-byte alignment) persistent 256-thread workgroups, two per CU, both passes in each wave.
+//   k_r32x16  (default) persistent workgroups, both passes in every wave.  HALVES = 2: one 512-thread workgroup per CU whose
+//             two 256-thread halves each own a tile and an exchange buffer and move through the phases in lockstep (measured
+//             6-30 % faster than two independent workgroups).  Linear / complex outputs load samples directly (per-lane
+//             float2, one tile ahead) and store unconditionally so the compiler can wait with vmcnt(32) instead of draining
+//             every store each tile; Mel-type outputs stage the tile's samples through LDS with coalesced 16-byte loads
+//             (ROUNDS = 5) and reduce |X|^2 on the LDS band table or, for dense banks, on the matrix cores.
+//   k_ws      (experimental, SGX_KERNEL=ws) wave-specialised pipeline: 4 producer waves (pass 1) + 4 consumer waves (pass 2,
+//             stores, global->LDS staging two tiles ahead), ex double-buffered.  Measured slower (204-235 us vs 164 us): the
+//             CU's vector-memory queue is in order, so the producers' loads still queue behind the consumers' stores.
 //
 // Reference semantics implemented: spectrogram.rs:1301-1334 (framing, window, R2C, |.|^2), :1845-1865,
 // :2068-2080; replaces the per-frame `R2cPlan::process` call at :1323 (fft_backend.rs:423-431).
