@@ -108,6 +108,11 @@ __global__ __launch_bounds__(256) void k_lds_radix2(StftArgs a) {
     const Cx<T> *tw = (const Cx<T> *)a.tw;
     const T eps = (T)a.eps;
     const unsigned tid = threadIdx.x;
+    if (a.tw_lds) {  // every stage and the real split index tw[0 .. n_fft/2): serve them from LDS instead of L1 gathers
+        Cx<T> *ltw = (Cx<T> *)(smem + a.tw_lds);
+        for (unsigned i = tid; i < m; i += 256) ltw[i] = tw[i];
+        tw = ltw;  // visible after the barrier that follows the frame load
+    }
 
     // 1. framing + window (S1, S4), bit-reversed placement of z[i] = x[2i] + i x[2i+1]
     for (unsigned idx = tid; idx < nf * m; idx += 256) {
@@ -420,9 +425,17 @@ static bool pick_frames_per_tile(StftArgs &a, F bytes_for) {
 bool plan_geometry_lds_radix2(StftArgs &a, int dtype) {
     if (a.n_fft < 4 || (a.n_fft & (a.n_fft - 1))) return false;
     const size_t es = elem_size(dtype);
-    return pick_frames_per_tile(a, [&](unsigned ft) {
+    auto tile_bytes = [&](unsigned ft) {
         return (size_t)ft * (a.m + 1) * 2 * es + (a.out_mode == OUT_MEL ? (size_t)ft * a.nb_fft * es : 0);
-    });
+    };
+    const size_t tw_bytes = (size_t)a.m * 2 * es;
+    a.tw_lds = 0;
+    if (!pick_frames_per_tile(a, tile_bytes)) return false;
+    // LDS twiddle copy only where it costs no frames per tile (measured: +15 % for f32 n_fft 512, but slower wherever it
+    // shrinks the tile: f32 2048, f64 1024)
+    const size_t off = (tile_bytes(a.ft) + 15) & ~size_t(15);
+    if (a.ft >= 8 && off + tw_bytes <= kLdsBudget) a.tw_lds = (unsigned)off;  // the per-tile copy needs >= 8 frames to pay off
+    return true;
 }
 
 bool plan_geometry_direct_dft(StftArgs &a, int dtype) {
@@ -458,6 +471,7 @@ hipError_t launch_lds_radix2(const StftArgs &a, int dtype, hipStream_t s) {
     if (!grid_ok(a, &g)) return hipErrorInvalidConfiguration;
     size_t es = elem_size(dtype);
     size_t lds = (size_t)a.ft * (a.m + 1) * 2 * es + (a.out_mode == OUT_MEL ? (size_t)a.ft * a.nb_fft * es : 0);
+    if (a.tw_lds) lds = (size_t)a.tw_lds + (size_t)a.m * 2 * es;
     if (dtype == SGX_F64)
         hipLaunchKernelGGL(k_lds_radix2<double>, dim3((unsigned)g), dim3(256), lds, s, a);
     else
