@@ -736,15 +736,16 @@ hipError_t launch_variant(const StftArgs &a, hipStream_t s) {
         }();
         // Sample loads: "direct" = per-lane float2 loads (4 x 128-byte segments per wave-instruction, every line requested ~4
         // times because frames overlap by 75 %); "staged" = the tile's samples fetched once with coalesced 16-byte loads,
-        // staged in LDS and re-read per frame from there.  Measured on MI355X (256 x 10 s): Mel-dB 162 us staged vs 186 us
-        // direct; linear power 189 us staged vs 171 us direct (there the coalesced loads queue right behind the tile's
-        // 33 KB store burst in the CU's in-order vector-memory pipe).  So Mel-type outputs stage, the others load directly;
-        // SGX_LOADS=staged|direct overrides.
+        // staged in LDS and re-read per frame from there (5 load instructions per thread instead of 32 through the CU's
+        // in-order vector-memory pipe).  Measured on MI355X (256 x 10 s): Mel-dB 162 us staged vs 186 us direct; linear power
+        // 147 us staged vs 171 us direct — once the loop no longer drained its stores every tile (vmcnt(32), see the kernel);
+        // before that fix staged was the slower one (189 us).  Complex output: 277 us staged vs 258 us direct, so the complex
+        // STFT keeps direct loads.  SGX_LOADS=staged|direct overrides.
         static const int loads_mode = [] {
             const char *v = getenv("SGX_LOADS");
             return !v ? 0 : v[0] == 's' ? 1 : v[0] == 'd' ? 2 : 0;
         }();
-        const bool want_staged = loads_mode == 1 || (loads_mode == 0 && MODE == OUT_MEL);
+        const bool want_staged = loads_mode == 1 || (loads_mode == 0 && MODE != OUT_COMPLEX);
         const bool stage5 = want_staged && aligned16 && chunks <= 5u * 256u;
         if (want_single) {
             static bool done = false;
