@@ -174,10 +174,11 @@ __device__ __forceinline__ void pass2_compute(const StftArgs &a, v2f (&A)[16], v
     };
     // pair (P, Q) = (Z[k], Z[512-k]), W = W_1024^k given as (wr, wi, wi, -wr):
     //   E = (P.x+Q.x, P.y-Q.y), D = (P.x-Q.x, P.y+Q.y) = (-O.y, O.x), T = W O, X[k] = E + T, X[512-k] = conj(E - T)
-    auto split = [&](unsigned offa, unsigned offb, unsigned k, v2f P, v2f Q, v4f w4) {
+    auto split = [&](unsigned offa, unsigned offb, unsigned k, v2f P, v2f Q, v2f w) {
         const v2f E = pfma(Q, (v2f){1.f, -1.f}, P);
         const v2f D = pfma(Q, (v2f){-1.f, 1.f}, P);
-        const v2f T = pfma(lo2(D), (v2f){w4.z, w4.w}, hi2(D) * (v2f){w4.x, w4.y});
+        // T = W O with O = (D.y, -D.x): (wr D.y + wi D.x, wi D.y - wr D.x) — two packed ops from the (wr, wi) pair alone
+        const v2f T = pfma(D, hi2(w), (v2f){D.y, -D.x} * lo2(w));
         emit(offa, k, E + T, false);
         emit(offb, 512u - k, E - T, true);
     };
@@ -341,7 +342,10 @@ __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned
     unsigned char *smem = smem_all + half * kExBytes;           // this half's ex / pw buffer
     unsigned char *tabs = smem_all + (HALVES - 1) * kExBytes;   // tables sit behind the last ex buffer (kWinOff etc. are relative to ex0 of a 1-half layout)
     if (threadIdx.x < 256u) ((v4f *)(tabs + kWinOff))[threadIdx.x] = ((const v4f *)a.window)[threadIdx.x];
-    for (unsigned i = threadIdx.x; i < kTw2Bytes / 16; i += 256 * HALVES) ((v4f *)(tabs + kTw2Off))[i] = ((const v4f *)a.tw2)[i];
+    for (unsigned i = threadIdx.x; i < 17u * 17u; i += 256 * HALVES) {  // LDS copy keeps (wr, wi) only: 8-byte reads in pass 2
+        const v4f q = ((const v4f *)a.tw2)[i];
+        ((v2f *)(tabs + kTw2Off))[i] = (v2f){q.x, q.y};
+    }
     v4f *lw4 = (v4f *)(tabs + kMelOff);
     unsigned *lptr = (unsigned *)(lw4 + a.mel_pchunks);
     unsigned *lcol = lptr + a.n_mels + 1;
@@ -507,10 +511,10 @@ __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned
             if (tid < 48u) ((float *)smem)[(tid / 3u) * kPS + 513u + tid % 3u] = 0.0f;
         }
         if (ALLSTORE || (active && p2f < nf)) {
-            const v4f *t2 = (const v4f *)(tabs + kTw2Off);
+            const v2f *t2 = (const v2f *)(tabs + kTw2Off);
             auto tw = [&](int i) {  // read from LDS where consumed (this kernel has no registers to keep them)
 #ifdef SGX_ABL_NOTW2
-                return (v4f){1.f, 0.5f, 0.5f, -1.f};
+                return (v2f){1.f, 0.5f};
 #endif
                 return i < 8 ? t2[(j == 0 ? 16u : j) * kTw2Stride + i] : t2[j == 0 ? (unsigned)(i - 8) : j * kTw2Stride + i];
             };
@@ -683,7 +687,7 @@ __global__ __launch_bounds__(512, 2) void k_ws(StftArgs a, unsigned per_xcd, uns
                 cf0 = (w - cb * a.tiles) * 16u;
                 cnf = min(16u, a.n_frames - cf0);
                 if (p2f < cnf)
-                    pass2_compute<MODE, AMP>(a, A, B, cb, cf0, p2f, j, eps, [&](int i) { return tw[i]; }, jo,
+                    pass2_compute<MODE, AMP>(a, A, B, cb, cf0, p2f, j, eps, [&](int i) { return (v2f){tw[i].x, tw[i].y}; }, jo,
                                              (float *)ex_r + p2f * kPS);
             }
             if constexpr (MODE == OUT_MEL) {
