@@ -56,6 +56,30 @@ def cpu_baseline(workload: str, budget_s: float = 12.0):
         op = orc.Params(n_fft=N_FFT, hop=HOP, n_mels=80, amp="db", floor_db=-80.0)
     out = orc.spectrogram_batch(op, x, nthreads=cores)  # warm-up, allocates the output once
     frames_per_pass = out.shape[0] * out.shape[2]
+    # the box may expose more hardware threads than this process can really use (cgroup quota, SMT): keep the thread count
+    # that is fastest on one pass, so the baseline is the best this host does, not an oversubscribed one
+    cands = set()
+    nt = cores
+    while nt >= 4:
+        cands.add(nt)
+        nt //= 2
+    try:  # cgroup v2 CPU quota: "max" or "<quota> <period>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cands.add(max(1, min(cores, -(-int(q) // int(per)))))
+    except Exception:
+        pass
+    best = (0.0, cores)
+    for nt in sorted(cands, reverse=True):
+        t0 = time.perf_counter()
+        n_pass = 0
+        while time.perf_counter() - t0 < 0.6:  # several scheduler periods: a CFS quota throttles in 100 ms slices
+            orc.spectrogram_batch(op, x, nthreads=nt, out=out)
+            n_pass += 1
+        rate = n_pass * frames_per_pass / (time.perf_counter() - t0)
+        if rate > best[0]:
+            best = (rate, nt)
+    cores = best[1]
     frames, reps = 0, 0
     t0 = time.perf_counter()
     while True:
@@ -73,7 +97,7 @@ def cpu_baseline(workload: str, budget_s: float = 12.0):
     single = 8 * out.shape[2] / dt1
     return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{reps} passes over the full {nsig}-utterance batch ({frames} frames, {dt:.1f} s wall, one plan per "
-                      f"thread, {cores} threads); one thread alone: {single:.0f} frames/s",
+                      f"thread, {cores} threads = the fastest of the thread counts tried); one thread alone: {single:.0f} frames/s",
             "single_thread_value": single}
 
 
