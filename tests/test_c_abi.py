@@ -26,3 +26,20 @@ def test_header_is_plain_c_and_host_entry_points_work(tmp_path):
     r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=120)
     assert r.returncode == 0, r.stdout
     assert "passed" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
+def test_device_smoke(tmp_path):
+    """No Python in the data path: a C program drives the library with hipMalloc'ed buffers through the C ABI."""
+    lib = sgbuild.build()
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "device_smoke")
+    src = os.path.join(ROOT, "tests", "c_abi", "device_smoke.c")
+    libdir = os.path.dirname(lib)
+    r = subprocess.run([hipcc, "-x", "c", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"),
+                        "-I/opt/rocm/include", src, "-o", exe, "-L" + libdir, "-lspectro_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lm",
+                        "-Wl,-rpath," + libdir + ":/opt/rocm/lib"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and "device smoke passed" in r.stdout, r.stdout
