@@ -26,6 +26,8 @@ def main():
         plan = pl.mel_power_plan(params, sg.MelParams(80, 0.0, 8000.0), dtype="float32")
     elif workload == "stft":
         plan = pl.stft_plan(params, dtype="float32")
+    elif workload == "erb_power":
+        plan = pl.erb_power_plan(params, sg.ErbParams(64, 0.0, 8000.0), dtype="float32")
     else:
         plan = pl.mel_db_plan(params, sg.MelParams(80, 0.0, 8000.0), sg.LogParams(-80.0), dtype="float32")
     host = np.stack([bench.cfg_signal(b) for b in range(batch)])
