@@ -107,7 +107,9 @@ def main() -> int:
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="linear_power", choices=["linear_power", "mel_db", "mel_power", "stft"])
-    ap.add_argument("--gather", action="store_true", help="RCCL all-gather of the output shards inside the timed region")
+    ap.add_argument("--gather", nargs="?", const="sync", default=None, choices=["sync", "overlap"],
+                    help="RCCL all-gather of the output shards inside the timed region: 'sync' (default when given) gathers "
+                         "after every launch on the launch stream; 'overlap' gathers step i asynchronously while step i+1 computes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -151,16 +153,27 @@ def main() -> int:
     oshape = (BATCH, n_bins, n_frames, 2) if args.workload == "stft" else (BATCH, n_bins, n_frames)
     outs = [torch.empty(oshape, dtype=torch.float32, device=dev) for _ in range(nsets)]
     gathered = None
+    overlap = None
     if args.gather and world > 1:
-        gathered = torch.empty((world,) + oshape, dtype=torch.float32, device=dev)
+        if args.gather == "overlap":
+            from spectrograms_amd.distributed import OverlappedGather
+            overlap = OverlappedGather(oshape, torch.float32, dev, depth=nsets)
+        else:
+            gathered = torch.empty((world * oshape[0],) + tuple(oshape[1:]), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev)
 
     def step(i: int) -> None:
+        if overlap is not None:
+            overlap.wait_slot(i)  # the gather that last read outs[i % nsets] is done before the kernel overwrites it
         plan.compute_batch(xs[i % nsets], out=outs[i % nsets])
-        if gathered is not None:
+        if overlap is not None:
+            overlap.submit(i, outs[i % nsets])  # travels while step i + 1 computes
+        elif gathered is not None:
             dist.all_gather_into_tensor(gathered, outs[i % nsets])
 
     def fence() -> None:
+        if overlap is not None:
+            overlap.finish()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -205,7 +218,7 @@ def main() -> int:
             "config": {"workload": f"configs[{ {'linear_power': 1, 'mel_db': 2, 'mel_power': 3}.get(args.workload, 1) }]: {BATCH} x 10 s "
                                    f"16 kHz f32 per GPU, {args.workload} n_fft=1024 hop=256 Hanning centre", "batch_per_gpu": BATCH,
                        "n_samples": N_SAMPLES, "frames_per_step": frames_per_step, "kernel": plan.kernel_name,
-                       "gather": bool(gathered is not None), "parallelism": f"utterance-shard x{world}"},
+                       "gather": (args.gather if (gathered is not None or overlap is not None) else False), "parallelism": f"utterance-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": dev_ms,
                          "algorithmic_bytes_per_frame": bpf, "frames_per_launch": BATCH * n_frames},

@@ -47,6 +47,51 @@ def gather_outputs(local, batch_total: int, group=None):
     return torch.cat(parts, dim=0)
 
 
+class OverlappedGather:
+    """All-gather of equal-sized output shards that overlaps the next launch.
+
+    `depth` result buffers rotate: `submit(i, shard)` starts an asynchronous `all_gather_into_tensor` of step i's shard (on
+    RCCL's own stream — it waits for the work already queued on the caller's stream, i.e. for the kernel that produced the
+    shard) and returns at once, so step i + 1's kernel runs while step i's shards travel over xGMI.  Before a shard buffer
+    or a gathered buffer is reused, `submit` waits for the collective that last used that slot.  `finish()` waits for all."""
+
+    def __init__(self, shard_shape, dtype, device, depth: int = 2, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.depth = depth
+        shard_shape = tuple(shard_shape)
+        # concatenated along dim 0 ([world * n0, ...]): the form both RCCL and gloo accept; `gathered[i].view(world, n0, ...)`
+        self._flat = [torch.empty((self.world * shard_shape[0],) + shard_shape[1:], dtype=dtype, device=device) for _ in range(depth)]
+        self.gathered = [t.view((self.world,) + shard_shape) for t in self._flat]
+        self._work = [None] * depth
+
+    def wait_slot(self, i: int) -> None:
+        w = self._work[i % self.depth]
+        if w is not None:
+            w.wait()  # makes the caller's stream (CPU thread for gloo) wait for that collective
+            self._work[i % self.depth] = None
+
+    def submit(self, i: int, shard):
+        """Start gathering step i's shard; returns the [world, ...] tensor that will hold it once `wait_slot(i)` returns."""
+        import torch.distributed as dist
+
+        self.wait_slot(i)
+        dst = self.gathered[i % self.depth]
+        if self.world == 1:
+            dst[0].copy_(shard)
+        else:
+            self._work[i % self.depth] = dist.all_gather_into_tensor(self._flat[i % self.depth], shard.contiguous(), group=self.group,
+                                                                     async_op=True)
+        return dst
+
+    def finish(self) -> None:
+        for i in range(self.depth):
+            self.wait_slot(i)
+
+
 class ShardedPlan:
     """Wraps a single-GPU `Plan`: `compute(x_full_or_local)` on this rank's utterances (+ optional gather)."""
 

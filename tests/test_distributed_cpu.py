@@ -57,6 +57,41 @@ def test_shard_and_gather_gloo(tmp_path, world, batch):
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
 
 
+def _overlap_worker(rank: int, world: int, port: int, tmp: str):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from spectrograms_amd.distributed import OverlappedGather
+
+        og = OverlappedGather((4, 3), torch.float32, torch.device("cpu"), depth=2)
+        shards = [torch.empty(4, 3) for _ in range(2)]  # the producer's rotating output buffers, as in bench.py
+        seen = {}
+        for i in range(7):
+            og.wait_slot(i)                     # the collective that last read shards[i % 2] has finished
+            shards[i % 2].fill_(100.0 * i + rank)   # "launch" step i
+            dst = og.submit(i, shards[i % 2])
+            seen[i] = dst
+            if i >= 1:                          # step i - 1 may be consumed once its slot is waited for
+                og.wait_slot(i - 1)
+                for r in range(world):
+                    assert torch.all(og.gathered[(i - 1) % 2][r] == 100.0 * (i - 1) + r)
+        og.finish()
+        for r in range(world):
+            assert torch.all(seen[6][r] == 600.0 + r)
+        open(os.path.join(tmp, f"ov{rank}"), "w").write("ok")
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_overlapped_gather_gloo(tmp_path, world):
+    port = _free_port()
+    mp.spawn(_overlap_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ov{r}").exists() for r in range(world))
+
+
 def test_shard_range_matches_reference_partition():
     from spectrograms_amd.distributed import shard_range
 
