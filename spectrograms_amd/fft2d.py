@@ -105,10 +105,16 @@ class Fft2dPlan:
 class Fft2dPlanner:
     """Plan cache keyed by shape (src/fft2d.rs:491-657)."""
 
-    def __init__(self):
+    def __init__(self, dtype=None):
         self._plans = {}
+        self._dtype = "float32" if parse_dtype(dtype) == _ffi.F32 else "float64"  # fixed for the planner's lifetime
+
+    @property
+    def dtype(self) -> str:
+        return self._dtype
 
     def _plan(self, shape, dtype) -> Fft2dPlan:
+        dtype = self._dtype if dtype is None else dtype
         key = (int(shape[0]), int(shape[1]), parse_dtype(dtype))
         if key not in self._plans:
             self._plans[key] = Fft2dPlan(key[0], key[1], dtype)
@@ -121,6 +127,13 @@ class Fft2dPlanner:
     def ifft2d(self, spectrum, output_ncols: int, dtype=None):
         s = np.asarray(spectrum)
         return self._plan((s.shape[0], output_ncols), dtype).inverse(s)[0]
+
+    def power_spectrum_2d(self, data):
+        s = self.fft2d(data)
+        return (s.real * s.real + s.imag * s.imag).astype(s.real.dtype)
+
+    def magnitude_spectrum_2d(self, data):
+        return np.abs(self.fft2d(data))
 
 
 def _as2d(a) -> np.ndarray:

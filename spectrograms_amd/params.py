@@ -23,6 +23,37 @@ class WindowType:
     def kaiser(cls, beta: float) -> "WindowType":
         return cls(_ffi.WIN_KAISER, beta)
 
+    # window generators of the Python class (src/python/params.rs:100-174 -> make_window, src/spectrogram.rs:2159-2235);
+    # the coefficients come from the engine's own table builder (host-only plan: no GPU needed)
+    @staticmethod
+    def _make(window: "WindowType", n: int, dtype) -> np.ndarray:
+        from .planner import Plan
+        if int(n) <= 0:
+            raise ValueError("n must be > 0")
+        params = SpectrogramParams(StftParams(int(n), int(n), window, False), 1.0)
+        w = Plan(params, _ffi.AMP_POWER, None, None, dtype, device=_ffi.DEVICE_HOST_ONLY).window()
+        return w.astype(np.float32 if parse_dtype(dtype) == _ffi.F32 else np.float64)
+
+    @classmethod
+    def make_hanning(cls, n: int, dtype=None) -> np.ndarray:
+        return cls._make(cls.hanning, n, dtype)
+
+    @classmethod
+    def make_hamming(cls, n: int, dtype=None) -> np.ndarray:
+        return cls._make(cls.hamming, n, dtype)
+
+    @classmethod
+    def make_blackman(cls, n: int, dtype=None) -> np.ndarray:
+        return cls._make(cls.blackman, n, dtype)
+
+    @classmethod
+    def make_kaiser(cls, n: int, beta: float, dtype=None) -> np.ndarray:
+        return cls._make(cls.kaiser(beta), n, dtype)
+
+    @classmethod
+    def make_gaussian(cls, n: int, std: float, dtype=None) -> np.ndarray:
+        return cls._make(cls.gaussian(std), n, dtype)
+
     @classmethod
     def gaussian(cls, std: float) -> "WindowType":
         return cls(_ffi.WIN_GAUSSIAN, std)

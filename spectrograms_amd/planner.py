@@ -105,11 +105,25 @@ class StftResult:
     n_frames = property(lambda s: s._data.shape[1])
     shape = property(lambda s: s._data.shape)
 
+    @property
+    def frequency_resolution(self) -> float:
+        return self.sample_rate / self.params.n_fft
+
+    @property
+    def time_resolution(self) -> float:
+        return self.params.hop_size / self.sample_rate
+
     def norm(self) -> np.ndarray:
         return np.abs(self._data)
 
     def __array__(self, dtype=None, copy=None):
         return self._data if dtype is None else self._data.astype(dtype)
+
+    def __dlpack__(self, **kwargs):
+        return self._data.__dlpack__(**kwargs)
+
+    def __dlpack_device__(self):
+        return self._data.__dlpack_device__()
 
 
 class Chromagram:
@@ -154,6 +168,12 @@ class Mfcc:
 
     def __array__(self, dtype=None, copy=None):
         return self._data if dtype is None else self._data.astype(dtype)
+
+    def __dlpack__(self, **kwargs):
+        return self._data.__dlpack__(**kwargs)
+
+    def __dlpack_device__(self):
+        return self._data.__dlpack_device__()
 
 
 class Plan:

@@ -180,3 +180,12 @@ def test_gpu_fused_column_stage_1024_rows(shape):
         for i in range(3):
             ref = orc.filter2d(x[i].astype(np.float64), kind, *args)
             assert np.max(np.abs(got[i] - ref)) <= 2e-5 * max(1.0, np.max(np.abs(ref)))
+
+
+@pytest.mark.gpu
+def test_gpu_planner_spectrum_helpers():
+    pl = sg.Fft2dPlanner(dtype="float32")
+    x = img((64, 48), 3, np.float32)
+    S = pl.fft2d(x)
+    assert S.dtype == np.complex64
+    assert np.allclose(pl.power_spectrum_2d(x), np.abs(S) ** 2, rtol=1e-6) and np.allclose(pl.magnitude_spectrum_2d(x), np.abs(S), rtol=1e-6)

@@ -85,3 +85,22 @@ def test_one_shot_functions_reuse_cached_plans():
     assert sg.fft_plan_cache_info() == (3, 1) and np.max(np.abs(y[256:3500] - x[256:3500])) < 1e-10
     sg.clear_fft_plan_cache()
     assert sg.fft_plan_cache_info() == (0, 0)
+
+
+def test_window_generators_and_result_members():
+    """WindowType.make_* (python/spectrograms/__init__.pyi:141-190) and the resolution / DLPack members of the result classes."""
+    from oracle import oracle as orc
+    from spectrograms_amd.planner import Mfcc, StftResult
+    for name, fn, args in (("hanning", sg.WindowType.make_hanning, ()), ("hamming", sg.WindowType.make_hamming, ()),
+                           ("blackman", sg.WindowType.make_blackman, ()), ("kaiser", sg.WindowType.make_kaiser, (8.6,)),
+                           ("gaussian", sg.WindowType.make_gaussian, (20.0,))):
+        w = fn(64, *args)
+        assert w.dtype == np.float64 and np.array_equal(w, orc.make_window(name, 64, *(args or (0.0,))))
+        assert fn(64, *args, dtype="float32").dtype == np.float32
+    st = sg.StftParams(512, 128, sg.WindowType.hanning, True)
+    r = StftResult(np.zeros((257, 4), np.complex64), np.arange(257.0), 16000.0, st)
+    assert r.frequency_resolution == 16000.0 / 512 and r.time_resolution == 128 / 16000.0
+    assert torch.from_dlpack(r).shape == (257, 4)
+    m = Mfcc(np.zeros((13, 4), np.float32), sg.MfccParams(13))
+    assert torch.from_dlpack(m).dtype == torch.float32
+    assert sg.Fft2dPlanner(dtype="float32").dtype == "float32" and sg.Fft2dPlanner().dtype == "float64"
