@@ -13,65 +13,74 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr double kCos64[64] = {1.0, 0.9951847266721969, 0.9807852804032304, 0.9569403357322088, 0.9238795325112867, 0.881921264348355, 0.8314696123025452, 0.773010453362737, 0.7071067811865476, 0.6343932841636455, 0.5555702330196023, 0.4713967368259978, 0.38268343236508984, 0.29028467725446233, 0.19509032201612833, 0.09801714032956077, 6.123233995736766e-17, -0.09801714032956065, -0.1950903220161282, -0.29028467725446216, -0.3826834323650897, -0.4713967368259977, -0.555570233019602, -0.6343932841636454, -0.7071067811865475, -0.773010453362737, -0.8314696123025453, -0.8819212643483549, -0.9238795325112867, -0.9569403357322088, -0.9807852804032304, -0.9951847266721968, -1.0, -0.9951847266721969, -0.9807852804032304, -0.9569403357322089, -0.9238795325112868, -0.881921264348355, -0.8314696123025455, -0.7730104533627371, -0.7071067811865477, -0.6343932841636459, -0.5555702330196022, -0.47139673682599786, -0.38268343236509034, -0.29028467725446244, -0.19509032201612866, -0.09801714032956045, -1.8369701987210297e-16, 0.09801714032956009, 0.1950903220161283, 0.29028467725446205, 0.38268343236509, 0.4713967368259976, 0.5555702330196018, 0.6343932841636456, 0.7071067811865474, 0.7730104533627367, 0.8314696123025452, 0.8819212643483548, 0.9238795325112865, 0.9569403357322088, 0.9807852804032303, 0.9951847266721969};
 constexpr double kSin64[64] = {0.0, 0.0980171403295606, 0.19509032201612825, 0.29028467725446233, 0.3826834323650898, 0.47139673682599764, 0.5555702330196022, 0.6343932841636455, 0.7071067811865475, 0.773010453362737, 0.8314696123025452, 0.8819212643483549, 0.9238795325112867, 0.9569403357322089, 0.9807852804032304, 0.9951847266721968, 1.0, 0.9951847266721969, 0.9807852804032304, 0.9569403357322089, 0.9238795325112867, 0.881921264348355, 0.8314696123025455, 0.7730104533627371, 0.7071067811865476, 0.6343932841636455, 0.5555702330196022, 0.47139673682599786, 0.3826834323650899, 0.2902846772544624, 0.1950903220161286, 0.09801714032956083, 1.2246467991473532e-16, -0.09801714032956059, -0.19509032201612836, -0.2902846772544621, -0.38268343236508967, -0.47139673682599764, -0.555570233019602, -0.6343932841636453, -0.7071067811865475, -0.7730104533627367, -0.8314696123025452, -0.8819212643483549, -0.9238795325112865, -0.9569403357322088, -0.9807852804032303, -0.9951847266721969, -1.0, -0.9951847266721969, -0.9807852804032304, -0.9569403357322089, -0.9238795325112866, -0.881921264348355, -0.8314696123025455, -0.7730104533627369, -0.7071067811865477, -0.6343932841636459, -0.5555702330196022, -0.4713967368259979, -0.3826834323650904, -0.2902846772544625, -0.19509032201612872, -0.0980171403295605};
 
-__device__ __forceinline__ v2f swp(v2f a) { return __builtin_shufflevector(a, a, 1, 0); }
-__device__ __forceinline__ v2f lo2(v2f a) { return __builtin_shufflevector(a, a, 0, 0); }
-__device__ __forceinline__ v2f hi2(v2f a) { return __builtin_shufflevector(a, a, 1, 1); }
-__device__ __forceinline__ v2f pfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ v2f cmulv(v2f x, v2f t) { return pfma(swp(x), (v2f){-t.y, t.y}, x * lo2(t)); }
+// The helpers below are generic in the 2-element vector type V (v2f: packed-f32 instructions; v2d: pairs of f64 ops).
+typedef double v2d __attribute__((ext_vector_type(2)));
+template <typename V> struct ElemOf;
+template <> struct ElemOf<v2f> { typedef float type; };
+template <> struct ElemOf<v2d> { typedef double type; };
+
+template <typename V> __device__ __forceinline__ V swp(V a) { return __builtin_shufflevector(a, a, 1, 0); }
+template <typename V> __device__ __forceinline__ V lo2(V a) { return __builtin_shufflevector(a, a, 0, 0); }
+template <typename V> __device__ __forceinline__ V hi2(V a) { return __builtin_shufflevector(a, a, 1, 1); }
+template <typename V> __device__ __forceinline__ V pfma(V a, V b, V c) { return __builtin_elementwise_fma(a, b, c); }
+template <typename V> __device__ __forceinline__ V cmulv(V x, V t) { return pfma(swp(x), (V){-t.y, t.y}, x * lo2(t)); }
 
 // x0 = e + W o, x1 = e - W o, W = W_N^K a compile-time constant; every case is 2-4 packed instructions
-template <int N, int K>
-__device__ __forceinline__ void bfly(v2f e, v2f o, v2f &x0, v2f &x1) {
+template <int N, int K, typename V>
+__device__ __forceinline__ void bfly(V e, V o, V &x0, V &x1) {
+    typedef typename ElemOf<V>::type E;
     constexpr int idx = K * (64 / N);
     if constexpr (idx == 0) {
         x0 = e + o;
         x1 = e - o;
     } else if constexpr (idx == 16) {  // W = -i : W o = (o.y, -o.x)
-        const v2f so = swp(o);
-        x0 = pfma(so, (v2f){1.f, -1.f}, e);
-        x1 = pfma(so, (v2f){-1.f, 1.f}, e);
+        const V so = swp(o);
+        x0 = pfma(so, (V){E(1), E(-1)}, e);
+        x1 = pfma(so, (V){E(-1), E(1)}, e);
     } else if constexpr (idx == 8) {  // W = c(1 - i): W o = c (o.x + o.y, o.y - o.x)
-        constexpr float c = 0.70710678118654752440f;
-        const v2f s = pfma(swp(o), (v2f){1.f, -1.f}, o);
-        x0 = pfma(s, (v2f){c, c}, e);
-        x1 = pfma(s, (v2f){-c, -c}, e);
+        constexpr E c = E(0.70710678118654752440);
+        const V s = pfma(swp(o), (V){E(1), E(-1)}, o);
+        x0 = pfma(s, (V){c, c}, e);
+        x1 = pfma(s, (V){-c, -c}, e);
     } else if constexpr (idx == 24) {  // W = c(-1 - i): W o = c (o.y - o.x, -o.x - o.y)
-        constexpr float c = 0.70710678118654752440f;
-        const v2f s = pfma(swp(o), (v2f){1.f, -1.f}, -o);
-        x0 = pfma(s, (v2f){c, c}, e);
-        x1 = pfma(s, (v2f){-c, -c}, e);
+        constexpr E c = E(0.70710678118654752440);
+        const V s = pfma(swp(o), (V){E(1), E(-1)}, -o);
+        x0 = pfma(s, (V){c, c}, e);
+        x1 = pfma(s, (V){-c, -c}, e);
     } else {
-        constexpr float wr = (float)kCos64[idx], wi = (float)(-kSin64[idx]);
-        const v2f so = swp(o);
-        x0 = pfma(so, (v2f){-wi, wi}, pfma(o, (v2f){wr, wr}, e));
-        x1 = pfma(so, (v2f){wi, -wi}, pfma(o, (v2f){-wr, -wr}, e));
+        constexpr E wr = (E)kCos64[idx], wi = (E)(-kSin64[idx]);
+        const V so = swp(o);
+        x0 = pfma(so, (V){-wi, wi}, pfma(o, (V){wr, wr}, e));
+        x1 = pfma(so, (V){wi, -wi}, pfma(o, (V){-wr, -wr}, e));
     }
 }
-template <int N, int K>
+template <int N, int K, typename V>
 struct Comb {
-    static __device__ __forceinline__ void run(v2f (&x)[N], const v2f (&e)[N / 2], const v2f (&o)[N / 2]) {
-        bfly<N, K>(e[K], o[K], x[K], x[K + N / 2]);
-        if constexpr (K + 1 < N / 2) Comb<N, K + 1>::run(x, e, o);
+    static __device__ __forceinline__ void run(V (&x)[N], const V (&e)[N / 2], const V (&o)[N / 2]) {
+        bfly<N, K, V>(e[K], o[K], x[K], x[K + N / 2]);
+        if constexpr (K + 1 < N / 2) Comb<N, K + 1, V>::run(x, e, o);
     }
 };
 // in-register radix-2 DIT, natural order in and out; all indices and twiddles are compile-time.
 // WIN: x holds raw samples and w the window; the multiply is fused into the first butterfly.
-template <int N, bool WIN>
+template <int N, bool WIN, typename V = v2f>
 struct Fft {
-    static __device__ __forceinline__ void run(v2f (&x)[N], const v2f (&w)[N]) {
-        if constexpr (N == 2) {
+    static __device__ __forceinline__ void run(V (&x)[N], const V (&w)[N]) {
+        if constexpr (N == 1) {
+            if constexpr (WIN) x[0] = x[0] * w[0];
+        } else if constexpr (N == 2) {
             if constexpr (WIN) {
-                const v2f t = x[0] * w[0];
-                const v2f u = x[1];
+                const V t = x[0] * w[0];
+                const V u = x[1];
                 x[0] = pfma(u, w[1], t);
                 x[1] = pfma(-u, w[1], t);
             } else {
-                const v2f a = x[0], b = x[1];
+                const V a = x[0], b = x[1];
                 x[0] = a + b;
                 x[1] = a - b;
             }
         } else {
-            v2f e[N / 2], o[N / 2], we[N / 2], wo[N / 2];
+            V e[N / 2], o[N / 2], we[N / 2], wo[N / 2];
 #pragma unroll
             for (int k = 0; k < N / 2; ++k) {
                 e[k] = x[2 * k];
@@ -79,9 +88,9 @@ struct Fft {
                 we[k] = w[2 * k];
                 wo[k] = w[2 * k + 1];
             }
-            Fft<N / 2, WIN>::run(e, we);
-            Fft<N / 2, WIN>::run(o, wo);
-            Comb<N, 0>::run(x, e, o);
+            Fft<N / 2, WIN, V>::run(e, we);
+            Fft<N / 2, WIN, V>::run(o, wo);
+            Comb<N, 0, V>::run(x, e, o);
         }
     }
 };

@@ -16,6 +16,7 @@
 // mapped (bin, frame) with frame fastest so global stores are contiguous along frames.
 #include <cstdlib>
 
+#include "fft_inreg.h"
 #include "sgx_internal.h"
 
 namespace sgx {
@@ -191,6 +192,163 @@ __global__ __launch_bounds__(256) void k_lds_radix2(StftArgs a) {
     if (a.out_mode == OUT_MEL) {
         __syncthreads();
         mel_stage<T>(a, b, f0, nf, pw, eps, smem, (size_t)a.ft * fs * sizeof(Cx<T>));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_reg_radix: power-of-two n_fft from 32 to 8192, f32 and f64 — the register-tiled replacement of k_lds_radix2's
+// log2(m) LDS stages.  The m = n_fft/2 = A * B * C point complex transform of z[n] = x[2n] + i x[2n+1] (C = 1 for
+// m <= 256) is split as n = (B C) n1 + r, r = C n2 + n3, k = k1 + A (k2 + B k3):
+//   pass 1  work item (frame, r): loads the A points n1 (windowed; lanes over r read contiguous samples), an A-point FFT
+//           in registers (compile-time twiddles), times W_m^(k1 r), to row k1 / position r of the frame's LDS tile
+//   pass 2  work item (frame, k1, n3): the B points n2 of its row, B-point FFT, times W_(BC)^(k2 n3), back in place
+//   pass 3  work item (frame, k1, k2): the C points n3, C-point FFT, back in place (Z[k] at row k1, position C k2 + k3)
+//           — passes 2 and 3 only touch elements the item owns, so each needs just the barrier that orders the passes
+//   split   X[k] = E[k] + W_n^k O[k] from Z[k], Z[m-k]; frame index fastest across lanes (contiguous stores along the
+//           frame axis, S9), then the shared epilogue (emit_bin / mel_stage).
+// 3-4 barriers per tile instead of log2(m)/2 + 2, and 2-3 LDS round trips per point instead of log2(m)/2 + 1; no
+// in-register transform is longer than 16 points, so f32 stays under 128 VGPRs (4 waves per SIMD).
+#ifndef SGX_RRW32
+#define SGX_RRW32 3  // waves per SIMD the register allocation of the f32 / f64 instances aims at
+#endif
+#ifndef SGX_RRW64
+#define SGX_RRW64 2
+#endif
+template <typename T> struct PairOf;
+template <> struct PairOf<float> { typedef inreg::v2f type; };
+template <> struct PairOf<double> { typedef inreg::v2d type; };
+
+// product of the table entries selected by the bits of k: p[j] = W^(2^j r)  ->  W^(k r)
+template <int L, typename V>
+__device__ __forceinline__ V rr_twiddle(const V (&p)[L], unsigned k) {
+    V t = p[0];
+    bool have = false;
+#pragma unroll
+    for (int j = 0; j < L; ++j)
+        if (k >> j & 1u) {
+            t = have ? inreg::cmulv(t, p[j]) : p[j];
+            have = true;
+        }
+    return t;
+}
+
+template <typename T, int LA, int LB, int LC>
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? SGX_RRW32 : SGX_RRW64) void k_reg_radix(StftArgs a) {
+    typedef typename PairOf<T>::type V;
+    constexpr unsigned A = 1u << LA, B = 1u << LB, C = 1u << LC, BC = B * C, M = A * BC;
+    constexpr unsigned RS = BC + 1;           // row stride (complex elements): lanes over k1 spread over the banks
+    constexpr unsigned FS = (A * RS) | 1u;    // frame stride, odd: lanes over frames are conflict-free in the split
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    V *buf = (V *)smem;                          // [ft][FS]
+    T *pw = (T *)(buf + (size_t)a.ft * FS);      // [ft][nb_fft] (Mel only)
+    const unsigned tile = blockIdx.x % a.tiles, b = blockIdx.x / a.tiles;
+    const unsigned f0 = tile * a.ft;
+    const unsigned nf = min(a.ft, a.n_frames - f0);
+    const T *xb = (const T *)a.x + (size_t)b * a.sample_stride;
+    const T *w = (const T *)a.window;
+    const V *tw = (const V *)a.tw;
+    const T eps = (T)a.eps;
+    const unsigned tid = threadIdx.x;
+    const long long lo = (long long)f0 * a.hop - (long long)a.pad;
+    const bool interior = lo >= 0 && (unsigned long long)(lo + (long long)(nf - 1) * a.hop + a.n_fft) <= a.n_samples;
+    const bool pair_ok = !((a.hop | a.pad | (unsigned)a.sample_stride) & 1u) && ((size_t)a.x & (2 * sizeof(T) - 1)) == 0;
+
+    for (unsigned idx = tid; idx < nf * BC; idx += 256) {
+        const unsigned f = idx / BC, r = idx % BC;
+        const long long s0 = lo + (long long)f * a.hop + 2ll * r;
+        V v[A];
+        const V *wp = (const V *)w + r;  // (w[2i], w[2i+1]), i = BC n1 + r: one 2-element load (the table is 16-byte aligned)
+        if (interior && pair_ok) {  // frames start on even sample offsets of an aligned row: one 2-element load per point
+            const V *xp = (const V *)(xb + s0);
+#pragma unroll
+            for (unsigned n1 = 0; n1 < A; ++n1) v[n1] = xp[BC * n1] * wp[BC * n1];
+        } else if (interior) {
+            const T *xp = xb + s0;
+#pragma unroll
+            for (unsigned n1 = 0; n1 < A; ++n1) v[n1] = (V){xp[2u * BC * n1], xp[2u * BC * n1 + 1]} * wp[BC * n1];
+        } else {
+#pragma unroll
+            for (unsigned n1 = 0; n1 < A; ++n1) {
+                const long long sx = s0 + 2ll * BC * n1;
+                v[n1] = (V){load_sample(xb, sx, a.n_samples), load_sample(xb, sx + 1, a.n_samples)} * wp[BC * n1];
+            }
+        }
+        inreg::Fft<A, false, V>::run(v, v);
+        V *dst = buf + (size_t)f * FS + r;
+        dst[0] = v[0];
+        // W_m^(k1 r) = W_n^(2 k1 r): one table gather per bit of k1 (W^(r), W^(2r), W^(4r), ...), products for the rest
+        // (at most LA - 1 roundings on top of the table's) instead of A - 1 scattered gathers per work item
+        V pw2[LA];
+#pragma unroll
+        for (int j = 0; j < LA; ++j) pw2[j] = tw[((2u << j) * r) & (a.n_fft - 1)];
+#pragma unroll
+        for (unsigned k1 = 1; k1 < A; ++k1) dst[k1 * RS] = inreg::cmulv(v[k1], rr_twiddle<LA>(pw2, k1));
+    }
+    __syncthreads();
+    for (unsigned idx = tid; idx < nf * A * C; idx += 256) {
+        const unsigned f = idx / (A * C), q = idx % (A * C), k1 = q >> LC, n3 = q & (C - 1);
+        V *row = buf + (size_t)f * FS + k1 * RS + n3;
+        V x[B];
+#pragma unroll
+        for (unsigned n2 = 0; n2 < B; ++n2) x[n2] = row[n2 * C];
+        inreg::Fft<B, false, V>::run(x, x);
+        row[0] = x[0];
+        if constexpr (LC > 0) {  // W_(BC)^(k2 n3) = W_n^(2 A k2 n3), same bit-wise construction
+            V pw2[LB];
+#pragma unroll
+            for (int j = 0; j < LB; ++j) pw2[j] = tw[((2u * A << j) * n3) & (a.n_fft - 1)];
+#pragma unroll
+            for (unsigned k2 = 1; k2 < B; ++k2) row[k2 * C] = inreg::cmulv(x[k2], rr_twiddle<LB>(pw2, k2));
+        } else {
+#pragma unroll
+            for (unsigned k2 = 1; k2 < B; ++k2) row[k2] = x[k2];
+        }
+    }
+    __syncthreads();
+    if constexpr (LC > 0) {
+        for (unsigned idx = tid; idx < nf * A * B; idx += 256) {
+            const unsigned f = idx / (A * B), q = idx % (A * B), k1 = q >> LB, k2 = q & (B - 1);
+            V *row = buf + (size_t)f * FS + k1 * RS + k2 * C;
+            V x[C];
+#pragma unroll
+            for (unsigned n3 = 0; n3 < C; ++n3) x[n3] = row[n3];
+            inreg::Fft<C, false, V>::run(x, x);
+#pragma unroll
+            for (unsigned k3 = 0; k3 < C; ++k3) row[k3] = x[k3];
+        }
+        __syncthreads();
+    }
+    // real split, frame index fastest across threads (a.ft is a power of two).  One work item per pair (k, m - k):
+    // with E = (Z[k] + conj Z[m-k]) / 2, P = W_n^k (Z[k] - conj Z[m-k]) / (2i):  X[k] = E + P,  X[m-k] = conj(E - P).
+    const unsigned lft = __ffs(a.ft) - 1u;
+    auto at = [](const V *fb, unsigned k) -> V {  // Z[k]: row k mod A, position C k2 + k3 with k / A = k2 + B k3
+        const unsigned q = k >> LA;
+        return fb[(k & (A - 1)) * RS + (q & (B - 1)) * C + (q >> LB)];
+    };
+    {
+        const unsigned f = tid & (a.ft - 1), kstep = 256u >> lft;  // a thread keeps its frame and walks the bins
+        const V *fb = buf + (size_t)f * FS;
+        if (f < nf)
+            for (unsigned k = tid >> lft; k <= M / 2; k += kstep) {
+                if (k == 0) {  // DC and Nyquist bins: exactly real
+                    const V z = fb[0];
+                    emit_bin<T>(a, b, f0 + f, f, 0, z.x + z.y, T(0), pw, eps);
+                    emit_bin<T>(a, b, f0 + f, f, M, z.x - z.y, T(0), pw, eps);
+                    continue;
+                }
+                const V z = at(fb, k), y = at(fb, M - k);
+                const T half = T(0.5);
+                const T er = (z.x + y.x) * half, ei = (z.y - y.y) * half;
+                const T orr = (z.y + y.y) * half, oi = (y.x - z.x) * half;
+                const V wv = tw[k];
+                const T pr = orr * wv.x - oi * wv.y, pi = orr * wv.y + oi * wv.x;
+                emit_bin<T>(a, b, f0 + f, f, k, er + pr, ei + pi, pw, eps);
+                if (k != M - k) emit_bin<T>(a, b, f0 + f, f, M - k, er - pr, pi - ei, pw, eps);
+            }
+    }
+    if (a.out_mode == OUT_MEL) {
+        __syncthreads();
+        mel_stage<T>(a, b, f0, nf, pw, eps, smem, (size_t)a.ft * FS * sizeof(V));
     }
 }
 
@@ -464,6 +622,79 @@ static bool grid_ok(const StftArgs &a, unsigned long long *blocks) {
     unsigned long long g = (unsigned long long)a.tiles * a.batch;
     *blocks = g;
     return g > 0 && g < 0x7fffffffull;
+}
+
+// ---- k_reg_radix geometry / launch ---------------------------------------------------------------------------------------
+static bool reg_radix_split(unsigned log2m, int dtype, unsigned *la, unsigned *lb, unsigned *lc) {
+    if (log2m < 4 || log2m > 12) return false;  // n_fft 32 .. 8192
+    // f32: in-register transforms up to 16 points (two passes up to m = 256); f64: up to 8 points where three passes
+    // reach (m <= 512) — a 16-point f64 pass with its samples, window and twiddles in flight exceeds 256 registers
+    const unsigned two_pass_max = dtype == SGX_F64 ? 6 : 8;
+    if (log2m <= two_pass_max) {
+        *la = (log2m + 1) / 2; *lb = log2m / 2; *lc = 0;
+    } else {
+        *la = (log2m + 2) / 3; *lb = (log2m + 1) / 3; *lc = log2m / 3;
+    }
+    return true;
+}
+
+static size_t reg_radix_bytes(const StftArgs &a, unsigned ft, unsigned la, unsigned lbc, size_t es) {
+    const size_t fs = (((size_t)1 << la) * (((size_t)1 << lbc) + 1)) | 1;
+    return ft * fs * 2 * es + (a.out_mode == OUT_MEL ? (size_t)ft * a.nb_fft * es : 0);
+}
+
+static const size_t kRegBudget = [] {
+    const char *v = std::getenv("SGX_REG_LDS_KB");
+    const long kb = v ? std::atol(v) : 0;
+    return (size_t)((kb >= 8 && kb <= 160) ? kb : 40) * 1024;
+}();
+static const size_t kRegHardLimit = 144 * 1024;  // a single frame of the largest sizes may take most of the CU
+
+bool plan_geometry_reg_radix(StftArgs &a, int dtype) {
+    static const bool off = [] { const char *v = std::getenv("SGX_GENERIC"); return v && v[0] == 'l'; }();  // SGX_GENERIC=lds
+    unsigned la, lb, lc;
+    if (off || a.n_fft < 32 || (a.n_fft & (a.n_fft - 1)) || !reg_radix_split(a.log2m, dtype, &la, &lb, &lc)) return false;
+    const size_t es = elem_size(dtype);
+    // measured (256 x 10 s): f32 spectra run best with ~4 tiles per CU; the Mel stage and f64 want the larger tile
+    static const bool fixed = std::getenv("SGX_REG_LDS_KB") != nullptr;
+    const size_t budget = fixed ? kRegBudget : (dtype == SGX_F32 && a.out_mode != OUT_MEL) ? 40 * 1024 : 72 * 1024;
+    for (unsigned ft = 32; ft >= 1; ft >>= 1)
+        if (reg_radix_bytes(a, ft, la, lb + lc, es) <= budget) {
+            a.ft = ft;
+            return true;
+        }
+    a.ft = 1;
+    return reg_radix_bytes(a, 1, la, lb + lc, es) <= kRegHardLimit;
+}
+
+template <typename T, int LA, int LB, int LC>
+static hipError_t launch_reg_radix_t(const StftArgs &a, unsigned g, size_t lds, hipStream_t s) {
+    if (lds > 64 * 1024) {
+        hipError_t e = set_max_dynamic_lds((const void *)k_reg_radix<T, LA, LB, LC>, (int)kRegHardLimit);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_reg_radix<T, LA, LB, LC>), dim3(g), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_reg_radix(const StftArgs &a, int dtype, hipStream_t s) {
+    unsigned long long g;
+    unsigned la, lb, lc;
+    if (!grid_ok(a, &g) || !reg_radix_split(a.log2m, dtype, &la, &lb, &lc) || (a.ft & (a.ft - 1))) return hipErrorInvalidConfiguration;
+    const size_t lds = reg_radix_bytes(a, a.ft, la, lb + lc, elem_size(dtype));
+    if (lds > kRegHardLimit) return hipErrorInvalidConfiguration;
+#define SGX_RR(T, LA, LB, LC) \
+    if (la == LA && lb == LB && lc == LC) return launch_reg_radix_t<T, LA, LB, LC>(a, (unsigned)g, lds, s)
+    if (dtype == SGX_F64) {
+        SGX_RR(double, 2, 2, 0); SGX_RR(double, 3, 2, 0); SGX_RR(double, 3, 3, 0);
+        SGX_RR(double, 3, 2, 2); SGX_RR(double, 3, 3, 2); SGX_RR(double, 3, 3, 3);
+        SGX_RR(double, 4, 3, 3); SGX_RR(double, 4, 4, 3); SGX_RR(double, 4, 4, 4);
+    } else {
+        SGX_RR(float, 2, 2, 0); SGX_RR(float, 3, 2, 0); SGX_RR(float, 3, 3, 0); SGX_RR(float, 4, 3, 0); SGX_RR(float, 4, 4, 0);
+        SGX_RR(float, 3, 3, 3); SGX_RR(float, 4, 3, 3); SGX_RR(float, 4, 4, 3); SGX_RR(float, 4, 4, 4);
+    }
+    return hipErrorInvalidConfiguration;
+#undef SGX_RR
 }
 
 hipError_t launch_lds_radix2(const StftArgs &a, int dtype, hipStream_t s) {

@@ -540,6 +540,7 @@ bool set_geometry(const sgx_plan *pl, StftArgs &a, KernelKind kind) {
     case K_LDS_RADIX2: ok = plan_geometry_lds_radix2(a, pl->dtype); break;
     case K_DIRECT_DFT: ok = plan_geometry_direct_dft(a, pl->dtype); break;
     case K_TWO_FACTOR: ok = plan_geometry_two_factor(a, pl->dtype); break;
+    case K_REG_RADIX: ok = plan_geometry_reg_radix(a, pl->dtype); break;
     }
     if (ok) a.tiles = (a.n_frames + a.ft - 1) / a.ft;
     return ok;
@@ -550,6 +551,7 @@ hipError_t launch(const sgx_plan *pl, const StftArgs &a, KernelKind kind, hipStr
     case K_R32X16_F32: return launch_r32x16_f32(a, s);
     case K_LDS_RADIX2: return launch_lds_radix2(a, pl->dtype, s);
     case K_TWO_FACTOR: return launch_two_factor(a, pl->dtype, s);
+    case K_REG_RADIX: return launch_reg_radix(a, pl->dtype, s);
     default: return launch_direct_dft(a, pl->dtype, s);
     }
 }
@@ -558,7 +560,7 @@ hipError_t launch(const sgx_plan *pl, const StftArgs &a, KernelKind kind, hipStr
 KernelKind pick_kernel(const sgx_plan *pl, const void *x, size_t stride) {
     if (pl->kind == K_R32X16_F32) {
         const bool aligned = (reinterpret_cast<uintptr_t>(x) % 8 == 0) && (stride % 2 == 0);
-        return aligned ? K_R32X16_F32 : K_LDS_RADIX2;
+        return aligned ? K_R32X16_F32 : K_REG_RADIX;
     }
     return pl->kind;
 }
@@ -599,8 +601,13 @@ sgx_status run_device(sgx_plan *pl, const void *x, size_t batch, size_t n_sample
     fill_args(pl, a, x, stage_out, batch, n_samples, stride, n_frames);
     KernelKind kind = pick_kernel(pl, x, stride);
     if (!set_geometry(pl, a, kind)) {
-        kind = (kind == K_R32X16_F32) ? K_LDS_RADIX2 : K_DIRECT_DFT;  // (a two-factor plan that no longer fits falls to the direct sum)
-        if (!set_geometry(pl, a, kind))
+        // fallback chain: tuned -> register-tiled -> LDS radix-2 -> direct sum (a two-factor plan that no longer fits goes direct)
+        const bool p2 = (a.n_fft & (a.n_fft - 1)) == 0;
+        bool ok = false;
+        if (kind == K_R32X16_F32) ok = set_geometry(pl, a, kind = K_REG_RADIX);
+        if (!ok && p2 && kind != K_LDS_RADIX2) ok = set_geometry(pl, a, kind = K_LDS_RADIX2);
+        if (!ok) ok = set_geometry(pl, a, kind = K_DIRECT_DFT);
+        if (!ok)
             return set_err(pl, SGX_BACKEND, "hip -- FFT backend error: n_fft too large for the on-chip frame tile");
     }
     if (kind == K_R32X16_F32) a.window = pl->d_window_half;
@@ -763,6 +770,7 @@ const char *sgx_kernel_name(const sgx_plan *plan) {
     case K_R32X16_F32: return "r32x16_f32";
     case K_LDS_RADIX2: return "lds_radix2";
     case K_TWO_FACTOR: return "two_factor_dft";
+    case K_REG_RADIX: return "reg_radix";
     default: return "direct_dft";
     }
 }
@@ -802,14 +810,16 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
     if (params->freq_scale == SGX_FREQ_ERB) build_erb_dense(pl->p, pl->mel_ptr, pl->mel_col, pl->mel_val, pl->loghz_freqs);
 
     const bool pow2 = params->n_fft >= 4 && (params->n_fft & (params->n_fft - 1)) == 0;
-    pl->kind = pow2 ? K_LDS_RADIX2 : K_TWO_FACTOR;  // composite lengths: two-factor DFT; primes fall through to the direct sum
+    // powers of two: register-tiled radix kernel (32..2048), LDS radix-2 for the rest; composite lengths: two-factor DFT;
+    // primes fall through to the direct sum
+    pl->kind = pow2 ? K_REG_RADIX : K_TWO_FACTOR;
     if (params->dtype == SGX_F32 && params->n_fft == 1024 && params->hop_size % 2 == 0) pl->kind = K_R32X16_F32;
     {
         StftArgs probe;
         fill_args(pl, probe, nullptr, nullptr, 1, params->n_fft, params->n_fft, 1);
         bool ok = set_geometry(pl, probe, pl->kind);
         while (!ok && pl->kind != K_DIRECT_DFT) {
-            pl->kind = (pl->kind == K_R32X16_F32 && pow2) ? K_LDS_RADIX2 : K_DIRECT_DFT;
+            pl->kind = (pl->kind == K_R32X16_F32) ? K_REG_RADIX : (pl->kind == K_REG_RADIX && pow2) ? K_LDS_RADIX2 : K_DIRECT_DFT;
             ok = set_geometry(pl, probe, pl->kind);
         }
         if (!ok) {

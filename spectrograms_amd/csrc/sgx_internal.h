@@ -19,7 +19,7 @@ namespace sgx {
 enum OutMode : int { OUT_LINEAR = 0, OUT_MEL = 1, OUT_COMPLEX = 2 };
 // AMP_MAG_IN: the mapping consumes sqrt(power) and its output is final (chromagram: bank applied to magnitudes)
 enum AmpMode : int { AMP_POWER = 0, AMP_MAGNITUDE = 1, AMP_DB = 2, AMP_MAG_IN = 3 };
-enum KernelKind : int { K_DIRECT_DFT = 0, K_LDS_RADIX2 = 1, K_R32X16_F32 = 2, K_TWO_FACTOR = 3 };
+enum KernelKind : int { K_DIRECT_DFT = 0, K_LDS_RADIX2 = 1, K_R32X16_F32 = 2, K_TWO_FACTOR = 3, K_REG_RADIX = 4 };
 
 // Kernel arguments (POD, passed by value).  Layouts in HBM:
 //   x      : [batch][sample_stride] T, row b valid for n_samples elements
@@ -78,6 +78,8 @@ bool plan_geometry_direct_dft(StftArgs &a, int dtype);
 bool plan_geometry_two_factor(StftArgs &a, int dtype);
 hipError_t launch_two_factor(const StftArgs &a, int dtype, hipStream_t s);
 bool plan_geometry_lds_radix2(StftArgs &a, int dtype);
+bool plan_geometry_reg_radix(StftArgs &a, int dtype);
+hipError_t launch_reg_radix(const StftArgs &a, int dtype, hipStream_t s);
 bool plan_geometry_r32x16_f32(StftArgs &a);
 
 // ---- 2-D FFT path (kernels_fft2d.hip)

@@ -125,11 +125,26 @@ def run_case(n, batch=3, seed=0, **kw):
 
 # ------------------------------------------------------------------ pow2 sizes, both kernels, both dtypes
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
-@pytest.mark.parametrize("n_fft,hop", [(4, 2), (8, 3), (64, 16), (256, 128), (512, 256), (1024, 256), (1024, 512),
-                                       (2048, 512), (4096, 1024)])
+@pytest.mark.parametrize("n_fft,hop", [(4, 2), (8, 3), (16, 5), (32, 7), (64, 16), (128, 33), (256, 128), (512, 256), (512, 171),
+                                       (1024, 256), (1024, 512), (1024, 333), (2048, 512), (4096, 1024), (8192, 2048)])
 @pytest.mark.parametrize("amp", ["complex", "power"])
 def test_pow2_sizes(n_fft, hop, amp, dtype):
-    run_case(n=6000, n_fft=n_fft, hop=hop, amp=amp, dtype=dtype)
+    """Every radix split of the register-tiled kernel (two passes up to n_fft 512 in f32 / 128 in f64, three above), odd hops
+    (unaligned frames), the LDS radix-2 kernel below 32 points."""
+    plan, _ = run_case(n=max(6000, 3 * n_fft), n_fft=n_fft, hop=hop, amp=amp, dtype=dtype)
+    if 32 <= n_fft <= 8192 and not (n_fft == 1024 and dtype == "float32" and hop % 2 == 0):
+        assert plan.kernel_name == "reg_radix"
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("n_fft,hop", [(64, 16), (512, 128), (2048, 512)])
+def test_pow2_short_and_ragged(n_fft, hop, dtype):
+    """Signals shorter than one frame, exactly one frame, and lengths that leave a partial last tile."""
+    for n in (1, n_fft // 2, n_fft, n_fft + 1, 5 * n_fft + 17):
+        for centre in (True, False):
+            if not centre and n < n_fft:
+                continue
+            run_case(n=n, batch=2, n_fft=n_fft, hop=hop, amp="power", dtype=dtype, centre=centre)
 
 
 # ------------------------------------------------------------------ arbitrary sizes (reference accepts any n_fft)
