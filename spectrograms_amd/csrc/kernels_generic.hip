@@ -14,6 +14,7 @@
 // accumulation in T in ascending-bin order (:102-117) -> Power / sqrt / 10*log10(max(p, eps))
 // (:1986-2036, :2068-2080) -> out[b][bin][frame] with the frame axis contiguous (S9).  Threads are
 // mapped (bin, frame) with frame fastest so global stores are contiguous along frames.
+#include <algorithm>
 #include <cstdlib>
 
 #include "fft_inreg.h"
@@ -70,28 +71,48 @@ __device__ inline void emit_bin(const StftArgs &a, unsigned b, unsigned frame, u
 // (scratch_bytes of it): when the bank's CSR arrays fit they are staged there once per tile — otherwise every (band, frame)
 // thread streams its band's values and columns from global memory, ft times redundantly.
 template <typename T>
-__device__ inline void mel_stage(const StftArgs &a, unsigned b, unsigned f0, unsigned nf, const T *pw, T eps,
-                                 unsigned char *scratch, size_t scratch_bytes) {
-    const T *val = (const T *)a.mel_val;
-    const unsigned *col = a.mel_col;
-    const unsigned *ptr = a.mel_ptr;
+struct MelCsr {
+    const T *val;
+    const unsigned *col, *ptr;
+};
+
+// CSR arrays of the bank: staged into `scratch` (LDS) when they fit, else left in global memory.  Ends with a barrier
+// when it staged (uniform branch).
+template <typename T>
+__device__ inline MelCsr<T> mel_resolve(const StftArgs &a, unsigned char *scratch, size_t scratch_bytes) {
+    MelCsr<T> c{(const T *)a.mel_val, a.mel_col, a.mel_ptr};
     const size_t need = (size_t)a.mel_nnz * (sizeof(T) + 4) + (size_t)(a.n_mels + 1) * 4;
     if (need <= scratch_bytes) {  // uniform
         T *sval = (T *)scratch;
         unsigned *scol = (unsigned *)(sval + a.mel_nnz), *sptr = scol + a.mel_nnz;
-        for (unsigned i = threadIdx.x; i < a.mel_nnz; i += blockDim.x) { sval[i] = val[i]; scol[i] = col[i]; }
-        for (unsigned i = threadIdx.x; i <= a.n_mels; i += blockDim.x) sptr[i] = ptr[i];
+        for (unsigned i = threadIdx.x; i < a.mel_nnz; i += blockDim.x) { sval[i] = c.val[i]; scol[i] = c.col[i]; }
+        for (unsigned i = threadIdx.x; i <= a.n_mels; i += blockDim.x) sptr[i] = c.ptr[i];
         __syncthreads();
-        val = sval; col = scol; ptr = sptr;
+        c.val = sval; c.col = scol; c.ptr = sptr;
     }
+    return c;
+}
+
+template <typename T>
+__device__ inline void mel_apply(const StftArgs &a, const MelCsr<T> &c, unsigned b, unsigned f0, unsigned nf, const T *pw, T eps) {
     T *o = (T *)a.out;
     for (unsigned idx = threadIdx.x; idx < nf * a.n_mels; idx += blockDim.x) {
         unsigned f = idx % nf, mm = idx / nf;
         T acc = T(0);
-        unsigned i0 = ptr[mm], i1 = ptr[mm + 1];
-        for (unsigned i = i0; i < i1; i++) acc = t_mul_add_unfused(val[i], pw[(size_t)f * a.nb_fft + col[i]], acc);
+        unsigned i0 = c.ptr[mm], i1 = c.ptr[mm + 1];
+        for (unsigned i = i0; i < i1; i++) acc = t_mul_add_unfused(c.val[i], pw[(size_t)f * a.nb_fft + c.col[i]], acc);
         o[((size_t)b * a.n_out + mm) * a.n_frames + f0 + f] = amp_apply(acc, a.amp, eps);
     }
+}
+
+// Mel stage: pw[f][k] holds the power spectrum of the tile's frames.  `scratch` is LDS the transform no longer needs
+// (scratch_bytes of it): when the bank's CSR arrays fit they are staged there once per tile — otherwise every (band, frame)
+// thread streams its band's values and columns from global memory, ft times redundantly.
+template <typename T>
+__device__ inline void mel_stage(const StftArgs &a, unsigned b, unsigned f0, unsigned nf, const T *pw, T eps,
+                                 unsigned char *scratch, size_t scratch_bytes) {
+    const MelCsr<T> c = mel_resolve<T>(a, scratch, scratch_bytes);
+    mel_apply<T>(a, c, b, f0, nf, pw, eps);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -232,123 +253,228 @@ __device__ __forceinline__ V rr_twiddle(const V (&p)[L], unsigned k) {
     return t;
 }
 
+// pass-1 work items per thread: the tile holds up to 256 * NI / (B C) frames (wider store segments for the long transforms)
+template <int LB, int LC>
+constexpr unsigned rr_items() { return LB + LC >= 5 ? 2 : 1; }
+
+// waves per SIMD (= resident workgroups per CU) the register allocation of an instance aims at: the largest transforms
+// (16-point passes in f64, the three-pass f32 sizes with a 16-point first pass) would spill at the default
 template <typename T, int LA, int LB, int LC>
-__global__ __launch_bounds__(256, sizeof(T) == 4 ? SGX_RRW32 : SGX_RRW64) void k_reg_radix(StftArgs a) {
+constexpr unsigned rr_waves() {
+    if (sizeof(T) == 8) return LA >= 4 ? 1 : SGX_RRW64;
+    return (LC > 0 && LA >= 4) ? 2 : SGX_RRW32;
+}
+
+template <typename T, int LA, int LB, int LC>
+__global__ __launch_bounds__(256, (rr_waves<T, LA, LB, LC>())) void k_reg_radix(StftArgs a, unsigned total_tiles, unsigned csr_lds, unsigned band_lds) {
     typedef typename PairOf<T>::type V;
     constexpr unsigned A = 1u << LA, B = 1u << LB, C = 1u << LC, BC = B * C, M = A * BC;
+    constexpr unsigned NI = rr_items<LB, LC>();
     constexpr unsigned RS = BC + 1;           // row stride (complex elements): lanes over k1 spread over the banks
     constexpr unsigned FS = (A * RS) | 1u;    // frame stride, odd: lanes over frames are conflict-free in the split
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     V *buf = (V *)smem;                          // [ft][FS]
-    T *pw = (T *)(buf + (size_t)a.ft * FS);      // [ft][nb_fft] (Mel only)
-    const unsigned tile = blockIdx.x % a.tiles, b = blockIdx.x / a.tiles;
-    const unsigned f0 = tile * a.ft;
-    const unsigned nf = min(a.ft, a.n_frames - f0);
-    const T *xb = (const T *)a.x + (size_t)b * a.sample_stride;
-    const T *w = (const T *)a.window;
+    V *stw = buf + (size_t)a.ft * FS;            // [M/2 + 1] split twiddles W_n^k
+    V *sw = stw + (M / 2 + 1);                   // [M] window pairs (w[2i], w[2i+1])
+    // [ft][pws] (Mel only, 32-byte aligned for the 4-element row reads), then the bank: padded band table or CSR arrays
+    T *pw = (T *)(smem + ((((size_t)a.ft * FS + M / 2 + 1 + M) * sizeof(V) + 31) & ~size_t(31)));
+    const unsigned pws = 4u * (((a.nb_fft + 3u) >> 2) | 1u);  // row stride: 4-element groups, an odd number of them
     const V *tw = (const V *)a.tw;
     const T eps = (T)a.eps;
     const unsigned tid = threadIdx.x;
-    const long long lo = (long long)f0 * a.hop - (long long)a.pad;
-    const bool interior = lo >= 0 && (unsigned long long)(lo + (long long)(nf - 1) * a.hop + a.n_fft) <= a.n_samples;
+    // Tables the tile loop needs come from LDS: a global load behind the split's stores would wait for all of them (loads
+    // and stores retire through one in-order counter).  The workgroup is persistent: tiles blockIdx.x, + gridDim.x, ...
+    for (unsigned i = tid; i <= M / 2; i += 256) stw[i] = tw[i];
+    for (unsigned i = tid; i < M; i += 256) sw[i] = ((const V *)a.window)[i];
+    MelCsr<T> csr{};
+    typedef T V4 __attribute__((ext_vector_type(4)));
+    const V4 *bw = nullptr;            // band table: 4 weights per group; row mm = groups [bptr[mm], bptr[mm+1]) from column bcol[mm]
+    const unsigned *bptr = nullptr, *bcol = nullptr;
+    if (a.out_mode == OUT_MEL) {
+        unsigned char *bank = (unsigned char *)(pw + (size_t)a.ft * pws);
+        if (band_lds) {  // uniform: rows are runs of consecutive columns and the padded table fits
+            V4 *lw = (V4 *)bank;
+            unsigned *lp = (unsigned *)(lw + a.mel_pchunks), *lc = lp + a.n_mels + 1;
+            for (unsigned i = tid; i < a.mel_pchunks; i += 256) lw[i] = ((const V4 *)a.mel_pw)[i];
+            for (unsigned i = tid; i <= a.n_mels; i += 256) lp[i] = a.mel_pptr[i];
+            for (unsigned i = tid; i < a.n_mels; i += 256) lc[i] = a.mel_pcol[i];
+            // columns nb_fft .. pws-1 of every row meet zero weights only, but must hold finite values
+            for (unsigned i = tid; i < a.ft * (pws - a.nb_fft); i += 256)
+                pw[(size_t)(i / (pws - a.nb_fft)) * pws + a.nb_fft + i % (pws - a.nb_fft)] = T(0);
+            bw = lw; bptr = lp; bcol = lc;
+        } else {
+            csr = mel_resolve<T>(a, bank, csr_lds);
+        }
+    }
+    // pass-1 work items of this thread (the geometry keeps ft * BC <= 256 NI): frames p1f + j * (256 / BC) of the tile,
+    // residue r — the same for every tile, so the twiddles W_m^(k1 r) = W_n^(2 k1 r) are built once: one table gather per
+    // bit of k1 (W^r, W^2r, W^4r, ...), products for the rest (at most LA - 1 roundings on top of the table's)
+    const unsigned p1f = tid / BC, r = tid % BC;
+    V pw2[LA];
+#pragma unroll
+    for (int j = 0; j < LA; ++j) pw2[j] = tw[((2u << j) * r) & (a.n_fft - 1)];
     const bool pair_ok = !((a.hop | a.pad | (unsigned)a.sample_stride) & 1u) && ((size_t)a.x & (2 * sizeof(T) - 1)) == 0;
 
-    for (unsigned idx = tid; idx < nf * BC; idx += 256) {
-        const unsigned f = idx / BC, r = idx % BC;
-        const long long s0 = lo + (long long)f * a.hop + 2ll * r;
-        V v[A];
-        const V *wp = (const V *)w + r;  // (w[2i], w[2i+1]), i = BC n1 + r: one 2-element load (the table is 16-byte aligned)
-        if (interior && pair_ok) {  // frames start on even sample offsets of an aligned row: one 2-element load per point
-            const V *xp = (const V *)(xb + s0);
+    // raw (unwindowed) samples of one tile's work items -> registers; issued one tile ahead
+    auto load_raw = [&](unsigned t, V (&raw)[NI][A]) {
+        const unsigned tile = t % a.tiles, b = t / a.tiles;
+        const unsigned f0 = tile * a.ft, nf = min(a.ft, a.n_frames - f0);
+        const T *xb = (const T *)a.x + (size_t)b * a.sample_stride;
+        const long long lo = (long long)f0 * a.hop - (long long)a.pad;
+        const bool interior = lo >= 0 && (unsigned long long)(lo + (long long)(nf - 1) * a.hop + a.n_fft) <= a.n_samples;
 #pragma unroll
-            for (unsigned n1 = 0; n1 < A; ++n1) v[n1] = xp[BC * n1] * wp[BC * n1];
-        } else if (interior) {
-            const T *xp = xb + s0;
+        for (unsigned j = 0; j < NI; ++j) {
+            const unsigned f = p1f + j * (256u / BC);
+            if (f >= nf) continue;
+            const long long s0 = lo + (long long)f * a.hop + 2ll * r;
+            if (interior && pair_ok) {  // frames start on even sample offsets of an aligned row: one 2-element load per point
+                const V *xp = (const V *)(xb + s0);
 #pragma unroll
-            for (unsigned n1 = 0; n1 < A; ++n1) v[n1] = (V){xp[2u * BC * n1], xp[2u * BC * n1 + 1]} * wp[BC * n1];
-        } else {
+                for (unsigned n1 = 0; n1 < A; ++n1) raw[j][n1] = xp[BC * n1];
+            } else if (interior) {
+                const T *xp = xb + s0;
 #pragma unroll
-            for (unsigned n1 = 0; n1 < A; ++n1) {
-                const long long sx = s0 + 2ll * BC * n1;
-                v[n1] = (V){load_sample(xb, sx, a.n_samples), load_sample(xb, sx + 1, a.n_samples)} * wp[BC * n1];
-            }
-        }
-        inreg::Fft<A, false, V>::run(v, v);
-        V *dst = buf + (size_t)f * FS + r;
-        dst[0] = v[0];
-        // W_m^(k1 r) = W_n^(2 k1 r): one table gather per bit of k1 (W^(r), W^(2r), W^(4r), ...), products for the rest
-        // (at most LA - 1 roundings on top of the table's) instead of A - 1 scattered gathers per work item
-        V pw2[LA];
+                for (unsigned n1 = 0; n1 < A; ++n1) raw[j][n1] = (V){xp[2u * BC * n1], xp[2u * BC * n1 + 1]};
+            } else {
 #pragma unroll
-        for (int j = 0; j < LA; ++j) pw2[j] = tw[((2u << j) * r) & (a.n_fft - 1)];
-#pragma unroll
-        for (unsigned k1 = 1; k1 < A; ++k1) dst[k1 * RS] = inreg::cmulv(v[k1], rr_twiddle<LA>(pw2, k1));
-    }
-    __syncthreads();
-    for (unsigned idx = tid; idx < nf * A * C; idx += 256) {
-        const unsigned f = idx / (A * C), q = idx % (A * C), k1 = q >> LC, n3 = q & (C - 1);
-        V *row = buf + (size_t)f * FS + k1 * RS + n3;
-        V x[B];
-#pragma unroll
-        for (unsigned n2 = 0; n2 < B; ++n2) x[n2] = row[n2 * C];
-        inreg::Fft<B, false, V>::run(x, x);
-        row[0] = x[0];
-        if constexpr (LC > 0) {  // W_(BC)^(k2 n3) = W_n^(2 A k2 n3), same bit-wise construction
-            V pw2[LB];
-#pragma unroll
-            for (int j = 0; j < LB; ++j) pw2[j] = tw[((2u * A << j) * n3) & (a.n_fft - 1)];
-#pragma unroll
-            for (unsigned k2 = 1; k2 < B; ++k2) row[k2 * C] = inreg::cmulv(x[k2], rr_twiddle<LB>(pw2, k2));
-        } else {
-#pragma unroll
-            for (unsigned k2 = 1; k2 < B; ++k2) row[k2] = x[k2];
-        }
-    }
-    __syncthreads();
-    if constexpr (LC > 0) {
-        for (unsigned idx = tid; idx < nf * A * B; idx += 256) {
-            const unsigned f = idx / (A * B), q = idx % (A * B), k1 = q >> LB, k2 = q & (B - 1);
-            V *row = buf + (size_t)f * FS + k1 * RS + k2 * C;
-            V x[C];
-#pragma unroll
-            for (unsigned n3 = 0; n3 < C; ++n3) x[n3] = row[n3];
-            inreg::Fft<C, false, V>::run(x, x);
-#pragma unroll
-            for (unsigned k3 = 0; k3 < C; ++k3) row[k3] = x[k3];
-        }
-        __syncthreads();
-    }
-    // real split, frame index fastest across threads (a.ft is a power of two).  One work item per pair (k, m - k):
-    // with E = (Z[k] + conj Z[m-k]) / 2, P = W_n^k (Z[k] - conj Z[m-k]) / (2i):  X[k] = E + P,  X[m-k] = conj(E - P).
-    const unsigned lft = __ffs(a.ft) - 1u;
-    auto at = [](const V *fb, unsigned k) -> V {  // Z[k]: row k mod A, position C k2 + k3 with k / A = k2 + B k3
-        const unsigned q = k >> LA;
-        return fb[(k & (A - 1)) * RS + (q & (B - 1)) * C + (q >> LB)];
-    };
-    {
-        const unsigned f = tid & (a.ft - 1), kstep = 256u >> lft;  // a thread keeps its frame and walks the bins
-        const V *fb = buf + (size_t)f * FS;
-        if (f < nf)
-            for (unsigned k = tid >> lft; k <= M / 2; k += kstep) {
-                if (k == 0) {  // DC and Nyquist bins: exactly real
-                    const V z = fb[0];
-                    emit_bin<T>(a, b, f0 + f, f, 0, z.x + z.y, T(0), pw, eps);
-                    emit_bin<T>(a, b, f0 + f, f, M, z.x - z.y, T(0), pw, eps);
-                    continue;
+                for (unsigned n1 = 0; n1 < A; ++n1) {
+                    const long long sx = s0 + 2ll * BC * n1;
+                    raw[j][n1] = (V){load_sample(xb, sx, a.n_samples), load_sample(xb, sx + 1, a.n_samples)};
                 }
-                const V z = at(fb, k), y = at(fb, M - k);
-                const T half = T(0.5);
-                const T er = (z.x + y.x) * half, ei = (z.y - y.y) * half;
-                const T orr = (z.y + y.y) * half, oi = (y.x - z.x) * half;
-                const V wv = tw[k];
-                const T pr = orr * wv.x - oi * wv.y, pi = orr * wv.y + oi * wv.x;
-                emit_bin<T>(a, b, f0 + f, f, k, er + pr, ei + pi, pw, eps);
-                if (k != M - k) emit_bin<T>(a, b, f0 + f, f, M - k, er - pr, pi - ei, pw, eps);
             }
-    }
-    if (a.out_mode == OUT_MEL) {
+        }
+    };
+
+    V raw[NI][A];
+#pragma unroll
+    for (unsigned j = 0; j < NI; ++j)
+#pragma unroll
+        for (unsigned n1 = 0; n1 < A; ++n1) raw[j][n1] = (V){T(0), T(0)};
+    load_raw(blockIdx.x, raw);
+    __syncthreads();
+    const unsigned lft = __ffs(a.ft) - 1u;
+    for (unsigned t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+        const unsigned tile = t % a.tiles, b = t / a.tiles;
+        const unsigned f0 = tile * a.ft, nf = min(a.ft, a.n_frames - f0);
+#pragma unroll
+        for (unsigned j = 0; j < NI; ++j) {
+            const unsigned f = p1f + j * (256u / BC);
+            if (f >= nf) continue;
+            V v[A];
+#pragma unroll
+            for (unsigned n1 = 0; n1 < A; ++n1) v[n1] = raw[j][n1] * sw[BC * n1 + r];
+            inreg::Fft<A, false, V>::run(v, v);
+            V *dst = buf + (size_t)f * FS + r;
+            dst[0] = v[0];
+#pragma unroll
+            for (unsigned k1 = 1; k1 < A; ++k1) dst[k1 * RS] = inreg::cmulv(v[k1], rr_twiddle<LA>(pw2, k1));
+        }
+        if (t + gridDim.x < total_tiles) load_raw(t + gridDim.x, raw);  // in flight behind passes 2 and 3
         __syncthreads();
-        mel_stage<T>(a, b, f0, nf, pw, eps, smem, (size_t)a.ft * FS * sizeof(V));
+        for (unsigned idx = tid; idx < nf * A * C; idx += 256) {
+            const unsigned f = idx / (A * C), q = idx % (A * C), k1 = q >> LC, n3 = q & (C - 1);
+            V *row = buf + (size_t)f * FS + k1 * RS + n3;
+            V x[B];
+#pragma unroll
+            for (unsigned n2 = 0; n2 < B; ++n2) x[n2] = row[n2 * C];
+            inreg::Fft<B, false, V>::run(x, x);
+            row[0] = x[0];
+            if constexpr (LC > 0) {  // W_(BC)^(k2 n3) = W_n^(2 A k2 n3), same bit-wise construction
+                V q2[LB];
+#pragma unroll
+                for (int j = 0; j < LB; ++j) q2[j] = tw[((2u * A << j) * n3) & (a.n_fft - 1)];
+#pragma unroll
+                for (unsigned k2 = 1; k2 < B; ++k2) row[k2 * C] = inreg::cmulv(x[k2], rr_twiddle<LB>(q2, k2));
+            } else {
+#pragma unroll
+                for (unsigned k2 = 1; k2 < B; ++k2) row[k2] = x[k2];
+            }
+        }
+        __syncthreads();
+        if constexpr (LC > 0) {
+            for (unsigned idx = tid; idx < nf * A * B; idx += 256) {
+                const unsigned f = idx / (A * B), q = idx % (A * B), k1 = q >> LB, k2 = q & (B - 1);
+                V *row = buf + (size_t)f * FS + k1 * RS + k2 * C;
+                V x[C];
+#pragma unroll
+                for (unsigned n3 = 0; n3 < C; ++n3) x[n3] = row[n3];
+                inreg::Fft<C, false, V>::run(x, x);
+#pragma unroll
+                for (unsigned k3 = 0; k3 < C; ++k3) row[k3] = x[k3];
+            }
+            __syncthreads();
+        }
+        // The next tile's samples have had passes 2 and 3 to arrive: collect them here, before the first store of the split,
+        // so that nothing issued after this point ever has to be waited for.
+#pragma unroll
+        for (unsigned j = 0; j < NI; ++j)
+#pragma unroll
+            for (unsigned n1 = 0; n1 < A; ++n1) asm volatile("" : "+v"(raw[j][n1]));
+        // real split, frame index fastest across threads (a.ft is a power of two).  One work item per pair (k, m - k):
+        // with E = (Z[k] + conj Z[m-k]) / 2, P = W_n^k (Z[k] - conj Z[m-k]) / (2i):  X[k] = E + P,  X[m-k] = conj(E - P).
+        auto at = [](const V *fb, unsigned k) -> V {  // Z[k]: row k mod A, position C k2 + k3 with k / A = k2 + B k3
+            const unsigned q = k >> LA;
+            return fb[(k & (A - 1)) * RS + (q & (B - 1)) * C + (q >> LB)];
+        };
+        {
+            const unsigned f = tid & (a.ft - 1), kstep = 256u >> lft;  // a thread keeps its frame and walks the bins
+            const V *fb = buf + (size_t)f * FS;
+            T *pf = pw + (size_t)f * pws;
+            auto emit = [&](unsigned k, T re, T im) {
+                if (a.out_mode == OUT_MEL) {
+                    const T p = re * re + im * im;
+                    pf[k] = a.amp == AMP_MAG_IN ? t_sqrt(p) : p;
+                } else {
+                    emit_bin<T>(a, b, f0 + f, f, k, re, im, pw, eps);
+                }
+            };
+            if (f < nf)
+                for (unsigned k = tid >> lft; k <= M / 2; k += kstep) {
+                    if (k == 0) {  // DC and Nyquist bins: exactly real
+                        const V z = fb[0];
+                        emit(0, z.x + z.y, T(0));
+                        emit(M, z.x - z.y, T(0));
+                        continue;
+                    }
+                    const V z = at(fb, k), y = at(fb, M - k);
+                    const T half = T(0.5);
+                    const T er = (z.x + y.x) * half, ei = (z.y - y.y) * half;
+                    const T orr = (z.y + y.y) * half, oi = (y.x - z.x) * half;
+                    const V wv = stw[k];
+                    const T pr = orr * wv.x - oi * wv.y, pi = orr * wv.y + oi * wv.x;
+                    emit(k, er + pr, ei + pi);
+                    if (k != M - k) emit(M - k, er - pr, pi - ei);
+                }
+        }
+        if (a.out_mode == OUT_MEL) {
+            __syncthreads();
+            // bank rows: thread = (frame, row) with the frame fastest; sequential un-fused accumulation in ascending column
+            // order (:102-117).  Rows that are one run of consecutive columns need no column look-up per term, so the LDS
+            // reads of a row are independent of each other and pipeline.
+            const unsigned f = tid & (a.ft - 1), mstep = 256u >> lft;
+            T *o = (T *)a.out + ((size_t)b * a.n_out) * a.n_frames + f0 + f;
+            const T *pf = pw + (size_t)f * pws;
+            if (f < nf)
+                for (unsigned mm = tid >> lft; mm < a.n_mels; mm += mstep) {
+                    T acc = T(0);
+                    if (bw) {  // 4 columns per step: one vector read of the weights, one of the row (zero weights pad the run)
+                        const unsigned c0 = bptr[mm], c1 = bptr[mm + 1];
+                        const V4 *xq = (const V4 *)(pf + bcol[mm]) - c0;
+                        for (unsigned c = c0; c < c1; ++c) {
+                            const V4 wq = bw[c], x = xq[c];
+                            acc = t_mul_add_unfused(wq.x, x.x, acc);
+                            acc = t_mul_add_unfused(wq.y, x.y, acc);
+                            acc = t_mul_add_unfused(wq.z, x.z, acc);
+                            acc = t_mul_add_unfused(wq.w, x.w, acc);
+                        }
+                    } else {
+                        const unsigned i0 = csr.ptr[mm], i1 = csr.ptr[mm + 1];
+                        for (unsigned i = i0; i < i1; ++i) acc = t_mul_add_unfused(csr.val[i], pf[csr.col[i]], acc);
+                    }
+                    o[(size_t)mm * a.n_frames] = amp_apply(acc, a.amp, eps);
+                }
+        }
+        __syncthreads();  // the tile buffer (and pw) is free for the next tile
     }
 }
 
@@ -638,42 +764,71 @@ static bool reg_radix_split(unsigned log2m, int dtype, unsigned *la, unsigned *l
     return true;
 }
 
-static size_t reg_radix_bytes(const StftArgs &a, unsigned ft, unsigned la, unsigned lbc, size_t es) {
+static size_t reg_radix_band_bytes(const StftArgs &a, size_t es) {  // padded band table (rows of consecutive columns only)
+    if (a.out_mode != OUT_MEL || !a.mel_pw) return 0;
+    return (((size_t)a.mel_pchunks * 4 * es + (size_t)(2 * a.n_mels + 1) * 4) + 15) & ~size_t(15);
+}
+
+static size_t reg_radix_csr_bytes(const StftArgs &a, size_t es) {
+    return a.out_mode == OUT_MEL ? (((size_t)a.mel_nnz * (es + 4) + (size_t)(a.n_mels + 1) * 4 + 15) & ~size_t(15)) : 0;
+}
+
+// LDS bytes of a tile of ft frames (the bank's CSR arrays ride along when `with_csr`)
+static size_t reg_radix_bytes(const StftArgs &a, unsigned ft, unsigned la, unsigned lbc, size_t es, bool with_csr) {
     const size_t fs = (((size_t)1 << la) * (((size_t)1 << lbc) + 1)) | 1;
-    return ft * fs * 2 * es + (a.out_mode == OUT_MEL ? (size_t)ft * a.nb_fft * es : 0);
+    const size_t m = (size_t)1 << (la + lbc);
+    const size_t pws = 4 * ((((size_t)a.nb_fft + 3) >> 2) | 1);
+    size_t bytes = (ft * fs + m / 2 + 1 + m) * 2 * es;
+    if (a.out_mode == OUT_MEL) bytes = ((bytes + 31) & ~size_t(31)) + (size_t)ft * pws * es;
+    bytes = (bytes + 15) & ~size_t(15);
+    return bytes + (with_csr ? reg_radix_csr_bytes(a, es) : 0);
 }
 
 static const size_t kRegBudget = [] {
     const char *v = std::getenv("SGX_REG_LDS_KB");
     const long kb = v ? std::atol(v) : 0;
-    return (size_t)((kb >= 8 && kb <= 160) ? kb : 40) * 1024;
+    return (size_t)((kb >= 8 && kb <= 160) ? kb : 72) * 1024;  // two persistent workgroups per CU at the least
 }();
 static const size_t kRegHardLimit = 144 * 1024;  // a single frame of the largest sizes may take most of the CU
+
+static unsigned reg_radix_ft_max(unsigned lb, unsigned lc) {
+    const unsigned ni = lb + lc >= 5 ? 2 : 1;  // rr_items
+    return std::min(32u, std::max(1u, (256u * ni) >> (lb + lc)));
+}
 
 bool plan_geometry_reg_radix(StftArgs &a, int dtype) {
     static const bool off = [] { const char *v = std::getenv("SGX_GENERIC"); return v && v[0] == 'l'; }();  // SGX_GENERIC=lds
     unsigned la, lb, lc;
     if (off || a.n_fft < 32 || (a.n_fft & (a.n_fft - 1)) || !reg_radix_split(a.log2m, dtype, &la, &lb, &lc)) return false;
     const size_t es = elem_size(dtype);
-    // measured (256 x 10 s): f32 spectra run best with ~4 tiles per CU; the Mel stage and f64 want the larger tile
-    static const bool fixed = std::getenv("SGX_REG_LDS_KB") != nullptr;
-    const size_t budget = fixed ? kRegBudget : (dtype == SGX_F32 && a.out_mode != OUT_MEL) ? 40 * 1024 : 72 * 1024;
-    for (unsigned ft = 32; ft >= 1; ft >>= 1)
-        if (reg_radix_bytes(a, ft, la, lb + lc, es) <= budget) {
+    // instances that run one workgroup per CU anyway (rr_waves == 1: f64 with a 16-point pass) may use most of its LDS
+    const size_t budget = (dtype == SGX_F64 && la >= 4) ? std::max(kRegBudget, kRegHardLimit - 16 * 1024) : kRegBudget;
+    for (unsigned ft = reg_radix_ft_max(lb, lc); ft >= 1; ft >>= 1)
+        if (reg_radix_bytes(a, ft, la, lb + lc, es, false) <= budget) {
             a.ft = ft;
             return true;
         }
     a.ft = 1;
-    return reg_radix_bytes(a, 1, la, lb + lc, es) <= kRegHardLimit;
+    return reg_radix_bytes(a, 1, la, lb + lc, es, false) <= kRegHardLimit;
 }
 
 template <typename T, int LA, int LB, int LC>
-static hipError_t launch_reg_radix_t(const StftArgs &a, unsigned g, size_t lds, hipStream_t s) {
+static hipError_t launch_reg_radix_t(const StftArgs &a, unsigned total, size_t lds, unsigned csr_lds, unsigned band_lds, hipStream_t s) {
     if (lds > 64 * 1024) {
         hipError_t e = set_max_dynamic_lds((const void *)k_reg_radix<T, LA, LB, LC>, (int)kRegHardLimit);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_reg_radix<T, LA, LB, LC>), dim3(g), dim3(256), lds, s, a);
+    // persistent workgroups: as many as are resident at once (registers: rr_waves per SIMD = workgroups per CU; LDS: 160 KB
+    // per CU), each walking tiles blockIdx.x, + gridDim.x, ...
+    static const unsigned cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return (unsigned)n;
+    }();
+    const unsigned by_regs = rr_waves<T, LA, LB, LC>();
+    const unsigned by_lds = (unsigned)std::max<size_t>(1, (160 * 1024) / (lds + 512));
+    const unsigned grid = std::min(total, cus * std::min(by_regs, by_lds));
+    hipLaunchKernelGGL((k_reg_radix<T, LA, LB, LC>), dim3(grid), dim3(256), lds, s, a, total, csr_lds, band_lds);
     return hipGetLastError();
 }
 
@@ -681,10 +836,24 @@ hipError_t launch_reg_radix(const StftArgs &a, int dtype, hipStream_t s) {
     unsigned long long g;
     unsigned la, lb, lc;
     if (!grid_ok(a, &g) || !reg_radix_split(a.log2m, dtype, &la, &lb, &lc) || (a.ft & (a.ft - 1))) return hipErrorInvalidConfiguration;
-    const size_t lds = reg_radix_bytes(a, a.ft, la, lb + lc, elem_size(dtype));
+    if (a.ft > reg_radix_ft_max(lb, lc)) return hipErrorInvalidConfiguration;
+    const size_t es = elem_size(dtype);
+    size_t lds = reg_radix_bytes(a, a.ft, la, lb + lc, es, false);
     if (lds > kRegHardLimit) return hipErrorInvalidConfiguration;
+    // the bank stays in LDS for the life of the workgroup when it fits beside the tile: the padded band table if the rows
+    // are runs of consecutive columns, else the CSR arrays (else CSR from global memory)
+    unsigned csr_lds = 0, band_lds = 0;
+    const size_t room = std::min(std::max(kRegBudget, lds) + 16 * 1024, kRegHardLimit);
+    const size_t band = reg_radix_band_bytes(a, es), csr = reg_radix_csr_bytes(a, es);
+    if (band && lds + band <= room) {
+        band_lds = (unsigned)band;
+        lds += band;
+    } else if (csr && lds + csr <= room) {
+        csr_lds = (unsigned)csr;
+        lds += csr;
+    }
 #define SGX_RR(T, LA, LB, LC) \
-    if (la == LA && lb == LB && lc == LC) return launch_reg_radix_t<T, LA, LB, LC>(a, (unsigned)g, lds, s)
+    if (la == LA && lb == LB && lc == LC) return launch_reg_radix_t<T, LA, LB, LC>(a, (unsigned)g, lds, csr_lds, band_lds, s)
     if (dtype == SGX_F64) {
         SGX_RR(double, 2, 2, 0); SGX_RR(double, 3, 2, 0); SGX_RR(double, 3, 3, 0);
         SGX_RR(double, 3, 2, 2); SGX_RR(double, 3, 3, 2); SGX_RR(double, 3, 3, 3);

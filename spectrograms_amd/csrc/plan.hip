@@ -372,15 +372,16 @@ sgx_status build_device_tables(sgx_plan *pl) {
         if ((st = upload<uint32_t>(pl, &pl->d_mel_ptr, pl->mel_ptr)) != SGX_OK) return st;
         if ((st = upload<uint32_t>(pl, &pl->d_mel_col, pl->mel_col)) != SGX_OK) return st;
         if ((st = upload_cast<T>(pl, &pl->d_mel_val, pl->mel_val)) != SGX_OK) return st;
-        // triangular bands are contiguous column runs; for the tuned f32 kernel build a 4-wide padded copy (16-byte
+        // triangular bands are contiguous column runs; build a 4-wide padded copy (4-element
         // aligned column groups, zero weights outside the true band) so the reduction reads LDS 16 bytes at a time
         bool contig = true;
         for (size_t m = 0; m < pl->p.n_mels && contig; ++m)
             for (uint32_t i = pl->mel_ptr[m]; i + 1 < pl->mel_ptr[m + 1]; ++i)
                 contig = contig && (pl->mel_col[i + 1] == pl->mel_col[i] + 1);
-        if (contig && std::is_same<T, float>::value) {
+        pl->mel_contig = contig ? 1u : 0u;
+        if (contig) {
             std::vector<uint32_t> pptr(pl->p.n_mels + 1, 0), pcol(pl->p.n_mels, 0);
-            std::vector<float> pw;
+            std::vector<T> pw;
             for (size_t m = 0; m < pl->p.n_mels; ++m) {
                 pptr[m] = uint32_t(pw.size() / 4);
                 const uint32_t a = pl->mel_ptr[m], b = pl->mel_ptr[m + 1];
@@ -388,13 +389,13 @@ sgx_status build_device_tables(sgx_plan *pl) {
                 const uint32_t c0 = pl->mel_col[a], c1 = pl->mel_col[b - 1];
                 const uint32_t s0 = c0 & ~3u, s1 = (c1 | 3u) + 1u;  // [s0, s1) multiple-of-4 cover
                 pcol[m] = s0;
-                for (uint32_t c = s0; c < s1; ++c) pw.push_back(c >= c0 && c <= c1 ? float(pl->mel_val[a + (c - c0)]) : 0.0f);
+                for (uint32_t c = s0; c < s1; ++c) pw.push_back(c >= c0 && c <= c1 ? T(pl->mel_val[a + (c - c0)]) : T(0));
             }
             pptr[pl->p.n_mels] = uint32_t(pw.size() / 4);
             pl->mel_pchunks = uint32_t(pw.size() / 4);
             if ((st = upload<uint32_t>(pl, &pl->d_mel_pptr, pptr)) != SGX_OK) return st;
             if ((st = upload<uint32_t>(pl, &pl->d_mel_pcol, pcol)) != SGX_OK) return st;
-            if ((st = upload<float>(pl, &pl->d_mel_pw, pw)) != SGX_OK) return st;
+            if ((st = upload<T>(pl, &pl->d_mel_pw, pw)) != SGX_OK) return st;
         }
         // Matrix-core epilogue of the tuned kernel (f32, n_fft = 1024): banks with wide rows (the dense ERB bank, very coarse
         // Mel banks) are applied as [16 rows x K] x [K x 16 frames] products on v_mfma_f32_16x16x4_f32, K restricted to the
@@ -523,6 +524,7 @@ void fill_args(const sgx_plan *pl, StftArgs &a, const void *x, void *out, size_t
     a.mel_pcol = (const unsigned *)pl->d_mel_pcol;
     a.mel_pw = pl->d_mel_pw;
     a.mel_pchunks = pl->mel_pchunks;
+    a.mel_contig = pl->mel_contig;
     a.mm_frag = pl->d_mm_frag;
     a.mm_blk = (const uint4 *)pl->d_mm_blk;
     a.mm_nblk = pl->mm_nblk;

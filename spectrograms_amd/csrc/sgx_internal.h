@@ -58,6 +58,7 @@ struct StftArgs {
     unsigned mm_nblk;
     unsigned n_mels;
     unsigned mel_nnz;
+    unsigned mel_contig;  // every row of the bank is one run of consecutive columns (Mel, log-Hz, ERB): col[i] = col[ptr] + (i - ptr)
     int out_mode;
     int amp;
     double eps;  // 10^(floor_db/10) in f64; cast to T in the kernel (T::from_f64, spectrogram.rs:2028)
@@ -176,6 +177,7 @@ struct sgx_plan {
     void *d_mel_ptr = nullptr, *d_mel_col = nullptr, *d_mel_val = nullptr, *d_mel_pptr = nullptr, *d_mel_pcol = nullptr, *d_mel_pw = nullptr, *d_mm_frag = nullptr, *d_mm_blk = nullptr;
     unsigned mm_nblk = 0;
     unsigned mel_pchunks = 0;
+    unsigned mel_contig = 0;
     void *d_ones = nullptr;  // rectangular window for sgx_r2c
     // MFCC epilogue: DCT-II basis [n_mfcc][n_mels] and lifter [n_mfcc] in T; Mel-dB scratch (grown on demand)
     void *d_dct = nullptr, *d_lifter = nullptr, *d_melbuf = nullptr;

@@ -132,7 +132,8 @@ def test_pow2_sizes(n_fft, hop, amp, dtype):
     """Every radix split of the register-tiled kernel (two passes up to n_fft 512 in f32 / 128 in f64, three above), odd hops
     (unaligned frames), the LDS radix-2 kernel below 32 points."""
     plan, _ = run_case(n=max(6000, 3 * n_fft), n_fft=n_fft, hop=hop, amp=amp, dtype=dtype)
-    if 32 <= n_fft <= 8192 and not (n_fft == 1024 and dtype == "float32" and hop % 2 == 0):
+    fits = n_fft <= (4096 if dtype == "float64" else 8192)  # an 8192-point f64 tile (164 KB with its tables) exceeds the CU's LDS
+    if 32 <= n_fft and fits and not (n_fft == 1024 and dtype == "float32" and hop % 2 == 0):
         assert plan.kernel_name == "reg_radix"
 
 

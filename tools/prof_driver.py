@@ -18,10 +18,14 @@ def main():
     workload = sys.argv[1] if len(sys.argv) > 1 else "linear_power"
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     batch = int(sys.argv[3]) if len(sys.argv) > 3 else bench.BATCH
-    params = sg.SpectrogramParams(sg.StftParams(bench.N_FFT, bench.HOP, sg.WindowType.hanning, True), bench.SR)
+    # SGX_PROF_NFFT / SGX_PROF_HOP / SGX_PROF_DTYPE: profile the shape-generic kernels on the same signals
+    n_fft = int(os.environ.get("SGX_PROF_NFFT", bench.N_FFT))
+    hop = int(os.environ.get("SGX_PROF_HOP", n_fft // 4))
+    dtype = os.environ.get("SGX_PROF_DTYPE", "float32")
+    params = sg.SpectrogramParams(sg.StftParams(n_fft, hop, sg.WindowType.hanning, True), bench.SR)
     pl = sg.SpectrogramPlanner()
     if workload == "linear_power":
-        plan = pl.linear_power_plan(params, dtype="float32")
+        plan = pl.linear_power_plan(params, dtype=dtype)
     elif workload == "mel_power":
         plan = pl.mel_power_plan(params, sg.MelParams(80, 0.0, 8000.0), dtype="float32")
     elif workload == "stft":
@@ -29,8 +33,8 @@ def main():
     elif workload == "erb_power":
         plan = pl.erb_power_plan(params, sg.ErbParams(64, 0.0, 8000.0), dtype="float32")
     else:
-        plan = pl.mel_db_plan(params, sg.MelParams(80, 0.0, 8000.0), sg.LogParams(-80.0), dtype="float32")
-    host = np.stack([bench.cfg_signal(b) for b in range(batch)])
+        plan = pl.mel_db_plan(params, sg.MelParams(80, 0.0, 8000.0), sg.LogParams(-80.0), dtype=dtype)
+    host = np.stack([bench.cfg_signal(b) for b in range(batch)]).astype(np.float32 if dtype == "float32" else np.float64)
     x = torch.from_numpy(host).cuda()
     out = None
     for _ in range(iters):

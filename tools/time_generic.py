@@ -5,7 +5,10 @@ import spectrograms_amd as sg
 from tests import helpers as H
 B = int(os.environ.get("B", 64))
 x32 = H.cfg2_batch(B)
+ONLY = os.environ.get("ONLY")
 for dtype, n_fft, hop in (("float32", 256, 64), ("float32", 512, 128), ("float32", 2048, 512), ("float32", 4096, 1024), ("float32", 400, 160), ("float64", 1024, 256), ("float64", 512, 128), ("float64", 2048, 512), ("float64", 400, 160)):
+    if ONLY and ONLY != f"{dtype}:{n_fft}":
+        continue
     tdt = torch.float32 if dtype == "float32" else torch.float64
     x = torch.from_numpy(x32).to(tdt).cuda()
     params = sg.SpectrogramParams(sg.StftParams(n_fft, hop, sg.WindowType.hanning, True), 16000.0)
