@@ -152,7 +152,7 @@ def test_host_only_plan_refuses_compute_loudly():
 def test_kernel_selection():
     assert host_plan(1024, 256, dtype="float32").kernel_name in ("r32x16_f32", "reg_radix")
     assert host_plan(1024, 256, dtype="float64").kernel_name == "reg_radix"
-    assert host_plan(4096, 1024, dtype="float64").kernel_name == "lds_radix2"
+    assert host_plan(4096, 1024, dtype="float64").kernel_name == "reg_radix"
     assert host_plan(16, 4, dtype="float32").kernel_name == "lds_radix2"
     assert host_plan(400, 160).kernel_name == "two_factor_dft"  # 20 x 20
     assert host_plan(401, 160).kernel_name == "direct_dft"      # prime length
