@@ -95,5 +95,107 @@ struct Fft {
     }
 };
 
+// ---- mixed radix (factors 2, 3, 5) -----------------------------------------------------------------------------------------
+// compile-time cos / sin (argument reduced to [-pi/2, pi/2], Taylor series in double: error ~1e-16)
+constexpr double kPiC = 3.14159265358979323846264338327950288;
+constexpr double ct_sin_reduced(double x) {  // |x| <= pi/2
+    double term = x, sum = x;
+    for (int i = 1; i < 16; ++i) {
+        term *= -x * x / double((2 * i) * (2 * i + 1));
+        sum += term;
+    }
+    return sum;
+}
+constexpr double ct_sin(double x) {  // any |x| <= 4 pi
+    while (x > kPiC) x -= 2.0 * kPiC;
+    while (x < -kPiC) x += 2.0 * kPiC;
+    if (x > 0.5 * kPiC) x = kPiC - x;
+    if (x < -0.5 * kPiC) x = -kPiC - x;
+    return ct_sin_reduced(x);
+}
+constexpr double ct_cos(double x) { return ct_sin(x + 0.5 * kPiC); }
+
+// x * W_N^E, E a compile-time exponent (forward transform: W = e^{-2 pi i / N})
+template <int N, int E, typename V>
+__device__ __forceinline__ V cmul_wn(V x) {
+    typedef typename ElemOf<V>::type T;
+    constexpr int e = E % N;
+    if constexpr (e == 0) {
+        return x;
+    } else {
+        constexpr T wr = (T)ct_cos(2.0 * kPiC * double(e) / double(N)), wi = (T)(-ct_sin(2.0 * kPiC * double(e) / double(N)));
+        return pfma(swp(x), (V){-wi, wi}, x * (V){wr, wr});
+    }
+}
+
+template <typename V>
+__device__ __forceinline__ void dft3(V (&c)[3]) {
+    typedef typename ElemOf<V>::type T;
+    constexpr T h = (T)0.86602540378443864676;  // sin(2 pi / 3)
+    const V s = c[1] + c[2], d = c[1] - c[2];
+    const V t = pfma(s, (V){T(-0.5), T(-0.5)}, c[0]);
+    const V u = swp(d) * (V){h, -h};  // -i h d
+    c[0] = c[0] + s;
+    c[1] = t + u;
+    c[2] = t - u;
+}
+
+template <typename V>
+__device__ __forceinline__ void dft5(V (&c)[5]) {
+    typedef typename ElemOf<V>::type T;
+    constexpr T c1 = (T)0.30901699437494742410, c2 = (T)-0.80901699437494742410;  // cos(2 pi / 5), cos(4 pi / 5)
+    constexpr T s1 = (T)0.95105651629515357212, s2 = (T)0.58778525229247312917;   // sin(2 pi / 5), sin(4 pi / 5)
+    const V a1 = c[1] + c[4], a2 = c[2] + c[3], b1 = c[1] - c[4], b2 = c[2] - c[3];
+    const V e1 = pfma(a2, (V){c2, c2}, pfma(a1, (V){c1, c1}, c[0]));
+    const V e2 = pfma(a2, (V){c1, c1}, pfma(a1, (V){c2, c2}, c[0]));
+    const V d1 = pfma(b2, (V){s2, s2}, b1 * (V){s1, s1});
+    const V d2 = pfma(b2, (V){-s1, -s1}, b1 * (V){s2, s2});
+    const V j1 = swp(d1) * (V){T(1), T(-1)}, j2 = swp(d2) * (V){T(1), T(-1)};  // -i d
+    c[0] = c[0] + a1 + a2;
+    c[1] = e1 + j1;
+    c[4] = e1 - j1;
+    c[2] = e2 + j2;
+    c[3] = e2 - j2;
+}
+
+// in-register N-point forward DFT, N = 2^a 3^b 5^c, natural order in and out (decimation in time over the odd factor)
+template <int N, typename V>
+struct MixFft {
+    static __device__ __forceinline__ void run(V (&x)[N]) {
+        if constexpr ((N & (N - 1)) == 0) {
+            Fft<N, false, V>::run(x, x);
+        } else {
+            constexpr int P = (N % 5 == 0) ? 5 : 3;
+            static_assert(N % P == 0, "MixFft: factors 2, 3 and 5 only");
+            constexpr int Q = N / P;
+            V t[P][Q];
+            step1<0>(x, t);
+#pragma unroll
+            for (int k1 = 0; k1 < P; ++k1) MixFft<Q, V>::run(t[k1]);
+#pragma unroll
+            for (int k1 = 0; k1 < P; ++k1)
+#pragma unroll
+                for (int k2 = 0; k2 < Q; ++k2) x[k1 + P * k2] = t[k1][k2];
+        }
+    }
+
+private:
+    // column n2: P-point DFT over n1 of x[Q n1 + n2], then the twiddle W_N^(k1 n2) (compile-time, hence the recursion)
+    template <int N2, int P, int Q>
+    static __device__ __forceinline__ void step1(const V (&x)[N], V (&t)[P][Q]) {
+        V c[P];
+#pragma unroll
+        for (int n1 = 0; n1 < P; ++n1) c[n1] = x[Q * n1 + N2];
+        if constexpr (P == 5) dft5(c); else dft3(c);
+        twid<N2, 0>(c, t);
+        if constexpr (N2 + 1 < Q) step1<N2 + 1>(x, t);
+    }
+    template <int N2, int K1, int P, int Q>
+    static __device__ __forceinline__ void twid(const V (&c)[P], V (&t)[P][Q]) {
+        t[K1][N2] = cmul_wn<N, K1 * N2, V>(c[K1]);
+        if constexpr (K1 + 1 < P) twid<N2, K1 + 1>(c, t);
+    }
+};
+
 }  // namespace inreg
 }  // namespace sgx

@@ -253,23 +253,29 @@ __device__ __forceinline__ V rr_twiddle(const V (&p)[L], unsigned k) {
     return t;
 }
 
+constexpr unsigned ct_log2_ceil(unsigned n) { unsigned l = 0; while ((1u << l) < n) ++l; return l; }
+constexpr bool ct_is_pow2(unsigned n) { return n && !(n & (n - 1)); }
+
 // pass-1 work items per thread: the tile holds up to 256 * NI / (B C) frames (wider store segments for the long transforms)
-template <int LB, int LC>
-constexpr unsigned rr_items() { return LB + LC >= 5 ? 2 : 1; }
+template <int B, int C>
+constexpr unsigned rr_items() { return (ct_is_pow2(B * C) && B * C >= 32) ? 2 : 1; }
 
 // waves per SIMD (= resident workgroups per CU) the register allocation of an instance aims at: the largest transforms
-// (16-point passes in f64, the three-pass f32 sizes with a 16-point first pass) would spill at the default
-template <typename T, int LA, int LB, int LC>
+// (16-point and longer passes in f64, the three-pass f32 sizes with a 16-point first pass) would spill at the default
+template <typename T, int A, int B, int C>
 constexpr unsigned rr_waves() {
-    if (sizeof(T) == 8) return LA >= 4 ? 1 : SGX_RRW64;
-    return (LC > 0 && LA >= 4) ? 2 : SGX_RRW32;
+    if (sizeof(T) == 8) return A >= 16 ? 1 : SGX_RRW64;
+    return ((C > 1 && A >= 16) || A > 16) ? 2 : SGX_RRW32;
 }
 
-template <typename T, int LA, int LB, int LC>
-__global__ __launch_bounds__(256, (rr_waves<T, LA, LB, LC>())) void k_reg_radix(StftArgs a, unsigned total_tiles, unsigned csr_lds, unsigned band_lds) {
+// A, B, C: lengths of the in-register passes (products of 2, 3, 5; C = 1: two passes), m = A B C
+template <typename T, int A_, int B_, int C_>
+__global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_reg_radix(StftArgs a, unsigned total_tiles, unsigned csr_lds, unsigned band_lds) {
     typedef typename PairOf<T>::type V;
-    constexpr unsigned A = 1u << LA, B = 1u << LB, C = 1u << LC, BC = B * C, M = A * BC;
-    constexpr unsigned NI = rr_items<LB, LC>();
+    constexpr unsigned A = A_, B = B_, C = C_, BC = B * C, M = A * BC;
+    constexpr unsigned NI = rr_items<B_, C_>();
+    constexpr int LA = ct_log2_ceil(A), LB = ct_log2_ceil(B);
+    constexpr bool P2 = ct_is_pow2(M);        // power-of-two n_fft: table indices wrap with a mask instead of a remainder
     constexpr unsigned RS = BC + 1;           // row stride (complex elements): lanes over k1 spread over the banks
     constexpr unsigned FS = (A * RS) | 1u;    // frame stride, odd: lanes over frames are conflict-free in the split
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(256, (rr_waves<T, LA, LB, LC>())) void k_reg_radix(
     const unsigned p1f = tid / BC, r = tid % BC;
     V pw2[LA];
 #pragma unroll
-    for (int j = 0; j < LA; ++j) pw2[j] = tw[((2u << j) * r) & (a.n_fft - 1)];
+    for (int j = 0; j < LA; ++j) pw2[j] = tw[P2 ? (((2u << j) * r) & (a.n_fft - 1)) : (((2u << j) * r) % a.n_fft)];
     const bool pair_ok = !((a.hop | a.pad | (unsigned)a.sample_stride) & 1u) && ((size_t)a.x & (2 * sizeof(T) - 1)) == 0;
 
     // raw (unwindowed) samples of one tile's work items -> registers; issued one tile ahead
@@ -363,7 +369,7 @@ __global__ __launch_bounds__(256, (rr_waves<T, LA, LB, LC>())) void k_reg_radix(
             V v[A];
 #pragma unroll
             for (unsigned n1 = 0; n1 < A; ++n1) v[n1] = raw[j][n1] * sw[BC * n1 + r];
-            inreg::Fft<A, false, V>::run(v, v);
+            inreg::MixFft<A, V>::run(v);
             V *dst = buf + (size_t)f * FS + r;
             dst[0] = v[0];
 #pragma unroll
@@ -372,17 +378,17 @@ __global__ __launch_bounds__(256, (rr_waves<T, LA, LB, LC>())) void k_reg_radix(
         if (t + gridDim.x < total_tiles) load_raw(t + gridDim.x, raw);  // in flight behind passes 2 and 3
         __syncthreads();
         for (unsigned idx = tid; idx < nf * A * C; idx += 256) {
-            const unsigned f = idx / (A * C), q = idx % (A * C), k1 = q >> LC, n3 = q & (C - 1);
+            const unsigned f = idx / (A * C), q = idx % (A * C), k1 = q / C, n3 = q % C;
             V *row = buf + (size_t)f * FS + k1 * RS + n3;
             V x[B];
 #pragma unroll
             for (unsigned n2 = 0; n2 < B; ++n2) x[n2] = row[n2 * C];
-            inreg::Fft<B, false, V>::run(x, x);
+            inreg::MixFft<B, V>::run(x);
             row[0] = x[0];
-            if constexpr (LC > 0) {  // W_(BC)^(k2 n3) = W_n^(2 A k2 n3), same bit-wise construction
+            if constexpr (C > 1) {  // W_(BC)^(k2 n3) = W_n^(2 A k2 n3), same bit-wise construction
                 V q2[LB];
 #pragma unroll
-                for (int j = 0; j < LB; ++j) q2[j] = tw[((2u * A << j) * n3) & (a.n_fft - 1)];
+                for (int j = 0; j < LB; ++j) q2[j] = tw[P2 ? (((2u * A << j) * n3) & (a.n_fft - 1)) : (((2u * A << j) * n3) % a.n_fft)];
 #pragma unroll
                 for (unsigned k2 = 1; k2 < B; ++k2) row[k2 * C] = inreg::cmulv(x[k2], rr_twiddle<LB>(q2, k2));
             } else {
@@ -391,14 +397,14 @@ __global__ __launch_bounds__(256, (rr_waves<T, LA, LB, LC>())) void k_reg_radix(
             }
         }
         __syncthreads();
-        if constexpr (LC > 0) {
+        if constexpr (C > 1) {
             for (unsigned idx = tid; idx < nf * A * B; idx += 256) {
-                const unsigned f = idx / (A * B), q = idx % (A * B), k1 = q >> LB, k2 = q & (B - 1);
+                const unsigned f = idx / (A * B), q = idx % (A * B), k1 = q / B, k2 = q % B;
                 V *row = buf + (size_t)f * FS + k1 * RS + k2 * C;
                 V x[C];
 #pragma unroll
                 for (unsigned n3 = 0; n3 < C; ++n3) x[n3] = row[n3];
-                inreg::Fft<C, false, V>::run(x, x);
+                inreg::MixFft<C, V>::run(x);
 #pragma unroll
                 for (unsigned k3 = 0; k3 < C; ++k3) row[k3] = x[k3];
             }
@@ -413,8 +419,8 @@ __global__ __launch_bounds__(256, (rr_waves<T, LA, LB, LC>())) void k_reg_radix(
         // real split, frame index fastest across threads (a.ft is a power of two).  One work item per pair (k, m - k):
         // with E = (Z[k] + conj Z[m-k]) / 2, P = W_n^k (Z[k] - conj Z[m-k]) / (2i):  X[k] = E + P,  X[m-k] = conj(E - P).
         auto at = [](const V *fb, unsigned k) -> V {  // Z[k]: row k mod A, position C k2 + k3 with k / A = k2 + B k3
-            const unsigned q = k >> LA;
-            return fb[(k & (A - 1)) * RS + (q & (B - 1)) * C + (q >> LB)];
+            const unsigned q = k / A;
+            return fb[(k % A) * RS + (q % B) * C + q / B];
         };
         {
             const unsigned f = tid & (a.ft - 1), kstep = 256u >> lft;  // a thread keeps its frame and walks the bins
@@ -534,14 +540,16 @@ __global__ __launch_bounds__(256) void k_two_factor(StftArgs a) {
     const unsigned n = a.n_fft, A = a.fac_a, B = a.fac_b;
     T *fr = (T *)smem;                                   // [ft][n] windowed frames
     Cx<T> *Y = (Cx<T> *)(fr + (size_t)a.ft * n);         // [ft][n]  (n2 * A + k1)
-    T *pw = (T *)(Y + (size_t)a.ft * n);                 // [ft][nb_fft] (Mel only)
+    Cx<T> *ltw = Y + (size_t)a.ft * n;                   // [n] twiddles W_n^m: every MAC below gathers one
+    T *pw = (T *)(ltw + n);                              // [ft][nb_fft] (Mel only)
     const unsigned tile = blockIdx.x % a.tiles, b = blockIdx.x / a.tiles;
     const unsigned f0 = tile * a.ft;
     const unsigned nf = min(a.ft, a.n_frames - f0);
     const T *xb = (const T *)a.x + (size_t)b * a.sample_stride;
     const T *w = (const T *)a.window;
-    const Cx<T> *tw = (const Cx<T> *)a.tw;
     const T eps = (T)a.eps;
+    for (unsigned i = threadIdx.x; i < n; i += 256) ltw[i] = ((const Cx<T> *)a.tw)[i];
+    const Cx<T> *tw = ltw;
     for (unsigned idx = threadIdx.x; idx < nf * n; idx += 256) {
         const unsigned f = idx / n, i = idx % n;
         const long long s = (long long)(f0 + f) * a.hop + (long long)i - (long long)a.pad;
@@ -584,7 +592,7 @@ __global__ __launch_bounds__(256) void k_two_factor(StftArgs a) {
     }
     if (a.out_mode == OUT_MEL) {
         __syncthreads();
-        mel_stage<T>(a, b, f0, nf, pw, eps, smem, (size_t)a.ft * n * 3 * sizeof(T));
+        mel_stage<T>(a, b, f0, nf, pw, eps, smem, (size_t)a.ft * n * 3 * sizeof(T));  // (frames and Y; the twiddles are done too)
     }
 }
 
@@ -730,7 +738,7 @@ bool plan_geometry_direct_dft(StftArgs &a, int dtype) {
 }
 
 static size_t two_factor_bytes(const StftArgs &a, unsigned ft, size_t es) {
-    return (size_t)ft * a.n_fft * 3 * es + (a.out_mode == OUT_MEL ? (size_t)ft * a.nb_fft * es : 0);
+    return (size_t)ft * a.n_fft * 3 * es + (size_t)a.n_fft * 2 * es + (a.out_mode == OUT_MEL ? (size_t)ft * a.nb_fft * es : 0);
 }
 
 bool plan_geometry_two_factor(StftArgs &a, int dtype) {
@@ -751,17 +759,52 @@ static bool grid_ok(const StftArgs &a, unsigned long long *blocks) {
 }
 
 // ---- k_reg_radix geometry / launch ---------------------------------------------------------------------------------------
-static bool reg_radix_split(unsigned log2m, int dtype, unsigned *la, unsigned *lb, unsigned *lc) {
-    if (log2m < 4 || log2m > 12) return false;  // n_fft 32 .. 8192
-    // f32: in-register transforms up to 16 points (two passes up to m = 256); f64: up to 8 points where three passes
-    // reach (m <= 512) — a 16-point f64 pass with its samples, window and twiddles in flight exceeds 256 registers
-    const unsigned two_pass_max = dtype == SGX_F64 ? 6 : 8;
-    if (log2m <= two_pass_max) {
-        *la = (log2m + 1) / 2; *lb = log2m / 2; *lc = 0;
-    } else {
-        *la = (log2m + 2) / 3; *lb = (log2m + 1) / 3; *lc = log2m / 3;
+// Pass lengths for m = n_fft / 2.  Powers of two: in-register transforms up to 16 points in f32 (two passes up to m = 256,
+// three above), up to 8 points in f64 where three passes reach (m <= 512) — a 16-point f64 pass with its samples and
+// twiddles in flight exceeds 256 registers.  Other even n_fft: the sizes below (two passes, factors 2, 3, 5), which cover
+// the usual speech / audio frames — 10, 20, 25, 30, 40, 50 ms at 8 / 16 / 32 / 48 kHz and their neighbours.
+struct RegSplit { unsigned m, a, b; };
+static const RegSplit kMixedSplits[] = {
+    {40, 8, 5},     // n_fft 80   (10 ms @ 8 kHz)
+    {60, 10, 6},    // 120
+    {80, 10, 8},    // 160  (10 ms @ 16 kHz, 20 ms @ 8 kHz)
+    {100, 10, 10},  // 200  (25 ms @ 8 kHz)
+    {120, 12, 10},  // 240  (30 ms @ 8 kHz, 15 ms @ 16 kHz)
+    {160, 16, 10},  // 320  (20 ms @ 16 kHz)
+    {200, 25, 8},   // 400  (25 ms @ 16 kHz)
+    {240, 16, 15},  // 480  (30 ms @ 16 kHz, 10 ms @ 48 kHz)
+    {300, 20, 15},  // 600
+    {320, 20, 16},  // 640  (40 ms @ 16 kHz, 20 ms @ 32 kHz)
+    {400, 25, 16},  // 800  (50 ms @ 16 kHz, 25 ms @ 32 kHz)
+    {480, 24, 20},  // 960  (20 ms @ 48 kHz)
+    {500, 25, 20},  // 1000
+    {600, 25, 24},  // 1200 (25 ms @ 48 kHz)
+    {720, 30, 24},  // 1440 (30 ms @ 48 kHz)
+    {800, 32, 25},  // 1600 (50 ms @ 32 kHz)
+    {960, 32, 30},  // 1920 (40 ms @ 48 kHz)
+};
+
+static bool reg_radix_split(const StftArgs &a, int dtype, unsigned *pa, unsigned *pb, unsigned *pc) {
+    if (a.n_fft < 32 || (a.n_fft & 1u)) return false;
+    if ((a.n_fft & (a.n_fft - 1)) == 0) {
+        const unsigned log2m = a.log2m;
+        if (log2m < 4 || log2m > 12) return false;  // n_fft 32 .. 8192
+        const unsigned two_pass_max = dtype == SGX_F64 ? 6 : 8;
+        unsigned la, lb, lc;
+        if (log2m <= two_pass_max) {
+            la = (log2m + 1) / 2; lb = log2m / 2; lc = 0;
+        } else {
+            la = (log2m + 2) / 3; lb = (log2m + 1) / 3; lc = log2m / 3;
+        }
+        *pa = 1u << la; *pb = 1u << lb; *pc = 1u << lc;
+        return true;
     }
-    return true;
+    for (const RegSplit &r : kMixedSplits)
+        if (r.m * 2 == a.n_fft) {
+            *pa = r.a; *pb = r.b; *pc = 1;
+            return true;
+        }
+    return false;
 }
 
 static size_t reg_radix_band_bytes(const StftArgs &a, size_t es) {  // padded band table (rows of consecutive columns only)
@@ -773,15 +816,14 @@ static size_t reg_radix_csr_bytes(const StftArgs &a, size_t es) {
     return a.out_mode == OUT_MEL ? (((size_t)a.mel_nnz * (es + 4) + (size_t)(a.n_mels + 1) * 4 + 15) & ~size_t(15)) : 0;
 }
 
-// LDS bytes of a tile of ft frames (the bank's CSR arrays ride along when `with_csr`)
-static size_t reg_radix_bytes(const StftArgs &a, unsigned ft, unsigned la, unsigned lbc, size_t es, bool with_csr) {
-    const size_t fs = (((size_t)1 << la) * (((size_t)1 << lbc) + 1)) | 1;
-    const size_t m = (size_t)1 << (la + lbc);
+// LDS bytes of a tile of ft frames with its tables (without the bank)
+static size_t reg_radix_bytes(const StftArgs &a, unsigned ft, unsigned fa, unsigned fbc, size_t es) {
+    const size_t fs = ((size_t)fa * (fbc + 1)) | 1;
+    const size_t m = (size_t)fa * fbc;
     const size_t pws = 4 * ((((size_t)a.nb_fft + 3) >> 2) | 1);
     size_t bytes = (ft * fs + m / 2 + 1 + m) * 2 * es;
     if (a.out_mode == OUT_MEL) bytes = ((bytes + 31) & ~size_t(31)) + (size_t)ft * pws * es;
-    bytes = (bytes + 15) & ~size_t(15);
-    return bytes + (with_csr ? reg_radix_csr_bytes(a, es) : 0);
+    return (bytes + 15) & ~size_t(15);
 }
 
 static const size_t kRegBudget = [] {
@@ -791,31 +833,34 @@ static const size_t kRegBudget = [] {
 }();
 static const size_t kRegHardLimit = 144 * 1024;  // a single frame of the largest sizes may take most of the CU
 
-static unsigned reg_radix_ft_max(unsigned lb, unsigned lc) {
-    const unsigned ni = lb + lc >= 5 ? 2 : 1;  // rr_items
-    return std::min(32u, std::max(1u, (256u * ni) >> (lb + lc)));
+static unsigned reg_radix_ft_max(unsigned fbc) {
+    const bool p2 = (fbc & (fbc - 1)) == 0;
+    const unsigned ni = (p2 && fbc >= 32) ? 2 : 1;  // rr_items
+    unsigned ft = 1;
+    while (ft < 32 && 2 * ft * fbc <= 256u * ni) ft *= 2;  // largest power of two with ft * BC <= 256 NI
+    return ft;
 }
 
 bool plan_geometry_reg_radix(StftArgs &a, int dtype) {
     static const bool off = [] { const char *v = std::getenv("SGX_GENERIC"); return v && v[0] == 'l'; }();  // SGX_GENERIC=lds
-    unsigned la, lb, lc;
-    if (off || a.n_fft < 32 || (a.n_fft & (a.n_fft - 1)) || !reg_radix_split(a.log2m, dtype, &la, &lb, &lc)) return false;
+    unsigned fa, fb, fc;
+    if (off || !reg_radix_split(a, dtype, &fa, &fb, &fc)) return false;
     const size_t es = elem_size(dtype);
-    // instances that run one workgroup per CU anyway (rr_waves == 1: f64 with a 16-point pass) may use most of its LDS
-    const size_t budget = (dtype == SGX_F64 && la >= 4) ? std::max(kRegBudget, kRegHardLimit - 16 * 1024) : kRegBudget;
-    for (unsigned ft = reg_radix_ft_max(lb, lc); ft >= 1; ft >>= 1)
-        if (reg_radix_bytes(a, ft, la, lb + lc, es, false) <= budget) {
+    // instances that run one workgroup per CU anyway (rr_waves == 1: f64 with a 16-point or longer pass) may use most of its LDS
+    const size_t budget = (dtype == SGX_F64 && fa >= 16) ? std::max(kRegBudget, kRegHardLimit - 16 * 1024) : kRegBudget;
+    for (unsigned ft = reg_radix_ft_max(fb * fc); ft >= 1; ft >>= 1)
+        if (reg_radix_bytes(a, ft, fa, fb * fc, es) <= budget) {
             a.ft = ft;
             return true;
         }
     a.ft = 1;
-    return reg_radix_bytes(a, 1, la, lb + lc, es, false) <= kRegHardLimit;
+    return reg_radix_bytes(a, 1, fa, fb * fc, es) <= kRegHardLimit;
 }
 
-template <typename T, int LA, int LB, int LC>
+template <typename T, int A, int B, int C>
 static hipError_t launch_reg_radix_t(const StftArgs &a, unsigned total, size_t lds, unsigned csr_lds, unsigned band_lds, hipStream_t s) {
     if (lds > 64 * 1024) {
-        hipError_t e = set_max_dynamic_lds((const void *)k_reg_radix<T, LA, LB, LC>, (int)kRegHardLimit);
+        hipError_t e = set_max_dynamic_lds((const void *)k_reg_radix<T, A, B, C>, (int)kRegHardLimit);
         if (e != hipSuccess) return e;
     }
     // persistent workgroups: as many as are resident at once (registers: rr_waves per SIMD = workgroups per CU; LDS: 160 KB
@@ -825,20 +870,20 @@ static hipError_t launch_reg_radix_t(const StftArgs &a, unsigned total, size_t l
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         return (unsigned)n;
     }();
-    const unsigned by_regs = rr_waves<T, LA, LB, LC>();
+    const unsigned by_regs = rr_waves<T, A, B, C>();
     const unsigned by_lds = (unsigned)std::max<size_t>(1, (160 * 1024) / (lds + 512));
     const unsigned grid = std::min(total, cus * std::min(by_regs, by_lds));
-    hipLaunchKernelGGL((k_reg_radix<T, LA, LB, LC>), dim3(grid), dim3(256), lds, s, a, total, csr_lds, band_lds);
+    hipLaunchKernelGGL((k_reg_radix<T, A, B, C>), dim3(grid), dim3(256), lds, s, a, total, csr_lds, band_lds);
     return hipGetLastError();
 }
 
 hipError_t launch_reg_radix(const StftArgs &a, int dtype, hipStream_t s) {
     unsigned long long g;
-    unsigned la, lb, lc;
-    if (!grid_ok(a, &g) || !reg_radix_split(a.log2m, dtype, &la, &lb, &lc) || (a.ft & (a.ft - 1))) return hipErrorInvalidConfiguration;
-    if (a.ft > reg_radix_ft_max(lb, lc)) return hipErrorInvalidConfiguration;
+    unsigned fa, fb, fc;
+    if (!grid_ok(a, &g) || !reg_radix_split(a, dtype, &fa, &fb, &fc) || (a.ft & (a.ft - 1))) return hipErrorInvalidConfiguration;
+    if (a.ft > reg_radix_ft_max(fb * fc)) return hipErrorInvalidConfiguration;
     const size_t es = elem_size(dtype);
-    size_t lds = reg_radix_bytes(a, a.ft, la, lb + lc, es, false);
+    size_t lds = reg_radix_bytes(a, a.ft, fa, fb * fc, es);
     if (lds > kRegHardLimit) return hipErrorInvalidConfiguration;
     // the bank stays in LDS for the life of the workgroup when it fits beside the tile: the padded band table if the rows
     // are runs of consecutive columns, else the CSR arrays (else CSR from global memory)
@@ -852,18 +897,26 @@ hipError_t launch_reg_radix(const StftArgs &a, int dtype, hipStream_t s) {
         csr_lds = (unsigned)csr;
         lds += csr;
     }
-#define SGX_RR(T, LA, LB, LC) \
-    if (la == LA && lb == LB && lc == LC) return launch_reg_radix_t<T, LA, LB, LC>(a, (unsigned)g, lds, csr_lds, band_lds, s)
+#define SGX_RR(T, A, B, C) \
+    if (fa == A && fb == B && fc == C) return launch_reg_radix_t<T, A, B, C>(a, (unsigned)g, lds, csr_lds, band_lds, s)
+#define SGX_RR2(A, B) \
+    if (fa == A && fb == B && fc == 1) \
+        return dtype == SGX_F64 ? launch_reg_radix_t<double, A, B, 1>(a, (unsigned)g, lds, csr_lds, band_lds, s) \
+                                : launch_reg_radix_t<float, A, B, 1>(a, (unsigned)g, lds, csr_lds, band_lds, s)
     if (dtype == SGX_F64) {
-        SGX_RR(double, 2, 2, 0); SGX_RR(double, 3, 2, 0); SGX_RR(double, 3, 3, 0);
-        SGX_RR(double, 3, 2, 2); SGX_RR(double, 3, 3, 2); SGX_RR(double, 3, 3, 3);
-        SGX_RR(double, 4, 3, 3); SGX_RR(double, 4, 4, 3); SGX_RR(double, 4, 4, 4);
+        SGX_RR(double, 4, 4, 1); SGX_RR(double, 8, 4, 1); SGX_RR(double, 8, 8, 1);
+        SGX_RR(double, 8, 4, 4); SGX_RR(double, 8, 8, 4); SGX_RR(double, 8, 8, 8);
+        SGX_RR(double, 16, 8, 8); SGX_RR(double, 16, 16, 8); SGX_RR(double, 16, 16, 16);
     } else {
-        SGX_RR(float, 2, 2, 0); SGX_RR(float, 3, 2, 0); SGX_RR(float, 3, 3, 0); SGX_RR(float, 4, 3, 0); SGX_RR(float, 4, 4, 0);
-        SGX_RR(float, 3, 3, 3); SGX_RR(float, 4, 3, 3); SGX_RR(float, 4, 4, 3); SGX_RR(float, 4, 4, 4);
+        SGX_RR(float, 4, 4, 1); SGX_RR(float, 8, 4, 1); SGX_RR(float, 8, 8, 1); SGX_RR(float, 16, 8, 1); SGX_RR(float, 16, 16, 1);
+        SGX_RR(float, 8, 8, 8); SGX_RR(float, 16, 8, 8); SGX_RR(float, 16, 16, 8); SGX_RR(float, 16, 16, 16);
     }
+    SGX_RR2(8, 5); SGX_RR2(10, 6); SGX_RR2(10, 8); SGX_RR2(10, 10); SGX_RR2(12, 10); SGX_RR2(16, 10); SGX_RR2(25, 8);
+    SGX_RR2(16, 15); SGX_RR2(20, 15); SGX_RR2(20, 16); SGX_RR2(25, 16); SGX_RR2(24, 20); SGX_RR2(25, 20); SGX_RR2(25, 24);
+    SGX_RR2(30, 24); SGX_RR2(32, 25); SGX_RR2(32, 30);
     return hipErrorInvalidConfiguration;
 #undef SGX_RR
+#undef SGX_RR2
 }
 
 hipError_t launch_lds_radix2(const StftArgs &a, int dtype, hipStream_t s) {

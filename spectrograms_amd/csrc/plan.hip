@@ -608,6 +608,7 @@ sgx_status run_device(sgx_plan *pl, const void *x, size_t batch, size_t n_sample
         bool ok = false;
         if (kind == K_R32X16_F32) ok = set_geometry(pl, a, kind = K_REG_RADIX);
         if (!ok && p2 && kind != K_LDS_RADIX2) ok = set_geometry(pl, a, kind = K_LDS_RADIX2);
+        if (!ok && !p2 && kind == K_REG_RADIX) ok = set_geometry(pl, a, kind = K_TWO_FACTOR);
         if (!ok) ok = set_geometry(pl, a, kind = K_DIRECT_DFT);
         if (!ok)
             return set_err(pl, SGX_BACKEND, "hip -- FFT backend error: n_fft too large for the on-chip frame tile");
@@ -812,16 +813,17 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
     if (params->freq_scale == SGX_FREQ_ERB) build_erb_dense(pl->p, pl->mel_ptr, pl->mel_col, pl->mel_val, pl->loghz_freqs);
 
     const bool pow2 = params->n_fft >= 4 && (params->n_fft & (params->n_fft - 1)) == 0;
-    // powers of two: register-tiled radix kernel (32..2048), LDS radix-2 for the rest; composite lengths: two-factor DFT;
-    // primes fall through to the direct sum
-    pl->kind = pow2 ? K_REG_RADIX : K_TWO_FACTOR;
+    // powers of two (32..8192) and the listed even composite sizes: register-tiled kernel; other powers of two: LDS radix-2;
+    // other composite lengths: two-factor DFT; primes fall through to the direct sum
+    pl->kind = (pow2 || params->n_fft % 2 == 0) ? K_REG_RADIX : K_TWO_FACTOR;  // (even sizes outside the register-tiled list fall through)
     if (params->dtype == SGX_F32 && params->n_fft == 1024 && params->hop_size % 2 == 0) pl->kind = K_R32X16_F32;
     {
         StftArgs probe;
         fill_args(pl, probe, nullptr, nullptr, 1, params->n_fft, params->n_fft, 1);
         bool ok = set_geometry(pl, probe, pl->kind);
         while (!ok && pl->kind != K_DIRECT_DFT) {
-            pl->kind = (pl->kind == K_R32X16_F32) ? K_REG_RADIX : (pl->kind == K_REG_RADIX && pow2) ? K_LDS_RADIX2 : K_DIRECT_DFT;
+            pl->kind = (pl->kind == K_R32X16_F32) ? K_REG_RADIX
+                       : (pl->kind == K_REG_RADIX) ? (pow2 ? K_LDS_RADIX2 : K_TWO_FACTOR) : K_DIRECT_DFT;
             ok = set_geometry(pl, probe, pl->kind);
         }
         if (!ok) {

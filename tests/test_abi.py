@@ -154,7 +154,9 @@ def test_kernel_selection():
     assert host_plan(1024, 256, dtype="float64").kernel_name == "reg_radix"
     assert host_plan(4096, 1024, dtype="float64").kernel_name == "reg_radix"
     assert host_plan(16, 4, dtype="float32").kernel_name == "lds_radix2"
-    assert host_plan(400, 160).kernel_name == "two_factor_dft"  # 20 x 20
+    assert host_plan(400, 160).kernel_name == "reg_radix"       # m = 200 = 25 x 8
+    assert host_plan(100, 40).kernel_name == "two_factor_dft"   # even, but not in the register-tiled list: 10 x 10
+    assert host_plan(441, 160).kernel_name == "two_factor_dft"  # odd: 21 x 21
     assert host_plan(401, 160).kernel_name == "direct_dft"      # prime length
     assert host_plan(2, 1).kernel_name == "direct_dft"
 

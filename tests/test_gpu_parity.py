@@ -137,6 +137,27 @@ def test_pow2_sizes(n_fft, hop, amp, dtype):
         assert plan.kernel_name == "reg_radix"
 
 
+MIXED = [80, 120, 160, 200, 240, 320, 400, 480, 600, 640, 800, 960, 1000, 1200, 1440, 1600, 1920]
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("n_fft", MIXED)
+@pytest.mark.parametrize("amp", ["complex", "power"])
+def test_mixed_radix_sizes(n_fft, amp, dtype):
+    """Even composite sizes on the register-tiled kernel (in-register passes with factors 2, 3 and 5)."""
+    hop = n_fft * 2 // 5
+    plan, _ = run_case(n=max(6000, 4 * n_fft), n_fft=n_fft, hop=hop, amp=amp, dtype=dtype)
+    assert plan.kernel_name == "reg_radix"
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("n_fft,hop", [(400, 160), (400, 161), (480, 160), (800, 320)])
+def test_mixed_radix_mel_and_odd_hop(n_fft, hop, dtype):
+    run_case(n=9000, n_fft=n_fft, hop=hop, n_mels=80, fmin=0.0, fmax=8000.0, amp="db", floor=-80.0, dtype=dtype)
+    for n in (1, n_fft // 2, n_fft + 1):
+        run_case(n=n, batch=2, n_fft=n_fft, hop=hop, amp="power", dtype=dtype)
+
+
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
 @pytest.mark.parametrize("n_fft,hop", [(64, 16), (512, 128), (2048, 512)])
 def test_pow2_short_and_ragged(n_fft, hop, dtype):
