@@ -816,7 +816,8 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
     // powers of two (32..8192) and the listed even composite sizes: register-tiled kernel; other powers of two: LDS radix-2;
     // other composite lengths: two-factor DFT; primes fall through to the direct sum
     pl->kind = (pow2 || params->n_fft % 2 == 0) ? K_REG_RADIX : K_TWO_FACTOR;  // (even sizes outside the register-tiled list fall through)
-    if (params->dtype == SGX_F32 && params->n_fft == 1024 && params->hop_size % 2 == 0) pl->kind = K_R32X16_F32;
+    static const bool no_tuned = [] { const char *v = std::getenv("SGX_TUNED"); return v && v[0] == '0'; }();  // A/B switch
+    if (params->dtype == SGX_F32 && params->n_fft == 1024 && params->hop_size % 2 == 0 && !no_tuned) pl->kind = K_R32X16_F32;
     {
         StftArgs probe;
         fill_args(pl, probe, nullptr, nullptr, 1, params->n_fft, params->n_fft, 1);
