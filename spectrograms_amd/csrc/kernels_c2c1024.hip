@@ -8,6 +8,7 @@
 //           the 16 lanes of a row hold 16 consecutive sequences, so out[(k1+32*k2)][s0..s0+15] is one 128-byte segment
 //           when the output is sequence-contiguous ([r][k] layout: both column passes of the 2-D path).
 // The load side follows whichever input stride is 1 (IN_SEQ_FAST).  Inverse = conj(FFT(conj(.))).
+#include <cstdlib>
 #include "fft_inreg.h"
 #include "sgx_internal.h"
 
@@ -281,11 +282,11 @@ __global__ __launch_bounds__(256, 2) void k_c2r1024(C2rArgs a, const v2f *twr /*
 
 // ---------------------------------------------------------------------------------------------------------------------
 // k_istft1024: fused f32 inverse STFT for n_fft = 1024 (src/spectrogram.rs:4860-4946).  A workgroup owns `nbk` consecutive
-// hop blocks of one signal's padded output and the 16 = nbk + ov frames that touch them (ov = floor(1023/hop) halo
+// hop blocks of one signal's padded output and the NF = nbk + ov frames that touch them (ov = floor(1023/hop) halo
 // frames are recomputed by the neighbouring workgroup instead of exchanging partial sums through HBM or atomics).
-//   load    [bin][frame] input (frame axis contiguous, S9): lane (r = tid & 15, n2 = tid >> 4) -> 128-byte segments
+//   load    [bin][frame] input (frame axis contiguous, S9): lane (r = tid mod NF, n2 = tid / NF) -> 128/256-byte segments
 //   C2R     exactly k_c2r1024's construction (32 x 16 split of the 512-point complex transform, one LDS exchange)
-//   frames  (x * 1/n) * w written as real rows fr[16][1024] over the dead exchange buffer
+//   frames  (x * 1/n) * w written as real rows fr[NF][1024] over the dead exchange buffer
 //   OLA     one thread per output sample: ascending-frame sum, norm = sum of w*w (unfused), divide where norm > 1e-10,
 //           centre trim by index shift; stores are contiguous runs of the output signal.
 struct IstftArgs {
@@ -298,9 +299,13 @@ struct IstftArgs {
     unsigned *bad_flag;
 };
 constexpr int kISeq = kRSeq + 32;     // row stride of the exchange buffer: lanes walk r in pass 1 -> spread rows over banks
-constexpr int kILds = 16 * kISeq;     // 74240 B -> two workgroups per CU (the real frames, 64 KiB, overlay it)
+// NF frames per workgroup of 16 NF threads: 16 -> 74 240 B, two workgroups per CU; 32 -> 148 480 B, one workgroup of 8 waves
+// (the real frames, NF * 4 KiB, overlay the exchange buffer).  32 halves the share of halo frames (3 of 32 instead of 3 of 16
+// at hop 256) and doubles the load segments to 256 bytes, but measures slower (see launch_istft1024): 16 is the default.
 
-__global__ __launch_bounds__(256, 2) void k_istft1024(IstftArgs a, const v2f *twr, const v2f *tw1) {
+template <int NF>
+__global__ __launch_bounds__(16 * NF, NF == 16 ? 2 : 1) void k_istft1024(IstftArgs a, const v2f *twr, const v2f *tw1) {
+    constexpr unsigned NT = 16u * NF;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned tid = threadIdx.x;
     const unsigned lb = xcd_logical_block(a.tiles * a.batch);
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void k_istft1024(IstftArgs a, const v2f *tw
     const long long fbase = h0 - (long long)a.ov;   // frame held in row 0
     const v2f *in = (const v2f *)a.spec + (size_t)b * 513u * a.n_frames;
     {
-        const unsigned r = tid & 15u, n2 = tid >> 4;
+        const unsigned r = tid & (NF - 1u), n2 = tid / NF;
         const long long f = fbase + r;
         const bool valid = f >= 0 && f < (long long)a.n_frames;
         const v2f *col = in + (valid ? f : 0);
@@ -318,22 +323,27 @@ __global__ __launch_bounds__(256, 2) void k_istft1024(IstftArgs a, const v2f *tw
         // conj(W_1024^(16 n1 + n2)) = e^{+2 pi i n1 / 64} (compile-time constant) * conj(W_1024^n2) (one load per lane): the
         // table loads (L1 hits, but 63 more instructions through the same in-order vector-memory pipe as the data) drop to 13
         const v2f wl = twr[n2];
+        // bins k = 16 n1 + n2 and 512 - k: two pointers stepped by 16 rows (one 64-bit add each, no per-load multiply)
+        const size_t step = (size_t)16u * a.n_frames;
+        const v2f *pa = col + (size_t)n2 * a.n_frames, *py = col + (size_t)(512u - n2) * a.n_frames;
 #pragma unroll
         for (int n1 = 0; n1 < 32; ++n1) {
             const unsigned k = 16u * n1 + n2;
-            v2f A = valid ? col[(size_t)k * a.n_frames] : (v2f){0.f, 0.f};
-            v2f Y = valid ? col[(size_t)(512u - k) * a.n_frames] : (v2f){0.f, 0.f};
+            v2f A = valid ? *pa : (v2f){0.f, 0.f};
+            v2f Y = valid ? *py : (v2f){0.f, 0.f};
+            pa += step;
+            py -= step;
             if (k == 0) {  // DC and Nyquist bins: realfft ignores (and reports) their imaginary parts
                 if (a.bad_flag && (A.y != 0.f || Y.y != 0.f)) atomicOr(a.bad_flag, 1u);
                 A.y = 0.f;
                 Y.y = 0.f;
             }
-            const v2f B = (v2f){Y.x, -Y.y};
-            const v2f S = A + B, D = A - B;
+            // S = A + conj Y, D = A - conj Y as fused multiply-adds with (1, -1) / (-1, 1): no separate sign flips
+            const v2f S = pfma(Y, (v2f){1.f, -1.f}, A), D = pfma(Y, (v2f){-1.f, 1.f}, A);
             const v2f cw = n1 == 0 ? wl : cmulv(wl, (v2f){(float)kCos64[n1], (float)kSin64[n1]});
             const v2f T = cmulv(D, cw);
-            const v2f Z = pfma(swp(T), (v2f){-1.f, 1.f}, S);
-            v[n1] = (v2f){Z.x, -Z.y};
+            // conj(S + i T) = (S.x - T.y, -(S.y + T.x)): the conjugate the forward-FFT inverse trick wants, in one fma
+            v[n1] = pfma(swp(T), (v2f){-1.f, -1.f}, S * (v2f){1.f, -1.f});
         }
         Fft<32, false>::run(v, v);
         unsigned char *dst = smem + r * kISeq + n2 * 8;
@@ -357,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void k_istft1024(IstftArgs a, const v2f *tw
     const unsigned k1 = tid & 31u;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-        const unsigned r = (tid >> 5) + 8u * it;
+        const unsigned r = (tid >> 5) + (NT / 32u) * it;
         v2f x[16];
         const v4f *rowp = (const v4f *)(smem + r * kISeq + k1 * kRRS);
 #pragma unroll
@@ -379,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void k_istft1024(IstftArgs a, const v2f *tw
             const v2f w = w2[32 * k2];
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
-                const unsigned r = (tid >> 5) + 8u * it;
+                const unsigned r = (tid >> 5) + (NT / 32u) * it;
                 const v2f sc = y[it][k2] * (v2f){a.scale, -a.scale};  // conj + 1/n: (x[2n], x[2n+1]), n = k1 + 32 k2
                 *(v2f *)(fr + r * 1024u + 2u * (k1 + 32u * k2)) = (v2f){__fmul_rn(sc.x, w.x), __fmul_rn(sc.y, w.y)};
             }
@@ -387,25 +397,42 @@ __global__ __launch_bounds__(256, 2) void k_istft1024(IstftArgs a, const v2f *tw
     }
     __syncthreads();
     {
+        // overlap-add, one thread per offset `off` inside a hop block, walking the tile's hop blocks: no division per sample.
+        // Position pos = (h0 + hb) hop + off receives frames f in [fh - q + 1, fh] (fh = h0 + hb, q = ceil((1024 - off) / hop)),
+        // clipped to [0, n_frames): ascending f as the reference adds them (:4906-4925), frame sample j = (fh - f) hop + off.
         const float *fr = (const float *)smem;
         const float *w = (const float *)a.win;
         float *o = (float *)a.out + (size_t)b * a.out_len;
-        const unsigned span = a.nbk * a.hop;
         const unsigned long long p0 = (unsigned long long)h0 * a.hop;
-        for (unsigned idx = tid; idx < span; idx += 256u) {
-            const unsigned long long pos = p0 + idx;
-            if (pos < a.start || pos - a.start >= a.out_len) continue;
-            const long long f_hi = min((long long)(pos / a.hop), (long long)a.n_frames - 1);
-            const long long f_lo = pos >= 1024ull ? (long long)((pos - 1024ull) / a.hop) + 1 : 0;
-            float acc = 0.f, nrm = 0.f;
-            for (long long f = f_lo; f <= f_hi; ++f) {
-                const unsigned j = (unsigned)(pos - (unsigned long long)f * a.hop);
-                acc += fr[(unsigned)(f - fbase) * 1024u + j];
-                const float wj = w[j];
-                nrm = __fadd_rn(nrm, __fmul_rn(wj, wj));
+        const long long last = (long long)a.n_frames - 1;
+        for (unsigned off = tid; off < a.hop; off += NT) {
+            const unsigned q = (1024u - off + a.hop - 1u) / a.hop;  // frames overlapping this offset (>= 1)
+            float nrm_full = 0.f;  // sum of w^2 over the q frames, same order: the value of every interior position
+            for (unsigned i = q; i-- > 0;) {
+                const float wj = w[i * a.hop + off];
+                nrm_full = __fadd_rn(nrm_full, __fmul_rn(wj, wj));
             }
-            if (nrm > 1e-10f) acc /= nrm;
-            o[pos - a.start] = acc;
+            for (unsigned hb = 0; hb < a.nbk; ++hb) {
+                const unsigned long long pos = p0 + (unsigned long long)hb * a.hop + off;
+                if (pos < a.start || pos - a.start >= a.out_len) continue;
+                const long long fh = h0 + hb;
+                const long long f_lo = max(fh - (long long)q + 1, 0ll), f_hi = min(fh, last);
+                float acc = 0.f, nrm;
+                const float *src = fr + (unsigned)(f_lo - fbase) * 1024u + (unsigned)(fh - f_lo) * a.hop + off;
+                const unsigned cnt = f_hi >= f_lo ? (unsigned)(f_hi - f_lo + 1) : 0u;
+                for (unsigned i = 0; i < cnt; ++i) acc += src[(int)i * (1024 - (int)a.hop)];  // next frame: row + 1, j - hop
+                if (cnt == q) {
+                    nrm = nrm_full;
+                } else {  // signal edges: fewer frames
+                    nrm = 0.f;
+                    for (long long f = f_lo; f <= f_hi; ++f) {
+                        const float wj = w[(unsigned)(fh - f) * a.hop + off];
+                        nrm = __fadd_rn(nrm, __fmul_rn(wj, wj));
+                    }
+                }
+                if (nrm > 1e-10f) acc /= nrm;
+                o[pos - a.start] = acc;
+            }
         }
     }
 }
@@ -421,7 +448,11 @@ hipError_t launch_istft1024(const void *spec, void *out, const void *win, unsign
     a.n_frames = n_frames; a.hop = hop; a.batch = batch;
     a.ov = 1023u / hop;
     if (a.ov >= 16) return hipErrorInvalidConfiguration;
-    a.nbk = 16u - a.ov;
+    // measured (256 x 626 frames, hop 256): 32 frames per workgroup 512 us, 16 frames 405 us — one 8-wave workgroup per CU
+    // keeps every wave in the same phase, two independent 4-wave workgroups overlap their load / transform / store phases
+    static const bool big = [] { const char *v = getenv("SGX_ISTFT_NF"); return v && v[0] == '3'; }();  // SGX_ISTFT_NF=32
+    const unsigned nfr = (n_frames >= 64 && big) ? 32u : 16u;
+    a.nbk = nfr - a.ov;
     const unsigned long long full = (unsigned long long)(n_frames - 1) * hop + 1024ull;
     const unsigned long long blocks = (full + hop - 1) / hop;
     a.tiles = (unsigned)((blocks + a.nbk - 1) / a.nbk);
@@ -429,10 +460,14 @@ hipError_t launch_istft1024(const void *spec, void *out, const void *win, unsign
     const unsigned long long g = (unsigned long long)a.tiles * batch;
     if (g == 0 || g >= 0x7fffffffull) return hipErrorInvalidConfiguration;
     {
-        hipError_t e = set_max_dynamic_lds((const void *)k_istft1024, kILds);
+        hipError_t e = nfr == 32 ? set_max_dynamic_lds((const void *)k_istft1024<32>, 32 * kISeq)
+                                 : set_max_dynamic_lds((const void *)k_istft1024<16>, 16 * kISeq);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_istft1024, dim3(xcd_grid(g)), dim3(256), kILds, s, a, (const v2f *)twr, (const v2f *)tw1);
+    if (nfr == 32)
+        hipLaunchKernelGGL(k_istft1024<32>, dim3(xcd_grid(g)), dim3(512), 32 * kISeq, s, a, (const v2f *)twr, (const v2f *)tw1);
+    else
+        hipLaunchKernelGGL(k_istft1024<16>, dim3(xcd_grid(g)), dim3(256), 16 * kISeq, s, a, (const v2f *)twr, (const v2f *)tw1);
     return hipGetLastError();
 }
 
