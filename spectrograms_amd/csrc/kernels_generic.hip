@@ -235,6 +235,9 @@ __global__ __launch_bounds__(256) void k_lds_radix2(StftArgs a) {
 #ifndef SGX_RRW64
 #define SGX_RRW64 2
 #endif
+#ifndef SGX_RR_NI2_MIN
+#define SGX_RR_NI2_MIN 32  // B C from which a thread takes two pass-1 work items (twice the frames per tile)
+#endif
 template <typename T> struct PairOf;
 template <> struct PairOf<float> { typedef inreg::v2f type; };
 template <> struct PairOf<double> { typedef inreg::v2d type; };
@@ -258,7 +261,7 @@ constexpr bool ct_is_pow2(unsigned n) { return n && !(n & (n - 1)); }
 
 // pass-1 work items per thread: the tile holds up to 256 * NI / (B C) frames (wider store segments for the long transforms)
 template <int B, int C>
-constexpr unsigned rr_items() { return (ct_is_pow2(B * C) && B * C >= 32) ? 2 : 1; }
+constexpr unsigned rr_items() { return (ct_is_pow2(B * C) && B * C >= SGX_RR_NI2_MIN) ? 2 : 1; }
 
 // waves per SIMD (= resident workgroups per CU) the register allocation of an instance aims at: the largest transforms
 // (16-point and longer passes in f64, the three-pass f32 sizes with a 16-point first pass) would spill at the default
@@ -835,7 +838,7 @@ static const size_t kRegHardLimit = 144 * 1024;  // a single frame of the larges
 
 static unsigned reg_radix_ft_max(unsigned fbc) {
     const bool p2 = (fbc & (fbc - 1)) == 0;
-    const unsigned ni = (p2 && fbc >= 32) ? 2 : 1;  // rr_items
+    const unsigned ni = (p2 && fbc >= SGX_RR_NI2_MIN) ? 2 : 1;  // rr_items
     unsigned ft = 1;
     while (ft < 32 && 2 * ft * fbc <= 256u * ni) ft *= 2;  // largest power of two with ft * BC <= 256 NI
     return ft;

@@ -375,3 +375,24 @@ def test_linearity_full_size(cfg2_x):
     Sab = sp.compute_batch((0.5 * a + 0.25 * b).astype(np.float32))
     ref = 0.5 * Sa.astype(np.complex128) + 0.25 * Sb.astype(np.complex128)
     assert np.max(np.abs(Sab - ref)) <= GUARD32 * np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("n_fft,hop,dtype", [(400, 160, "float32"), (512, 128, "float32"), (400, 160, "float64"), (2048, 512, "float32")])
+def test_full_size_register_tiled_kernel(cfg2_x, n_fft, hop, dtype):
+    """256 x 10 s through the persistent register-tiled kernel (more tiles than resident workgroups): whole-output parity with
+    the CPU restatement in the same precision, plus Parseval per frame."""
+    plan, op = make(n_fft, hop, dtype=dtype)
+    x = cfg2_x if dtype == "float32" else cfg2_x.astype(np.float64)
+    got = plan.compute_batch(x)
+    assert plan.kernel_name == "reg_radix"
+    nf = (160000 + 2 * (n_fft // 2) - n_fft) // hop + 1
+    assert got.shape == (256, n_fft // 2 + 1, nf)
+    ref = orc.spectrogram_batch(op, x, nthreads=orc.max_threads())
+    scale = ref.max(axis=(1, 2), keepdims=True)
+    assert np.max(np.abs(got - ref) / scale) <= (GUARD32 if dtype == "float32" else 1e-12)
+    w = orc.make_window("hanning", n_fft).astype(np.float64)
+    for b in (0, 1, 255):
+        fr = H.np_frames(x[b], n_fft, hop, True).astype(np.float64) * w[None, :]
+        lhs = 2.0 * got[b].astype(np.float64).sum(axis=0) - got[b, 0] - got[b, n_fft // 2]
+        rhs = float(n_fft) * (fr ** 2).sum(axis=1)
+        assert np.max(np.abs(lhs - rhs)) <= (1e-4 if dtype == "float32" else 1e-10) * rhs.max()
