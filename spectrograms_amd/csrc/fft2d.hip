@@ -91,7 +91,7 @@ sgx_status forward_dev(sgx_fft2d *p, const void *img, size_t batch, void *spec, 
         a.tile = 16; a.tiles = unsigned((Cb + 15) / 16);
         F2_HIP(p, launch_c2c1024(a, p->d_tw1c, s));
     } else {
-        F2_HIP(p, launch_c2c_tile(a, p->dtype, s));
+        F2_HIP(p, launch_c2c_any(a, p->dtype, s));
     }
     return SGX_OK;
 }
@@ -117,7 +117,7 @@ sgx_status inverse_dev(sgx_fft2d *p, const void *spec, size_t batch, void *img, 
         F2_HIP(p, launch_c2c1024(a, p->d_tw1c, s));
         c.in_ks = 1; c.in_rs = Cb; c.k_fast = 1;
     } else {
-        F2_HIP(p, launch_c2c_tile(a, p->dtype, s));
+        F2_HIP(p, launch_c2c_any(a, p->dtype, s));
         c.in_ks = R; c.in_rs = 1; c.k_fast = 0;
     }
     c.tile = p->tile_c; c.tiles = unsigned((R + c.tile - 1) / c.tile);
@@ -126,7 +126,7 @@ sgx_status inverse_dev(sgx_fft2d *p, const void *spec, size_t batch, void *img, 
         c.tile = 16; c.tiles = unsigned((R + 15) / 16);
         F2_HIP(p, launch_c2r1024(c, p->d_twr, p->d_tw1r, s));
     } else {
-        F2_HIP(p, launch_c2r_rows(c, p->dtype, s));
+        F2_HIP(p, launch_c2r_any(c, p->dtype, s));
     }
     return SGX_OK;
 }
@@ -157,7 +157,7 @@ sgx_status fused_product_dev(sgx_fft2d *p, const void *img, size_t batch, const 
         F2_HIP(p, launch_c2r1024(c, p->d_twr, p->d_tw1r, s));
     } else {
         c.tile = p->tile_c; c.tiles = unsigned((R + c.tile - 1) / c.tile);
-        F2_HIP(p, launch_c2r_rows(c, p->dtype, s));
+        F2_HIP(p, launch_c2r_any(c, p->dtype, s));
     }
     return SGX_OK;
 }

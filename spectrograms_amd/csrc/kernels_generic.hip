@@ -17,8 +17,7 @@
 #include <algorithm>
 #include <cstdlib>
 
-#include "fft_inreg.h"
-#include "sgx_internal.h"
+#include "reg_radix.h"
 
 namespace sgx {
 
@@ -229,48 +228,6 @@ __global__ __launch_bounds__(256) void k_lds_radix2(StftArgs a) {
 //           frame axis, S9), then the shared epilogue (emit_bin / mel_stage).
 // 3-4 barriers per tile instead of log2(m)/2 + 2, and 2-3 LDS round trips per point instead of log2(m)/2 + 1; no
 // in-register transform is longer than 16 points, so f32 stays under 128 VGPRs (4 waves per SIMD).
-#ifndef SGX_RRW32
-#define SGX_RRW32 3  // waves per SIMD the register allocation of the f32 / f64 instances aims at
-#endif
-#ifndef SGX_RRW64
-#define SGX_RRW64 2
-#endif
-#ifndef SGX_RR_NI2_MIN
-#define SGX_RR_NI2_MIN 32  // B C from which a thread takes two pass-1 work items (twice the frames per tile)
-#endif
-template <typename T> struct PairOf;
-template <> struct PairOf<float> { typedef inreg::v2f type; };
-template <> struct PairOf<double> { typedef inreg::v2d type; };
-
-// product of the table entries selected by the bits of k: p[j] = W^(2^j r)  ->  W^(k r)
-template <int L, typename V>
-__device__ __forceinline__ V rr_twiddle(const V (&p)[L], unsigned k) {
-    V t = p[0];
-    bool have = false;
-#pragma unroll
-    for (int j = 0; j < L; ++j)
-        if (k >> j & 1u) {
-            t = have ? inreg::cmulv(t, p[j]) : p[j];
-            have = true;
-        }
-    return t;
-}
-
-constexpr unsigned ct_log2_ceil(unsigned n) { unsigned l = 0; while ((1u << l) < n) ++l; return l; }
-constexpr bool ct_is_pow2(unsigned n) { return n && !(n & (n - 1)); }
-
-// pass-1 work items per thread: the tile holds up to 256 * NI / (B C) frames (wider store segments for the long transforms)
-template <int B, int C>
-constexpr unsigned rr_items() { return (ct_is_pow2(B * C) && B * C >= SGX_RR_NI2_MIN) ? 2 : 1; }
-
-// waves per SIMD (= resident workgroups per CU) the register allocation of an instance aims at: the largest transforms
-// (16-point and longer passes in f64, the three-pass f32 sizes with a 16-point first pass) would spill at the default
-template <typename T, int A, int B, int C>
-constexpr unsigned rr_waves() {
-    if (sizeof(T) == 8) return A >= 16 ? 1 : SGX_RRW64;
-    return ((C > 1 && A >= 16) || A > 16) ? 2 : SGX_RRW32;
-}
-
 // A, B, C: lengths of the in-register passes (products of 2, 3, 5; C = 1: two passes), m = A B C
 template <typename T, int A_, int B_, int C_>
 __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_reg_radix(StftArgs a, unsigned total_tiles, unsigned csr_lds, unsigned band_lds) {
@@ -762,52 +719,9 @@ static bool grid_ok(const StftArgs &a, unsigned long long *blocks) {
 }
 
 // ---- k_reg_radix geometry / launch ---------------------------------------------------------------------------------------
-// Pass lengths for m = n_fft / 2.  Powers of two: in-register transforms up to 16 points in f32 (two passes up to m = 256,
-// three above), up to 8 points in f64 where three passes reach (m <= 512) — a 16-point f64 pass with its samples and
-// twiddles in flight exceeds 256 registers.  Other even n_fft: the sizes below (two passes, factors 2, 3, 5), which cover
-// the usual speech / audio frames — 10, 20, 25, 30, 40, 50 ms at 8 / 16 / 32 / 48 kHz and their neighbours.
-struct RegSplit { unsigned m, a, b; };
-static const RegSplit kMixedSplits[] = {
-    {40, 8, 5},     // n_fft 80   (10 ms @ 8 kHz)
-    {60, 10, 6},    // 120
-    {80, 10, 8},    // 160  (10 ms @ 16 kHz, 20 ms @ 8 kHz)
-    {100, 10, 10},  // 200  (25 ms @ 8 kHz)
-    {120, 12, 10},  // 240  (30 ms @ 8 kHz, 15 ms @ 16 kHz)
-    {160, 16, 10},  // 320  (20 ms @ 16 kHz)
-    {200, 25, 8},   // 400  (25 ms @ 16 kHz)
-    {240, 16, 15},  // 480  (30 ms @ 16 kHz, 10 ms @ 48 kHz)
-    {300, 20, 15},  // 600
-    {320, 20, 16},  // 640  (40 ms @ 16 kHz, 20 ms @ 32 kHz)
-    {400, 25, 16},  // 800  (50 ms @ 16 kHz, 25 ms @ 32 kHz)
-    {480, 24, 20},  // 960  (20 ms @ 48 kHz)
-    {500, 25, 20},  // 1000
-    {600, 25, 24},  // 1200 (25 ms @ 48 kHz)
-    {720, 30, 24},  // 1440 (30 ms @ 48 kHz)
-    {800, 32, 25},  // 1600 (50 ms @ 32 kHz)
-    {960, 32, 30},  // 1920 (40 ms @ 48 kHz)
-};
-
 static bool reg_radix_split(const StftArgs &a, int dtype, unsigned *pa, unsigned *pb, unsigned *pc) {
     if (a.n_fft < 32 || (a.n_fft & 1u)) return false;
-    if ((a.n_fft & (a.n_fft - 1)) == 0) {
-        const unsigned log2m = a.log2m;
-        if (log2m < 4 || log2m > 12) return false;  // n_fft 32 .. 8192
-        const unsigned two_pass_max = dtype == SGX_F64 ? 6 : 8;
-        unsigned la, lb, lc;
-        if (log2m <= two_pass_max) {
-            la = (log2m + 1) / 2; lb = log2m / 2; lc = 0;
-        } else {
-            la = (log2m + 2) / 3; lb = (log2m + 1) / 3; lc = log2m / 3;
-        }
-        *pa = 1u << la; *pb = 1u << lb; *pc = 1u << lc;
-        return true;
-    }
-    for (const RegSplit &r : kMixedSplits)
-        if (r.m * 2 == a.n_fft) {
-            *pa = r.a; *pb = r.b; *pc = 1;
-            return true;
-        }
-    return false;
+    return reg_split_len(a.n_fft / 2, dtype, pa, pb, pc);
 }
 
 static size_t reg_radix_band_bytes(const StftArgs &a, size_t es) {  // padded band table (rows of consecutive columns only)
@@ -900,26 +814,20 @@ hipError_t launch_reg_radix(const StftArgs &a, int dtype, hipStream_t s) {
         csr_lds = (unsigned)csr;
         lds += csr;
     }
-#define SGX_RR(T, A, B, C) \
-    if (fa == A && fb == B && fc == C) return launch_reg_radix_t<T, A, B, C>(a, (unsigned)g, lds, csr_lds, band_lds, s)
-#define SGX_RR2(A, B) \
-    if (fa == A && fb == B && fc == 1) \
-        return dtype == SGX_F64 ? launch_reg_radix_t<double, A, B, 1>(a, (unsigned)g, lds, csr_lds, band_lds, s) \
-                                : launch_reg_radix_t<float, A, B, 1>(a, (unsigned)g, lds, csr_lds, band_lds, s)
+#define SGX_RR_F32(A, B, C) \
+    if (fa == A && fb == B && fc == C) return launch_reg_radix_t<float, A, B, C>(a, (unsigned)g, lds, csr_lds, band_lds, s);
+#define SGX_RR_F64(A, B, C) \
+    if (fa == A && fb == B && fc == C) return launch_reg_radix_t<double, A, B, C>(a, (unsigned)g, lds, csr_lds, band_lds, s);
     if (dtype == SGX_F64) {
-        SGX_RR(double, 4, 4, 1); SGX_RR(double, 8, 4, 1); SGX_RR(double, 8, 8, 1);
-        SGX_RR(double, 8, 4, 4); SGX_RR(double, 8, 8, 4); SGX_RR(double, 8, 8, 8);
-        SGX_RR(double, 16, 8, 8); SGX_RR(double, 16, 16, 8); SGX_RR(double, 16, 16, 16);
+        SGX_RR_SPLITS_F64(SGX_RR_F64)
+        SGX_RR_SPLITS_MIXED(SGX_RR_F64)
     } else {
-        SGX_RR(float, 4, 4, 1); SGX_RR(float, 8, 4, 1); SGX_RR(float, 8, 8, 1); SGX_RR(float, 16, 8, 1); SGX_RR(float, 16, 16, 1);
-        SGX_RR(float, 8, 8, 8); SGX_RR(float, 16, 8, 8); SGX_RR(float, 16, 16, 8); SGX_RR(float, 16, 16, 16);
+        SGX_RR_SPLITS_F32(SGX_RR_F32)
+        SGX_RR_SPLITS_MIXED(SGX_RR_F32)
     }
-    SGX_RR2(8, 5); SGX_RR2(10, 6); SGX_RR2(10, 8); SGX_RR2(10, 10); SGX_RR2(12, 10); SGX_RR2(16, 10); SGX_RR2(25, 8);
-    SGX_RR2(16, 15); SGX_RR2(20, 15); SGX_RR2(20, 16); SGX_RR2(25, 16); SGX_RR2(24, 20); SGX_RR2(25, 20); SGX_RR2(25, 24);
-    SGX_RR2(30, 24); SGX_RR2(32, 25); SGX_RR2(32, 30);
     return hipErrorInvalidConfiguration;
-#undef SGX_RR
-#undef SGX_RR2
+#undef SGX_RR_F32
+#undef SGX_RR_F64
 }
 
 hipError_t launch_lds_radix2(const StftArgs &a, int dtype, hipStream_t s) {

@@ -1,0 +1,317 @@
+// kernels_reg2d.hip — register-tiled complex transforms for the 2-D path and the generic inverse row transform, f32 / f64.
+//
+// Same construction as k_reg_radix (kernels_generic.hip): a length-N transform as two or three in-register passes (lengths
+// A, B, C from reg_split_len: powers of two, and the mixed 2-3-5 sizes) around LDS exchanges, every pass after the first
+// in place on the elements its work item owns.
+//
+//   k_c2c_reg   `tile` complex sequences of length N = A B C per workgroup, arbitrary element strides on both sides
+//               (the thread mapping of the loads / stores follows the unit stride), forward or inverse (conjugate trick),
+//               scale.  Column pass of fft2d / ifft2d (src/fft_backend.rs:674-688, :760-779) for every N with a split.
+//   k_c2r_reg   half spectrum (m + 1 bins, m = A B C) -> 2 m real samples per row: Hermitian fold
+//               Z'[k] = (X[k] + conj X[m-k]) + i conj(W_2m^k) (X[k] - conj X[m-k]), m-point inverse transform, x[2n] + i x[2n+1];
+//               DC / Nyquist bins forced real and reported (fft_backend.rs:782-793), optional synthesis window.  Inverse row
+//               pass of ifft2d / convolve_fft and the per-frame C2R of the generic inverse STFT (src/spectrogram.rs:4789-4811).
+#include <algorithm>
+#include <cstdlib>
+
+#include "reg_radix.h"
+
+namespace sgx {
+namespace {
+
+constexpr size_t kR2Budget = 72 * 1024;  // LDS per workgroup: two workgroups per CU
+size_t elem_size(int dtype) { return dtype == SGX_F64 ? 8 : 4; }
+
+template <typename T, int A_, int B_, int C_>
+__global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_c2c_reg(C2cArgs a, unsigned ltile) {
+    typedef typename PairOf<T>::type V;
+    constexpr unsigned A = A_, B = B_, C = C_, BC = B * C, N = A * BC;
+    constexpr int LA = ct_log2_ceil(A), LB = ct_log2_ceil(B);
+    constexpr bool P2 = ct_is_pow2(N);
+    constexpr unsigned RS = BC + 1, FS = (A * RS) | 1u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    V *buf = (V *)smem;  // [tile][FS]
+    const unsigned tid = threadIdx.x, tile = 1u << ltile;
+    const unsigned t = blockIdx.x % a.tiles, b = blockIdx.x / a.tiles;
+    const unsigned s0 = t * tile;
+    const unsigned ns = min(tile, a.nseq - s0);
+    const V *in = (const V *)a.in + (size_t)b * a.in_img;
+    V *out = (V *)a.out + (size_t)b * a.out_img;
+    const V *tw = (const V *)a.tw;  // W_N^k, N entries
+    const T cj = a.inverse ? T(-1) : T(1);  // inverse = conj(forward(conj x))
+    auto wrap = [](unsigned e) { return P2 ? (e & (N - 1)) : (e % N); };
+
+    // pass 1, software-pipelined: the loads of work item idx + 256 are in flight while item idx is transformed
+    auto item = [&](unsigned idx, unsigned &s, unsigned &r) {
+        if (a.in_seq_fast) { s = idx & (tile - 1); r = idx >> ltile; } else { r = idx % BC; s = idx / BC; }
+        return idx < tile * BC && s < ns;
+    };
+    auto fetch = [&](unsigned idx, V (&v)[A]) {
+        unsigned s, r;
+        if (!item(idx, s, r)) return;
+        const V *p = in + (size_t)(s0 + s) * a.in_ss + (size_t)r * a.in_is;
+        const size_t step = (size_t)BC * a.in_is;
+#pragma unroll
+        for (unsigned n1 = 0; n1 < A; ++n1) v[n1] = p[n1 * step];
+    };
+    V nxt[A];
+#pragma unroll
+    for (unsigned n1 = 0; n1 < A; ++n1) nxt[n1] = (V){T(0), T(0)};
+    fetch(tid, nxt);
+    for (unsigned idx = tid; idx < tile * BC; idx += 256) {
+        V v[A];
+#pragma unroll
+        for (unsigned n1 = 0; n1 < A; ++n1) v[n1] = nxt[n1] * (V){T(1), cj};
+        fetch(idx + 256, nxt);
+        unsigned s, r;
+        if (!item(idx, s, r)) continue;
+        inreg::MixFft<A, V>::run(v);
+        V pw2[LA];
+#pragma unroll
+        for (int j = 0; j < LA; ++j) pw2[j] = tw[wrap((1u << j) * r)];
+        V *dst = buf + (size_t)s * FS + r;
+        dst[0] = v[0];
+#pragma unroll
+        for (unsigned k1 = 1; k1 < A; ++k1) dst[k1 * RS] = inreg::cmulv(v[k1], rr_twiddle<LA>(pw2, k1));
+    }
+    __syncthreads();
+    for (unsigned idx = tid; idx < ns * A * C; idx += 256) {
+        const unsigned s = idx / (A * C), q = idx % (A * C), k1 = q / C, n3 = q % C;
+        V *row = buf + (size_t)s * FS + k1 * RS + n3;
+        V x[B];
+#pragma unroll
+        for (unsigned n2 = 0; n2 < B; ++n2) x[n2] = row[n2 * C];
+        inreg::MixFft<B, V>::run(x);
+        row[0] = x[0];
+        if constexpr (C > 1) {  // W_(BC)^(k2 n3) = W_N^(A k2 n3)
+            V q2[LB];
+#pragma unroll
+            for (int j = 0; j < LB; ++j) q2[j] = tw[wrap((A << j) * n3)];
+#pragma unroll
+            for (unsigned k2 = 1; k2 < B; ++k2) row[k2 * C] = inreg::cmulv(x[k2], rr_twiddle<LB>(q2, k2));
+        } else {
+#pragma unroll
+            for (unsigned k2 = 1; k2 < B; ++k2) row[k2] = x[k2];
+        }
+    }
+    __syncthreads();
+    if constexpr (C > 1) {
+        for (unsigned idx = tid; idx < ns * A * B; idx += 256) {
+            const unsigned s = idx / (A * B), q = idx % (A * B), k1 = q / B, k2 = q % B;
+            V *row = buf + (size_t)s * FS + k1 * RS + k2 * C;
+            V x[C];
+#pragma unroll
+            for (unsigned n3 = 0; n3 < C; ++n3) x[n3] = row[n3];
+            inreg::MixFft<C, V>::run(x);
+#pragma unroll
+            for (unsigned k3 = 0; k3 < C; ++k3) row[k3] = x[k3];
+        }
+        __syncthreads();
+    }
+    // X[k], k = k1 + A (k2 + B k3), sits at row k1, position C k2 + k3
+    const T sc = (T)a.scale;
+    for (unsigned idx = tid; idx < tile * N; idx += 256) {
+        unsigned s, k;
+        if (a.out_seq_fast) { s = idx & (tile - 1); k = idx >> ltile; } else { k = idx % N; s = idx / N; }
+        if (s >= ns) continue;
+        const unsigned q = k / A;
+        const V v = buf[(size_t)s * FS + (k % A) * RS + (q % B) * C + q / B];
+        out[(size_t)(s0 + s) * a.out_ss + (size_t)k * a.out_is] = v * (V){sc, cj * sc};
+    }
+}
+
+template <typename T, int A_, int B_, int C_>
+__global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_c2r_reg(C2rArgs a, unsigned ltile) {
+    typedef typename PairOf<T>::type V;
+    constexpr unsigned A = A_, B = B_, C = C_, BC = B * C, M = A * BC, CN = 2 * M;
+    constexpr int LA = ct_log2_ceil(A), LB = ct_log2_ceil(B);
+    constexpr bool P2 = ct_is_pow2(M);
+    constexpr unsigned RS = BC + 1, FS = (A * RS) | 1u;
+    constexpr unsigned SXS = (M + 1) | 1u;  // row stride of the staged half spectrum (odd)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned tid = threadIdx.x, tile = 1u << ltile;
+    V *sx = (V *)smem;                    // [tile][SXS] bins 0 .. M
+    V *buf = sx + (size_t)tile * SXS;     // [tile][FS]
+    const unsigned t = blockIdx.x % a.tiles, b = blockIdx.x / a.tiles;
+    const unsigned r0 = t * tile;
+    const unsigned nr = min(tile, a.nrows - r0);
+    const V *in = (const V *)a.in + (size_t)b * a.in_img;
+    T *out = (T *)a.out + (size_t)b * a.nrows * CN;
+    const V *tw = (const V *)a.tw;  // W_CN^k, CN entries
+    auto wrap = [](unsigned e) { return P2 ? (e & (CN - 1)) : (e % CN); };
+
+    // stage the half spectrum, 8 loads in flight per thread
+    for (unsigned base = 0; base < tile * (M + 1); base += 8u * 256u) {
+        V v[8];
+        unsigned rr[8], k[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned idx = base + u * 256u + tid;
+            if (a.k_fast) { k[u] = idx % (M + 1); rr[u] = idx / (M + 1); } else { rr[u] = idx & (tile - 1); k[u] = idx >> ltile; }
+            if (idx >= tile * (M + 1)) rr[u] = nr;  // past the tile: skipped below
+            v[u] = rr[u] < nr ? in[(size_t)k[u] * a.in_ks + (size_t)(r0 + rr[u]) * a.in_rs] : (V){T(0), T(0)};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (rr[u] >= nr) continue;
+            if (k[u] == 0 || k[u] == M) {  // DC / Nyquist columns forced real; realfft reports a non-zero imaginary part
+                if (a.bad_flag && v[u].y != T(0)) atomicOr(a.bad_flag, 1u);
+                v[u].y = T(0);
+            }
+            sx[(size_t)rr[u] * SXS + k[u]] = v[u];
+        }
+    }
+    __syncthreads();
+    for (unsigned idx = tid; idx < nr * BC; idx += 256) {
+        const unsigned r = idx % BC, rr = idx / BC;
+        const V *xr = sx + (size_t)rr * SXS;
+        V v[A];
+#pragma unroll
+        for (unsigned n1 = 0; n1 < A; ++n1) {
+            const unsigned k = BC * n1 + r;
+            const V Xa = xr[k], Yb = xr[M - k], w = tw[k];
+            // S = X[k] + conj X[m-k], D = X[k] - conj X[m-k], T = conj(W^k) D; the forward-transform trick wants conj(S + i T)
+            const V S = inreg::pfma(Yb, (V){T(1), T(-1)}, Xa), D = inreg::pfma(Yb, (V){T(-1), T(1)}, Xa);
+            const V Tt = inreg::cmulv(D, (V){w.x, -w.y});
+            v[n1] = inreg::pfma(inreg::swp(Tt), (V){T(-1), T(-1)}, S * (V){T(1), T(-1)});
+        }
+        inreg::MixFft<A, V>::run(v);
+        V pw2[LA];
+#pragma unroll
+        for (int j = 0; j < LA; ++j) pw2[j] = tw[wrap((2u << j) * r)];  // W_m^e = W_CN^(2e)
+        V *dst = buf + (size_t)rr * FS + r;
+        dst[0] = v[0];
+#pragma unroll
+        for (unsigned k1 = 1; k1 < A; ++k1) dst[k1 * RS] = inreg::cmulv(v[k1], rr_twiddle<LA>(pw2, k1));
+    }
+    __syncthreads();
+    for (unsigned idx = tid; idx < nr * A * C; idx += 256) {
+        const unsigned rr = idx / (A * C), q = idx % (A * C), k1 = q / C, n3 = q % C;
+        V *row = buf + (size_t)rr * FS + k1 * RS + n3;
+        V x[B];
+#pragma unroll
+        for (unsigned n2 = 0; n2 < B; ++n2) x[n2] = row[n2 * C];
+        inreg::MixFft<B, V>::run(x);
+        row[0] = x[0];
+        if constexpr (C > 1) {
+            V q2[LB];
+#pragma unroll
+            for (int j = 0; j < LB; ++j) q2[j] = tw[wrap((2u * A << j) * n3)];
+#pragma unroll
+            for (unsigned k2 = 1; k2 < B; ++k2) row[k2 * C] = inreg::cmulv(x[k2], rr_twiddle<LB>(q2, k2));
+        } else {
+#pragma unroll
+            for (unsigned k2 = 1; k2 < B; ++k2) row[k2] = x[k2];
+        }
+    }
+    __syncthreads();
+    if constexpr (C > 1) {
+        for (unsigned idx = tid; idx < nr * A * B; idx += 256) {
+            const unsigned rr = idx / (A * B), q = idx % (A * B), k1 = q / B, k2 = q % B;
+            V *row = buf + (size_t)rr * FS + k1 * RS + k2 * C;
+            V x[C];
+#pragma unroll
+            for (unsigned n3 = 0; n3 < C; ++n3) x[n3] = row[n3];
+            inreg::MixFft<C, V>::run(x);
+#pragma unroll
+            for (unsigned k3 = 0; k3 < C; ++k3) row[k3] = x[k3];
+        }
+        __syncthreads();
+    }
+    // z[n] = conj(result[n]) * scale = (x[2n], x[2n+1]); lanes over n: contiguous row stores
+    const T sc = (T)a.scale;
+    const V *win = (const V *)a.win;
+    for (unsigned idx = tid; idx < nr * M; idx += 256) {
+        const unsigned n = idx % M, rr = idx / M;
+        const unsigned q = n / A;
+        V v = buf[(size_t)rr * FS + (n % A) * RS + (q % B) * C + q / B] * (V){sc, -sc};
+        if (win) v = v * win[n];
+        *(V *)(out + (size_t)(r0 + rr) * CN + 2u * n) = v;
+    }
+}
+
+template <typename T, int A, int B, int C>
+hipError_t launch_c2c_t(const C2cArgs &a, unsigned ltile, size_t lds, hipStream_t s) {
+    if (lds > 64 * 1024) {
+        hipError_t e = set_max_dynamic_lds((const void *)k_c2c_reg<T, A, B, C>, (int)kR2Budget);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_c2c_reg<T, A, B, C>), dim3(a.tiles * a.batch), dim3(256), lds, s, a, ltile);
+    return hipGetLastError();
+}
+
+template <typename T, int A, int B, int C>
+hipError_t launch_c2r_t(const C2rArgs &a, unsigned ltile, size_t lds, hipStream_t s) {
+    if (lds > 64 * 1024) {
+        hipError_t e = set_max_dynamic_lds((const void *)k_c2r_reg<T, A, B, C>, (int)kR2Budget);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_c2r_reg<T, A, B, C>), dim3(a.tiles * a.batch), dim3(256), lds, s, a, ltile);
+    return hipGetLastError();
+}
+
+const bool kRegOff = [] { const char *v = std::getenv("SGX_GENERIC"); return v && v[0] == 'l'; }();  // SGX_GENERIC=lds
+
+}  // namespace
+
+// hipErrorNotSupported: no split for this length / layout — the caller uses the LDS-tile kernels instead
+hipError_t launch_c2c_reg(const C2cArgs &a0, int dtype, hipStream_t s) {
+    unsigned fa, fb, fc;
+    if (kRegOff || !reg_split_len(a0.n, dtype, &fa, &fb, &fc)) return hipErrorNotSupported;
+    const size_t es = elem_size(dtype);
+    if (((size_t)a0.in | (size_t)a0.out) & (2 * es - 1)) return hipErrorNotSupported;
+    const size_t fs = ((size_t)fa * (fb * fc + 1)) | 1;
+    unsigned ltile = 5;  // up to 32 sequences per workgroup; no more than the job has
+    while (ltile > 0 && ((size_t)(1u << ltile) * fs * 2 * es > kR2Budget || (1u << (ltile - 1)) >= a0.nseq)) --ltile;
+    const size_t lds = (size_t)(1u << ltile) * fs * 2 * es;
+    if (lds > kR2Budget) return hipErrorNotSupported;
+    C2cArgs a = a0;
+    a.tile = 1u << ltile;
+    a.tiles = (a.nseq + a.tile - 1) / a.tile;
+    const unsigned long long g = (unsigned long long)a.tiles * a.batch;
+    if (g == 0 || g >= 0x7fffffffull) return hipErrorInvalidConfiguration;
+#define SGX_C2C_F32(A, B, C) if (fa == A && fb == B && fc == C) return launch_c2c_t<float, A, B, C>(a, ltile, lds, s);
+#define SGX_C2C_F64(A, B, C) if (fa == A && fb == B && fc == C) return launch_c2c_t<double, A, B, C>(a, ltile, lds, s);
+    if (dtype == SGX_F64) {
+        SGX_RR_SPLITS_F64(SGX_C2C_F64)
+        SGX_RR_SPLITS_MIXED(SGX_C2C_F64)
+    } else {
+        SGX_RR_SPLITS_F32(SGX_C2C_F32)
+        SGX_RR_SPLITS_MIXED(SGX_C2C_F32)
+    }
+#undef SGX_C2C_F32
+#undef SGX_C2C_F64
+    return hipErrorNotSupported;
+}
+
+hipError_t launch_c2r_reg(const C2rArgs &a0, int dtype, hipStream_t s) {
+    unsigned fa, fb, fc;
+    if (kRegOff || (a0.ncols & 1u) || !reg_split_len(a0.ncols / 2, dtype, &fa, &fb, &fc)) return hipErrorNotSupported;
+    const size_t es = elem_size(dtype);
+    if (((size_t)a0.in | (size_t)a0.out | (size_t)a0.win) & (2 * es - 1)) return hipErrorNotSupported;
+    const size_t m = a0.ncols / 2;
+    const size_t per = ((((size_t)fa * (fb * fc + 1)) | 1) + ((m + 1) | 1)) * 2 * es;
+    unsigned ltile = 5;
+    while (ltile > 0 && ((size_t)(1u << ltile) * per > kR2Budget || (1u << (ltile - 1)) >= a0.nrows)) --ltile;
+    const size_t lds = (size_t)(1u << ltile) * per;
+    if (lds > kR2Budget) return hipErrorNotSupported;
+    C2rArgs a = a0;
+    a.tile = 1u << ltile;
+    a.tiles = (a.nrows + a.tile - 1) / a.tile;
+    const unsigned long long g = (unsigned long long)a.tiles * a.batch;
+    if (g == 0 || g >= 0x7fffffffull) return hipErrorInvalidConfiguration;
+#define SGX_C2R_F32(A, B, C) if (fa == A && fb == B && fc == C) return launch_c2r_t<float, A, B, C>(a, ltile, lds, s);
+#define SGX_C2R_F64(A, B, C) if (fa == A && fb == B && fc == C) return launch_c2r_t<double, A, B, C>(a, ltile, lds, s);
+    if (dtype == SGX_F64) {
+        SGX_RR_SPLITS_F64(SGX_C2R_F64)
+        SGX_RR_SPLITS_MIXED(SGX_C2R_F64)
+    } else {
+        SGX_RR_SPLITS_F32(SGX_C2R_F32)
+        SGX_RR_SPLITS_MIXED(SGX_C2R_F32)
+    }
+#undef SGX_C2R_F32
+#undef SGX_C2R_F64
+    return hipErrorNotSupported;
+}
+
+}  // namespace sgx

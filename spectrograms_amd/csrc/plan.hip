@@ -716,7 +716,7 @@ sgx_status launch_c2r_frames(sgx_plan *pl, const void *spec, void *frames, size_
     c.scale = pl->dtype == SGX_F64 ? 1.0 / double(n) : double(1.0f / float(n));  // T::one() / T::from_usize(n_fft)
     c.win = win;
     c.bad_flag = (unsigned *)pl->d_flag;
-    SGX_HIP(pl, launch_c2r_rows(c, pl->dtype, s));
+    SGX_HIP(pl, launch_c2r_any(c, pl->dtype, s));
     return SGX_OK;
 }
 

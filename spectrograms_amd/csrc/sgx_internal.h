@@ -118,6 +118,18 @@ hipError_t launch_istft_ola(const void *frames, const void *win, void *out, unsi
                             unsigned long long start, unsigned long long out_len, unsigned batch, int dtype, hipStream_t s);
 hipError_t launch_c2c_tile(const C2cArgs &a, int dtype, hipStream_t s);
 hipError_t launch_c2r_rows(const C2rArgs &a, int dtype, hipStream_t s);
+// register-tiled versions (kernels_reg2d.hip); they pick their own tile.  hipErrorNotSupported: no pass split for this length
+// or layout — use the LDS-tile kernels above.
+hipError_t launch_c2c_reg(const C2cArgs &a, int dtype, hipStream_t s);
+hipError_t launch_c2r_reg(const C2rArgs &a, int dtype, hipStream_t s);
+inline hipError_t launch_c2c_any(const C2cArgs &a, int dtype, hipStream_t s) {
+    const hipError_t e = launch_c2c_reg(a, dtype, s);
+    return e == hipErrorNotSupported ? launch_c2c_tile(a, dtype, s) : e;
+}
+inline hipError_t launch_c2r_any(const C2rArgs &a, int dtype, hipStream_t s) {
+    const hipError_t e = launch_c2r_reg(a, dtype, s);
+    return e == hipErrorNotSupported ? launch_c2r_rows(a, dtype, s) : e;
+}
 // tuned f32 1024-point C2C, 16 sequences per workgroup; tw1c = W_1024^(k1*n2), [32][32] complex f32; output must be
 // sequence-contiguous for coalesced stores (a.out_ss == 1)
 hipError_t launch_c2c1024(const C2cArgs &a, const void *tw1c, hipStream_t s);

@@ -16,7 +16,7 @@ import spectrograms_amd as sg
 def main():
     batch = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-    R = C = 1024
+    R = C = int(os.environ.get("SIDE", 1024))
     rng = np.random.default_rng(7)
     r, c = np.meshgrid(np.arange(R), np.arange(C), indexing="ij")
     base = (np.sin(0.01 * r) + np.cos(0.02 * c)).astype(np.float32)
@@ -40,7 +40,7 @@ def main():
         ms = e0.elapsed_time(e1) / iters
         res[name] = {"ms_per_batch": ms, "images_per_s": batch / (ms * 1e-3), "algorithmic_GBps": batch * bytes_per_img / (ms * 1e-3) / 1e9,
                      "frac_of_8TBps": batch * bytes_per_img / (ms * 1e-3) / 8e12}
-    print(json.dumps({"workload": f"configs[4]: {batch} x 1024x1024 f32", **res}))
+    print(json.dumps({"workload": f"configs[4]-like: {batch} x {R}x{C} f32", **res}))
 
 
 if __name__ == "__main__":

@@ -9,12 +9,15 @@ from tests import helpers as H
 
 B = int(os.environ.get("B", 256))
 x = torch.from_numpy(H.cfg2_batch(B)).cuda()
-params = sg.SpectrogramParams(sg.StftParams(1024, 256, sg.WindowType.hanning, True), 16000.0)
-plan = sg.Plan(params, _ffi.AMP_COMPLEX, None, None, "float32")
+if os.environ.get("DTYPE", "float32") == "float64":
+    x = x.double()
+N_FFT = int(os.environ.get("N_FFT", 1024)); HOP = int(os.environ.get("HOP", N_FFT // 4)); DT = os.environ.get("DTYPE", "float32")
+params = sg.SpectrogramParams(sg.StftParams(N_FFT, HOP, sg.WindowType.hanning, True), 16000.0)
+plan = sg.Plan(params, _ffi.AMP_COMPLEX, None, None, DT)
 S = plan.compute_batch(x).contiguous()
 y = plan.istft_batch(S)
 torch.cuda.synchronize()
-err = float((y[:, 512:159000] - x[:, 512:159000]).abs().max())
+err = float((y[:, 1024:159000] - x[:, 1024:159000]).abs().max())
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 iters = 20
 for _ in range(3):
@@ -26,6 +29,7 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / iters
 frames = B * S.shape[2]
-alg = frames * 513 * 8 + y.numel() * 4
-print(json.dumps({"op": "istft", "batch": B, "ms": ms, "frames_per_s": frames / ms * 1e3, "algorithmic_GBps": alg / ms / 1e6,
+esz = 4 if DT == "float32" else 8
+alg = frames * (N_FFT // 2 + 1) * 2 * esz + y.numel() * esz
+print(json.dumps({"op": "istft", "n_fft": N_FFT, "hop": HOP, "dtype": DT, "batch": B, "ms": ms, "frames_per_s": frames / ms * 1e3, "algorithmic_GBps": alg / ms / 1e6,
                   "hbm_frac": alg / ms / 1e6 / 8000, "roundtrip_max_err": err}))
