@@ -73,7 +73,10 @@ sgx_status upload_tw(sgx_fft2d *p, void **dst, size_t n) {
 }
 
 // device pointers in, device pointers out
-sgx_status forward_dev(sgx_fft2d *p, const void *img, size_t batch, void *spec, hipStream_t s) {
+// `mul` (optional): kernel spectrum / real mask [R][Cb] multiplied into the result (convolve_fft, filters) — fused into the
+// column kernel's store where the register-tiled kernel runs, a k_pointwise launch otherwise
+sgx_status forward_dev(sgx_fft2d *p, const void *img, size_t batch, void *spec, hipStream_t s, const void *mul = nullptr,
+                       int mul_real = 0) {
     const size_t R = p->nrows, C = p->ncols, Cb = p->cb;
     sgx_status st = grow2(p, &p->d_inter, &p->inter_bytes, batch * Cb * R * 2 * p->elem);
     if (st != SGX_OK) return st;
@@ -87,12 +90,22 @@ sgx_status forward_dev(sgx_fft2d *p, const void *img, size_t batch, void *spec, 
     a.in_ss = R; a.in_is = 1; a.out_ss = 1; a.out_is = Cb;
     a.tile = p->tile_r; a.tiles = unsigned((Cb + a.tile - 1) / a.tile);
     a.tw = p->d_tw_r; a.inverse = 0; a.in_seq_fast = 0; a.out_seq_fast = 1; a.scale = 1.0;
+    bool fused_mul = false;
     if (p->d_tw1c) {
         a.tile = 16; a.tiles = unsigned((Cb + 15) / 16);
         F2_HIP(p, launch_c2c1024(a, p->d_tw1c, s));
     } else {
-        F2_HIP(p, launch_c2c_any(a, p->dtype, s));
+        a.mul = mul; a.mul_ks = Cb; a.mul_real = mul_real;
+        const hipError_t e = launch_c2c_reg(a, p->dtype, s);
+        if (e == hipErrorNotSupported) {
+            a.mul = nullptr;
+            F2_HIP(p, launch_c2c_tile(a, p->dtype, s));
+        } else {
+            F2_HIP(p, e);
+            fused_mul = true;
+        }
     }
+    if (mul && !fused_mul) F2_HIP(p, launch_pointwise(spec, mul, spec, batch * R * Cb, R * Cb, mul_real, p->dtype, s));
     return SGX_OK;
 }
 
@@ -344,8 +357,7 @@ sgx_status sgx_fft2d_convolve(sgx_fft2d *p, const void *images, size_t batch, co
         if (use_fused(p)) return fused_product_dev(p, i, batch, p->d_kspec, false, o, s);
         sgx_status s2 = grow2(p, &p->d_spec, &p->spec_bytes, batch * R * Cb * 2 * p->elem);
         if (s2 != SGX_OK) return s2;
-        if ((s2 = forward_dev(p, i, batch, p->d_spec, s)) != SGX_OK) return s2;
-        F2_HIP(p, launch_pointwise(p->d_spec, p->d_kspec, p->d_spec, batch * R * Cb, R * Cb, 0, p->dtype, s));
+        if ((s2 = forward_dev(p, i, batch, p->d_spec, s, p->d_kspec, 0)) != SGX_OK) return s2;
         return inverse_dev(p, p->d_spec, batch, o, s);
     });
 }
@@ -385,8 +397,7 @@ sgx_status sgx_fft2d_filter(sgx_fft2d *p, const void *images, size_t batch, int3
         if (use_fused(p)) return fused_product_dev(p, i, batch, p->d_mask, true, o, s);
         sgx_status s2 = grow2(p, &p->d_spec, &p->spec_bytes, batch * R * Cb * 2 * p->elem);
         if (s2 != SGX_OK) return s2;
-        if ((s2 = forward_dev(p, i, batch, p->d_spec, s)) != SGX_OK) return s2;
-        F2_HIP(p, launch_pointwise(p->d_spec, p->d_mask, p->d_spec, batch * R * Cb, R * Cb, 1, p->dtype, s));
+        if ((s2 = forward_dev(p, i, batch, p->d_spec, s, p->d_mask, 1)) != SGX_OK) return s2;
         return inverse_dev(p, p->d_spec, batch, o, s);
     });
 }

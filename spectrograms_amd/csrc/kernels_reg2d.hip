@@ -115,8 +115,18 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_c2c_reg(C2
         if (a.out_seq_fast) { s = idx & (tile - 1); k = idx >> ltile; } else { k = idx % N; s = idx / N; }
         if (s >= ns) continue;
         const unsigned q = k / A;
-        const V v = buf[(size_t)s * FS + (k % A) * RS + (q % B) * C + q / B];
-        out[(size_t)(s0 + s) * a.out_ss + (size_t)k * a.out_is] = v * (V){sc, cj * sc};
+        V v = buf[(size_t)s * FS + (k % A) * RS + (q % B) * C + q / B] * (V){sc, cj * sc};
+        if (a.mul) {  // fused spectrum product (uniform branch)
+            const size_t mi = (size_t)k * a.mul_ks + (s0 + s);
+            if (a.mul_real) {
+                const T mk = ((const T *)a.mul)[mi];
+                v = v * (V){mk, mk};
+            } else {
+                const V y = ((const V *)a.mul)[mi];  // (a.re b.re - a.im b.im, a.re b.im + a.im b.re), as k_pointwise
+                v = (V){v.x * y.x - v.y * y.y, v.x * y.y + v.y * y.x};
+            }
+        }
+        out[(size_t)(s0 + s) * a.out_ss + (size_t)k * a.out_is] = v;
     }
 }
 

@@ -96,6 +96,11 @@ struct C2cArgs {
     int inverse;
     int in_seq_fast, out_seq_fast;  // which of (sequence, index) is the unit-stride side: drives the thread mapping
     double scale;
+    // optional product fused into the store of the register-tiled kernel (convolve_fft / filters): output element k of
+    // sequence q is multiplied by mul[k * mul_ks + q] — complex (mul_real == 0) or real mask (mul_real == 1)
+    const void *mul;
+    unsigned long long mul_ks;
+    int mul_real;
 };
 struct C2rArgs {
     const void *in;  // half spectrum, element (row r, col k) at in[b*in_img + k*in_ks + r*in_rs]
