@@ -396,3 +396,37 @@ def test_full_size_register_tiled_kernel(cfg2_x, n_fft, hop, dtype):
         lhs = 2.0 * got[b].astype(np.float64).sum(axis=0) - got[b, 0] - got[b, n_fft // 2]
         rhs = float(n_fft) * (fr ** 2).sum(axis=1)
         assert np.max(np.abs(lhs - rhs)) <= (1e-4 if dtype == "float32" else 1e-10) * rhs.max()
+
+
+def test_fuzz_shapes():
+    """Seeded random sweep over (n_fft, hop, centre, window, length, dtype, output) — every kernel family (tuned, register-tiled
+    power-of-two / mixed radix, LDS radix-2, two-factor, direct) against the oracle, including hops that do not divide n_fft,
+    odd hops (unaligned frames), signals shorter than a frame and lengths that leave partial tiles."""
+    rng = np.random.default_rng(20260)
+    pool = [4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048] + MIXED + [6, 10, 30, 50, 100, 250, 330, 441, 97, 127]
+    seen = set()
+    for case in range(90):
+        n_fft = int(pool[rng.integers(len(pool))])
+        hop = int(rng.integers(1, n_fft + 1))
+        centre = bool(rng.integers(2))
+        window = sorted(WINDOWS)[rng.integers(len(WINDOWS))]
+        dtype = ["float32", "float64"][rng.integers(2)]
+        kind = rng.integers(4)
+        n = int(rng.integers(1, 6 * n_fft + 50))
+        if not centre and n < n_fft:
+            n = n_fft + int(rng.integers(0, 3 * n_fft))
+        kw = dict(n_fft=n_fft, hop=hop, centre=centre, window=window, dtype=dtype)
+        if kind == 0:
+            kw["amp"] = "complex"
+        elif kind == 1:
+            kw["amp"] = "power"
+        elif kind == 2:
+            kw.update(amp="db", floor=-80.0)
+        else:
+            if n_fft < 32:
+                kw["amp"] = "magnitude"
+            else:
+                kw.update(n_mels=int(rng.integers(4, 41)), fmin=0.0, fmax=8000.0, amp="power")
+        plan, _ = run_case(n=n, batch=int(rng.integers(1, 4)), seed=case, **kw)
+        seen.add(plan.kernel_name)
+    assert {"reg_radix", "two_factor_dft", "direct_dft", "lds_radix2"} <= seen, seen
