@@ -188,3 +188,39 @@ def test_gpu_single_frame_helpers(dtype, tol):
     assert abs(dc[0] - 3.0) < 1e-6 and sg.compute_magnitude_spectrum(np.array([1.0, 2.0, 3.0]), 8, sg.WindowType.hanning).shape == (5,)
     with pytest.raises(sg.InvalidInputError, match="exceeds FFT size"):
         sg.compute_fft(np.zeros(10), 8)
+
+
+@pytest.mark.gpu
+def test_gpu_istft_fuzz_shapes():
+    """Seeded random sweep of the inverse path over every row kernel (fused n_fft = 1024, register-tiled power-of-two and mixed
+    radix, LDS radix-2, direct) against the oracle: hops that do not divide n_fft, short inputs, both dtypes."""
+    rng = np.random.default_rng(77)
+    pool = [8, 16, 32, 64, 128, 256, 512, 1024, 2048, 80, 160, 200, 240, 320, 400, 480, 640, 800, 960, 1200, 30, 100, 441, 97]
+    wins = ["hanning", "hamming", "blackman", "rectangular"]
+    for case in range(40):
+        n_fft = int(pool[rng.integers(len(pool))])
+        hop = int(rng.integers(max(1, n_fft // 8), n_fft + 1))
+        centre = bool(rng.integers(2))
+        window = wins[rng.integers(len(wins))]
+        dtype = ["float32", "float64"][rng.integers(2)]
+        rdt, cdt = (np.float32, np.complex64) if dtype == "float32" else (np.float64, np.complex128)
+        n = int(rng.integers(n_fft, 8 * n_fft + 100))
+        x = rng.standard_normal((int(rng.integers(1, 4)), n)).astype(rdt)
+        params = sg.SpectrogramParams(sg.StftParams(n_fft, hop, getattr(sg.WindowType, window), centre), 16000.0)
+        plan = sg.Plan(params, _ffi.AMP_COMPLEX, None, None, dtype)
+        S = np.stack([orc.stft(orc.Params(n_fft=n_fft, hop=hop, centre=centre, window=window), r) for r in x]).astype(cdt)
+        got = plan.istft_batch(S)
+        ref = np.stack([orc.istft(s, n_fft, hop, window, centre) for s in S])
+        assert got.shape == ref.shape, (n_fft, hop, centre, window, dtype)
+        # the division by sum(w^2) is ill-conditioned where the windows barely overlap (hop close to n_fft with a tapered
+        # window): weigh the error by min(1, sum w^2) there
+        w = orc.make_window(window, n_fft)
+        nf = S.shape[2]
+        nrm = np.zeros((nf - 1) * hop + n_fft)
+        for f in range(nf):
+            nrm[f * hop:f * hop + n_fft] += w * w
+        pad = n_fft // 2 if centre else 0
+        nrm = nrm[pad:pad + ref.shape[1]] if ref.shape[1] != len(nrm) else nrm
+        wgt = np.minimum(1.0, nrm)[None, :]
+        tol = 1e-10 if dtype == "float64" else 3e-5
+        assert np.max(np.abs(got - ref) * wgt) < tol * max(1.0, np.max(np.abs(ref) * wgt)), (n_fft, hop, centre, window, dtype)
