@@ -189,3 +189,32 @@ def test_gpu_planner_spectrum_helpers():
     S = pl.fft2d(x)
     assert S.dtype == np.complex64
     assert np.allclose(pl.power_spectrum_2d(x), np.abs(S) ** 2, rtol=1e-6) and np.allclose(pl.magnitude_spectrum_2d(x), np.abs(S), rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_gpu_fft2d_fuzz_shapes():
+    """Seeded random sweep over image shapes — every column / row kernel family (tuned 1024, register-tiled power-of-two and
+    mixed-radix lengths, LDS radix-2, direct) for fft2d, ifft2d, convolve_fft and a filter, both dtypes."""
+    rng = np.random.default_rng(4242)
+    rows = [16, 32, 64, 128, 256, 512, 40, 60, 80, 100, 120, 200, 240, 480, 600, 12, 30, 97, 1024]
+    cols = [32, 64, 128, 256, 512, 80, 160, 200, 240, 320, 400, 480, 640, 30, 50, 99, 101, 1024]
+    for case in range(24):
+        shape = (int(rows[rng.integers(len(rows))]), int(cols[rng.integers(len(cols))]))
+        dtype = ["float32", "float64"][rng.integers(2)]
+        npdt = np.float32 if dtype == "float32" else np.float64
+        x = img(shape, 100 + case, npdt)
+        S = sg.fft2d(x, dtype=dtype)
+        ref = orc.fft2d(x.astype(np.float64))
+        tol = 1e-10 if dtype == "float64" else 3e-5
+        assert np.max(np.abs(S - ref)) <= tol * max(1.0, np.max(np.abs(ref))), (shape, dtype)
+        y = sg.ifft2d(S, shape[1], dtype=dtype)
+        assert np.max(np.abs(y - x)) <= (1e-10 if dtype == "float64" else 2e-5) * max(1.0, np.max(np.abs(x))), (shape, dtype)
+        ksz = int([3, 5, 9][rng.integers(3)])
+        if ksz <= min(shape):
+            k = sg.gaussian_kernel_2d(ksz, 1.5, dtype=dtype)
+            got = sg.convolve_fft(x, k, dtype=dtype)
+            refc = orc.convolve_fft(x.astype(np.float64), k.astype(np.float64))
+            assert np.max(np.abs(got - refc)) <= (1e-9 if dtype == "float64" else 3e-5) * max(1.0, np.max(np.abs(refc))), (shape, dtype)
+        got = sg.lowpass_filter(x, 0.4, dtype=dtype)
+        reff = orc.filter2d(x.astype(np.float64), 0, 0.4)
+        assert np.max(np.abs(got - reff)) <= (1e-9 if dtype == "float64" else 3e-5) * max(1.0, np.max(np.abs(reff))), (shape, dtype)
