@@ -334,8 +334,14 @@ __device__ unsigned long long g_stamps[32];
 // ahead), staged in LDS (xs, overlaying this half's ex) and re-read per frame from there: a per-lane float2 load costs the
 // CU's memory pipe ~17 cycles per wave-instruction (4 x 128-byte segments; tools/ubench/vmem_issue.hip) and every line is
 // requested ~4 times because frames overlap by 75 %.  ROUNDS == 0 keeps the direct loads (any even hop, 8-byte alignment).
-template <int MODE, int AMP, int HALVES, int ROUNDS>
+// WIDE (HALVES = 2, linear / complex outputs): pass 2 runs across the whole workgroup — lane (jq = 0..1, f = 0..31) of wave
+// w = 0..7 owns job w + 8 jq of frame f of the PAIR of tiles (frames 16..31 live in the second half's ex buffer, which
+// directly follows the first: kExBytes = 16 kFS).  The two halves own neighbouring tiles, so the 32 lanes of a job hold one
+// bin of 32 consecutive frames: a store instruction covers 2 rows x 128 bytes instead of 4 rows x 64 bytes (the CU's
+// address path charges per segment, tools/ubench/vmem_issue.hip) and L2 receives whole-line-sized runs.
+template <int MODE, int AMP, int HALVES, int ROUNDS, bool WIDE = false>
 __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned per_xcd, unsigned total, unsigned slots) {
+    static_assert(!WIDE || (HALVES == 2 && MODE != OUT_MEL), "wide pass 2 needs both halves and a per-bin output");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     const unsigned half = HALVES == 2 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0u;
     const unsigned tid = threadIdx.x & 255u;
@@ -366,8 +372,11 @@ __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned
     unsigned lead = lo + slot * HALVES;  // the first half's tile: uniform loop control for the whole workgroup
 
     const unsigned p1f = tid >> 4, n2 = tid & 15u;  // pass-1 identity
-    const unsigned lane = tid & 63u, wv_ = tid >> 6, jq = lane >> 4, p2f = lane & 15u;  // pass-2 identity
-    const unsigned j = wv_ + 4u * jq;
+    // pass-2 identity
+    const unsigned lane = tid & 63u;
+    const unsigned wv_ = WIDE ? threadIdx.x >> 6 : tid >> 6;
+    const unsigned jq = WIDE ? lane >> 5 : lane >> 4, p2f = WIDE ? lane & 31u : lane & 15u;
+    const unsigned j = WIDE ? wv_ + 8u * jq : wv_ + 4u * jq;
     const unsigned ra = j, rb = j == 0 ? 16u : 32u - j;
     const float eps = (float)a.eps;
     const JobOfs jo = job_offsets(j, a.n_frames);
@@ -500,10 +509,29 @@ __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned
         // tile's loads (see the prologue).  A lane whose frame does not exist (last tile of a signal) mirrors the tile's last
         // frame, an idle second half (odd tile count) mirrors the first half's tile: same values to the same addresses.
         constexpr bool ALLSTORE = MODE != OUT_MEL;
-        const unsigned p2f_eff = ALLSTORE ? min(p2f, nf - 1u) : p2f;
-        const unsigned char *ex_src = (ALLSTORE && !active) ? smem_all : smem;
+        // WIDE: this lane's frame belongs to the first half's tile (`lead`) or, for p2f >= 16, to the second half's (`lead + 1`,
+        // if it exists — otherwise the lane mirrors the first tile).  All of it is two uniform decodes and a per-lane select.
+        unsigned p2b = b, p2ofs, p2ex;
+        if constexpr (WIDE) {
+            const unsigned w1 = lead + 1u < hi ? lead + 1u : lead;
+            const unsigned b0 = lead / a.tiles, f00 = (lead - b0 * a.tiles) * 16u;
+            const unsigned b1 = w1 / a.tiles, f01 = (w1 - b1 * a.tiles) * 16u;
+            const unsigned nf0 = min(16u, a.n_frames - f00), nf1 = min(16u, a.n_frames - f01);
+            const bool second = p2f >= 16u && w1 != lead;
+            const unsigned fle = min(p2f & 15u, (second ? nf1 : nf0) - 1u);
+            p2ex = (second ? 16u : 0u) + fle;
+            // one uniform base (signal b0) for the whole workgroup; a second tile in the next signal is one signal further
+            // (513 n_frames elements: the host guarantees 2 * 513 * n_frames * 8 < 2^32)
+            p2ofs = (second ? f01 : f00) + fle + ((second && b1 != b0) ? 513u * a.n_frames : 0u);
+            p2b = b0;
+        } else {
+            const unsigned p2f_eff = ALLSTORE ? min(p2f, nf - 1u) : p2f;
+            p2ex = p2f_eff;
+            p2ofs = f0 + p2f_eff;
+        }
+        const unsigned char *ex_src = WIDE ? smem_all : (ALLSTORE && !active) ? smem_all : smem;
         v2f A[16], B[16];
-        read_rows(ex_src + p2f_eff * kFS, ra, rb, A, B);
+        read_rows(ex_src + p2ex * kFS, ra, rb, A, B);
         SGX_STAMP(4);
         __syncthreads();  // ex consumed: the next pass 1 (or the pw overlay) may overwrite it
         SGX_STAMP(5);
@@ -518,7 +546,7 @@ __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned
 #endif
                 return i < 8 ? t2[(j == 0 ? 16u : j) * kTw2Stride + i] : t2[j == 0 ? (unsigned)(i - 8) : j * kTw2Stride + i];
             };
-            pass2_compute<MODE, AMP>(a, A, B, b, f0, p2f_eff, j, eps, tw, jo, (float *)smem + p2f * kPS);
+            pass2_compute<MODE, AMP>(a, A, B, p2b, p2ofs, 0u, j, eps, tw, jo, (float *)smem + p2f * kPS);
         }
         if constexpr (MODE == OUT_MEL) {
             __syncthreads();
@@ -759,15 +787,28 @@ hipError_t launch_variant(const StftArgs &a, hipStream_t s) {
         } else {
             const unsigned pairs = (per_xcd + 1) / 2;
             const unsigned slots = pairs < 32u ? pairs : 32u;  // one 512-thread workgroup per CU
+            // pass 2 across both halves (32-frame rows per store instruction) for the per-bin outputs; SGX_WIDE=0 keeps the
+            // per-half mapping for A/B runs
+            static const bool want_wide = [] {
+                const char *v = getenv("SGX_WIDE");
+                return !(v && v[0] == '0');
+            }();
+            constexpr bool CAN_WIDE = MODE != OUT_MEL;
+            auto go = [&](auto kernel) -> hipError_t {
+                static bool done = false;
+                hipError_t e2 = set_lds_once(kernel, lds + kExBytes, done);
+                if (e2 != hipSuccess) return e2;
+                hipLaunchKernelGGL(kernel, dim3(slots * 8), dim3(512), lds + kExBytes, s, a, per_xcd, total, slots);
+                return hipSuccess;
+            };
             if (stage5) {
-                static bool done = false;
-                if ((e = set_lds_once(k_r32x16<MODE, AMP, 2, 5>, lds + kExBytes, done)) != hipSuccess) return e;
-                hipLaunchKernelGGL((k_r32x16<MODE, AMP, 2, 5>), dim3(slots * 8), dim3(512), lds + kExBytes, s, a, per_xcd, total, slots);
+                if (CAN_WIDE && want_wide) e = go(k_r32x16<MODE, AMP, 2, 5, CAN_WIDE>);
+                else e = go(k_r32x16<MODE, AMP, 2, 5, false>);
             } else {
-                static bool done = false;
-                if ((e = set_lds_once(k_r32x16<MODE, AMP, 2, 0>, lds + kExBytes, done)) != hipSuccess) return e;
-                hipLaunchKernelGGL((k_r32x16<MODE, AMP, 2, 0>), dim3(slots * 8), dim3(512), lds + kExBytes, s, a, per_xcd, total, slots);
+                if (CAN_WIDE && want_wide) e = go(k_r32x16<MODE, AMP, 2, 0, CAN_WIDE>);
+                else e = go(k_r32x16<MODE, AMP, 2, 0, false>);
             }
+            if (e != hipSuccess) return e;
         }
     }
     return hipGetLastError();
