@@ -53,7 +53,7 @@ constexpr int kTw2Bytes = 17 * 17 * 16;  // float4 tw2[17][17] = (wr, wi, wi, -w
 constexpr int kWinOff = kExBytes;
 constexpr int kTw2Off = kWinOff + 4096;
 constexpr int kMelOff = kTw2Off + kTw2Bytes;   // padded Mel bank (Mel modes): w4[chunks] (float4) | pptr[n_mels+1] | pcol[n_mels]
-constexpr int kMelMaxRows = 160, kMelMaxChunks = 512;
+constexpr int kMelMaxRows = 160, kMelMaxChunks = 376;  // 376: kLdsMel = 81824 B, so that two independent workgroups would still fit 160 KiB
 constexpr int kMelBytes = kMelMaxChunks * 16 + (2 * kMelMaxRows + 1) * 4 + 12;  // 9488
 constexpr int kLds = kTw2Off + kTw2Bytes;      // 74512 B -> two workgroups per CU (160 KiB LDS)
 constexpr int kLdsMel = kMelOff + kMelBytes;   // 82208 B -> still two per CU
@@ -175,6 +175,10 @@ __device__ __forceinline__ void pass2_compute(const StftArgs &a, v2f (&A)[16], v
     // pair (P, Q) = (Z[k], Z[512-k]), W = W_1024^k given as (wr, wi, wi, -wr):
     //   E = (P.x+Q.x, P.y-Q.y), D = (P.x-Q.x, P.y+Q.y) = (-O.y, O.x), T = W O, X[k] = E + T, X[512-k] = conj(E - T)
     auto split = [&](unsigned offa, unsigned offb, unsigned k, v2f P, v2f Q, v2f w) {
+#ifdef SGX_ABL_NOSPLIT
+        asm volatile("" ::"v"(P), "v"(Q));
+        return;
+#endif
         const v2f E = pfma(Q, (v2f){1.f, -1.f}, P);
         const v2f D = pfma(Q, (v2f){-1.f, 1.f}, P);
         // T = W O with O = (D.y, -D.x): (wr D.y + wi D.x, wi D.y - wr D.x) — two packed ops from the (wr, wi) pair alone
@@ -218,15 +222,24 @@ __device__ __forceinline__ void mel_tile(const StftArgs &a, const float *pwall, 
 // Same reduction with the 4-wide padded band table resident in LDS: 16-byte reads of weights and powers.  The padding
 // weights are +0, and w*p = +0 added to a non-negative partial sum leaves it unchanged, so the result is bit-identical
 // to the sequential ascending-bin accumulation of the reference (spectrogram.rs:102-117; unfused multiply-add).
+// Lane -> (band, frame) map: ds_read_b128 is served in four fixed 16-lane groups, {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and
+// the same + 32 (MI355X LDS), and only lanes of one group conflict.  Each group gets ONE band and all 16 frames: its weight
+// read is a broadcast and its power reads fall on 16 different 16-byte slots (pw rows are 516 floats = 129 slots apart)
+// whatever the band's first column — with frames on the low lane bits two bands shared a group and collided wherever their
+// column offsets differed.
 template <int AMP>
 __device__ __forceinline__ void mel_tile_lds(const StftArgs &a, const float *pwall, const v4f *lw4, const unsigned *lptr,
                                              const unsigned *lcol, unsigned b, unsigned f0, unsigned nf, float eps,
                                              unsigned t, unsigned nthreads) {
     float *o = (float *)a.out + ((size_t)b * a.n_out) * a.n_frames + f0;
-    for (unsigned idx = t; idx < 16u * a.n_mels; idx += nthreads) {
-        const unsigned ff = idx & 15u, mm = idx >> 4;
+    const unsigned l5 = t & 31u;
+    const bool g0 = l5 < 4u || (l5 >= 12u && l5 < 16u) || (l5 >= 20u && l5 < 28u);
+    const unsigned ff = g0 ? (l5 < 4u ? l5 : l5 < 16u ? l5 - 8u : l5 - 12u) : (l5 < 12u ? l5 - 4u : l5 < 20u ? l5 - 8u : l5 - 16u);
+    const unsigned mloc = (t >> 6) * 4u + ((t >> 5) & 1u) * 2u + (g0 ? 0u : 1u);  // band inside a block of nthreads / 16
+    const float *prow = pwall + ff * kPS;
+    for (unsigned mm = mloc; mm < a.n_mels; mm += nthreads >> 4) {
         const unsigned c0 = lptr[mm], c1 = lptr[mm + 1];
-        const v4f *p4 = (const v4f *)(pwall + ff * kPS + lcol[mm]);
+        const v4f *p4 = (const v4f *)(prow + lcol[mm]);
         float acc = 0.0f;
         for (unsigned c = c0; c < c1; ++c) {
             const v4f w = lw4[c], p = p4[c - c0];
@@ -340,8 +353,13 @@ __device__ unsigned long long g_stamps[32];
 // bin of 32 consecutive frames: a store instruction covers 2 rows x 128 bytes instead of 4 rows x 64 bytes (the CU's
 // address path charges per segment, tools/ubench/vmem_issue.hip) and L2 receives whole-line-sized runs.
 template <int MODE, int AMP, int HALVES, int ROUNDS, bool WIDE = false>
-__global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned per_xcd, unsigned total, unsigned slots) {
+__global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned per_xcd, unsigned total, unsigned slots, unsigned skew) {
     static_assert(!WIDE || (HALVES == 2 && MODE != OUT_MEL), "wide pass 2 needs both halves and a per-bin output");
+#ifdef SGX_LATEBAR  // experiment (measured equal or 1 % slower): the barrier that frees ex moved behind pass 2
+    constexpr bool LATEBAR = MODE != OUT_MEL;  // Mel-type outputs overlay |X|^2 on ex during pass 2: they need the barrier early
+#else
+    constexpr bool LATEBAR = false;
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     const unsigned half = HALVES == 2 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0u;
     const unsigned tid = threadIdx.x & 255u;
@@ -390,11 +408,19 @@ __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned
     auto load_tile = [&](unsigned w) {
         const unsigned b = w / a.tiles, tile = w - b * a.tiles;
         const unsigned f0 = tile * 16u;
+#ifdef SGX_ABL_L2LOAD  // timing experiment: every load hits L2 (4 signals = 2.5 MB)
+        const float *xb = (const float *)a.x + (size_t)(b & 3u) * a.sample_stride;
+#else
         const float *xb = (const float *)a.x + (size_t)b * a.sample_stride;
+#endif
         const long long tile_lo = (long long)f0 * a.hop - (long long)a.pad;
         const long long tile_hi = (long long)(f0 + 15u) * a.hop - (long long)a.pad + 1024;
         const bool interior = tile_lo >= 0 && tile_hi <= (long long)a.n_samples;  // wave-uniform
         if constexpr (ROUNDS > 0) {
+#ifdef SGX_ABL_NOGLOAD
+            for (int r = 0; r < ROUNDS; ++r) creg[r] = (v4f){(float)w, 1.f, 2.f, (float)r};
+            return;
+#endif
             if (interior) {
                 const v4f *xp = (const v4f *)(xb + tile_lo) + tid;
 #pragma unroll
@@ -444,6 +470,9 @@ __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned
         }
     };
 
+    // (HALVES = 2) a second half without a tile of its own (odd run length: the last round of an XCD) repeats the first half's
+    // tile — same values to the same addresses — so both halves always run the same number of rounds and barriers
+    if (HALVES == 2 && wid >= hi) wid = lead;
     if (wid < hi) load_tile(wid);
     if constexpr (ROUNDS == 0 && MODE != OUT_MEL) {
         // "use" the first tile's samples here: the compiler then waits for these loads in the prologue, and inside the
@@ -455,23 +484,52 @@ __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned
         for (int n1 = 0; n1 < 32; ++n1) asm volatile("" : "+v"(xr[n1]));
     }
     __syncthreads();  // tables visible
+    // Phase skew (experiment, SGX_SKEW=n, default 0; HALVES = 2 with the per-half pass 2): the second half enters the loop `skew`
+    // barriers late and the first half leaves it `skew` barriers late.  s_barrier counts arrivals, not call sites, so from then
+    // on the halves meet at every barrier one or more phases apart: while one half is in an LDS-bound phase (staging, column /
+    // window reads, row reads) the other is in an arithmetic one on the same SIMDs.  Every hazard the barriers protect is
+    // internal to a half (own ex buffer).  Measured SLOWER at every skew (linear 139 -> 164 / 202 / 209 us for 1 / 2 / 3): each
+    // interval then lasts as long as the longer of two different phases, and a phase run by one wave per SIMD is barely
+    // shorter than the same phase run by two in lockstep — the phases are latency-bound per wave, not throughput-bound.
+    if (HALVES == 2 && half == 1u)
+        for (unsigned q = 0; q < skew; ++q) __syncthreads();
 #ifdef SGX_STAMPS
     unsigned long long st_acc[8] = {0}, st_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
 #endif
 
     while (lead < hi) {
-        const bool active = wid < hi;  // (HALVES = 2) the second half may run out one tile earlier; it still joins the barriers
-        const unsigned b = (active ? wid : lead) / a.tiles, tile = (active ? wid : lead) - b * a.tiles;
+        const unsigned b = wid / a.tiles, tile = wid - b * a.tiles;
         const unsigned f0 = tile * 16u;
         const unsigned nf = min(16u, a.n_frames - f0);
+        // (LATEBAR) the barrier that frees ex sits here, AFTER the previous tile's pass 2, not between its row reads and its
+        // arithmetic: a wave starts its 16-point transforms as soon as its own rows have arrived instead of meeting the other
+        // seven at a barrier first, and the row-read latency overlaps the first transform
+        if constexpr (LATEBAR) __syncthreads();
+        v2f wn[32];
+        auto read_window = [&]() {
+            const v2f *w2 = (const v2f *)(tabs + kWinOff) + n2;
+#pragma unroll
+#ifdef SGX_ABL_NOWIN
+            for (int n1 = 0; n1 < 32; ++n1) wn[n1] = (v2f){0.5f, 0.25f};
+#else
+            for (int n1 = 0; n1 < 32; ++n1) wn[n1] = w2[16 * n1];
+#endif
+        };
+#ifdef SGX_ABL_NOXS
+        for (int n1 = 0; n1 < 32; ++n1) xr[n1] = (v2f){creg[n1 % ROUNDS].x + n1, creg[n1 % ROUNDS].y};
+        if constexpr (false) {
+#else
         if constexpr (ROUNDS > 0) {
+#endif
             // stage: chunk c of the tile -> xs (this half's ex is free: barrier 2 of the previous tile / the prologue)
 #pragma unroll
             for (int r = 0; r < ROUNDS; ++r) {
                 const unsigned c = r * 256u + tid;
                 if (c < chunks) *(v4f *)(smem + c * 16u + (xs_pad ? (c >> 6) * 128u : 0u)) = creg[r];
             }
+            SGX_STAMP(7);  // wait for the tile's samples + stage writes
+            if constexpr (LATEBAR) read_window();  // table reads fill the short interval between the two barriers
             __syncthreads();
             const unsigned o = p1f * a.hop + 2u * n2;  // float offset of this lane's column inside the tile
             if (xs_pad) {
@@ -485,20 +543,16 @@ __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned
             }
         }
         {
-            v2f wn[32];
-            const v2f *w2 = (const v2f *)(tabs + kWinOff) + n2;
-#pragma unroll
-#ifdef SGX_ABL_NOWIN
-            for (int n1 = 0; n1 < 32; ++n1) wn[n1] = (v2f){0.5f, 0.25f};
-#else
-            for (int n1 = 0; n1 < 32; ++n1) wn[n1] = w2[16 * n1];
-#endif
-            if constexpr (ROUNDS > 0) __syncthreads();  // every wave has read xs: pass 1 may overwrite it with ex
+            if constexpr (!(LATEBAR && ROUNDS > 0)) read_window();
+#ifndef SGX_ABL_NOXS
+            if constexpr (ROUNDS > 0) __syncthreads();
+#endif  // every wave has read xs: pass 1 may overwrite it with ex
             SGX_STAMP(0);
-            if (active) pass1_compute(xr, wn, twa, twb, smem + p1f * kFS + n2 * 8);
+            pass1_compute(xr, wn, twa, twb, smem + p1f * kFS + n2 * 8);
             SGX_STAMP(1);
         }
-        const unsigned next = wid + slots * HALVES;
+        unsigned next = lead + slots * HALVES + half;
+        if (HALVES == 2 && next >= hi) next -= half;  // no tile of its own next round: repeat the first half's
         // requested after pass 1 so the previous tile's store burst has had that long to drain: a vector load issued while
         // the CU's store FIFO is backed up stalls its wave for thousands of cycles
         if (next < hi) load_tile(next);  // in flight during pass 2
@@ -513,7 +567,7 @@ __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned
         // if it exists — otherwise the lane mirrors the first tile).  All of it is two uniform decodes and a per-lane select.
         unsigned p2b = b, p2ofs, p2ex;
         if constexpr (WIDE) {
-            const unsigned w1 = lead + 1u < hi ? lead + 1u : lead;
+            const unsigned w1 = lead + 1u < hi ? lead + 1u : lead;  // = the second half's wid
             const unsigned b0 = lead / a.tiles, f00 = (lead - b0 * a.tiles) * 16u;
             const unsigned b1 = w1 / a.tiles, f01 = (w1 - b1 * a.tiles) * 16u;
             const unsigned nf0 = min(16u, a.n_frames - f00), nf1 = min(16u, a.n_frames - f01);
@@ -529,16 +583,16 @@ __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned
             p2ex = p2f_eff;
             p2ofs = f0 + p2f_eff;
         }
-        const unsigned char *ex_src = WIDE ? smem_all : (ALLSTORE && !active) ? smem_all : smem;
+        const unsigned char *ex_src = WIDE ? smem_all : smem;
         v2f A[16], B[16];
         read_rows(ex_src + p2ex * kFS, ra, rb, A, B);
         SGX_STAMP(4);
-        __syncthreads();  // ex consumed: the next pass 1 (or the pw overlay) may overwrite it
+        if constexpr (!LATEBAR) __syncthreads();  // ex consumed: the next pass 1 (or the pw overlay) may overwrite it
         SGX_STAMP(5);
         if constexpr (MODE == OUT_MEL) {  // pw rows are 516 floats wide: bins 513..515 are read with zero weights
             if (tid < 48u) ((float *)smem)[(tid / 3u) * kPS + 513u + tid % 3u] = 0.0f;
         }
-        if (ALLSTORE || (active && p2f < nf)) {
+        if (ALLSTORE || p2f < nf) {
             const v2f *t2 = (const v2f *)(tabs + kTw2Off);
             auto tw = [&](int i) {  // read from LDS where consumed (this kernel has no registers to keep them)
 #ifdef SGX_ABL_NOTW2
@@ -551,7 +605,7 @@ __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned
         if constexpr (MODE == OUT_MEL) {
             __syncthreads();
 #ifndef SGX_ABL_NOMELTILE
-            if (active) {
+            {
                 if (a.mm_frag) map_tile_mfma<AMP>(a, (const float *)smem, b, f0, nf, eps, tid, 2u * half);
                 else if (mel_lds) mel_tile_lds<AMP>(a, (const float *)smem, lw4, lptr, lcol, b, f0, nf, eps, tid, 256u);
                 else mel_tile<AMP>(a, (const float *)smem, b, f0, nf, eps, tid, 256u);
@@ -563,10 +617,13 @@ __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned
         wid = next;
         lead += slots * HALVES;
     }
+    if (HALVES == 2 && half == 0u)
+        for (unsigned q = 0; q < skew; ++q) __syncthreads();
 #ifdef SGX_STAMPS
     if ((threadIdx.x & 63u) == 0) {
         for (int q = 0; q < 7; ++q) atomicAdd(&g_stamps[q], st_acc[q]);
         atomicAdd(&g_stamps[7], 1ull);
+        atomicAdd(&g_stamps[16], st_acc[7]);
     }
 #endif
 }
@@ -781,24 +838,33 @@ hipError_t launch_variant(const StftArgs &a, hipStream_t s) {
         const bool stage5 = want_staged && aligned16 && chunks <= 5u * 256u;
         if (want_single) {
             static bool done = false;
-            if ((e = set_lds_once(k_r32x16<MODE, AMP, 1, 0>, lds, done)) != hipSuccess) return e;
             const unsigned slots = per_xcd < 64u ? per_xcd : 64u;  // two workgroups per CU (LDS-limited)
-            hipLaunchKernelGGL((k_r32x16<MODE, AMP, 1, 0>), dim3(slots * 8), dim3(256), lds, s, a, per_xcd, total, slots);
+            if (stage5) {
+                if ((e = set_lds_once(k_r32x16<MODE, AMP, 1, 5>, lds, done)) != hipSuccess) return e;
+                hipLaunchKernelGGL((k_r32x16<MODE, AMP, 1, 5>), dim3(slots * 8), dim3(256), lds, s, a, per_xcd, total, slots, 0u);
+            } else {
+                if ((e = set_lds_once(k_r32x16<MODE, AMP, 1, 0>, lds, done)) != hipSuccess) return e;
+                hipLaunchKernelGGL((k_r32x16<MODE, AMP, 1, 0>), dim3(slots * 8), dim3(256), lds, s, a, per_xcd, total, slots, 0u);
+            }
         } else {
             const unsigned pairs = (per_xcd + 1) / 2;
             const unsigned slots = pairs < 32u ? pairs : 32u;  // one 512-thread workgroup per CU
             // pass 2 across both halves (32-frame rows per store instruction) for the per-bin outputs; SGX_WIDE=0 keeps the
             // per-half mapping for A/B runs
+            static const unsigned skew = [] {
+                const char *v = getenv("SGX_SKEW");
+                return v ? (unsigned)atoi(v) % 8u : 0u;
+            }();
             static const bool want_wide = [] {
                 const char *v = getenv("SGX_WIDE");
-                return !(v && v[0] == '0');
+                return !(v && v[0] == '0') && skew == 0u;  // the wide pass 2 reads both halves' ex buffers: lockstep only
             }();
             constexpr bool CAN_WIDE = MODE != OUT_MEL;
             auto go = [&](auto kernel) -> hipError_t {
                 static bool done = false;
                 hipError_t e2 = set_lds_once(kernel, lds + kExBytes, done);
                 if (e2 != hipSuccess) return e2;
-                hipLaunchKernelGGL(kernel, dim3(slots * 8), dim3(512), lds + kExBytes, s, a, per_xcd, total, slots);
+                hipLaunchKernelGGL(kernel, dim3(slots * 8), dim3(512), lds + kExBytes, s, a, per_xcd, total, slots, skew);
                 return hipSuccess;
             };
             if (stage5) {

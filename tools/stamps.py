@@ -8,11 +8,12 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-lib = "/tmp/libsgx_stamps.so"
+lib = os.environ.get("SGX_STAMPS_LIB", "/tmp/libsgx_stamps.so")  # prebuilt (tools/mkvariant.sh stamps -DSGX_STAMPS) or built here
 flags = sys.argv[2:] if len(sys.argv) > 2 else []
-subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-DSGX_STAMPS", *flags,
+if "SGX_STAMPS_LIB" not in os.environ:
+  subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-DSGX_STAMPS", *flags,
                 "-I" + ROOT + "/include", "-I" + ROOT + "/spectrograms_amd/csrc", "-o", lib] +
-               [ROOT + "/spectrograms_amd/csrc/" + f for f in ("plan.hip", "fft2d.hip", "kernels_generic.hip", "kernels_r32x16.hip", "kernels_fft2d.hip", "kernels_c2c1024.hip")], check=True)
+               [ROOT + "/spectrograms_amd/csrc/" + f for f in ("plan.hip", "fft2d.hip", "kernels_generic.hip", "kernels_r32x16.hip", "kernels_fft2d.hip", "kernels_c2c1024.hip", "kernels_reg2d.hip")], check=True)
 os.environ["SGX_LIB_PATH"] = lib
 import numpy as np
 import torch
@@ -52,3 +53,5 @@ for role, base in roles:
     for i, n in enumerate(names):
         print(f"  {n:30s} {buf[base + i] / max(waves, 1) / ticks:10.0f} cyc/wave/tile  {100.0 * buf[base + i] / max(tot, 1):5.1f} %")
     print(f"  total {tot / max(waves, 1) / ticks:.0f} cycles per wave per tile")
+    if not ws:
+        print(f"  (separately) sample wait + stage writes {buf[16] / max(waves, 1) / ticks:10.0f} cyc/wave/tile — the first row then holds barrier + column / window reads + barrier only")
