@@ -4,7 +4,7 @@ HIPCC ?= hipcc
 ARCH  ?= gfx950
 CSRC  := spectrograms_amd/csrc
 SRCS  := $(CSRC)/plan.hip $(CSRC)/fft2d.hip $(CSRC)/kernels_generic.hip $(CSRC)/kernels_r32x16.hip \
-         $(CSRC)/kernels_fft2d.hip $(CSRC)/kernels_c2c1024.hip $(CSRC)/kernels_reg2d.hip
+         $(CSRC)/kernels_fft2d.hip $(CSRC)/kernels_c2c1024.hip $(CSRC)/kernels_reg2d.hip $(CSRC)/kernels_q16x32.hip
 LIB   := spectrograms_amd/libspectro_hip.so
 
 .PHONY: all lib oracle test-cpu clean

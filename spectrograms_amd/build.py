@@ -9,7 +9,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libspectro_hip.so")
-SOURCES = ["plan.hip", "fft2d.hip", "kernels_generic.hip", "kernels_r32x16.hip", "kernels_fft2d.hip", "kernels_c2c1024.hip", "kernels_reg2d.hip"]
+SOURCES = ["plan.hip", "fft2d.hip", "kernels_generic.hip", "kernels_r32x16.hip", "kernels_fft2d.hip", "kernels_c2c1024.hip", "kernels_reg2d.hip", "kernels_q16x32.hip"]
 ARCH = "gfx950"
 
 

@@ -904,6 +904,11 @@ bool plan_geometry_r32x16_f32(StftArgs &a) {
 hipError_t launch_r32x16_f32(const StftArgs &a, hipStream_t s) {
     const unsigned long long total64 = (unsigned long long)a.tiles * a.batch;
     if (total64 == 0 || total64 >= 0x7ffffff0ull) return hipErrorInvalidConfiguration;
+    static const bool want_q = [] {
+        const char *v = getenv("SGX_KERNEL");
+        return v && v[0] == 'q';  // experimental 16-values-per-lane kernel (kernels_q16x32.hip)
+    }();
+    if (want_q && q16x32_takes(a)) return launch_q16x32_f32(a, s);
     if (a.out_mode == OUT_COMPLEX) return launch_variant<OUT_COMPLEX, AMP_POWER>(a, s);
     if (a.out_mode == OUT_MEL) {
         if (a.amp == AMP_MAGNITUDE) return launch_variant<OUT_MEL, AMP_MAGNITUDE>(a, s);

@@ -71,6 +71,8 @@ struct StftArgs {
 hipError_t launch_direct_dft(const StftArgs &a, int dtype, hipStream_t s);
 hipError_t launch_lds_radix2(const StftArgs &a, int dtype, hipStream_t s);
 hipError_t launch_r32x16_f32(const StftArgs &a, hipStream_t s);
+bool q16x32_takes(const StftArgs &a);                          // kernels_q16x32.hip (experimental, SGX_KERNEL=q)
+hipError_t launch_q16x32_f32(const StftArgs &a, hipStream_t s);
 // MFCC epilogue over a Mel-dB tensor [batch][n_mels][n_frames] -> [batch][n_out][n_frames]; basis [n_mfcc][n_mels], lifter [n_mfcc]
 hipError_t launch_mfcc(const void *mel, void *out, const void *basis, const void *lifter, unsigned batch, unsigned n_mels,
                        unsigned n_frames, unsigned n_mfcc, unsigned skip, int has_lifter, int dtype, hipStream_t s);

@@ -7,12 +7,12 @@ NAME=$1; shift
 CS=spectrograms_amd/csrc
 CF="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Iinclude -I$CS"
 mkdir -p build/obj
-for f in plan fft2d kernels_generic kernels_fft2d kernels_c2c1024 kernels_reg2d; do
+for f in plan fft2d kernels_generic kernels_fft2d kernels_c2c1024 kernels_reg2d kernels_q16x32; do
   if [ ! -f build/obj/$f.o ] || [ $CS/$f.hip -nt build/obj/$f.o ] || [ $CS/sgx_internal.h -nt build/obj/$f.o ]; then
     hipcc $CF -c $CS/$f.hip -o build/obj/$f.o &
   fi
 done
 hipcc $CF "$@" -c ${VARIANT_SRC:-$CS/kernels_r32x16.hip} -o build/obj/r32x16_$NAME.o
 wait
-hipcc --offload-arch=gfx950 -shared -fPIC -o build/libsgx_$NAME.so build/obj/{plan,fft2d,kernels_generic,kernels_fft2d,kernels_c2c1024,kernels_reg2d}.o build/obj/r32x16_$NAME.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o build/libsgx_$NAME.so build/obj/{plan,fft2d,kernels_generic,kernels_fft2d,kernels_c2c1024,kernels_reg2d,kernels_q16x32}.o build/obj/r32x16_$NAME.o
 echo build/libsgx_$NAME.so

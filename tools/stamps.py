@@ -13,7 +13,7 @@ flags = sys.argv[2:] if len(sys.argv) > 2 else []
 if "SGX_STAMPS_LIB" not in os.environ:
   subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-DSGX_STAMPS", *flags,
                 "-I" + ROOT + "/include", "-I" + ROOT + "/spectrograms_amd/csrc", "-o", lib] +
-               [ROOT + "/spectrograms_amd/csrc/" + f for f in ("plan.hip", "fft2d.hip", "kernels_generic.hip", "kernels_r32x16.hip", "kernels_fft2d.hip", "kernels_c2c1024.hip", "kernels_reg2d.hip")], check=True)
+               [ROOT + "/spectrograms_amd/csrc/" + f for f in ("plan.hip", "fft2d.hip", "kernels_generic.hip", "kernels_r32x16.hip", "kernels_fft2d.hip", "kernels_c2c1024.hip", "kernels_reg2d.hip", "kernels_q16x32.hip")], check=True)
 os.environ["SGX_LIB_PATH"] = lib
 import numpy as np
 import torch
