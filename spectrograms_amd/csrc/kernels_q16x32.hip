@@ -1,22 +1,31 @@
-// kernels_q16x32.hip — f32, n_fft = 1024 STFT kernel with 16 values per lane (experimental, SGX_KERNEL=q): the same
-// transform as k_r32x16 (kernels_r32x16.hip) laid out for FOUR waves per SIMD instead of two.
+// kernels_q16x32.hip — f32, n_fft = 1024 STFT kernel with 16 values per lane (EXPERIMENT, SGX_KERNEL=q; parity-green, slower
+// than k_r32x16: 174-184 us vs 136-140 us per 256 x 10 s, see DESIGN.md §4 "Second look").  The same transform as k_r32x16
+// (kernels_r32x16.hip) laid out for FOUR waves per SIMD instead of two.
 //
 // k_r32x16 keeps 32 complex values per lane (a 32-point and two 16-point transforms in registers), which costs ~250 VGPRs
-// and pins the CU at 2 waves per SIMD: every LDS round trip between two barriers is exposed ("Second look").
-// Here the 512-point complex transform of z[n] = w[2n] x[2n] + i w[2n+1] x[2n+1] is split 16 x 32 with the 32 done as
-// 2 x 16 across a lane pair, so no lane ever holds more than 16 values:
+// and pins the CU at 2 waves per SIMD.  Here the 512-point complex transform of z[n] = w[2n] x[2n] + i w[2n+1] x[2n+1] is
+// split 16 x 32 with the 32 done as 2 x 16 across a lane pair, so no lane ever holds more than 16 values (104-118 VGPRs):
 //
-//   tile    16 consecutive frames of one signal, one 512-thread workgroup; two workgroups per CU (16 waves, <= 128 VGPRs).
-//   pass 1  lane (f = 0..15, n2 = 0..31) owns z[32 n1 + n2], n1 = 0..15: window fused into a 16-point FFT over n1, twiddle
-//           W_512^(k1 n2) (two 3-entry per-lane tables), ds_write_b64 to ex[f][k1][n2].
-//   pass 2  wave q = 0..7 owns the row pair (q, 16 - q) (wave 0: rows 0 and 8) of all 16 frames; lane = 4 f + m, quad member
-//           m = (row, parity p).  A lane reads the 16 values n2 = 2 i + p of its row, runs a 16-point FFT over i, the odd
-//           lane multiplies by -W_32^k2 (compile-time constants), and one v_add_f32_dpp per component with the neighbour
-//           (quad_perm [1,0,3,2]) gives Z[k1 + 16 k2]: k2 = 0..15 in the even lane, 16..31 in the odd one.
-//   split   X[k] = E + W_1024^k O needs Z[512 - k], which is register 15 - i of the lane diagonally opposite in the quad
+//   tile    16 consecutive frames of one signal, one 512-thread workgroup; two workgroups per CU (16 waves).
+//   front   lane (f = 0..15, n2 = 0..31) owns z[32 n1 + n2], n1 = 0..15: window fused into a 16-point FFT over n1, twiddle
+//           W_512^(k1 n2) (two 3-entry per-lane tables), ds_write_b64 to ex[f][k1][n2]; then wave q = 0..7 reads the row pair
+//           (q, 16 - q) (wave 0: rows 0 and 8) of all 16 frames: lane = 4 f + m, quad member m = (row, parity p), 16 values
+//           n2 = 2 i + p by 8 conflict-free ds_read_b128.
+//   back    16-point FFT over i, the odd lane multiplies by W_32^k2 (compile-time constants), and one DPP exchange with the
+//           neighbour (quad_perm [1,0,3,2]) gives Z[k1 + 16 k2]: k2 = 0..15 in the even lane, 16..31 in the odd one.
+//           X[k] = E + W_1024^k O needs Z[512 - k], which is register 15 - i of the lane diagonally opposite in the quad
 //           (quad_perm [3,2,1,0]): every lane produces its OWN 16 bins from DPP reads, no second exchange.  Wave 0 (rows 0
 //           and 8 pair with themselves) uses the neighbour lane and its own index maps; it also stores bin 512.
-//   store   the 16 lanes of a quad member hold one bin of 16 consecutive frames: 64-byte runs, as in k_r32x16.
+//   pipe    the samples of tile t + 1 are staged and the loads of tile t + 2 issued before the back half (and the stores) of
+//           tile t.
+//
+// What the measurement says (MI355X): without loads and stores the kernel takes 115 us against k_r32x16's 92-96 us although
+// it runs 4 waves per SIMD and its VALU pipe demand is within 8 % — one workgroup per CU (2 waves per SIMD) already reaches
+// 130 us, i.e. doubling the occupancy buys 12 %.  Both kernels fit  time = VALU pipe cycles + LDS pipe cycles  per CU round
+// (q: 8.4 k + 5.8 k, r32x16: 7.8 k + 5.1 k at the measured issue rates), so occupancy is not what limits them, and q has
+// more of both (64 DPP moves per lane, twice the lanes reading window / twiddle tables).  Its stores cost 49 us (r32x16:
+// 11-16 us): a quad must sit in 4 consecutive lanes for DPP, so a 16-lane quarter wave holds 4 bins x 4 frames = four
+// 16-byte pieces per store instruction instead of one 64-byte run.
 //
 // Reference semantics: spectrogram.rs:1301-1334 (framing, window, R2C, |.|^2), :2068-2080 (amplitude scaling).
 #include <cstdlib>
@@ -105,6 +114,10 @@ __global__ __launch_bounds__(512, 2) void k_q16x32(StftArgs a, unsigned per_xcd,
         const float *xb = (const float *)a.x + (size_t)b * a.sample_stride;
         const long long tile_lo = (long long)f0 * a.hop - (long long)a.pad;
         const long long tile_hi = (long long)(f0 + 15u) * a.hop - (long long)a.pad + 1024;
+#ifdef SGX_ABL_NOGLOAD
+        for (int r = 0; r < kQRounds; ++r) creg[r] = (v4f){(float)w, 1.f, 2.f, (float)r};
+        return;
+#endif
         if (tile_lo >= 0 && tile_hi <= (long long)a.n_samples) {  // interior tile (uniform)
             const v4f *xp = (const v4f *)(xb + tile_lo) + tid;
 #pragma unroll
@@ -122,22 +135,24 @@ __global__ __launch_bounds__(512, 2) void k_q16x32(StftArgs a, unsigned per_xcd,
                 c.w = (sx + 3 >= 0 && sx + 3 < n) ? xb[sx + 3] : 0.0f;
                 creg[r] = c;
             }
+            // consume the edge tile's samples here (2 tiles in 40): with predicated loads still pending at the join the compiler
+            // guards the interior path with s_waitcnt vmcnt(0), i.e. a full drain of the previous tile's stores on EVERY tile
+#pragma unroll
+            for (int r = 0; r < kQRounds; ++r) asm volatile("" : "+v"(creg[r]));
         }
     };
-    if (wid < hi) load_tile(wid);
-    __syncthreads();  // tables visible
-
-    while (wid < hi) {
-        const unsigned b = wid / a.tiles, tile = wid - b * a.tiles;
-        const unsigned f0 = tile * 16u;
-        const unsigned nf = min(16u, a.n_frames - f0);
-        // ---- stage the tile's samples (xs overlays ex: free since the barrier behind the previous tile's row reads)
+    auto stage_tile = [&]() {  // registers -> xs (overlays ex, which is free behind the barrier that follows the row reads)
 #pragma unroll
         for (int r = 0; r < kQRounds; ++r) {
             const unsigned c = r * 512u + tid;
             if (c < chunks) *(v4f *)(smem + c * 16u) = creg[r];
         }
-        __syncthreads();
+    };
+    v2f R[16];  // pass-2 rows of the tile `cur`
+    // front half of a tile: staged samples -> pass 1 -> ex -> this lane's row in R (three barriers; the last one frees ex)
+    auto front = [&](unsigned w) {
+        const unsigned b = w / a.tiles, tile = w - b * a.tiles;
+        const unsigned nf = min(16u, a.n_frames - tile * 16u);
         v2f xr[16], wn[16];
         {
             const unsigned char *src = smem + (p1f * a.hop + 2u * n2) * 4u;
@@ -148,7 +163,6 @@ __global__ __launch_bounds__(512, 2) void k_q16x32(StftArgs a, unsigned per_xcd,
             for (int n1 = 0; n1 < 16; ++n1) wn[n1] = w2[32 * n1];
         }
         __syncthreads();  // every wave has read xs: pass 1 may overwrite it with ex
-        // ---- pass 1
         Fft<16, true>::run(xr, wn);
         {
             unsigned char *dst = smem + p1f * kQFS + (n2 & 1u) * 128u + (n2 >> 1) * 8u;
@@ -161,23 +175,23 @@ __global__ __launch_bounds__(512, 2) void k_q16x32(StftArgs a, unsigned per_xcd,
                 *(v2f *)(dst + (k1 * 256 + (k1 >= 8 ? 64 : 0))) = r;
             }
         }
-        const unsigned next = wid + slots;
-        if (next < hi) load_tile(next);  // in flight during pass 2
         __syncthreads();
-        // ---- pass 2: 16 values n2 = 2 i + par of this lane's row
         const unsigned fe = min(p2f, nf - 1u);  // a lane whose frame does not exist mirrors the tile's last frame
-        v2f R[16];
-        {
-            const v4f *src = (const v4f *)(smem + fe * kQFS + q_row_off(row) + par * 128u);
+        const v4f *src = (const v4f *)(smem + fe * kQFS + q_row_off(row) + par * 128u);
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const v4f v = src[c];
-                R[2 * c] = (v2f){v.x, v.y};
-                R[2 * c + 1] = (v2f){v.z, v.w};
-            }
+        for (int c = 0; c < 8; ++c) {
+            const v4f v = src[c];
+            R[2 * c] = (v2f){v.x, v.y};
+            R[2 * c + 1] = (v2f){v.z, v.w};
         }
-        // split twiddles of this lane's bins (4 distinct addresses per wave: broadcast reads)
         __syncthreads();  // ex consumed: the next tile's staging may overwrite it
+    };
+    // back half: 16-point FFT of the row, radix-2 and real split across the quad by DPP, output
+    auto back = [&](unsigned w) {
+        const unsigned b = w / a.tiles, tile = w - b * a.tiles;
+        const unsigned f0 = tile * 16u;
+        const unsigned nf = min(16u, a.n_frames - f0);
+        const unsigned fe = min(p2f, nf - 1u);
         const v2f *tw = (const v2f *)(smem + kQTw) + kbase;  // split twiddles of this lane's bins: 4 addresses per wave
         Fft<16, false>::run(R, R);
         if (par) mul_w32<0>(R);
@@ -186,12 +200,15 @@ __global__ __launch_bounds__(512, 2) void k_q16x32(StftArgs a, unsigned per_xcd,
 #pragma unroll
             for (int i = 0; i < 16; ++i) R[i] = pfma(R[i], sg, dpp2<0>(R[i]));  // Z[row + 16 (i + 16 par)]
         }
-
         constexpr unsigned ES = MODE == OUT_COMPLEX ? 8u : 4u;
         unsigned char *ob = (unsigned char *)a.out + ((size_t)b * 513u) * a.n_frames * ES;
         const unsigned step = 16u * a.n_frames * ES;
         const unsigned off0 = (kbase * a.n_frames + f0 + fe) * ES;
         auto emit = [&](unsigned off, v2f X) {
+#ifdef SGX_ABL_NOSTORE  // timing experiment only (tools/mkvariant.sh)
+            asm volatile("" ::"v"(X), "v"(off));
+            return;
+#endif
             if constexpr (MODE == OUT_COMPLEX) *(v2f *)(ob + off) = X;
             else *(float *)(ob + off) = q_amp<AMP>(__builtin_fmaf(X.x, X.x, X.y * X.y), eps);
         };
@@ -223,7 +240,32 @@ __global__ __launch_bounds__(512, 2) void k_q16x32(StftArgs a, unsigned per_xcd,
                 emit((512u * a.n_frames + f0 + fe) * ES, (v2f){2.0f * (P.x - P.y), 0.0f});
             }
         }
-        wid = next;
+    };
+
+    // Software pipeline over the workgroup's tiles.  The samples of tile t + 1 are staged into LDS and the loads of tile t + 2
+    // issued BEFORE the back half (and the output stores) of tile t: a sample load never queues behind this CU's own stores in
+    // the in-order vector-memory path, has a whole tile of time to arrive, and the wait in front of the staging writes only
+    // meets stores that were issued most of a tile earlier.
+    unsigned cur = wid, nxt = wid + slots;
+    if (cur < hi) {
+        load_tile(cur);
+        stage_tile();
+    }
+    if (nxt < hi) load_tile(nxt);
+    __syncthreads();  // xs and tables visible
+    if (cur < hi) front(cur);
+    while (cur < hi) {
+        const unsigned nn = nxt + slots;
+        if (nxt < hi) {
+            stage_tile();
+            if (nn < hi) load_tile(nn);
+        }
+        back(cur);
+        if (nxt >= hi) break;
+        __syncthreads();  // xs visible
+        front(nxt);
+        cur = nxt;
+        nxt = nn;
     }
 }
 
@@ -231,7 +273,11 @@ template <int MODE, int AMP>
 hipError_t launch_q(const StftArgs &a, hipStream_t s) {
     const unsigned total = a.tiles * a.batch;
     const unsigned per_xcd = (total + 7) / 8;
-    const unsigned slots = per_xcd < 64u ? per_xcd : 64u;  // two workgroups per CU
+    static const unsigned max_slots = [] {
+        const char *v = getenv("SGX_Q_SLOTS");  // experiment: workgroups per XCD (64 = two per CU)
+        return v ? (unsigned)atoi(v) : 64u;
+    }();
+    const unsigned slots = per_xcd < max_slots ? per_xcd : max_slots;  // two workgroups per CU
     hipError_t e = set_max_dynamic_lds((const void *)k_q16x32<MODE, AMP>, kQLds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_q16x32<MODE, AMP>), dim3(slots * 8), dim3(512), kQLds, s, a, per_xcd, total, slots);
