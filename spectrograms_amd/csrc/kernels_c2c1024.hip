@@ -318,6 +318,7 @@ __global__ __launch_bounds__(16 * NF, NF == 16 ? 2 : 1) void k_istft1024(IstftAr
         const unsigned r = tid & (NF - 1u), n2 = tid / NF;
         const long long f = fbase + r;
         const bool valid = f >= 0 && f < (long long)a.n_frames;
+        const float vm = valid ? 1.f : 0.f;
         const v2f *col = in + (valid ? f : 0);
         v2f v[32];
         // conj(W_1024^(16 n1 + n2)) = e^{+2 pi i n1 / 64} (compile-time constant) * conj(W_1024^n2) (one load per lane): the
@@ -329,12 +330,14 @@ __global__ __launch_bounds__(16 * NF, NF == 16 ? 2 : 1) void k_istft1024(IstftAr
 #pragma unroll
         for (int n1 = 0; n1 < 32; ++n1) {
             const unsigned k = 16u * n1 + n2;
-            v2f A = valid ? *pa : (v2f){0.f, 0.f};
-            v2f Y = valid ? *py : (v2f){0.f, 0.f};
+            // a frame outside the signal reads frame 0 (col is clamped) and is zeroed by `vm` in the last multiply-add below:
+            // unconditional loads instead of 64 exec-masked branches
+            v2f A = *pa;
+            v2f Y = *py;
             pa += step;
             py -= step;
             if (k == 0) {  // DC and Nyquist bins: realfft ignores (and reports) their imaginary parts
-                if (a.bad_flag && (A.y != 0.f || Y.y != 0.f)) atomicOr(a.bad_flag, 1u);
+                if (a.bad_flag && valid && (A.y != 0.f || Y.y != 0.f)) atomicOr(a.bad_flag, 1u);
                 A.y = 0.f;
                 Y.y = 0.f;
             }
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(16 * NF, NF == 16 ? 2 : 1) void k_istft1024(IstftAr
             const v2f cw = n1 == 0 ? wl : cmulv(wl, (v2f){(float)kCos64[n1], (float)kSin64[n1]});
             const v2f T = cmulv(D, cw);
             // conj(S + i T) = (S.x - T.y, -(S.y + T.x)): the conjugate the forward-FFT inverse trick wants, in one fma
-            v[n1] = pfma(swp(T), (v2f){-1.f, -1.f}, S * (v2f){1.f, -1.f});
+            v[n1] = pfma(swp(T), (v2f){-vm, -vm}, S * (v2f){vm, -vm});
         }
         Fft<32, false>::run(v, v);
         unsigned char *dst = smem + r * kISeq + n2 * 8;
