@@ -298,7 +298,11 @@ struct IstftArgs {
     float scale;
     unsigned *bad_flag;
 };
-constexpr int kISeq = kRSeq + 32;     // row stride of the exchange buffer: lanes walk r in pass 1 -> spread rows over banks
+// Row (frame) stride of the exchange buffer.  In pass 1 the 16 contiguous lanes of a ds_write_b64 group walk r, so the stride
+// in dwords must spread them over the 32 write banks: 4624 B = 1156 dwords = 4 (mod 32) gives 8 distinct bank pairs (2-way,
+// the best a 16-byte aligned stride allows; 4640 B = 8 (mod 32) was 4-way: SQ_LDS_BANK_CONFLICT 48 % of the LDS cycles);
+// 4624 / 16 = 289 = 1 (mod 16) keeps the pass-2 ds_read_b128 (lanes over k1, 144-byte rows) conflict-free.
+constexpr int kISeq = kRSeq + 16;
 // NF frames per workgroup of 16 NF threads: 16 -> 74 240 B, two workgroups per CU; 32 -> 148 480 B, one workgroup of 8 waves
 // (the real frames, NF * 4 KiB, overlay the exchange buffer).  32 halves the share of halo frames (3 of 32 instead of 3 of 16
 // at hop 256) and doubles the load segments to 256 bytes, but measures slower (see launch_istft1024): 16 is the default.
