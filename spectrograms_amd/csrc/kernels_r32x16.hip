@@ -352,7 +352,11 @@ __device__ unsigned long long g_stamps[32];
 // directly follows the first: kExBytes = 16 kFS).  The two halves own neighbouring tiles, so the 32 lanes of a job hold one
 // bin of 32 consecutive frames: a store instruction covers 2 rows x 128 bytes instead of 4 rows x 64 bytes (the CU's
 // address path charges per segment, tools/ubench/vmem_issue.hip) and L2 receives whole-line-sized runs.
-template <int MODE, int AMP, int HALVES, int ROUNDS, bool WIDE = false>
+// XSPAD (staged loads): the staging buffer carries 128 B of padding per KiB, which keeps the 4 frames of a wave on distinct banks
+// when hop is a multiple of 256 samples.  It is a template parameter so that each variant addresses its 32 column reads with
+// immediates off ONE base register: as a run-time switch the compiler hoisted both variants' 2 x 24 addresses into VGPRs and
+// copied one set per tile.
+template <int MODE, int AMP, int HALVES, int ROUNDS, bool WIDE = false, bool XSPAD = true>
 __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned per_xcd, unsigned total, unsigned slots, unsigned skew) {
     static_assert(!WIDE || (HALVES == 2 && MODE != OUT_MEL), "wide pass 2 needs both halves and a per-bin output");
 #ifdef SGX_LATEBAR  // experiment (measured equal or 1 % slower): the barrier that frees ex moved behind pass 2
@@ -402,10 +406,20 @@ __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned
     load_tw1(a, n2, twa, twb);
 
     v2f xr[32];                          // raw samples of this lane's (frame, n2) column
-    v4f creg[ROUNDS > 0 ? ROUNDS : 1];   // staged path: this thread's 16-byte chunks of the tile being prefetched
+    // staged path: this thread's 16-byte chunks of the tile(s) being prefetched.  AHEAD2 (experiment, -DSGX_AHEAD2): two sets, the
+    // tile staged in round t was requested in round t - 2 (into the set that round's staging had just freed) and the loop body is
+    // instantiated once per set.  Parity-green, no spills in the linear variants (242-251 VGPRs) — and 1.5 % SLOWER (147 vs 145 us):
+    // the cost of the sample loads is not their latency but their place in the CU's in-order vector-memory queue.
+#ifdef SGX_AHEAD2
+    constexpr bool AHEAD2 = ROUNDS > 0 && MODE != OUT_MEL;  // the Mel variants have no registers to spare (2-8 spilled dwords)
+#else
+    constexpr bool AHEAD2 = false;
+#endif
+    constexpr int NCR = ROUNDS > 0 ? ROUNDS : 1;
+    v4f cregA[NCR], cregB[AHEAD2 ? NCR : 1];
     const unsigned chunks = (15u * a.hop + 1024u) >> 2;
-    const bool xs_pad = (a.hop & 255u) == 0;  // +128 B per KiB keeps the 4 frames of a wave on distinct banks
-    auto load_tile = [&](unsigned w) {
+    constexpr bool xs_pad = XSPAD;  // host: (hop & 255) == 0
+    auto load_tile = [&](unsigned w, v4f (&creg)[NCR]) {
         const unsigned b = w / a.tiles, tile = w - b * a.tiles;
         const unsigned f0 = tile * 16u;
 #ifdef SGX_ABL_L2LOAD  // timing experiment: every load hits L2 (4 signals = 2.5 MB)
@@ -473,7 +487,13 @@ __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned
     // (HALVES = 2) a second half without a tile of its own (odd run length: the last round of an XCD) repeats the first half's
     // tile — same values to the same addresses — so both halves always run the same number of rounds and barriers
     if (HALVES == 2 && wid >= hi) wid = lead;
-    if (wid < hi) load_tile(wid);
+    if (wid < hi) load_tile(wid, cregA);
+    if constexpr (AHEAD2) {  // second round's tile
+        const unsigned lead1 = lead + slots * HALVES;
+        unsigned w1 = lead1 + half;
+        if (HALVES == 2 && w1 >= hi) w1 = lead1;
+        if (lead1 < hi) load_tile(w1, cregB);
+    }
     if constexpr (ROUNDS == 0 && MODE != OUT_MEL) {
         // "use" the first tile's samples here: the compiler then waits for these loads in the prologue, and inside the
         // loop every sample load is followed by this half's >= 32 unconditional output stores — which lets it emit
@@ -498,7 +518,7 @@ __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
 #endif
 
-    while (lead < hi) {
+    auto round = [&](v4f (&creg)[NCR]) {
         const unsigned b = wid / a.tiles, tile = wid - b * a.tiles;
         const unsigned f0 = tile * 16u;
         const unsigned nf = min(16u, a.n_frames - f0);
@@ -555,7 +575,14 @@ __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned
         if (HALVES == 2 && next >= hi) next -= half;  // no tile of its own next round: repeat the first half's
         // requested after pass 1 so the previous tile's store burst has had that long to drain: a vector load issued while
         // the CU's store FIFO is backed up stalls its wave for thousands of cycles
-        if (next < hi) load_tile(next);  // in flight during pass 2
+        if constexpr (AHEAD2) {  // the set staged above is free: request the tile of the round after next
+            const unsigned lead2 = lead + 2u * slots * HALVES;
+            unsigned w2 = lead2 + half;
+            if (HALVES == 2 && w2 >= hi) w2 = lead2;
+            if (lead2 < hi) load_tile(w2, creg);
+        } else {
+            if (next < hi) load_tile(next, creg);  // in flight during pass 2
+        }
         SGX_STAMP(2);
         __syncthreads();
         SGX_STAMP(3);
@@ -616,6 +643,13 @@ __global__ __launch_bounds__(256 * HALVES, 2) void k_r32x16(StftArgs a, unsigned
         SGX_STAMP(6);
         wid = next;
         lead += slots * HALVES;
+    };
+    while (lead < hi) {
+        round(cregA);
+        if constexpr (AHEAD2) {
+            if (!(lead < hi)) break;
+            round(cregB);
+        }
     }
     if (HALVES == 2 && half == 0u)
         for (unsigned q = 0; q < skew; ++q) __syncthreads();
@@ -839,7 +873,7 @@ hipError_t launch_variant(const StftArgs &a, hipStream_t s) {
         if (want_single) {
             static bool done = false;
             const unsigned slots = per_xcd < 64u ? per_xcd : 64u;  // two workgroups per CU (LDS-limited)
-            if (stage5) {
+            if (stage5 && (a.hop & 255u) == 0) {
                 if ((e = set_lds_once(k_r32x16<MODE, AMP, 1, 5>, lds, done)) != hipSuccess) return e;
                 hipLaunchKernelGGL((k_r32x16<MODE, AMP, 1, 5>), dim3(slots * 8), dim3(256), lds, s, a, per_xcd, total, slots, 0u);
             } else {
@@ -867,9 +901,12 @@ hipError_t launch_variant(const StftArgs &a, hipStream_t s) {
                 hipLaunchKernelGGL(kernel, dim3(slots * 8), dim3(512), lds + kExBytes, s, a, per_xcd, total, slots, skew);
                 return hipSuccess;
             };
-            if (stage5) {
-                if (CAN_WIDE && want_wide) e = go(k_r32x16<MODE, AMP, 2, 5, CAN_WIDE>);
-                else e = go(k_r32x16<MODE, AMP, 2, 5, false>);
+            if (stage5 && (a.hop & 255u) == 0) {
+                if (CAN_WIDE && want_wide) e = go(k_r32x16<MODE, AMP, 2, 5, CAN_WIDE, true>);
+                else e = go(k_r32x16<MODE, AMP, 2, 5, false, true>);
+            } else if (stage5) {
+                if (CAN_WIDE && want_wide) e = go(k_r32x16<MODE, AMP, 2, 5, CAN_WIDE, false>);
+                else e = go(k_r32x16<MODE, AMP, 2, 5, false, false>);
             } else {
                 if (CAN_WIDE && want_wide) e = go(k_r32x16<MODE, AMP, 2, 0, CAN_WIDE>);
                 else e = go(k_r32x16<MODE, AMP, 2, 0, false>);
