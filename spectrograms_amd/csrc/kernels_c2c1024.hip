@@ -323,23 +323,25 @@ __global__ __launch_bounds__(16 * NF, NF == 16 ? 2 : 1) void k_istft1024(IstftAr
         const long long f = fbase + r;
         const bool valid = f >= 0 && f < (long long)a.n_frames;
         const float vm = valid ? 1.f : 0.f;
-        const v2f *col = in + (valid ? f : 0);
         v2f v[32];
         // conj(W_1024^(16 n1 + n2)) = e^{+2 pi i n1 / 64} (compile-time constant) * conj(W_1024^n2) (one load per lane): the
         // table loads (L1 hits, but 63 more instructions through the same in-order vector-memory pipe as the data) drop to 13
         const v2f wl = twr[n2];
-        // bins k = 16 n1 + n2 and 512 - k: two pointers stepped by 16 rows (one 64-bit add each, no per-load multiply)
-        const size_t step = (size_t)16u * a.n_frames;
-        const v2f *pa = col + (size_t)n2 * a.n_frames, *py = col + (size_t)(512u - n2) * a.n_frames;
+        // bins k = 16 n1 + n2 and 512 - k: one uniform base (the signal) + two 32-bit byte offsets stepped by 16 rows — one
+        // VALU add per load instead of a 64-bit pointer update (the host guarantees 513 * n_frames * 8 < 2^31)
+        const unsigned char *inb = (const unsigned char *)in;
+        const unsigned stepb = 16u * a.n_frames * 8u;
+        const unsigned fcl = valid ? (unsigned)f : 0u;
+        unsigned oa = (n2 * a.n_frames + fcl) * 8u, oy = ((512u - n2) * a.n_frames + fcl) * 8u;
 #pragma unroll
         for (int n1 = 0; n1 < 32; ++n1) {
             const unsigned k = 16u * n1 + n2;
             // a frame outside the signal reads frame 0 (col is clamped) and is zeroed by `vm` in the last multiply-add below:
             // unconditional loads instead of 64 exec-masked branches
-            v2f A = *pa;
-            v2f Y = *py;
-            pa += step;
-            py -= step;
+            v2f A = *(const v2f *)(inb + oa);
+            v2f Y = *(const v2f *)(inb + oy);
+            oa += stepb;
+            oy -= stepb;
             if (k == 0) {  // DC and Nyquist bins: realfft ignores (and reports) their imaginary parts
                 if (a.bad_flag && valid && (A.y != 0.f || Y.y != 0.f)) atomicOr(a.bad_flag, 1u);
                 A.y = 0.f;

@@ -725,7 +725,8 @@ sgx_status run_istft(sgx_plan *pl, const void *spec, size_t batch, size_t n_fram
     if (st != SGX_OK) return st;
     const size_t n = pl->p.n_fft;
     SGX_HIP(pl, hipMemsetAsync(pl->d_flag, 0, sizeof(unsigned), s));
-    if (pl->d_itwr && !std::getenv("SGX_ISTFT_GENERIC")) {  // fused tuned kernel: no frame scratch in HBM
+    // fused tuned kernel: no frame scratch in HBM; it addresses one signal's spectrum with 32-bit byte offsets
+    if (pl->d_itwr && n_frames * 513ull * 8ull < 0x7fffffffull && !std::getenv("SGX_ISTFT_GENERIC")) {
         const size_t pad0 = pl->p.centre ? n / 2 : 0;
         const size_t full0 = (n_frames - 1) * size_t(pl->p.hop_size) + n;
         SGX_HIP(pl, launch_istft1024(spec, out, pl->d_window, unsigned(n_frames), pl->p.hop_size, unsigned(batch),
