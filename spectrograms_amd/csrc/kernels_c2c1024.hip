@@ -307,6 +307,90 @@ constexpr int kISeq = kRSeq + 16;
 // (the real frames, NF * 4 KiB, overlay the exchange buffer).  32 halves the share of halo frames (3 of 32 instead of 3 of 16
 // at hop 256) and doubles the load segments to 256 bytes, but measures slower (see launch_istft1024): 16 is the default.
 
+// Overlap-add of a tile's NF windowed real frames fr[NF][1024] (LDS) into the output signal; shared by both fused kernels.
+template <unsigned NF, unsigned NT>
+__device__ __forceinline__ void istft_ola(const IstftArgs &a, const unsigned char *smem, unsigned tid, unsigned b, long long h0,
+                                          long long fbase) {
+        // overlap-add, one thread per offset `off` inside a hop block, walking the tile's hop blocks: no division per sample.
+        // Position pos = (h0 + hb) hop + off receives frames f in [fh - q + 1, fh] (fh = h0 + hb, q = ceil((1024 - off) / hop)),
+        // clipped to [0, n_frames): ascending f as the reference adds them (:4906-4925), frame sample j = (fh - f) hop + off.
+        const float *fr = (const float *)smem;
+        const float *w = (const float *)a.win;
+        float *o = (float *)a.out + (size_t)b * a.out_len;
+        const unsigned long long p0 = (unsigned long long)h0 * a.hop;
+        const long long last = (long long)a.n_frames - 1;
+        // Interior tiles (47 of 49 per signal at hop 256) with hop | 1024: every position of the tile is inside the output, every
+        // frame exists and q = 1024 / hop frames overlap every offset, so the walk needs no per-block bounds, frame clipping or
+        // edge normalisation — same sums in the same (ascending-frame) order.
+        const bool interior = fbase >= 0 && fbase + (long long)(NF - 1u) <= last && p0 >= a.start &&
+                              p0 + (unsigned long long)a.nbk * a.hop <= a.start + a.out_len && (1024u % a.hop) == 0u;
+        if (interior) {
+            const unsigned q = 1024u / a.hop, fstride = 1024u - a.hop;
+            for (unsigned off = tid; off < a.hop; off += NT) {
+                float nrm = 0.f;
+                for (unsigned i = q; i-- > 0;) {
+                    const float wj = w[i * a.hop + off];
+                    nrm = __fadd_rn(nrm, __fmul_rn(wj, wj));
+                }
+                const float *src = fr + (a.ov + 1u - q) * 1024u + (q - 1u) * a.hop + off;  // frame fh - q + 1 of block 0, sample j
+                float *op = o + (p0 - a.start) + off;
+                const bool div = nrm > 1e-10f;
+                if (q == 4u) {
+                    for (unsigned hb = 0; hb < a.nbk; ++hb) {
+                        float acc = 0.f;
+                        acc += src[0];
+                        acc += src[fstride];
+                        acc += src[2u * fstride];
+                        acc += src[3u * fstride];
+                        if (div) acc /= nrm;
+                        *op = acc;
+                        src += 1024u;
+                        op += a.hop;
+                    }
+                } else {
+                    for (unsigned hb = 0; hb < a.nbk; ++hb) {
+                        float acc = 0.f;
+                        for (unsigned i = 0; i < q; ++i) acc += src[i * fstride];
+                        if (div) acc /= nrm;
+                        *op = acc;
+                        src += 1024u;
+                        op += a.hop;
+                    }
+                }
+            }
+            return;
+        }
+        for (unsigned off = tid; off < a.hop; off += NT) {
+            const unsigned q = (1024u - off + a.hop - 1u) / a.hop;  // frames overlapping this offset (>= 1)
+            float nrm_full = 0.f;  // sum of w^2 over the q frames, same order: the value of every interior position
+            for (unsigned i = q; i-- > 0;) {
+                const float wj = w[i * a.hop + off];
+                nrm_full = __fadd_rn(nrm_full, __fmul_rn(wj, wj));
+            }
+            for (unsigned hb = 0; hb < a.nbk; ++hb) {
+                const unsigned long long pos = p0 + (unsigned long long)hb * a.hop + off;
+                if (pos < a.start || pos - a.start >= a.out_len) continue;
+                const long long fh = h0 + hb;
+                const long long f_lo = max(fh - (long long)q + 1, 0ll), f_hi = min(fh, last);
+                float acc = 0.f, nrm;
+                const float *src = fr + (unsigned)(f_lo - fbase) * 1024u + (unsigned)(fh - f_lo) * a.hop + off;
+                const unsigned cnt = f_hi >= f_lo ? (unsigned)(f_hi - f_lo + 1) : 0u;
+                for (unsigned i = 0; i < cnt; ++i) acc += src[(int)i * (1024 - (int)a.hop)];  // next frame: row + 1, j - hop
+                if (cnt == q) {
+                    nrm = nrm_full;
+                } else {  // signal edges: fewer frames
+                    nrm = 0.f;
+                    for (long long f = f_lo; f <= f_hi; ++f) {
+                        const float wj = w[(unsigned)(fh - f) * a.hop + off];
+                        nrm = __fadd_rn(nrm, __fmul_rn(wj, wj));
+                    }
+                }
+                if (nrm > 1e-10f) acc /= nrm;
+                o[pos - a.start] = acc;
+            }
+        }
+    }
+
 template <int NF>
 __global__ __launch_bounds__(16 * NF, NF == 16 ? 2 : 1) void k_istft1024(IstftArgs a, const v2f *twr, const v2f *tw1) {
     constexpr unsigned NT = 16u * NF;
@@ -405,86 +489,129 @@ __global__ __launch_bounds__(16 * NF, NF == 16 ? 2 : 1) void k_istft1024(IstftAr
         }
     }
     __syncthreads();
+    istft_ola<NF, NT>(a, smem, tid, b, h0, fbase);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_istft1024b: the same fused inverse STFT with the forward kernel's dataflow run backwards, so that every (k, 512 - k) pair
+// of a frame's spectrum is loaded ONCE and folded ONCE (k_istft1024 loads and folds each pair in two lanes):
+//   A  lane (jq, f), job j = wave + 4 jq, owns rows j and 32 - j (job 0: rows 0 and 16) of v[k1 + 32 k2], v = conj(Z'):
+//      16 pairs P = X[k], Q = X[512 - k] with S = P + conj Q, T = conj(W^k)(P - conj Q): v[k] = conj(S + i T) and
+//      v[512 - k] = S - i T (conj(W^k) from an LDS copy of the plan's table); 16-point transforms of both rows;
+//      ds_write_b128 to ex[f][k1][n2].
+//   B  lane (f, n2): column n2 of the 32 rows, twiddle W_512^(k1 n2) (two per-lane register tables), 32-point transform:
+//      y[n2 + 16 n1] -> (x[2n], x[2n+1]) = conj(y) / 1024, times the window, real frames fr[f][1024] over the dead ex.
+//   C  overlap-add (istft_ola).
+// DFT_512 over m = k1 + 32 k2 -> n = n2 + 16 n1:  W^(mn) = W_16^(k2 n2) W_512^(k1 n2) W_32^(k1 n1).
+constexpr int kBFS = 4240;               // bytes per frame of ex[f][32][16] (1060 dwords = 4 mod 32: conflict-free b128 writes)
+constexpr int kBTw = 16 * kBFS;          // 67 840: conj(W_1024^k), k < 512 (4096 B)
+constexpr int kBWin = kBTw + 4096;       // 71 936: the window (4096 B): 32 ds_read_b64 per lane instead of 32 more loads through the
+                                         // in-order vector-memory pipe
+constexpr int kBLds = kBWin + 4096;      // 76 032 B -> two workgroups per CU
+
+__global__ __launch_bounds__(256, 2) void k_istft1024b(IstftArgs a, const v2f *twr, const v2f *tw1) {
+    constexpr unsigned NF = 16, NT = 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned tid = threadIdx.x;
+    const unsigned lb = xcd_logical_block(a.tiles * a.batch);
+    if (lb >= a.tiles * a.batch) return;
+    const unsigned t = lb % a.tiles, b = lb / a.tiles;
+    const long long h0 = (long long)t * a.nbk;      // first hop block of this tile
+    const long long fbase = h0 - (long long)a.ov;   // frame held in row 0
+    v2f *twl = (v2f *)(smem + kBTw);
+    twl[tid] = twr[tid];
+    twl[tid + 256u] = twr[tid + 256u];
+    ((v4f *)(smem + kBWin))[tid] = ((const v4f *)a.win)[tid];
+    __syncthreads();
     {
-        // overlap-add, one thread per offset `off` inside a hop block, walking the tile's hop blocks: no division per sample.
-        // Position pos = (h0 + hb) hop + off receives frames f in [fh - q + 1, fh] (fh = h0 + hb, q = ceil((1024 - off) / hop)),
-        // clipped to [0, n_frames): ascending f as the reference adds them (:4906-4925), frame sample j = (fh - f) hop + off.
-        const float *fr = (const float *)smem;
-        const float *w = (const float *)a.win;
-        float *o = (float *)a.out + (size_t)b * a.out_len;
-        const unsigned long long p0 = (unsigned long long)h0 * a.hop;
-        const long long last = (long long)a.n_frames - 1;
-        // Interior tiles (47 of 49 per signal at hop 256) with hop | 1024: every position of the tile is inside the output, every
-        // frame exists and q = 1024 / hop frames overlap every offset, so the walk needs no per-block bounds, frame clipping or
-        // edge normalisation — same sums in the same (ascending-frame) order.
-        const bool interior = fbase >= 0 && fbase + (long long)(NF - 1u) <= last && p0 >= a.start &&
-                              p0 + (unsigned long long)a.nbk * a.hop <= a.start + a.out_len && (1024u % a.hop) == 0u;
-        if (interior) {
-            const unsigned q = 1024u / a.hop, fstride = 1024u - a.hop;
-            for (unsigned off = tid; off < a.hop; off += NT) {
-                float nrm = 0.f;
-                for (unsigned i = q; i-- > 0;) {
-                    const float wj = w[i * a.hop + off];
-                    nrm = __fadd_rn(nrm, __fmul_rn(wj, wj));
-                }
-                const float *src = fr + (a.ov + 1u - q) * 1024u + (q - 1u) * a.hop + off;  // frame fh - q + 1 of block 0, sample j
-                float *op = o + (p0 - a.start) + off;
-                const bool div = nrm > 1e-10f;
-                if (q == 4u) {
-                    for (unsigned hb = 0; hb < a.nbk; ++hb) {
-                        float acc = 0.f;
-                        acc += src[0];
-                        acc += src[fstride];
-                        acc += src[2u * fstride];
-                        acc += src[3u * fstride];
-                        if (div) acc /= nrm;
-                        *op = acc;
-                        src += 1024u;
-                        op += a.hop;
-                    }
-                } else {
-                    for (unsigned hb = 0; hb < a.nbk; ++hb) {
-                        float acc = 0.f;
-                        for (unsigned i = 0; i < q; ++i) acc += src[i * fstride];
-                        if (div) acc /= nrm;
-                        *op = acc;
-                        src += 1024u;
-                        op += a.hop;
-                    }
+        const unsigned lane = tid & 63u, jq = lane >> 4, fl = lane & 15u;
+        const unsigned j = (tid >> 6) + 4u * jq;
+        const bool j0 = j == 0u;
+        const long long f = fbase + fl;
+        const bool valid = f >= 0 && f < (long long)a.n_frames;
+        const float vm = valid ? 1.f : 0.f;  // a frame outside the signal reads frame 0 and is zeroed in the fold
+        const unsigned fcl = valid ? (unsigned)f : 0u;
+        const unsigned char *inb = (const unsigned char *)a.spec + (size_t)b * 513u * a.n_frames * 8u;
+        const unsigned nf8 = a.n_frames * 8u;
+        // pair p: bin kp and its mirror 512 - kp.  General job: kp = j + 32 p.  Job 0: kp = 16 + 32 p (row 16) for p < 8 and
+        // kp = 32 (p - 8) (row 0) for p >= 8; bin 256 pairs with itself and is handled apart.
+        const unsigned ka = j0 ? 16u : j, kb = j0 ? 0u : j + 256u;
+        v2f PA[16], QB[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const unsigned kp = (p < 8 ? ka : kb) + 32u * (unsigned)(p & 7);
+            v2f P = *(const v2f *)(inb + kp * nf8 + fcl * 8u);
+            v2f Q = *(const v2f *)(inb + (512u - kp) * nf8 + fcl * 8u);
+            if (p == 8) {  // job 0: kp = 0 — DC and Nyquist bins: realfft ignores (and reports) their imaginary parts
+                if (j0) {
+                    if (a.bad_flag && valid && (P.y != 0.f || Q.y != 0.f)) atomicOr(a.bad_flag, 1u);
+                    P.y = 0.f;
+                    Q.y = 0.f;
                 }
             }
-            return;
+            const v2f cw = twl[kp & 511u];  // conj(W_1024^kp)
+            const v2f S = pfma(Q, (v2f){1.f, -1.f}, P), D = pfma(Q, (v2f){-1.f, 1.f}, P);
+            const v2f T = cmulv(D, cw);
+            PA[p] = pfma(swp(T), (v2f){-vm, -vm}, S * (v2f){vm, -vm});  // conj(S + i T)
+            QB[p] = pfma(swp(T), (v2f){vm, -vm}, S * (v2f){vm, vm});    // S - i T
         }
-        for (unsigned off = tid; off < a.hop; off += NT) {
-            const unsigned q = (1024u - off + a.hop - 1u) / a.hop;  // frames overlapping this offset (>= 1)
-            float nrm_full = 0.f;  // sum of w^2 over the q frames, same order: the value of every interior position
-            for (unsigned i = q; i-- > 0;) {
-                const float wj = w[i * a.hop + off];
-                nrm_full = __fadd_rn(nrm_full, __fmul_rn(wj, wj));
-            }
-            for (unsigned hb = 0; hb < a.nbk; ++hb) {
-                const unsigned long long pos = p0 + (unsigned long long)hb * a.hop + off;
-                if (pos < a.start || pos - a.start >= a.out_len) continue;
-                const long long fh = h0 + hb;
-                const long long f_lo = max(fh - (long long)q + 1, 0ll), f_hi = min(fh, last);
-                float acc = 0.f, nrm;
-                const float *src = fr + (unsigned)(f_lo - fbase) * 1024u + (unsigned)(fh - f_lo) * a.hop + off;
-                const unsigned cnt = f_hi >= f_lo ? (unsigned)(f_hi - f_lo + 1) : 0u;
-                for (unsigned i = 0; i < cnt; ++i) acc += src[(int)i * (1024 - (int)a.hop)];  // next frame: row + 1, j - hop
-                if (cnt == q) {
-                    nrm = nrm_full;
-                } else {  // signal edges: fewer frames
-                    nrm = 0.f;
-                    for (long long f = f_lo; f <= f_hi; ++f) {
-                        const float wj = w[(unsigned)(fh - f) * a.hop + off];
-                        nrm = __fadd_rn(nrm, __fmul_rn(wj, wj));
-                    }
-                }
-                if (nrm > 1e-10f) acc /= nrm;
-                o[pos - a.start] = acc;
-            }
+        v2f A[16], B[16];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            A[i] = j0 ? PA[8 + i] : PA[i];        // job 0: v[32 i]
+            B[8 + i] = QB[7 - i];                 // both: element 15 - p of the mirror row, p = 7 - i
+            B[i] = j0 ? PA[i] : QB[15 - i];       // job 0: v[16 + 32 i]
+        }
+        {
+            // job 0, bin 256: v[256] = conj(Z'[256]) = 2 X[256]
+            const v2f X256 = *(const v2f *)(inb + 256u * nf8 + fcl * 8u);
+            A[8] = j0 ? X256 * (v2f){2.f * vm, 2.f * vm} : PA[8];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) A[8 + i] = j0 ? QB[16 - i] : PA[8 + i];  // job 0: v[512 - 32 (8 - i)] = v[32 (8 + i)]
+        }
+        Fft<16, false>::run(A, A);
+        Fft<16, false>::run(B, B);
+        const unsigned ra = j, rb = j0 ? 16u : 32u - j;
+        v4f *da = (v4f *)(smem + fl * kBFS + ra * 128u), *db = (v4f *)(smem + fl * kBFS + rb * 128u);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            da[c] = (v4f){A[2 * c].x, A[2 * c].y, A[2 * c + 1].x, A[2 * c + 1].y};
+            db[c] = (v4f){B[2 * c].x, B[2 * c].y, B[2 * c + 1].x, B[2 * c + 1].y};
         }
     }
+    __syncthreads();
+    const unsigned f2 = tid >> 4, n2 = tid & 15u;
+    v2f v[32];
+    {
+        const unsigned char *src = smem + f2 * kBFS + n2 * 8u;
+#pragma unroll
+        for (int k1 = 0; k1 < 32; ++k1) v[k1] = *(const v2f *)(src + k1 * 128);
+        v2f twa[4], twb[8];  // W_512^(k1 n2) = twa[k1 >> 3] * twb[k1 & 7]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) twa[q] = tw1[16 * 8 * q + n2];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) twb[q] = tw1[16 * q + n2];
+#pragma unroll
+        for (int k1 = 1; k1 < 32; ++k1) {
+            const int qa = k1 >> 3, qb = k1 & 7;
+            if (qb) v[k1] = cmulv(v[k1], twb[qb]);
+            if (qa) v[k1] = cmulv(v[k1], twa[qa]);
+        }
+        Fft<32, false>::run(v, v);
+    }
+    __syncthreads();  // exchange buffer consumed: overlay the real frames
+    {
+        const v2f *w2 = (const v2f *)(smem + kBWin) + n2;
+        v2f *fr2 = (v2f *)smem + f2 * 512u + n2;
+#pragma unroll
+        for (int n1 = 0; n1 < 32; ++n1) {
+            const v2f w = w2[16 * n1];
+            const v2f sc = v[n1] * (v2f){a.scale, -a.scale};  // conj + 1/n: (x[2n], x[2n+1]), n = n2 + 16 n1
+            fr2[16 * n1] = (v2f){__fmul_rn(sc.x, w.x), __fmul_rn(sc.y, w.y)};
+        }
+    }
+    __syncthreads();
+    istft_ola<NF, NT>(a, smem, tid, b, h0, fbase);
 }
 
 }  // namespace
@@ -513,6 +640,13 @@ hipError_t launch_istft1024(const void *spec, void *out, const void *win, unsign
         hipError_t e = nfr == 32 ? set_max_dynamic_lds((const void *)k_istft1024<32>, 32 * kISeq)
                                  : set_max_dynamic_lds((const void *)k_istft1024<16>, 16 * kISeq);
         if (e != hipSuccess) return e;
+    }
+    static const bool old_a = [] { const char *v = getenv("SGX_ISTFT"); return v && v[0] == 'a'; }();  // SGX_ISTFT=a: k_istft1024
+    if (nfr == 16 && !old_a) {
+        hipError_t e = set_max_dynamic_lds((const void *)k_istft1024b, kBLds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_istft1024b, dim3(xcd_grid(g)), dim3(256), kBLds, s, a, (const v2f *)twr, (const v2f *)tw1);
+        return hipGetLastError();
     }
     if (nfr == 32)
         hipLaunchKernelGGL(k_istft1024<32>, dim3(xcd_grid(g)), dim3(512), 32 * kISeq, s, a, (const v2f *)twr, (const v2f *)tw1);
