@@ -38,6 +38,13 @@ for batch, n, hop in ((3, 16000, 256), (5, 41234, 256), (2, 9000, 128), (1, 3000
     ed = np.max(np.abs(D[msk] - refd[msk]))
     assert ed < 1e-3, ("mel_db", batch, n, hop, ed)
     worst = max(worst, e, ep)
+    # inverse STFT of the oracle-checked spectrum: the fused kernels against the CPU oracle's istft
+    from spectrograms_amd import _ffi
+    iplan = sg.Plan(params, _ffi.AMP_COMPLEX, None, None, "float32")
+    y = iplan.istft_batch(torch.from_numpy(S).cuda()).cpu().numpy()
+    yref = np.stack([orc.istft(S[i].astype(np.complex128), 1024, hop, "hanning", True) for i in range(batch)])
+    ei = np.max(np.abs(y - yref)) / max(np.max(np.abs(yref)), 1e-30)
+    assert y.shape == yref.shape and ei < 2e-5, ("istft", batch, n, hop, ei)
 torch.cuda.synchronize()
 print("ok", worst)
 """
@@ -51,6 +58,8 @@ print("ok", worst)
     {"SGX_LOADS": "direct"},              # per-lane sample loads
     {"SGX_KERNEL": "single"},             # two independent 256-thread workgroups per CU
     {"SGX_KERNEL": "q"},                  # 16 values per lane, radix-2 / real split across lanes by DPP
+    {"SGX_ISTFT": "a"},                   # first fused inverse-STFT kernel (every spectrum pair loaded by two lanes)
+    {"SGX_ISTFT_GENERIC": "1"},           # C2R rows + gather overlap-add instead of the fused kernel
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "default")
 def test_switch_variant_matches_oracle(env):
     full = dict(os.environ)
