@@ -537,11 +537,21 @@ __global__ __launch_bounds__(256, 2) void k_istft1024b(IstftArgs a, const v2f *t
         // kp = 32 (p - 8) (row 0) for p >= 8; bin 256 pairs with itself and is handled apart.
         const unsigned ka = j0 ? 16u : j, kb = j0 ? 0u : j + 256u;
         v2f PA[16], QB[16];
+        // byte offsets of bin kp and of its mirror, stepped by 32 bins (no per-load multiply); the twiddles sit 32 entries apart
+        const unsigned st = 32u * nf8;
+        unsigned oa = ka * nf8 + fcl * 8u, oy = (512u - ka) * nf8 + fcl * 8u;
+        const v2f *tp = twl + ka;
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
-            const unsigned kp = (p < 8 ? ka : kb) + 32u * (unsigned)(p & 7);
-            v2f P = *(const v2f *)(inb + kp * nf8 + fcl * 8u);
-            v2f Q = *(const v2f *)(inb + (512u - kp) * nf8 + fcl * 8u);
+            if (p == 8) {
+                oa = kb * nf8 + fcl * 8u;
+                oy = (512u - kb) * nf8 + fcl * 8u;
+                tp = twl + kb;
+            }
+            v2f P = *(const v2f *)(inb + oa);
+            v2f Q = *(const v2f *)(inb + oy);
+            oa += st;
+            oy -= st;
             if (p == 8) {  // job 0: kp = 0 — DC and Nyquist bins: realfft ignores (and reports) their imaginary parts
                 if (j0) {
                     if (a.bad_flag && valid && (P.y != 0.f || Q.y != 0.f)) atomicOr(a.bad_flag, 1u);
@@ -549,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void k_istft1024b(IstftArgs a, const v2f *t
                     Q.y = 0.f;
                 }
             }
-            const v2f cw = twl[kp & 511u];  // conj(W_1024^kp)
+            const v2f cw = tp[32 * (p & 7)];  // conj(W_1024^kp)
             const v2f S = pfma(Q, (v2f){1.f, -1.f}, P), D = pfma(Q, (v2f){-1.f, 1.f}, P);
             const v2f T = cmulv(D, cw);
             PA[p] = pfma(swp(T), (v2f){-vm, -vm}, S * (v2f){vm, -vm});  // conj(S + i T)
