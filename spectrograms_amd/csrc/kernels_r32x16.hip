@@ -862,13 +862,15 @@ hipError_t launch_variant(const StftArgs &a, hipStream_t s) {
         // staged in LDS and re-read per frame from there (5 load instructions per thread instead of 32 through the CU's
         // in-order vector-memory pipe).  Measured on MI355X (256 x 10 s): Mel-dB 162 us staged vs 186 us direct; linear power
         // 147 us staged vs 171 us direct — once the loop no longer drained its stores every tile (vmcnt(32), see the kernel);
-        // before that fix staged was the slower one (189 us).  Complex output: 277 us staged vs 258 us direct, so the complex
-        // STFT keeps direct loads.  SGX_LOADS=staged|direct overrides.
+        // before that fix staged was the slower one (189 us).  Complex output: 277 us staged vs 258 us direct at that time, 226 vs
+        // 240 us since the staging pad became a template parameter (40 VGPRs freed).  SGX_LOADS=staged|direct overrides.
         static const int loads_mode = [] {
             const char *v = getenv("SGX_LOADS");
             return !v ? 0 : v[0] == 's' ? 1 : v[0] == 'd' ? 2 : 0;
         }();
-        const bool want_staged = loads_mode == 1 || (loads_mode == 0 && MODE != OUT_COMPLEX);
+        // (late round 1: with the staging pad a template parameter the staged complex variant no longer runs out of registers and
+        // wins too — 226 us vs 240 us — so every output stages its samples by default)
+        const bool want_staged = loads_mode != 2;
         const bool stage5 = want_staged && aligned16 && chunks <= 5u * 256u;
         if (want_single) {
             static bool done = false;
