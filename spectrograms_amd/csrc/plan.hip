@@ -11,6 +11,7 @@
 #include <new>
 #include <type_traits>
 
+#include "r32x16_layout.h"
 #include "sgx_internal.h"
 
 using namespace sgx;
@@ -401,10 +402,8 @@ sgx_status build_device_tables(sgx_plan *pl) {
         // Mel banks) are applied as [16 rows x K] x [K x 16 frames] products on v_mfma_f32_16x16x4_f32, K restricted to the
         // block's own bin range.  Measured on MI355X (256 x 10 s): ERB-64 266 us vs 4.3 ms on the CSR loop; Mel-80 (12.5
         // non-zeros per row) 183 us on the matrix cores vs 169 us on the LDS band table — so ordinary Mel banks and log-Hz
-        // (<= 2 non-zeros) stay on the band table above.  SGX_MEL=mfma|lds overrides the choice for experiments.
-        const char *force = std::getenv("SGX_MEL");
-        const bool wide = pl->mel_val.size() >= size_t(48) * pl->p.n_mels;
-        const bool want_mm = force ? std::string(force) == "mfma" : wide;
+        // (<= 2 non-zeros) stay on the scheduled band reduction below.
+        const bool want_mm = pl->mel_val.size() >= size_t(48) * pl->p.n_mels;
         if (std::is_same<T, float>::value && pl->p.n_fft == 1024 && want_mm) {
             const unsigned nm = pl->p.n_mels, nblk = (nm + 15) / 16, nb = 513;
             std::vector<uint32_t> blk(size_t(nblk) * 4, 0);
@@ -453,6 +452,90 @@ sgx_status build_device_tables(sgx_plan *pl) {
             if ((st = upload<float>(pl, &pl->d_mm_frag, frag)) != SGX_OK) return st;
             if ((st = upload<uint32_t>(pl, &pl->d_mm_blk, blk)) != SGX_OK) return st;
         }
+        // Band schedule of the tuned kernel (f32, n_fft = 1024; r32x16_layout.h): contiguous banks that do not go to the matrix
+        // cores.  Bands sorted by length, 8 consecutive ranks = one group = the 8 slots of a wave for one segment; groups dealt
+        // longest-first to the wave with the least work (LPT), so the four waves of a half finish together.  Slot q starts at a
+        // bin congruent to q mod 4 (zero weights in front) so the slots of a read group hit different banks; a slot shorter than
+        // its group is padded with zero weights behind — or in front, if it would run past the zeroed rows 513..519.
+        if (std::is_same<T, float>::value && pl->kind == K_R32X16_F32 && contig && !pl->d_mm_frag) {
+            const unsigned nm = pl->p.n_mels;
+            std::vector<unsigned> order(nm);
+            for (unsigned m = 0; m < nm; ++m) order[m] = m;
+            auto len = [&](unsigned m) { return pl->mel_ptr[m + 1] - pl->mel_ptr[m]; };
+            std::stable_sort(order.begin(), order.end(), [&](unsigned x, unsigned y) { return len(x) > len(y); });
+            const unsigned ngroups = (nm + 7) / 8;
+            struct Slot { unsigned band, ks, steps; };
+            struct Group { unsigned L; Slot s[8]; };
+            std::vector<Group> groups(ngroups);
+            for (unsigned g = 0; g < ngroups; ++g) {
+                Group &G = groups[g];
+                G.L = 0;
+                for (unsigned q = 0; q < 8; ++q) {
+                    Slot &S = G.s[q];
+                    S = Slot{0xffffffffu, q, 0};
+                    if (8 * g + q >= nm) continue;
+                    S.band = order[8 * g + q];
+                    if (len(S.band) == 0) continue;  // degenerate triangle: empty sum, still written
+                    const unsigned c0 = pl->mel_col[pl->mel_ptr[S.band]], c1 = pl->mel_col[pl->mel_ptr[S.band + 1] - 1];
+                    const unsigned back = (c0 + 4u - (q & 3u)) & 3u;  // (c0 - q) mod 4
+                    S.ks = c0 >= back ? c0 - back : c0;
+                    S.steps = c1 - S.ks + 1;
+                    G.L = std::max(G.L, (S.steps + 3u) & ~3u);
+                }
+            }
+            std::vector<std::vector<unsigned>> per_wave(4);
+            unsigned load[4] = {0, 0, 0, 0};
+            for (unsigned g = 0; g < ngroups; ++g) {  // groups are already in descending length order
+                unsigned best = 0;
+                for (unsigned w = 1; w < 4; ++w) if (load[w] < load[best]) best = w;
+                per_wave[best].push_back(g);
+                load[best] += groups[g].L + 8;  // + the per-segment epilogue
+            }
+            unsigned nseg = 0;
+            for (auto &v : per_wave) nseg = std::max<unsigned>(nseg, unsigned(v.size()));
+            std::vector<uint32_t> words(r32x16::kSchedHdr + nseg * 16 + nseg * 64, 0);
+            words[0] = nseg;
+            bool ok = true;
+            for (unsigned seg = 0; seg < nseg; ++seg)
+                for (unsigned w = 0; w < 4; ++w) {
+                    uint32_t *h = &words[r32x16::kSchedHdr + (seg * 4 + w) * 4];
+                    const size_t so = r32x16::kSchedHdr + nseg * 16 + ((seg * 4 + w) * 8) * 2;
+                    for (unsigned q = 0; q < 8; ++q) { words[so + 2 * q] = 0xffffffffu; words[so + 2 * q + 1] = q; }
+                    if (seg >= per_wave[w].size()) { h[0] = 0; h[1] = 0; h[2] = 4; continue; }
+                    const Group &G = groups[per_wave[w][seg]];
+                    const unsigned L = G.L, lpad = ((L / 4) & 1u) ? L : L + 4;
+                    const unsigned woff = unsigned((words.size() + 3) & ~size_t(3));
+                    words.resize(woff + 8 * size_t(lpad), 0);
+                    h = &words[r32x16::kSchedHdr + (seg * 4 + w) * 4];
+                    h[0] = L; h[1] = woff; h[2] = lpad;
+                    for (unsigned q = 0; q < 8; ++q) {
+                        Slot S = G.s[q];
+                        if (S.band != 0xffffffffu && S.steps > 0) {
+                            const unsigned c1 = S.ks + S.steps - 1;
+                            if (c1 + (L - S.steps) > 519u) {  // would read past the zeroed rows: pad in front instead
+                                const unsigned d = (c1 + (L - S.steps) - 519u + 3u) / 4u;
+                                if (S.ks < 4 * d) { ok = false; break; }
+                                S.ks -= 4 * d;
+                                S.steps += 4 * d;
+                            }
+                            const uint32_t p0 = pl->mel_ptr[S.band], c0 = pl->mel_col[p0];
+                            for (uint32_t i = p0; i < pl->mel_ptr[S.band + 1]; ++i) {
+                                const float wv = float(pl->mel_val[i]);
+                                uint32_t bits;
+                                std::memcpy(&bits, &wv, 4);
+                                words[woff + q * lpad + (c0 - S.ks) + (i - p0)] = bits;
+                            }
+                        }
+                        words[so + 2 * q] = S.band;
+                        words[so + 2 * q + 1] = S.ks;
+                    }
+                }
+            words[1] = uint32_t(words.size());
+            if (ok && words.size() <= size_t(r32x16::kMelMaxWords)) {
+                pl->mel_sched_words = unsigned(words.size());
+                if ((st = upload<uint32_t>(pl, &pl->d_mel_sched, words)) != SGX_OK) return st;
+            }
+        }
     }
     if (pl->p.n_mfcc > 0) {
         const unsigned nm = pl->p.n_mels, nc = pl->p.n_mfcc;
@@ -468,21 +551,24 @@ sgx_status build_device_tables(sgx_plan *pl) {
     if (pl->kind == K_R32X16_F32) {
         // tw1[k1][n2] = W_512^(k1*n2) (pass-1 twiddles), tw2[j][k2] = W_1024^(j + 32*k2) (real-split twiddles)
         // tw1[k1][n2] = W_512^(k1*n2); tw2[row][idx] = (wr, wi, wi, -wr) of W_1024^(row + 32*idx), row stride 17 float4
-        std::vector<float> t1(2 * 32 * 16), t2(17 * 17 * 4, 0.0f);
+        std::vector<float> t1(2 * 32 * 16), t2(16 * 17 * 4, 0.0f);
         for (unsigned k1 = 0; k1 < 32; ++k1)
             for (unsigned n2 = 0; n2 < 16; ++n2) {
                 const double a = -2.0 * kPi * double(k1 * n2) / 512.0;
                 t1[2 * (k1 * 16 + n2)] = float(std::cos(a));
                 t1[2 * (k1 * 16 + n2) + 1] = float(std::sin(a));
             }
-        for (unsigned j = 0; j < 17; ++j)
-            for (unsigned k2 = 0; k2 < 16; ++k2) {
-                const double a = -2.0 * kPi * double(j + 32 * k2) / 1024.0;
-                float *q = &t2[4 * (j * 17 + k2)];
-                q[0] = float(std::cos(a));
-                q[1] = float(std::sin(a));
-                q[2] = q[1];
-                q[3] = -q[0];
+        // tw2[job][i], i < 16: the pair the job splits i-th is (Z[k], Z[512 - k]) with k = c1 + 32 i (i < 8) or c2 + 32 (i - 8),
+        // c1 = j, c2 = j + 256 (job 0: 16 and 0).  With W = W_1024^k = (wr, wi) the kernel needs W' = -i W = (wi, -wr) and
+        // W'^perp = (-W'.y, W'.x) = (wr, wi):  T = D.x W' + D.y W'^perp.
+        for (unsigned j = 0; j < 16; ++j)
+            for (unsigned i = 0; i < 16; ++i) {
+                const unsigned c1 = j == 0 ? 16u : j, c2 = j == 0 ? 0u : j + 256u;
+                const unsigned k = i < 8 ? c1 + 32 * i : c2 + 32 * (i - 8);
+                const double a = -2.0 * kPi * double(k) / 1024.0;
+                const float wr = float(std::cos(a)), wi = float(std::sin(a));
+                float *q = &t2[4 * (j * 17 + i)];
+                q[0] = wi; q[1] = -wr; q[2] = wr; q[3] = wi;
             }
         if ((st = upload<float>(pl, &pl->d_tw1, t1)) != SGX_OK) return st;
         if ((st = upload<float>(pl, &pl->d_tw2, t2)) != SGX_OK) return st;
@@ -528,6 +614,8 @@ void fill_args(const sgx_plan *pl, StftArgs &a, const void *x, void *out, size_t
     a.mm_frag = pl->d_mm_frag;
     a.mm_blk = (const uint4 *)pl->d_mm_blk;
     a.mm_nblk = pl->mm_nblk;
+    a.mel_sched = (const unsigned *)pl->d_mel_sched;
+    a.mel_sched_words = pl->mel_sched_words;
     a.n_mels = p.n_mels;
     a.mel_nnz = unsigned(pl->mel_col.size());
     a.out_mode = pl->out_mode;
@@ -647,7 +735,7 @@ sgx_status grow(sgx_plan *pl, void **buf, size_t *have, size_t need) {
 
 void free_device(sgx_plan *pl) {
     void **bufs[] = {&pl->d_window, &pl->d_tw, &pl->d_tw1, &pl->d_tw2, &pl->d_mel_ptr, &pl->d_mel_col,
-                     &pl->d_mel_val, &pl->d_dct, &pl->d_lifter, &pl->d_melbuf, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_mm_frag, &pl->d_mm_blk, &pl->d_itw, &pl->d_itwr, &pl->d_itw1, &pl->d_frames, &pl->d_flag, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half};
+                     &pl->d_mel_val, &pl->d_dct, &pl->d_lifter, &pl->d_melbuf, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_mm_frag, &pl->d_mm_blk, &pl->d_mel_sched, &pl->d_itw, &pl->d_itwr, &pl->d_itw1, &pl->d_frames, &pl->d_flag, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half};
     for (void **b : bufs)
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
@@ -726,7 +814,7 @@ sgx_status run_istft(sgx_plan *pl, const void *spec, size_t batch, size_t n_fram
     const size_t n = pl->p.n_fft;
     SGX_HIP(pl, hipMemsetAsync(pl->d_flag, 0, sizeof(unsigned), s));
     // fused tuned kernel: no frame scratch in HBM; it addresses one signal's spectrum with 32-bit byte offsets
-    if (pl->d_itwr && n_frames * 513ull * 8ull < 0x7fffffffull && !std::getenv("SGX_ISTFT_GENERIC")) {
+    if (pl->d_itwr && n_frames * 513ull * 8ull < 0x7fffffffull) {
         const size_t pad0 = pl->p.centre ? n / 2 : 0;
         const size_t full0 = (n_frames - 1) * size_t(pl->p.hop_size) + n;
         SGX_HIP(pl, launch_istft1024(spec, out, pl->d_window, unsigned(n_frames), pl->p.hop_size, unsigned(batch),
@@ -817,8 +905,7 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
     // powers of two (32..8192) and the listed even composite sizes: register-tiled kernel; other powers of two: LDS radix-2;
     // other composite lengths: two-factor DFT; primes fall through to the direct sum
     pl->kind = (pow2 || params->n_fft % 2 == 0) ? K_REG_RADIX : K_TWO_FACTOR;  // (even sizes outside the register-tiled list fall through)
-    static const bool no_tuned = [] { const char *v = std::getenv("SGX_TUNED"); return v && v[0] == '0'; }();  // A/B switch
-    if (params->dtype == SGX_F32 && params->n_fft == 1024 && params->hop_size % 2 == 0 && !no_tuned) pl->kind = K_R32X16_F32;
+    if (params->dtype == SGX_F32 && params->n_fft == 1024 && params->hop_size % 2 == 0) pl->kind = K_R32X16_F32;
     {
         StftArgs probe;
         fill_args(pl, probe, nullptr, nullptr, 1, params->n_fft, params->n_fft, 1);

@@ -64,15 +64,16 @@ struct StftArgs {
     double eps;  // 10^(floor_db/10) in f64; cast to T in the kernel (T::from_f64, spectrogram.rs:2028)
     // tuned-kernel tables (K_R32X16_F32)
     const void *tw1;  // [32][16] complex<f32>: W_512^(k1*n2)
-    const void *tw2;  // [16][16] complex<f32>: W_1024^(j + 32*k2) etc.
+    const void *tw2;  // float4 [16 jobs][17]: the real-split twiddles in each job's consumption order (r32x16_layout.h)
+    // filterbank schedule of the tuned kernel (r32x16_layout.h), nullptr: bank not schedulable (matrix cores / CSR path)
+    const unsigned *mel_sched;
+    unsigned mel_sched_words;
 };
 
 // launchers (kernels_generic.hip / kernels_r32x16.hip); return hipSuccess or the launch error
 hipError_t launch_direct_dft(const StftArgs &a, int dtype, hipStream_t s);
 hipError_t launch_lds_radix2(const StftArgs &a, int dtype, hipStream_t s);
 hipError_t launch_r32x16_f32(const StftArgs &a, hipStream_t s);
-bool q16x32_takes(const StftArgs &a);                          // kernels_q16x32.hip (experimental, SGX_KERNEL=q)
-hipError_t launch_q16x32_f32(const StftArgs &a, hipStream_t s);
 // MFCC epilogue over a Mel-dB tensor [batch][n_mels][n_frames] -> [batch][n_out][n_frames]; basis [n_mfcc][n_mels], lifter [n_mfcc]
 hipError_t launch_mfcc(const void *mel, void *out, const void *basis, const void *lifter, unsigned batch, unsigned n_mels,
                        unsigned n_frames, unsigned n_mfcc, unsigned skip, int has_lifter, int dtype, hipStream_t s);
@@ -193,7 +194,8 @@ struct sgx_plan {
 
     // device tables
     void *d_window = nullptr, *d_tw = nullptr, *d_tw1 = nullptr, *d_tw2 = nullptr;
-    void *d_mel_ptr = nullptr, *d_mel_col = nullptr, *d_mel_val = nullptr, *d_mel_pptr = nullptr, *d_mel_pcol = nullptr, *d_mel_pw = nullptr, *d_mm_frag = nullptr, *d_mm_blk = nullptr;
+    void *d_mel_ptr = nullptr, *d_mel_col = nullptr, *d_mel_val = nullptr, *d_mel_pptr = nullptr, *d_mel_pcol = nullptr, *d_mel_pw = nullptr, *d_mm_frag = nullptr, *d_mm_blk = nullptr, *d_mel_sched = nullptr;
+    unsigned mel_sched_words = 0;
     unsigned mm_nblk = 0;
     unsigned mel_pchunks = 0;
     unsigned mel_contig = 0;
