@@ -62,6 +62,25 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, un
 }
 __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)p; }  // low half of a flat LDS address
 
+#ifdef SGX_STAMPS  // diagnostic build only (tools/stamps.py): a wave's cycles per phase
+__device__ unsigned long long g_stamps[32];
+#define SGX_STAMP(i)                                                                        \
+    do {                                                                                    \
+        unsigned long long t_;                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        st_acc[i] += t_ - st_prev;                                                          \
+        st_prev = t_;                                                                       \
+    } while (0)
+#define SGX_STAMP_PARAMS , unsigned long long *st_acc, unsigned long long &st_prev
+#define SGX_STAMP_ARGS , st_acc, st_prev
+#else
+#define SGX_STAMP(i)
+#define SGX_STAMP_PARAMS
+#define SGX_STAMP_ARGS
+#endif
+
 // ---- single-issue LDS reads -------------------------------------------------------------------------------------------
 // hipcc fuses neighbouring 8-byte LDS reads into ds_read2_b64, which the LDS serves at 128 B/clk; a plain ds_read_b64 gets
 // 256 B/clk.  These reads are issued from inline asm (the compiler neither fuses nor counts them) and collected by an asm
@@ -69,6 +88,10 @@ __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(
 template <int OFF>
 __device__ __forceinline__ void ds_read64(v2f &d, unsigned addr) {
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void ds_read128(v4f &d, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
 }
 template <int N>
 __device__ __forceinline__ void tie8(v2f *d) {  // N < 0: no instruction, ordering only ("+v" counts twice towards the 30-operand limit)
@@ -151,7 +174,7 @@ struct PwAddr {
 template <int MODE, int AMP, bool PWT>
 __device__ __forceinline__ void pass2_compute(v2f (&A)[16], v2f (&B)[16], bool j0, float eps, const v4f *tw, __amdgpu_buffer_rsrc_t ro,
                                               unsigned oa1, unsigned ob1, unsigned oa2, unsigned ob2, unsigned omid, unsigned step,
-                                              float *pw_c1, float *pw_m1, float *pw_c2, float *pw_m2, float *pw_mid) {
+                                              float *pw_c1, float *pw_m1, float *pw_c2, float *pw_m2, float *pw_mid SGX_STAMP_PARAMS) {
     // Job 0 owns the two self-paired rows 0 and 16.  Its transformed rows rearranged once, under a branch only its lanes take, it runs the general
     // pairing below: first loop (A[i], B[15-i]), second loop (A[8+t], B[7-t]).
     //   first  loop wants (B[i], B[15-i])            -> A'[i] = B[i], B'[8..15] unchanged
@@ -172,6 +195,7 @@ __device__ __forceinline__ void pass2_compute(v2f (&A)[16], v2f (&B)[16], bool j
         for (int i = 0; i < 8; ++i) B[i] = nB[i];
         asm volatile("" ::: "memory");  // keeps this a branch (the compiler turned the selects into 48 v_cndmask per tile)
     }
+    SGX_STAMP(9);  // 16-point transforms
     constexpr int PSTEP = PWT ? 32 * 16 : 32;  // floats between bins k and k + 32 in the |X|^2 tile
     auto emit = [&](unsigned voff, unsigned soff, float *pwp, v2f X, bool conj) {
 #ifdef SGX_ABL_NOSTORE  // timing experiment only: keep the value alive, drop the store
@@ -182,6 +206,10 @@ __device__ __forceinline__ void pass2_compute(v2f (&A)[16], v2f (&B)[16], bool j
             const v2f V = conj ? (v2f){X.x, -X.y} : X;
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, V), ro, (int)voff, (int)soff, 0);
         } else if constexpr (MODE == OUT_MEL) {
+#ifdef SGX_ABL_NOPW
+            asm volatile("" ::"v"(X), "v"(pwp));
+            return;
+#endif
             *pwp = AMP == AMP_MAG_IN ? sqrtf(power_of(X)) : power_of(X);
         } else {
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, amp_f32<AMP>(power_of(X), eps)), ro, (int)voff, (int)soff, 0);
@@ -211,6 +239,7 @@ __device__ __forceinline__ void pass2_compute(v2f (&A)[16], v2f (&B)[16], bool j
         emit(ob2, (7 - t) * step, pw_m2 + (7 - t) * PSTEP, Y, true);
     }
     if (j0) emit(omid, 0u, pw_mid, a8 * (v2f){2.f, -2.f}, false);  // X[256] = 2 conj(Z[256]) (row 0, k2 = 8)
+    SGX_STAMP(10);  // real split (+ direct stores / LDS writes)
 }
 
 // ---- filterbank stage, generic forms (|X|^2 tile stored pw[f][k], kPS floats per frame) -----------------------------------
@@ -300,12 +329,14 @@ __device__ __forceinline__ void map_tile_mfma(const StftArgs &a, const float *pw
 }
 
 // ---- filterbank stage on the schedule (banks whose rows are runs of consecutive bins: Mel, log-Hz) ------------------------
-// |X|^2 tile transposed: pwT[k][f], 16 frames = 64 bytes per bin.  Lane (slot = lane >> 3, fp = lane & 7) of wave w reduces
-// frames (2 fp, 2 fp + 1) of the band the schedule gives (segment, w, slot): one ds_read_b64 serves both frames of a bin, the
-// weights come four bins at a time (ds_read_b128 from the slot's contiguous row), and the two running sums are one packed
+// |X|^2 tile transposed and paired: bins (2m, 2m+1) x frames (2p, 2p+1) are one 16-byte group, 8 groups = 128 bytes per bin
+// pair (pwt_index below).  Lane (slot = lane >> 3, fp = lane & 7) of wave w reduces frames (2 fp, 2 fp + 1) of the band the
+// schedule gives (segment, w, slot): one ds_read_b128 serves two bins of both frames (16-byte reads keep the LDS rate at two
+// waves per SIMD, 8-byte reads do not), the weights come four bins at a time, and the two running sums are one packed
 // multiply and one packed add per bin — un-fused and in ascending-bin order exactly like SparseMatrix::multiply_vec
 // (spectrogram.rs:102-117).  Padding steps carry weight +0: 0 * p = +0 added to a non-negative partial sum is exact.
-// The host starts slot s at a bin congruent to s mod 4, so the four slots of a 32-lane read group fall on different banks.
+// The host starts slots 0, 1 at a bin = 0 mod 4 and slots 2, 3 at a bin = 2 mod 4, so the slots of a read group fall on different banks.
+__host__ __device__ constexpr unsigned pwt_index(unsigned k, unsigned f) { return (k >> 1) * 32u + (f >> 1) * 4u + (k & 1u) * 2u + (f & 1u); }
 __device__ __forceinline__ v2f mul_add_unfused(float w, v2f p, v2f acc) {
 #pragma clang fp contract(off)
     const v2f m = (v2f){w, w} * p;
@@ -315,30 +346,36 @@ template <int AMP>
 __device__ __forceinline__ void mel_tile_sched(const StftArgs &a, const float *pwT, const unsigned *sched, unsigned b, unsigned f0,
                                                unsigned nf, float eps, unsigned tid) {
     const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u, slot = lane >> 3, fp = lane & 7u;
-    const unsigned nseg = sched[0];
-    float *o = (float *)a.out + ((size_t)b * a.n_out) * a.n_frames + f0 + 2u * fp;
-    for (unsigned seg = 0; seg < nseg; ++seg) {
-        const unsigned *h = sched + kSchedHdr + (seg * 4u + wave) * 4u;
-        const unsigned L = __builtin_amdgcn_readfirstlane(h[0]);
-        const unsigned woff = __builtin_amdgcn_readfirstlane(h[1]), lpad = __builtin_amdgcn_readfirstlane(h[2]);
-        const unsigned *si = sched + kSchedHdr + nseg * 16u + ((seg * 4u + wave) * 8u + slot) * 2u;
-        const unsigned band = si[0], ks = si[1];
-        const float *wrow = (const float *)sched + woff + slot * lpad;
-        const v2f *pp = (const v2f *)pwT + ks * 8u + fp;
+    // out[b][band][f0 + 2 fp ..]: one descriptor per tile; a lane without a frame or a slot without a band gets an offset past
+    // its range and the hardware drops the store.  The stores are unconditional and the segment loop has a fixed trip count so
+    // that the compiler can count them behind the next tile's sample loads (vmcnt(2 kSchedSegs), not vmcnt(0): the loop must
+    // never wait for its own stores).
+    const unsigned obytes = (a.n_out * a.n_frames - f0) * 4u;
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc((const float *)a.out + (size_t)b * a.n_out * a.n_frames + f0, obytes);
+    constexpr unsigned kDrop = 0x80000000u;
+    const unsigned fo0 = 2u * fp < nf ? 8u * fp : kDrop, fo1 = 2u * fp + 1u < nf ? 8u * fp + 4u : kDrop;
+    // one 16-byte record per (segment, wave, slot): {L of the wave, word offset of the slot's weight row, first bin, band}
+    const uint4 *info = (const uint4 *)(sched + kSchedHdr) + wave * 8u + slot;
+    uint4 cur = info[0];
+#pragma unroll
+    for (unsigned seg = 0; seg < (unsigned)kSchedSegs; ++seg) {
+        const uint4 nxt = info[(seg + 1u) * 32u];  // fetched ahead; the table always holds kSchedSegs + 1 segments
+        const unsigned L = __builtin_amdgcn_readfirstlane(cur.x);
+        const v4f *wr = (const v4f *)((const float *)sched + cur.y);
+        const v4f *pr = (const v4f *)(pwT + (cur.z >> 1) * 32u) + fp;  // kstart is even
         v2f acc = {0.0f, 0.0f};
-        for (unsigned t = 0; t < L; t += 4u) {
-            const v4f w = *(const v4f *)(wrow + t);
-            const v2f p0 = pp[(t + 0u) * 8u], p1 = pp[(t + 1u) * 8u], p2 = pp[(t + 2u) * 8u], p3 = pp[(t + 3u) * 8u];
-            acc = mul_add_unfused(w.x, p0, acc);
-            acc = mul_add_unfused(w.y, p1, acc);
-            acc = mul_add_unfused(w.z, p2, acc);
-            acc = mul_add_unfused(w.w, p3, acc);
+        for (unsigned t = 0; t < L; t += 4u) {  // q0 = (bin t: frames f, f+1; bin t+1: frames f, f+1)
+            const v4f w4 = wr[t >> 2], q0 = pr[(t >> 1) * 8u], q1 = pr[(t >> 1) * 8u + 8u];
+            acc = mul_add_unfused(w4.x, (v2f){q0.x, q0.y}, acc);
+            acc = mul_add_unfused(w4.y, (v2f){q0.z, q0.w}, acc);
+            acc = mul_add_unfused(w4.z, (v2f){q1.x, q1.y}, acc);
+            acc = mul_add_unfused(w4.w, (v2f){q1.z, q1.w}, acc);
         }
-        if (band != 0xffffffffu) {
-            float *ob = o + (size_t)band * a.n_frames;
-            if (2u * fp < nf) ob[0] = amp_f32<AMP>(acc.x, eps);
-            if (2u * fp + 1u < nf) ob[1] = amp_f32<AMP>(acc.y, eps);
-        }
+        const bool have = cur.w != 0xffffffffu;
+        const unsigned bo = cur.w * a.n_frames * 4u;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, amp_f32<AMP>(acc.x, eps)), ro, (int)((have && fo0 != kDrop) ? bo + fo0 : kDrop), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, amp_f32<AMP>(acc.y, eps)), ro, (int)((have && fo1 != kDrop) ? bo + fo1 : kDrop), 0, 0);
+        cur = nxt;
     }
 }
 
@@ -454,6 +491,25 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
     const unsigned xaddr = lds_addr(smem) + p1f * hop * 4u + n2 * 8u + (XSPAD ? p1f * 128u : 0u);
     const unsigned waddr = lds_addr(tabs + kWinOff) + n2 * 8u;
 
+#ifdef SGX_SKEW  // experiment (Mel-type outputs: the halves are independent): the second half enters the loop SGX_SKEW barriers late
+    if (MODE == OUT_MEL && half == 1u)
+        for (unsigned q = 0; q < SGX_SKEW; ++q) __syncthreads();
+#endif
+    // Per-bin outputs: the workgroups of an XCD start a few hundred cycles apart (slot s waits ~256 s cycles, one round at most).
+    // All CUs run the same program on the same amount of work, so without this their store bursts (66 KB per CU per round) hit
+    // the memory system together and their arithmetic phases leave it idle together: measured 141 -> 129 us (linear power),
+    // 240 -> 221 us (complex); the filterbank outputs write little and lose 3 % (left alone).
+#ifndef SGX_STAGGER
+#define SGX_STAGGER 4u
+#endif
+    if constexpr (MODE != OUT_MEL) {
+        for (unsigned q = 0; q < (blockIdx.x >> 3) * SGX_STAGGER; ++q) __builtin_amdgcn_s_sleep(1);
+        __syncthreads();
+    }
+#ifdef SGX_STAMPS
+    unsigned long long st_acc[16] = {0}, st_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+#endif
     while (lead < hi) {
         const unsigned b = wid / a.tiles, tile = wid - b * a.tiles;
         const unsigned f0 = tile * 16u;
@@ -468,7 +524,9 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
                     const unsigned c = r * 256u + tid;
                     if (XSPAD || c < chunks) *(v4f *)(smem + c * 16u + (XSPAD ? (c >> 6) * 128u : 0u)) = creg[r];
                 }
+                SGX_STAMP(0);  // wait for the samples + staging writes
                 __syncthreads();  // barrier 1: xs complete
+                SGX_STAMP(1);
                 read_cols<XSPAD, 0>(e, we, xaddr, waddr, std::make_integer_sequence<int, 16>{});
                 read_cols<XSPAD, 1>(o, wo, xaddr, waddr, std::make_integer_sequence<int, 16>{});
                 tie16<15>(e);  // at most 15 of the 64 reads outstanding: the 32 of (e, we) have landed
@@ -491,16 +549,21 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
             Fft<16, true>::run(o, wo);
             Comb<32, 0, v2f>::run(xr, e, o);
         }
+        SGX_STAMP(2);  // column / window reads + 32-point transform
         // barrier 2: every wave has read its columns of xs; pass 1 may overwrite it with ex.  It sits behind the arithmetic:
         // by now the slowest wave's reads landed long ago, so nobody waits here.
         if constexpr (ROUNDS > 0) __syncthreads();
+        SGX_STAMP(3);  // barrier 2
         twiddle_store(xr, twa, twb, smem + p1f * kFS + n2 * 8);
+        SGX_STAMP(4);  // twiddles + ex writes
         unsigned next = lead + slots * 2u + half;
         if (next >= hi) next -= half;  // no tile of its own next round: repeat the first half's
         // requested after pass 1 so the previous tile's store burst has had that long to drain: a vector load issued while
         // the CU's store FIFO is backed up stalls its wave for thousands of cycles
         if (lead + slots * 2u < hi) load_tile(next);  // in flight during pass 2
+        SGX_STAMP(5);  // load issue
         __syncthreads();  // barrier 3: ex complete
+        SGX_STAMP(6);
         // Linear / complex outputs: every lane runs pass 2 and stores, so the compiler can count the stores behind the next
         // tile's loads (one in-order counter for loads and stores: it then waits with vmcnt(33), not vmcnt(0)).  A lane whose
         // frame does not exist (last tile of a signal) mirrors the tile's last frame, an idle second half (odd tile count)
@@ -528,36 +591,56 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
         }
         v2f A[16], B[16];
         read_rows((WIDE ? smem_all : smem) + p2ex * kFS, ra, rb, A, B);
+        SGX_STAMP(7);  // row reads
         __syncthreads();  // barrier 4: ex consumed: the next staging (or the pw overlay) may overwrite it
-        float *pwf = (float *)smem;
+        SGX_STAMP(8);
+        float *pwf = (float *)(smem + (PWT ? kOutOff : 0));  // PWT: above the staged samples, so the next staging does not wait for it
         if constexpr (MODE == OUT_MEL) {
-            if constexpr (PWT) {  // bins 513..519 are read with zero weights
-                if (tid < 112u) pwf[513u * 16u + tid] = 0.0f;
+            if constexpr (PWT) {  // bins 513..523 are read with zero weights
+                if (tid < 176u) pwf[pwt_index(513u + (tid >> 4), tid & 15u)] = 0.0f;
             } else {
                 if (tid < 48u) pwf[(tid / 3u) * kPS + 513u + tid % 3u] = 0.0f;
             }
         }
         if (ALLSTORE || p2f < nf) {
             const unsigned c1 = j == 0 ? 16u : j, c2 = j == 0 ? 0u : j + 256u;
-            // |X|^2 slots of this lane: bin k of frame p2f at pwf[k * 16 + p2f] (PWT) or pwf[p2f * kPS + k]
-            constexpr int KS = PWT ? 16 : 1;
-            float *pb = pwf + (PWT ? p2f : p2f * kPS);
             const unsigned long long obytes = (unsigned long long)min(2u, a.batch - p2b) * 513ull * a.n_frames * ES;
             const __amdgpu_buffer_rsrc_t ro = make_rsrc((unsigned char *)a.out + (size_t)p2b * 513u * a.n_frames * ES, (unsigned)obytes);
-            pass2_compute<MODE, AMP, PWT>(A, B, j == 0, eps, twj, ro, (jo.a1 + p2ofs) * ES, (jo.b1 + p2ofs) * ES, (jo.a2 + p2ofs) * ES,
-                                          (jo.b2 + p2ofs) * ES, (jo.mid + p2ofs) * ES, step, pb + c1 * KS, pb + (512u - 224u - c1) * KS,
-                                          pb + c2 * KS, pb + (512u - 224u - c2) * KS, pb + 256 * KS);
+            {
+                auto slot_of = [&](unsigned k) { return pwf + (PWT ? pwt_index(k, p2f) : p2f * kPS + k); };  // bins k + 32 i follow at i * PSTEP
+                pass2_compute<MODE, AMP, PWT>(A, B, j == 0, eps, twj, ro, (jo.a1 + p2ofs) * ES, (jo.b1 + p2ofs) * ES, (jo.a2 + p2ofs) * ES,
+                                                     (jo.b2 + p2ofs) * ES, (jo.mid + p2ofs) * ES, step, slot_of(c1), slot_of(512u - 224u - c1),
+                                                     slot_of(c2), slot_of(512u - 224u - c2), slot_of(256u) SGX_STAMP_ARGS);
+            }
         }
         if constexpr (MODE == OUT_MEL) {
             __syncthreads();
+            SGX_STAMP(11);  // barrier: |X|^2 tile complete
+#ifdef SGX_ABL_NOMEL
+            if (a.n_mels == 12345u)
+#endif
             if constexpr (PWT) mel_tile_sched<AMP>(a, pwf, sched, b, f0, nf, eps, tid);
             else if (a.mm_frag) map_tile_mfma<AMP>(a, pwf, b, f0, nf, eps, tid, 2u * half);
             else mel_tile_csr<AMP>(a, pwf, b, f0, nf, eps, tid, 256u);
-            __syncthreads();  // pw consumed before the next staging overwrites it
+            if constexpr (!PWT) __syncthreads();  // pw consumed before the next staging overwrites it
         }
+        SGX_STAMP(14);  // filterbank stage
         wid = next;
         lead += slots * 2u;
+#ifdef SGX_STAMPS
+        st_acc[15] += 1;
+#endif
     }
+#ifdef SGX_SKEW
+    if (MODE == OUT_MEL && half == 0u)
+        for (unsigned q = 0; q < SGX_SKEW; ++q) __syncthreads();
+#endif
+#ifdef SGX_STAMPS
+    if ((threadIdx.x & 63u) == 0) {
+        for (int q = 0; q < 16; ++q) atomicAdd(&g_stamps[q], st_acc[q]);
+        atomicAdd(&g_stamps[16], 1ull);
+    }
+#endif
 }
 
 template <int MODE, int AMP>
@@ -566,7 +649,10 @@ hipError_t launch_variant(const StftArgs &a, hipStream_t s) {
     const unsigned per_xcd = (total + 7) / 8;
     const unsigned chunks = (15u * a.hop + 1024u) >> 2;
     const unsigned pairs = (per_xcd + 1) / 2;
-    const unsigned nslots = pairs < 32u ? pairs : 32u;  // one 512-thread workgroup per CU
+#ifndef SGX_SLOTS
+#define SGX_SLOTS 32u
+#endif
+    const unsigned nslots = pairs < SGX_SLOTS ? pairs : SGX_SLOTS;  // one 512-thread workgroup per CU
     const bool pwt = MODE == OUT_MEL && a.mel_sched != nullptr;
     auto go = [&](auto kernel) -> hipError_t {
         hipError_t e = set_max_dynamic_lds((const void *)kernel, kLdsBytes);
@@ -588,6 +674,17 @@ hipError_t launch_variant(const StftArgs &a, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef SGX_STAMPS
+extern "C" int sgx_debug_read_stamps(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[32] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 
 bool plan_geometry_r32x16_f32(StftArgs &a) {
     if (a.n_fft != 1024 || (a.hop & 1u)) return false;

@@ -454,9 +454,9 @@ sgx_status build_device_tables(sgx_plan *pl) {
         }
         // Band schedule of the tuned kernel (f32, n_fft = 1024; r32x16_layout.h): contiguous banks that do not go to the matrix
         // cores.  Bands sorted by length, 8 consecutive ranks = one group = the 8 slots of a wave for one segment; groups dealt
-        // longest-first to the wave with the least work (LPT), so the four waves of a half finish together.  Slot q starts at a
-        // bin congruent to q mod 4 (zero weights in front) so the slots of a read group hit different banks; a slot shorter than
-        // its group is padded with zero weights behind — or in front, if it would run past the zeroed rows 513..519.
+        // longest-first to the wave with the least work (LPT), so the four waves of a half finish together.  Slots start at an
+        // even bin, = 0 or 2 mod 4 by slot (zero weights in front), so the slots of a read group hit different banks; a slot shorter
+        // than its group is padded with zero weights behind — or in front, if it would run past the zeroed rows 513..523.
         if (std::is_same<T, float>::value && pl->kind == K_R32X16_F32 && contig && !pl->d_mm_frag) {
             const unsigned nm = pl->p.n_mels;
             std::vector<unsigned> order(nm);
@@ -477,10 +477,11 @@ sgx_status build_device_tables(sgx_plan *pl) {
                     S.band = order[8 * g + q];
                     if (len(S.band) == 0) continue;  // degenerate triangle: empty sum, still written
                     const unsigned c0 = pl->mel_col[pl->mel_ptr[S.band]], c1 = pl->mel_col[pl->mel_ptr[S.band + 1] - 1];
-                    const unsigned back = (c0 + 4u - (q & 3u)) & 3u;  // (c0 - q) mod 4
-                    S.ks = c0 >= back ? c0 - back : c0;
+                    const unsigned want = (q & 2u) ? 2u : 0u;        // slots 0, 1 start at 0 mod 4, slots 2, 3 at 2 mod 4 (bank halves)
+                    const unsigned back = (c0 + 4u - want) & 3u;      // (c0 - want) mod 4
+                    S.ks = c0 >= back ? c0 - back : (c0 & ~1u);       // always even: the kernel reads bin pairs
                     S.steps = c1 - S.ks + 1;
-                    G.L = std::max(G.L, (S.steps + 3u) & ~3u);
+                    G.L = std::max(G.L, (S.steps + 3u) & ~3u);  // the kernel takes 4 steps per trip
                 }
             }
             std::vector<std::vector<unsigned>> per_wave(4);
@@ -493,27 +494,24 @@ sgx_status build_device_tables(sgx_plan *pl) {
             }
             unsigned nseg = 0;
             for (auto &v : per_wave) nseg = std::max<unsigned>(nseg, unsigned(v.size()));
-            std::vector<uint32_t> words(r32x16::kSchedHdr + nseg * 16 + nseg * 64, 0);
+            const unsigned kSegs = r32x16::kSchedSegs;
+            std::vector<uint32_t> words(r32x16::kSchedHdr + (kSegs + 1) * 32 * 4, 0);
             words[0] = nseg;
-            bool ok = true;
-            for (unsigned seg = 0; seg < nseg; ++seg)
+            bool ok = nseg <= kSegs;
+            for (unsigned seg = 0; ok && seg <= kSegs; ++seg)
                 for (unsigned w = 0; w < 4; ++w) {
-                    uint32_t *h = &words[r32x16::kSchedHdr + (seg * 4 + w) * 4];
-                    const size_t so = r32x16::kSchedHdr + nseg * 16 + ((seg * 4 + w) * 8) * 2;
-                    for (unsigned q = 0; q < 8; ++q) { words[so + 2 * q] = 0xffffffffu; words[so + 2 * q + 1] = q; }
-                    if (seg >= per_wave[w].size()) { h[0] = 0; h[1] = 0; h[2] = 4; continue; }
-                    const Group &G = groups[per_wave[w][seg]];
-                    const unsigned L = G.L, lpad = ((L / 4) & 1u) ? L : L + 4;
+                    const size_t ro = r32x16::kSchedHdr + ((seg * 4 + w) * 8) * 4;
+                    const bool have = seg < per_wave[w].size();
+                    const Group *G = have ? &groups[per_wave[w][seg]] : nullptr;
+                    const unsigned L = have ? G->L : 0, lpad = ((L / 4) & 1u) ? L : L + 4;  // lpad / 4 odd: the 8 slots' rows start on different banks
                     const unsigned woff = unsigned((words.size() + 3) & ~size_t(3));
                     words.resize(woff + 8 * size_t(lpad), 0);
-                    h = &words[r32x16::kSchedHdr + (seg * 4 + w) * 4];
-                    h[0] = L; h[1] = woff; h[2] = lpad;
                     for (unsigned q = 0; q < 8; ++q) {
-                        Slot S = G.s[q];
+                        Slot S = have ? G->s[q] : Slot{0xffffffffu, q, 0};
                         if (S.band != 0xffffffffu && S.steps > 0) {
                             const unsigned c1 = S.ks + S.steps - 1;
-                            if (c1 + (L - S.steps) > 519u) {  // would read past the zeroed rows: pad in front instead
-                                const unsigned d = (c1 + (L - S.steps) - 519u + 3u) / 4u;
+                            if (c1 + (L - S.steps) > 523u) {  // would read past the zeroed rows: pad in front instead
+                                const unsigned d = (c1 + (L - S.steps) - 523u + 3u) / 4u;  // (keeps kstart = slot mod 4)
                                 if (S.ks < 4 * d) { ok = false; break; }
                                 S.ks -= 4 * d;
                                 S.steps += 4 * d;
@@ -526,10 +524,11 @@ sgx_status build_device_tables(sgx_plan *pl) {
                                 words[woff + q * lpad + (c0 - S.ks) + (i - p0)] = bits;
                             }
                         }
-                        words[so + 2 * q] = S.band;
-                        words[so + 2 * q + 1] = S.ks;
+                        uint32_t *r = &words[ro + 4 * q];
+                        r[0] = L; r[1] = woff + q * lpad; r[2] = S.ks; r[3] = S.band;
                     }
                 }
+            words.resize(words.size() + 4, 0);
             words[1] = uint32_t(words.size());
             if (ok && words.size() <= size_t(r32x16::kMelMaxWords)) {
                 pl->mel_sched_words = unsigned(words.size());
