@@ -22,6 +22,15 @@
  *    from sgx_last_error() / sgx_last_create_error().
  *  - There is no CPU fallback: without a usable HIP device every compute entry
  *    point returns SGX_BACKEND.
+ *  - The library keeps no mutable global state and reads no environment
+ *    variables; an entry point leaves the caller's current HIP device as it
+ *    found it.
+ *  - Allocation: everything the per-frame entry points (sgx_r2c / sgx_c2r, the
+ *    analogues of R2cPlan / C2rPlan::process) touch is allocated by
+ *    sgx_plan_create.  The batched entry points need scratch that depends on the
+ *    call's size (host staging, the MFCC Mel tensor, the generic inverse path's
+ *    frames): sgx_reserve sizes it ahead; a call that fits what was reserved
+ *    allocates nothing, a larger one grows the scratch once.
  */
 #ifndef SPECTRO_HIP_H
 #define SPECTRO_HIP_H
@@ -33,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SGX_ABI_VERSION 4
+#define SGX_ABI_VERSION 5
 
 typedef struct sgx_plan sgx_plan; /* opaque */
 
@@ -157,9 +166,48 @@ sgx_status sgx_window(const sgx_plan *plan, double *out /*n_fft*/);
 sgx_status sgx_mel_weights(const sgx_plan *plan, size_t *nnz, uint32_t *row_ptr /*n_mels+1*/,
                            uint32_t *cols, double *vals);
 
-/* Utterance sharding for one-process-per-GPU runs: contiguous blocks, remainder to
- * the low ranks. */
+/* Pre-sizes the plan-owned scratch of the batched entry points for calls of up to `batch` signals of `n_samples` samples:
+ * the MFCC plan's Mel-dB tensor always; with `inverse` the frame scratch of sgx_istft (generic path) for spectra of that many
+ * frames; with `host_staging` the device staging of the SGX_MEM_HOST paths.  After it, such calls do not allocate
+ * ("plans own scratch, no allocation in process", src/fft_backend.rs:21-24). */
+sgx_status sgx_reserve(sgx_plan *plan, size_t batch, size_t n_samples, int32_t host_staging, int32_t inverse);
+
+/* The HIP device ordinal the plan is bound to (resolved at creation when the params said -1); -2 for a host-only plan. */
+int32_t sgx_plan_device(const sgx_plan *plan);
+
+/* DimensionMismatch { expected, got } (src/error.rs:19-21, raised by validate_fft_io src/fft_backend.rs:264-282 and
+ * compute_into src/spectrogram.rs:423-434): the two numbers of the plan's most recent SGX_DIM_MISMATCH. */
+sgx_status sgx_last_dim_mismatch(const sgx_plan *plan, size_t *expected, size_t *got);
+
+/* ---- multi-GPU (BASELINE config 4): utterances shard across ranks in contiguous blocks (remainder to the low
+ * ranks), one process or thread per GPU, no data-path collective unless the caller asks for the gathered output. */
 sgx_status sgx_shard_range(size_t batch, int32_t world_size, int32_t rank, size_t *start, size_t *count);
+
+/* RCCL communicator, resolved at run time (the library does not link RCCL; a host that already carries one gets that copy).
+ * sgx_comm_unique_id: rank 0 makes the 128-byte id and hands it to the other ranks by its own means (ncclGetUniqueId);
+ * sgx_comm_create: ncclCommInitRank on `device` (-1 = current); collective over all ranks.
+ * sgx_comm_adopt: wraps an ncclComm_t the host created itself (not destroyed by sgx_comm_destroy). */
+#define SGX_COMM_ID_BYTES 128
+typedef struct sgx_comm sgx_comm; /* opaque; one per rank */
+sgx_status sgx_comm_unique_id(void *id128);
+sgx_status sgx_comm_create(const void *id128, int32_t world_size, int32_t rank, int32_t device, sgx_comm **out);
+sgx_status sgx_comm_adopt(void *nccl_comm, int32_t world_size, int32_t rank, int32_t device, sgx_comm **out);
+void sgx_comm_destroy(sgx_comm *comm);
+const char *sgx_comm_last_error(const sgx_comm *comm); /* NULL: the text of a failed create / adopt / unique_id */
+
+/* All-gather of per-rank shards of `global_batch` items of `elems_per_item` elements (dtype SGX_F32 / SGX_F64; a complex value
+ * counts as two): rank r contributes its sgx_shard_range block from `send`, every rank receives all blocks in rank order in
+ * `recv` (device pointers; `send` may be the rank's own slice of `recv`).  Asynchronous on `hip_stream`.  Equal shards are one
+ * ncclAllGather, ragged ones a group of ncclBroadcast. */
+sgx_status sgx_gather(sgx_comm *comm, const void *send, void *recv, size_t global_batch, size_t elems_per_item, int32_t dtype,
+                      void *hip_stream);
+
+/* This rank's part of a `global_batch`-signal job: runs the plan on its shard (`shard_samples`: device pointer to the rank's
+ * own sgx_shard_range block, rows `sample_stride` apart) into `shard_out` — or, if that is NULL, straight into its slice of
+ * `gathered_out` — and, when `gathered_out` is not NULL, gathers all shards into it ([global_batch][n_bins][n_frames] on every
+ * rank).  Asynchronous on `hip_stream`.  The plan and the communicator must be on the same device. */
+sgx_status sgx_shard_execute(sgx_plan *plan, sgx_comm *comm, const void *shard_samples, size_t global_batch, size_t n_samples,
+                             size_t sample_stride, void *shard_out, void *gathered_out, void *hip_stream);
 
 /* ---- 2-D FFT path (BASELINE config 5): R2cPlan2d / C2rPlan2d (src/fft_backend.rs:169-246, 614-819), fft2d / ifft2d
  * (src/fft2d.rs:77-185), convolve_fft and the radial filters (src/image_ops.rs:80-432).  Batched: `batch` images of
@@ -182,6 +230,10 @@ sgx_status sgx_fft2d_convolve(sgx_fft2d *plan, const void *images, size_t batch,
  * spectrum's own dimensions (image_ops.rs:236-267, 301-432 — the reference's quirk S14 is reproduced) */
 sgx_status sgx_fft2d_filter(sgx_fft2d *plan, const void *images, size_t batch, int32_t kind, double cut_lo, double cut_hi,
                             void *out, int32_t mem_kind, void *hip_stream);
+/* Pre-sizes the plan-owned intermediates (and, with `host_staging`, the device staging of the SGX_MEM_HOST paths) for calls of
+ * up to `batch` images, so that those calls do not allocate. */
+sgx_status sgx_fft2d_reserve(sgx_fft2d *plan, size_t batch, int32_t host_staging);
+int32_t sgx_fft2d_device(const sgx_fft2d *plan); /* the HIP device ordinal the plan is bound to */
 const char *sgx_fft2d_last_error(const sgx_fft2d *plan);
 
 const char *sgx_last_error(const sgx_plan *plan);

@@ -27,7 +27,9 @@ SYMBOLS = [
     "sgx_r2c", "sgx_c2r", "sgx_istft", "sgx_istft_length", "sgx_window", "sgx_mel_weights", "sgx_shard_range", "sgx_last_error", "sgx_last_create_error",
     "sgx_kernel_name", "sgx_abi_version", "sgx_device_count",
     "sgx_fft2d_create", "sgx_fft2d_destroy", "sgx_fft2d_forward", "sgx_fft2d_inverse", "sgx_fft2d_convolve",
-    "sgx_fft2d_filter", "sgx_fft2d_last_error",
+    "sgx_fft2d_filter", "sgx_fft2d_last_error", "sgx_fft2d_reserve", "sgx_fft2d_device",
+    "sgx_reserve", "sgx_plan_device", "sgx_last_dim_mismatch",
+    "sgx_comm_unique_id", "sgx_comm_create", "sgx_comm_adopt", "sgx_comm_destroy", "sgx_comm_last_error", "sgx_gather", "sgx_shard_execute",
 ]
 
 
@@ -52,7 +54,11 @@ class InvalidInputError(SpectrogramError):
 
 
 class DimensionMismatchError(SpectrogramError):
-    pass
+    """DimensionMismatch { expected, got } (src/error.rs:19-21): the two numbers are attributes when the library reported them."""
+
+    def __init__(self, msg="", expected=None, got=None):
+        super().__init__(msg)
+        self.expected, self.got = expected, got
 
 
 class FFTBackendError(SpectrogramError):
@@ -115,6 +121,22 @@ def lib() -> C.CDLL:
     L.sgx_fft2d_filter.argtypes = [vp, vp, sz, C.c_int32, C.c_double, C.c_double, vp, C.c_int32, vp]
     L.sgx_fft2d_last_error.argtypes = [vp]
     L.sgx_fft2d_last_error.restype = C.c_char_p
+    L.sgx_fft2d_reserve.argtypes = [vp, sz, C.c_int32]
+    L.sgx_fft2d_device.argtypes = [vp]
+    L.sgx_fft2d_device.restype = C.c_int32
+    L.sgx_reserve.argtypes = [vp, sz, sz, C.c_int32, C.c_int32]
+    L.sgx_plan_device.argtypes = [vp]
+    L.sgx_plan_device.restype = C.c_int32
+    L.sgx_last_dim_mismatch.argtypes = [vp, C.POINTER(sz), C.POINTER(sz)]
+    L.sgx_comm_unique_id.argtypes = [vp]
+    L.sgx_comm_create.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.sgx_comm_adopt.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.sgx_comm_destroy.argtypes = [vp]
+    L.sgx_comm_destroy.restype = None
+    L.sgx_comm_last_error.argtypes = [vp]
+    L.sgx_comm_last_error.restype = C.c_char_p
+    L.sgx_gather.argtypes = [vp, vp, vp, sz, sz, C.c_int32, vp]
+    L.sgx_shard_execute.argtypes = [vp, vp, vp, sz, sz, sz, vp, vp, vp]
     _lib = L
     return L
 
@@ -124,4 +146,9 @@ def raise_status(status: int, plan=None) -> None:
         return
     L = lib()
     msg = (L.sgx_last_error(plan) if plan else L.sgx_last_create_error()) or b""
-    raise _ERR.get(status, InternalError)(msg.decode() or f"status {status}")
+    text = msg.decode() or f"status {status}"
+    if status == SGX_DIM_MISMATCH and plan:
+        e, g = C.c_size_t(), C.c_size_t()
+        if L.sgx_last_dim_mismatch(plan, C.byref(e), C.byref(g)) == SGX_OK:
+            raise DimensionMismatchError(text, e.value, g.value)
+    raise _ERR.get(status, InternalError)(text)

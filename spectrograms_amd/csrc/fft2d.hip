@@ -175,10 +175,7 @@ sgx_status fused_product_dev(sgx_fft2d *p, const void *img, size_t batch, const 
     return SGX_OK;
 }
 
-bool use_fused(const sgx_fft2d *p) {
-    static const bool off = [] { const char *v = std::getenv("SGX_FFT2D_FUSED"); return v && v[0] == '0'; }();
-    return p->d_tw1c && !off;
-}
+bool use_fused(const sgx_fft2d *p) { return p->d_tw1c != nullptr; }
 
 // create_lowpass_mask (image_ops.rs:236-267) on the half spectrum's own dims (quirk S14), f64 logic
 void lowpass_mask(size_t nrows, size_t ncols, double cutoff, std::vector<double> &m) {
@@ -197,7 +194,8 @@ void lowpass_mask(size_t nrows, size_t ncols, double cutoff, std::vector<double>
 template <typename F>
 sgx_status with_staging(sgx_fft2d *p, const void *in, size_t in_bytes, void *out, size_t out_bytes, int mem_kind,
                         hipStream_t s, F body) {
-    F2_HIP(p, hipSetDevice(p->device));
+    DeviceGuard dg;
+    F2_HIP(p, dg.enter(p->device));
     if (mem_kind == SGX_MEM_DEVICE) return body(in, out);
     if (mem_kind != SGX_MEM_HOST) return fail(p, SGX_INVALID_INPUT, "Invalid input: unknown mem_kind");
     sgx_status st;
@@ -221,6 +219,24 @@ sgx_status check(sgx_fft2d *p, const void *a, const void *b, size_t batch) {
 }  // namespace
 
 extern "C" {
+
+int32_t sgx_fft2d_device(const sgx_fft2d *p) { return p ? p->device : -2; }
+
+sgx_status sgx_fft2d_reserve(sgx_fft2d *p, size_t batch, int32_t host_staging) {
+    if (!p || batch == 0) return SGX_INVALID_INPUT;
+    DeviceGuard dg;
+    F2_HIP(p, dg.enter(p->device));
+    const size_t R = p->nrows, C = p->ncols, Cb = p->cb;
+    sgx_status st;
+    if ((st = grow2(p, &p->d_inter, &p->inter_bytes, batch * Cb * R * 2 * p->elem)) != SGX_OK) return st;
+    if ((st = grow2(p, &p->d_spec, &p->spec_bytes, batch * R * Cb * 2 * p->elem)) != SGX_OK) return st;
+    if (host_staging) {
+        const size_t big = batch * R * Cb * 2 * p->elem;  // a half spectrum is the larger of (image, spectrum)
+        if ((st = grow2(p, &p->d_in, &p->in_bytes, big)) != SGX_OK) return st;
+        if ((st = grow2(p, &p->d_out, &p->out_bytes, big)) != SGX_OK) return st;
+    }
+    return SGX_OK;
+}
 
 const char *sgx_fft2d_last_error(const sgx_fft2d *plan) { return plan ? plan->err.c_str() : g_err2d.c_str(); }
 
@@ -254,7 +270,8 @@ sgx_status sgx_fft2d_create(size_t nrows, size_t ncols, int32_t dtype, int32_t d
     }
     p->device = p->rows->device;
     auto tables = [&]() -> sgx_status {
-        F2_HIP(p, hipSetDevice(p->device));
+        DeviceGuard dg;
+    F2_HIP(p, dg.enter(p->device));
         sgx_status s1 = dtype == SGX_F64 ? upload_tw<double>(p, &p->d_tw_r, nrows) : upload_tw<float>(p, &p->d_tw_r, nrows);
         if (s1 != SGX_OK) return s1;
         s1 = dtype == SGX_F64 ? upload_tw<double>(p, &p->d_tw_c, ncols) : upload_tw<float>(p, &p->d_tw_c, ncols);
@@ -301,7 +318,8 @@ sgx_status sgx_fft2d_create(size_t nrows, size_t ncols, int32_t dtype, int32_t d
 void sgx_fft2d_destroy(sgx_fft2d *p) {
     if (!p) return;
     if (p->rows) {
-        (void)hipSetDevice(p->device);
+        DeviceGuard dg;
+        (void)dg.enter(p->device);
         void *bufs[] = {p->d_tw_r, p->d_tw_c, p->d_tw1c, p->d_twr, p->d_tw1r, p->d_inter, p->d_spec, p->d_kspec, p->d_mask, p->d_in, p->d_out, p->d_kimg};
         for (void *b : bufs)
             if (b) (void)hipFree(b);
@@ -338,7 +356,8 @@ sgx_status sgx_fft2d_convolve(sgx_fft2d *p, const void *images, size_t batch, co
     if (krows == 0 || kcols == 0) return fail(p, SGX_INVALID_INPUT, "Invalid input: kernel dimensions must be > 0");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t R = p->nrows, C = p->ncols, Cb = p->cb;
-    F2_HIP(p, hipSetDevice(p->device));
+    DeviceGuard dg;
+    F2_HIP(p, dg.enter(p->device));
     // pad_kernel_for_fft (image_ops.rs:123-152): kernel centre -> (0,0), wrapped
     std::vector<unsigned char> padded(R * C * p->elem, 0);
     const long cr = long(krows / 2), cc = long(kcols / 2);
@@ -377,7 +396,8 @@ sgx_status sgx_fft2d_filter(sgx_fft2d *p, const void *images, size_t batch, int3
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t R = p->nrows, C = p->ncols, Cb = p->cb;
-    F2_HIP(p, hipSetDevice(p->device));
+    DeviceGuard dg;
+    F2_HIP(p, dg.enter(p->device));
     std::vector<double> m, m2;
     lowpass_mask(R, Cb, cut_lo, m);  // spectrum.dim() = (nrows, ncols/2+1): S14
     if (kind == 1) for (double &v : m) v = 1.0 - v;

@@ -307,7 +307,7 @@ constexpr int kISeq = kRSeq + 16;
 // (the real frames, NF * 4 KiB, overlay the exchange buffer).  32 halves the share of halo frames (3 of 32 instead of 3 of 16
 // at hop 256) and doubles the load segments to 256 bytes, but measures slower (see launch_istft1024): 16 is the default.
 
-// Overlap-add of a tile's NF windowed real frames fr[NF][1024] (LDS) into the output signal; shared by both fused kernels.
+// Overlap-add of a tile's NF windowed real frames fr[NF][1024] (LDS) into the output signal.
 template <unsigned NF, unsigned NT>
 __device__ __forceinline__ void istft_ola(const IstftArgs &a, const unsigned char *smem, unsigned tid, unsigned b, long long h0,
                                           long long fbase) {
@@ -391,106 +391,6 @@ __device__ __forceinline__ void istft_ola(const IstftArgs &a, const unsigned cha
         }
     }
 
-template <int NF>
-__global__ __launch_bounds__(16 * NF, NF == 16 ? 2 : 1) void k_istft1024(IstftArgs a, const v2f *twr, const v2f *tw1) {
-    constexpr unsigned NT = 16u * NF;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const unsigned tid = threadIdx.x;
-    const unsigned lb = xcd_logical_block(a.tiles * a.batch);
-    if (lb >= a.tiles * a.batch) return;
-    const unsigned t = lb % a.tiles, b = lb / a.tiles;
-    const long long h0 = (long long)t * a.nbk;      // first hop block of this tile
-    const long long fbase = h0 - (long long)a.ov;   // frame held in row 0
-    const v2f *in = (const v2f *)a.spec + (size_t)b * 513u * a.n_frames;
-    {
-        const unsigned r = tid & (NF - 1u), n2 = tid / NF;
-        const long long f = fbase + r;
-        const bool valid = f >= 0 && f < (long long)a.n_frames;
-        const float vm = valid ? 1.f : 0.f;
-        v2f v[32];
-        // conj(W_1024^(16 n1 + n2)) = e^{+2 pi i n1 / 64} (compile-time constant) * conj(W_1024^n2) (one load per lane): the
-        // table loads (L1 hits, but 63 more instructions through the same in-order vector-memory pipe as the data) drop to 13
-        const v2f wl = twr[n2];
-        // bins k = 16 n1 + n2 and 512 - k: one uniform base (the signal) + two 32-bit byte offsets stepped by 16 rows — one
-        // VALU add per load instead of a 64-bit pointer update (the host guarantees 513 * n_frames * 8 < 2^31)
-        const unsigned char *inb = (const unsigned char *)in;
-        const unsigned stepb = 16u * a.n_frames * 8u;
-        const unsigned fcl = valid ? (unsigned)f : 0u;
-        unsigned oa = (n2 * a.n_frames + fcl) * 8u, oy = ((512u - n2) * a.n_frames + fcl) * 8u;
-#pragma unroll
-        for (int n1 = 0; n1 < 32; ++n1) {
-            const unsigned k = 16u * n1 + n2;
-            // a frame outside the signal reads frame 0 (col is clamped) and is zeroed by `vm` in the last multiply-add below:
-            // unconditional loads instead of 64 exec-masked branches
-            v2f A = *(const v2f *)(inb + oa);
-            v2f Y = *(const v2f *)(inb + oy);
-            oa += stepb;
-            oy -= stepb;
-            if (k == 0) {  // DC and Nyquist bins: realfft ignores (and reports) their imaginary parts
-                if (a.bad_flag && valid && (A.y != 0.f || Y.y != 0.f)) atomicOr(a.bad_flag, 1u);
-                A.y = 0.f;
-                Y.y = 0.f;
-            }
-            // S = A + conj Y, D = A - conj Y as fused multiply-adds with (1, -1) / (-1, 1): no separate sign flips
-            const v2f S = pfma(Y, (v2f){1.f, -1.f}, A), D = pfma(Y, (v2f){-1.f, 1.f}, A);
-            const v2f cw = n1 == 0 ? wl : cmulv(wl, (v2f){(float)kCos64[n1], (float)kSin64[n1]});
-            const v2f T = cmulv(D, cw);
-            // conj(S + i T) = (S.x - T.y, -(S.y + T.x)): the conjugate the forward-FFT inverse trick wants, in one fma
-            v[n1] = pfma(swp(T), (v2f){-vm, -vm}, S * (v2f){vm, -vm});
-        }
-        Fft<32, false>::run(v, v);
-        unsigned char *dst = smem + r * kISeq + n2 * 8;
-        *(v2f *)dst = v[0];
-        v2f twa[4], twb[8];  // W_512^(k1 n2) = twa[k1 >> 3] * twb[k1 & 7]
-#pragma unroll
-        for (int q = 0; q < 4; ++q) twa[q] = tw1[16 * 8 * q + n2];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) twb[q] = tw1[16 * q + n2];
-#pragma unroll
-        for (int k1 = 1; k1 < 32; ++k1) {
-            const int qa = k1 >> 3, qb = k1 & 7;
-            v2f r2 = v[k1];
-            if (qb) r2 = cmulv(r2, twb[qb]);
-            if (qa) r2 = cmulv(r2, twa[qa]);
-            *(v2f *)(dst + k1 * kRRS) = r2;
-        }
-    }
-    __syncthreads();
-    v2f y[2][16];
-    const unsigned k1 = tid & 31u;
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const unsigned r = (tid >> 5) + (NT / 32u) * it;
-        v2f x[16];
-        const v4f *rowp = (const v4f *)(smem + r * kISeq + k1 * kRRS);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const v4f q = rowp[c];
-            x[2 * c] = (v2f){q.x, q.y};
-            x[2 * c + 1] = (v2f){q.z, q.w};
-        }
-        Fft<16, false>::run(x, x);
-#pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) y[it][k2] = x[k2];
-    }
-    __syncthreads();  // exchange buffer consumed: overlay the real frames
-    {
-        const v2f *w2 = (const v2f *)a.win + k1;
-        float *fr = (float *)smem;
-#pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) {
-            const v2f w = w2[32 * k2];
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const unsigned r = (tid >> 5) + (NT / 32u) * it;
-                const v2f sc = y[it][k2] * (v2f){a.scale, -a.scale};  // conj + 1/n: (x[2n], x[2n+1]), n = k1 + 32 k2
-                *(v2f *)(fr + r * 1024u + 2u * (k1 + 32u * k2)) = (v2f){__fmul_rn(sc.x, w.x), __fmul_rn(sc.y, w.y)};
-            }
-        }
-    }
-    __syncthreads();
-    istft_ola<NF, NT>(a, smem, tid, b, h0, fbase);
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // k_istft1024b: the same fused inverse STFT with the forward kernel's dataflow run backwards, so that every (k, 512 - k) pair
@@ -635,33 +535,18 @@ hipError_t launch_istft1024(const void *spec, void *out, const void *win, unsign
     a.n_frames = n_frames; a.hop = hop; a.batch = batch;
     a.ov = 1023u / hop;
     if (a.ov >= 16) return hipErrorInvalidConfiguration;
-    // measured (256 x 626 frames, hop 256): 32 frames per workgroup 512 us, 16 frames 405 us — one 8-wave workgroup per CU
-    // keeps every wave in the same phase, two independent 4-wave workgroups overlap their load / transform / store phases
-    static const bool big = [] { const char *v = getenv("SGX_ISTFT_NF"); return v && v[0] == '3'; }();  // SGX_ISTFT_NF=32
-    const unsigned nfr = (n_frames >= 64 && big) ? 32u : 16u;
-    a.nbk = nfr - a.ov;
+    // measured in round 1 (256 x 626 frames, hop 256): one 8-wave workgroup of 32 frames per CU keeps every wave in the same
+    // phase (512 us); two independent 4-wave workgroups of 16 frames overlap their load / transform / store phases (316 us)
+    a.nbk = 16u - a.ov;
     const unsigned long long full = (unsigned long long)(n_frames - 1) * hop + 1024ull;
     const unsigned long long blocks = (full + hop - 1) / hop;
     a.tiles = (unsigned)((blocks + a.nbk - 1) / a.nbk);
     a.start = start; a.out_len = out_len; a.scale = scale; a.bad_flag = bad_flag;
     const unsigned long long g = (unsigned long long)a.tiles * batch;
     if (g == 0 || g >= 0x7fffffffull) return hipErrorInvalidConfiguration;
-    {
-        hipError_t e = nfr == 32 ? set_max_dynamic_lds((const void *)k_istft1024<32>, 32 * kISeq)
-                                 : set_max_dynamic_lds((const void *)k_istft1024<16>, 16 * kISeq);
-        if (e != hipSuccess) return e;
-    }
-    static const bool old_a = [] { const char *v = getenv("SGX_ISTFT"); return v && v[0] == 'a'; }();  // SGX_ISTFT=a: k_istft1024
-    if (nfr == 16 && !old_a) {
-        hipError_t e = set_max_dynamic_lds((const void *)k_istft1024b, kBLds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_istft1024b, dim3(xcd_grid(g)), dim3(256), kBLds, s, a, (const v2f *)twr, (const v2f *)tw1);
-        return hipGetLastError();
-    }
-    if (nfr == 32)
-        hipLaunchKernelGGL(k_istft1024<32>, dim3(xcd_grid(g)), dim3(512), 32 * kISeq, s, a, (const v2f *)twr, (const v2f *)tw1);
-    else
-        hipLaunchKernelGGL(k_istft1024<16>, dim3(xcd_grid(g)), dim3(256), 16 * kISeq, s, a, (const v2f *)twr, (const v2f *)tw1);
+    hipError_t e = set_max_dynamic_lds((const void *)k_istft1024b, kBLds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_istft1024b, dim3(xcd_grid(g)), dim3(256), kBLds, s, a, (const v2f *)twr, (const v2f *)tw1);
     return hipGetLastError();
 }
 

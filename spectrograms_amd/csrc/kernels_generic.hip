@@ -647,13 +647,9 @@ hipError_t launch_chroma_norm(void *data, unsigned batch, unsigned n_frames, int
     return hipGetLastError();
 }
 
-static const size_t kLdsBudget = [] {
-    // frames per tile are chosen to fill this much LDS.  32 KB (4-5 workgroups per CU) measured 5-20 % faster than 64 KB for
-    // the sizes in tools/time_generic.py: shorter store segments, but more waves to hide the LDS / barrier latency
-    const char *v = getenv("SGX_GENERIC_LDS_KB");
-    const long kb = v ? atol(v) : 32;
-    return (size_t)(kb >= 4 && kb <= 64 ? kb : 32) * 1024;
-}();
+// frames per tile are chosen to fill this much LDS.  32 KB (4-5 workgroups per CU) measured 5-20 % faster than 64 KB for
+// the sizes in tools/time_generic.py: shorter store segments, but more waves to hide the LDS / barrier latency
+static const size_t kLdsBudget = 32 * 1024;
 
 static const size_t kLdsHardLimit = 64 * 1024;  // static + dynamic LDS a kernel gets without the large-LDS opt-in
 
@@ -743,11 +739,7 @@ static size_t reg_radix_bytes(const StftArgs &a, unsigned ft, unsigned fa, unsig
     return (bytes + 15) & ~size_t(15);
 }
 
-static const size_t kRegBudget = [] {
-    const char *v = std::getenv("SGX_REG_LDS_KB");
-    const long kb = v ? std::atol(v) : 0;
-    return (size_t)((kb >= 8 && kb <= 160) ? kb : 72) * 1024;  // two persistent workgroups per CU at the least
-}();
+static const size_t kRegBudget = 72 * 1024;  // two persistent workgroups per CU at the least
 static const size_t kRegHardLimit = 144 * 1024;  // a single frame of the largest sizes may take most of the CU
 
 static unsigned reg_radix_ft_max(unsigned fbc) {
@@ -759,9 +751,8 @@ static unsigned reg_radix_ft_max(unsigned fbc) {
 }
 
 bool plan_geometry_reg_radix(StftArgs &a, int dtype) {
-    static const bool off = [] { const char *v = std::getenv("SGX_GENERIC"); return v && v[0] == 'l'; }();  // SGX_GENERIC=lds
     unsigned fa, fb, fc;
-    if (off || !reg_radix_split(a, dtype, &fa, &fb, &fc)) return false;
+    if (!reg_radix_split(a, dtype, &fa, &fb, &fc)) return false;
     const size_t es = elem_size(dtype);
     // instances that run one workgroup per CU anyway (rr_waves == 1: f64 with a 16-point or longer pass) may use most of its LDS
     const size_t budget = (dtype == SGX_F64 && fa >= 16) ? std::max(kRegBudget, kRegHardLimit - 16 * 1024) : kRegBudget;

@@ -260,7 +260,7 @@ hipError_t launch_c2r_t(const C2rArgs &a, unsigned ltile, size_t lds, hipStream_
     return hipGetLastError();
 }
 
-const bool kRegOff = [] { const char *v = std::getenv("SGX_GENERIC"); return v && v[0] == 'l'; }();  // SGX_GENERIC=lds
+constexpr bool kRegOff = false;
 
 }  // namespace
 

@@ -27,6 +27,11 @@ sgx_status set_err(const sgx_plan *p, sgx_status st, const std::string &msg) {
     return st;
 }
 
+sgx_status dim_err(const sgx_plan *p, size_t expected, size_t got) {  // DimensionMismatch{expected, got} (src/error.rs:19-21)
+    if (p) { p->dm_expected = expected; p->dm_got = got; }
+    return set_err(p, SGX_DIM_MISMATCH, "Dimension mismatch: expected " + std::to_string(expected) + ", got " + std::to_string(got));
+}
+
 sgx_status create_fail(sgx_status st, const std::string &msg) {
     g_create_err = msg;
     return st;
@@ -645,14 +650,9 @@ hipError_t launch(const sgx_plan *pl, const StftArgs &a, KernelKind kind, hipStr
     }
 }
 
-// The tuned kernel needs 8-byte aligned float2 loads: even hop, aligned base and even row stride.
-KernelKind pick_kernel(const sgx_plan *pl, const void *x, size_t stride) {
-    if (pl->kind == K_R32X16_F32) {
-        const bool aligned = (reinterpret_cast<uintptr_t>(x) % 8 == 0) && (stride % 2 == 0);
-        return aligned ? K_R32X16_F32 : K_REG_RADIX;
-    }
-    return pl->kind;
-}
+// The tuned kernel reads the samples through bounds-checked buffer loads, which only need the element's own alignment: any
+// base address and any row stride run on it (round 1 fell back to the register-tiled kernel for odd strides).
+KernelKind pick_kernel(const sgx_plan *pl, const void *, size_t) { return pl->kind; }
 
 sgx_status check_call(sgx_plan *pl, const void *samples, size_t batch, size_t n_samples, size_t stride,
                       void *out, size_t out_elems, size_t *n_frames_out) {
@@ -666,8 +666,7 @@ sgx_status check_call(sgx_plan *pl, const void *samples, size_t batch, size_t n_
     if (nf > 0x7fffffffull) return set_err(pl, SGX_INVALID_INPUT, "Invalid input: too many frames");
     const size_t expect = batch * size_t(pl->n_final) * nf * (pl->out_mode == OUT_COMPLEX ? 2 : 1);
     if (out_elems != expect)  // compute_into: DimensionMismatch{expected, got} (:423-434)
-        return set_err(pl, SGX_DIM_MISMATCH, "Dimension mismatch: expected " + std::to_string(expect) + ", got " +
-                                                 std::to_string(out_elems));
+        return dim_err(pl, expect, out_elems);
     if (!pl->device_ready)
         return set_err(pl, SGX_BACKEND, "hip -- FFT backend error: plan has no HIP device (host-only plan)");
     *n_frames_out = nf;
@@ -681,8 +680,7 @@ sgx_status run_device(sgx_plan *pl, const void *x, size_t batch, size_t n_sample
     StftArgs a;
     void *stage_out = out;
     const bool mfcc = pl->p.n_mfcc > 0;
-    if (mfcc) {  // Mel-dB goes to plan-owned scratch, the DCT/lifter epilogue writes the caller's buffer
-        SGX_HIP(pl, hipSetDevice(pl->device));
+    if (mfcc) {  // Mel-dB goes to plan-owned scratch (sgx_reserve sizes it ahead), the DCT/lifter epilogue writes the caller's buffer
         sgx_status st = grow(pl, &pl->d_melbuf, &pl->d_melbuf_bytes, batch * size_t(pl->n_out) * n_frames * pl->elem);
         if (st != SGX_OK) return st;
         stage_out = pl->d_melbuf;
@@ -701,7 +699,6 @@ sgx_status run_device(sgx_plan *pl, const void *x, size_t batch, size_t n_sample
             return set_err(pl, SGX_BACKEND, "hip -- FFT backend error: n_fft too large for the on-chip frame tile");
     }
     if (kind == K_R32X16_F32) a.window = pl->d_window_half;
-    SGX_HIP(pl, hipSetDevice(pl->device));
     if (ms) SGX_HIP(pl, hipEventRecord(pl->ev0, s));
     const unsigned skip = pl->p.n_mfcc - pl->n_final * (mfcc ? 1u : 0u);
     for (int i = 0; i < iters; ++i) {
@@ -808,8 +805,7 @@ sgx_status launch_c2r_frames(sgx_plan *pl, const void *spec, void *frames, size_
 }
 
 sgx_status run_istft(sgx_plan *pl, const void *spec, size_t batch, size_t n_frames, void *out, size_t out_len, hipStream_t s) {
-    sgx_status st = pl->dtype == SGX_F64 ? inverse_tables<double>(pl) : inverse_tables<float>(pl);
-    if (st != SGX_OK) return st;
+    sgx_status st;
     const size_t n = pl->p.n_fft;
     SGX_HIP(pl, hipMemsetAsync(pl->d_flag, 0, sizeof(unsigned), s));
     // fused tuned kernel: no frame scratch in HBM; it addresses one signal's spectrum with 32-bit byte offsets
@@ -936,11 +932,23 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
             return create_fail(SGX_INVALID_INPUT, "Invalid input: device ordinal out of range");
         }
         pl->device = dev;
+        DeviceGuard dg;
         auto dev_init = [&]() -> sgx_status {
-            SGX_HIP(pl, hipSetDevice(dev));
+            SGX_HIP(pl, dg.enter(dev));
             SGX_HIP(pl, hipEventCreate(&pl->ev0));
             SGX_HIP(pl, hipEventCreate(&pl->ev1));
-            return pl->dtype == SGX_F64 ? build_device_tables<double>(pl) : build_device_tables<float>(pl);
+            sgx_status s2 = pl->dtype == SGX_F64 ? build_device_tables<double>(pl) : build_device_tables<float>(pl);
+            if (s2 != SGX_OK) return s2;
+            // Everything the per-frame entry points (sgx_r2c / sgx_c2r = R2cPlan / C2rPlan::process) need is allocated here, so
+            // that `process` never allocates (src/fft_backend.rs:21-24): one frame of staging each way, the rectangular window,
+            // the inverse tables and the DC/Nyquist flag.  Batched calls size their scratch through sgx_reserve.
+            const size_t frame_bytes = 2 * size_t(pl->nb_fft) * pl->elem;
+            if ((s2 = grow(pl, &pl->d_in, &pl->d_in_bytes, frame_bytes)) != SGX_OK) return s2;
+            if ((s2 = grow(pl, &pl->d_out, &pl->d_out_bytes, frame_bytes)) != SGX_OK) return s2;
+            std::vector<double> ones(pl->p.n_fft, 1.0);
+            s2 = pl->dtype == SGX_F64 ? upload_cast<double>(pl, &pl->d_ones, ones) : upload_cast<float>(pl, &pl->d_ones, ones);
+            if (s2 != SGX_OK) return s2;
+            return pl->dtype == SGX_F64 ? inverse_tables<double>(pl) : inverse_tables<float>(pl);
         };
         st = dev_init();
         if (st != SGX_OK) {
@@ -958,7 +966,8 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
 void sgx_plan_destroy(sgx_plan *plan) {
     if (!plan) return;
     if (plan->device_ready) {
-        (void)hipSetDevice(plan->device);
+        DeviceGuard dg;
+        (void)dg.enter(plan->device);
         free_device(plan);
     }
     delete plan;
@@ -978,10 +987,11 @@ sgx_status sgx_execute(sgx_plan *plan, const void *samples, size_t batch, size_t
     sgx_status st = check_call(plan, samples, batch, n_samples, sample_stride, out, out_elems, &nf);
     if (st != SGX_OK) return st;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if (mem_kind != SGX_MEM_HOST && mem_kind != SGX_MEM_DEVICE) return set_err(plan, SGX_INVALID_INPUT, "Invalid input: unknown mem_kind");
+    DeviceGuard dg;
+    SGX_HIP(plan, dg.enter(plan->device));
     if (mem_kind == SGX_MEM_DEVICE) return run_device(plan, samples, batch, n_samples, sample_stride, out, nf, s, 1, nullptr);
-    if (mem_kind != SGX_MEM_HOST) return set_err(plan, SGX_INVALID_INPUT, "Invalid input: unknown mem_kind");
-    // host pointers: plan-owned staging (grown on demand, reused across calls), synchronous
-    SGX_HIP(plan, hipSetDevice(plan->device));
+    // host pointers: plan-owned staging (sized by sgx_reserve, else grown on demand; reused across calls), synchronous
     const size_t in_bytes = ((batch - 1) * sample_stride + n_samples) * plan->elem;
     const size_t out_bytes = out_elems * plan->elem;
     if ((st = grow(plan, &plan->d_in, &plan->d_in_bytes, in_bytes)) != SGX_OK) return st;
@@ -1001,6 +1011,8 @@ sgx_status sgx_execute_timed(sgx_plan *plan, const void *samples, size_t batch, 
     sgx_status st = check_call(plan, samples, batch, n_samples, sample_stride, out, out_elems, &nf);
     if (st != SGX_OK) return st;
     if (iters < 1 || !ms_per_launch) return set_err(plan, SGX_INVALID_INPUT, "Invalid input: iters must be >= 1");
+    DeviceGuard dg;
+    SGX_HIP(plan, dg.enter(plan->device));
     return run_device(plan, samples, batch, n_samples, sample_stride, out, nf, static_cast<hipStream_t>(hip_stream),
                       iters, ms_per_launch);
 }
@@ -1037,21 +1049,13 @@ sgx_status sgx_r2c(sgx_plan *plan, const void *in, size_t in_len, void *out, siz
     if (!in || !out) return set_err(plan, SGX_INVALID_INPUT, "Invalid input: null buffer");
     const size_t n = plan->p.n_fft, nb = plan->nb_fft;
     if (in_len != n)  // validate_fft_io src/fft_backend.rs:264-282
-        return set_err(plan, SGX_DIM_MISMATCH, "Dimension mismatch: expected " + std::to_string(n) + ", got " + std::to_string(in_len));
+        return dim_err(plan, n, in_len);
     if (out_len != nb)
-        return set_err(plan, SGX_DIM_MISMATCH, "Dimension mismatch: expected " + std::to_string(nb) + ", got " + std::to_string(out_len));
+        return dim_err(plan, nb, out_len);
     if (!plan->device_ready)
         return set_err(plan, SGX_BACKEND, "hip -- FFT backend error: plan has no HIP device (host-only plan)");
-    SGX_HIP(plan, hipSetDevice(plan->device));
-    sgx_status st;
-    if (!plan->d_ones) {
-        std::vector<double> ones(n, 1.0);
-        st = plan->dtype == SGX_F64 ? upload_cast<double>(plan, &plan->d_ones, ones)
-                                    : upload_cast<float>(plan, &plan->d_ones, ones);
-        if (st != SGX_OK) return st;
-    }
-    if ((st = grow(plan, &plan->d_in, &plan->d_in_bytes, n * plan->elem)) != SGX_OK) return st;
-    if ((st = grow(plan, &plan->d_out, &plan->d_out_bytes, 2 * nb * plan->elem)) != SGX_OK) return st;
+    DeviceGuard dg;
+    SGX_HIP(plan, dg.enter(plan->device));  // staging, window of ones: allocated at plan creation
     SGX_HIP(plan, hipMemcpy(plan->d_in, in, n * plan->elem, hipMemcpyHostToDevice));
     StftArgs a;
     fill_args(plan, a, plan->d_in, plan->d_out, 1, n, n, 1);
@@ -1085,14 +1089,15 @@ sgx_status sgx_istft(sgx_plan *plan, const void *stft, size_t batch, size_t n_bi
     if (!stft || !out) return set_err(plan, SGX_INVALID_INPUT, "Invalid input: null buffer");
     if (batch == 0 || n_frames == 0) return set_err(plan, SGX_INVALID_INPUT, "Invalid input: stft matrix must be non-empty");
     if (n_bins != plan->nb_fft)  // :4876-4879
-        return set_err(plan, SGX_DIM_MISMATCH, "Dimension mismatch: expected " + std::to_string(plan->nb_fft) + ", got " + std::to_string(n_bins));
+        return dim_err(plan, plan->nb_fft, n_bins);
     if (batch > 65535 || n_frames > 0x7fffffffull) return set_err(plan, SGX_INVALID_INPUT, "Invalid input: batch or frame count too large");
     const size_t len = istft_length(plan->p, n_frames);
     if (out_elems != batch * len)
-        return set_err(plan, SGX_DIM_MISMATCH, "Dimension mismatch: expected " + std::to_string(batch * len) + ", got " + std::to_string(out_elems));
+        return dim_err(plan, batch * len, out_elems);
     if (!plan->device_ready)
         return set_err(plan, SGX_BACKEND, "hip -- FFT backend error: plan has no HIP device (host-only plan)");
-    SGX_HIP(plan, hipSetDevice(plan->device));
+    DeviceGuard dg;
+    SGX_HIP(plan, dg.enter(plan->device));
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     if (mem_kind == SGX_MEM_DEVICE) return run_istft(plan, stft, batch, n_frames, out, len, s);
     if (mem_kind != SGX_MEM_HOST) return set_err(plan, SGX_INVALID_INPUT, "Invalid input: unknown mem_kind");
@@ -1111,21 +1116,53 @@ sgx_status sgx_c2r(sgx_plan *plan, const void *in, size_t in_len, void *out, siz
     if (!in || !out) return set_err(plan, SGX_INVALID_INPUT, "Invalid input: null buffer");
     const size_t n = plan->p.n_fft, nb = plan->nb_fft;
     if (in_len != nb)  // fft_backend.rs:538-544
-        return set_err(plan, SGX_DIM_MISMATCH, "Dimension mismatch: expected " + std::to_string(nb) + ", got " + std::to_string(in_len));
+        return dim_err(plan, nb, in_len);
     if (out_len != n)  // :545-550
-        return set_err(plan, SGX_DIM_MISMATCH, "Dimension mismatch: expected " + std::to_string(n) + ", got " + std::to_string(out_len));
+        return dim_err(plan, n, out_len);
     if (!plan->device_ready)
         return set_err(plan, SGX_BACKEND, "hip -- FFT backend error: plan has no HIP device (host-only plan)");
-    SGX_HIP(plan, hipSetDevice(plan->device));
-    sgx_status st = plan->dtype == SGX_F64 ? inverse_tables<double>(plan) : inverse_tables<float>(plan);
-    if (st != SGX_OK) return st;
-    if ((st = grow(plan, &plan->d_in, &plan->d_in_bytes, 2 * nb * plan->elem)) != SGX_OK) return st;
-    if ((st = grow(plan, &plan->d_out, &plan->d_out_bytes, n * plan->elem)) != SGX_OK) return st;
+    DeviceGuard dg;
+    SGX_HIP(plan, dg.enter(plan->device));  // staging, inverse tables, flag: allocated at plan creation
+    sgx_status st;
     SGX_HIP(plan, hipMemcpy(plan->d_in, in, 2 * nb * plan->elem, hipMemcpyHostToDevice));
     SGX_HIP(plan, hipMemsetAsync(plan->d_flag, 0, sizeof(unsigned), nullptr));
     if ((st = launch_c2r_frames(plan, plan->d_in, plan->d_out, 1, 1, false, nullptr, nullptr)) != SGX_OK) return st;
     SGX_HIP(plan, hipMemcpy(out, plan->d_out, n * plan->elem, hipMemcpyDeviceToHost));
     return check_flag(plan, nullptr);
+}
+
+int32_t sgx_plan_device(const sgx_plan *plan) { return plan ? plan->device : -2; }
+
+sgx_status sgx_last_dim_mismatch(const sgx_plan *plan, size_t *expected, size_t *got) {
+    if (!plan || !expected || !got) return SGX_INVALID_INPUT;
+    *expected = plan->dm_expected;
+    *got = plan->dm_got;
+    return SGX_OK;
+}
+
+sgx_status sgx_reserve(sgx_plan *plan, size_t batch, size_t n_samples, int32_t host_staging, int32_t inverse) {
+    if (!plan) return SGX_INVALID_INPUT;
+    if (batch == 0 || n_samples == 0) return set_err(plan, SGX_INVALID_INPUT, "Invalid input: samples must be non-empty");
+    if (!plan->device_ready)
+        return set_err(plan, SGX_BACKEND, "hip -- FFT backend error: plan has no HIP device (host-only plan)");
+    DeviceGuard dg;
+    SGX_HIP(plan, dg.enter(plan->device));
+    const size_t nf = frame_count(plan->p, n_samples);
+    const size_t spec_elems = batch * size_t(plan->n_final) * nf * (plan->out_mode == OUT_COMPLEX ? 2 : 1);
+    sgx_status st;
+    if (plan->p.n_mfcc > 0 &&
+        (st = grow(plan, &plan->d_melbuf, &plan->d_melbuf_bytes, batch * size_t(plan->n_out) * nf * plan->elem)) != SGX_OK)
+        return st;
+    if (inverse) {  // sgx_istft of `batch` spectra whose frame count is that of n_samples-long signals
+        const bool fused = plan->d_itwr && nf * 513ull * 8ull < 0x7fffffffull;
+        if (!fused && (st = grow(plan, &plan->d_frames, &plan->d_frames_bytes, batch * nf * plan->p.n_fft * plan->elem)) != SGX_OK) return st;
+    }
+    if (host_staging) {
+        const size_t sig_bytes = batch * n_samples * plan->elem, spec_bytes = std::max(spec_elems, batch * size_t(plan->nb_fft) * nf * 2) * plan->elem;
+        if ((st = grow(plan, &plan->d_in, &plan->d_in_bytes, inverse ? spec_bytes : sig_bytes)) != SGX_OK) return st;
+        if ((st = grow(plan, &plan->d_out, &plan->d_out_bytes, inverse ? sig_bytes + batch * plan->p.n_fft * plan->elem : spec_bytes)) != SGX_OK) return st;
+    }
+    return SGX_OK;
 }
 
 sgx_status sgx_window(const sgx_plan *plan, double *out) {

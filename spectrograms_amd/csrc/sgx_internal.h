@@ -172,6 +172,24 @@ inline hipError_t set_max_dynamic_lds(const void *fn, int bytes) {
     return e;
 }
 
+// Entry points run on the plan's device and leave the caller's current device as they found it.
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    hipError_t enter(int dev) {
+        hipError_t e = hipGetDevice(&prev);
+        if (e != hipSuccess) return e;
+        if (prev != dev) {
+            e = hipSetDevice(dev);
+            changed = e == hipSuccess;
+        }
+        return e;
+    }
+    ~DeviceGuard() {
+        if (changed) (void)hipSetDevice(prev);
+    }
+};
+
 }  // namespace sgx
 
 struct sgx_plan {
@@ -216,4 +234,5 @@ struct sgx_plan {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     mutable std::string err;
+    mutable size_t dm_expected = 0, dm_got = 0;  // the last DimensionMismatch{expected, got} (src/error.rs:19-21)
 };

@@ -1,0 +1,211 @@
+// shard.hip — multi-GPU entry points of the C ABI: utterance sharding with an optional RCCL all-gather of the output shards
+// (BASELINE config 4).  One process (or thread) per GPU; each rank runs the single-GPU plan on its contiguous
+// block of utterances (sgx_shard_range) and, if asked, every rank receives the whole [batch][n_bins][n_frames] output.
+//
+// RCCL is resolved at run time (dlsym on the process first, then dlopen of librccl.so.1): the library has no link-time
+// dependency on it, a host that already carries an RCCL (a Rust binary linked against librccl, PyTorch's bundled copy) gets
+// THAT copy — which is what makes sgx_comm_adopt of the host's own ncclComm_t valid — and single-GPU users never load it.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+
+#include "sgx_internal.h"
+
+using namespace sgx;
+
+struct sgx_comm {
+    ncclComm_t comm = nullptr;
+    int world = 0, rank = 0;
+    int device = -1;
+    bool owned = false;  // created by sgx_comm_create (destroyed with it) vs adopted from the host
+    std::string err;
+};
+
+namespace {
+
+struct Rccl {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+    std::string why;
+};
+
+const Rccl &rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void *h = RTLD_DEFAULT;
+        if (!dlsym(RTLD_DEFAULT, "ncclAllGather")) {
+            h = nullptr;
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+                if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+            if (!h) {
+                r.why = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed");
+                return;
+            }
+        }
+        auto sym = [&](const char *n) { return dlsym(h, n); };
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+        r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.Broadcast && r.GroupStart && r.GroupEnd;
+        if (!r.ok) r.why = "RCCL library lacks a required symbol";
+    });
+    return r;
+}
+
+thread_local std::string g_comm_err;
+
+sgx_status comm_fail(sgx_comm *c, sgx_status st, const std::string &msg) {
+    (c ? c->err : g_comm_err) = msg;
+    return st;
+}
+
+std::string nccl_text(ncclResult_t e) {
+    const Rccl &r = rccl();
+    return std::string("hip -- FFT backend error: RCCL: ") + (r.GetErrorString ? r.GetErrorString(e) : "error ") + " (" + std::to_string(int(e)) + ")";
+}
+
+#define SGX_NCCL(c, call)                                                \
+    do {                                                                 \
+        ncclResult_t e_ = (call);                                        \
+        if (e_ != ncclSuccess) return comm_fail(c, SGX_BACKEND, nccl_text(e_)); \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+const char *sgx_comm_last_error(const sgx_comm *c) { return c ? c->err.c_str() : g_comm_err.c_str(); }
+
+sgx_status sgx_comm_unique_id(void *id128) {
+    if (!id128) return comm_fail(nullptr, SGX_INVALID_INPUT, "Invalid input: null argument");
+    const Rccl &r = rccl();
+    if (!r.ok) return comm_fail(nullptr, SGX_BACKEND, "hip -- FFT backend error: " + r.why);
+    static_assert(sizeof(ncclUniqueId) == SGX_COMM_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    SGX_NCCL(nullptr, r.GetUniqueId(&id));
+    std::memcpy(id128, &id, sizeof id);
+    return SGX_OK;
+}
+
+sgx_status sgx_comm_create(const void *id128, int32_t world_size, int32_t rank, int32_t device, sgx_comm **out) {
+    if (out) *out = nullptr;
+    if (!id128 || !out || world_size <= 0 || rank < 0 || rank >= world_size)
+        return comm_fail(nullptr, SGX_INVALID_INPUT, "Invalid input: bad communicator arguments");
+    const Rccl &r = rccl();
+    if (!r.ok) return comm_fail(nullptr, SGX_BACKEND, "hip -- FFT backend error: " + r.why);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return comm_fail(nullptr, SGX_BACKEND, "hip -- FFT backend error: no HIP device available");
+    int dev = device;
+    if (dev == -1 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (dev < 0 || dev >= ndev) return comm_fail(nullptr, SGX_INVALID_INPUT, "Invalid input: device ordinal out of range");
+    sgx_comm *c = new (std::nothrow) sgx_comm();
+    if (!c) return comm_fail(nullptr, SGX_INTERNAL, "Internal error: out of memory");
+    c->world = world_size; c->rank = rank; c->device = dev; c->owned = true;
+    DeviceGuard dg;
+    if (dg.enter(dev) != hipSuccess) { delete c; return comm_fail(nullptr, SGX_BACKEND, "hip -- FFT backend error: hipSetDevice failed"); }
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    ncclResult_t e = r.CommInitRank(&c->comm, world_size, id, rank);
+    if (e != ncclSuccess) { delete c; return comm_fail(nullptr, SGX_BACKEND, nccl_text(e)); }
+    *out = c;
+    return SGX_OK;
+}
+
+sgx_status sgx_comm_adopt(void *nccl_comm, int32_t world_size, int32_t rank, int32_t device, sgx_comm **out) {
+    if (out) *out = nullptr;
+    if (!nccl_comm || !out || world_size <= 0 || rank < 0 || rank >= world_size)
+        return comm_fail(nullptr, SGX_INVALID_INPUT, "Invalid input: bad communicator arguments");
+    const Rccl &r = rccl();
+    if (!r.ok) return comm_fail(nullptr, SGX_BACKEND, "hip -- FFT backend error: " + r.why);
+    int dev = device;
+    if (dev == -1 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+    sgx_comm *c = new (std::nothrow) sgx_comm();
+    if (!c) return comm_fail(nullptr, SGX_INTERNAL, "Internal error: out of memory");
+    c->comm = static_cast<ncclComm_t>(nccl_comm);
+    c->world = world_size; c->rank = rank; c->device = dev; c->owned = false;
+    *out = c;
+    return SGX_OK;
+}
+
+void sgx_comm_destroy(sgx_comm *c) {
+    if (!c) return;
+    if (c->owned && c->comm && rccl().ok) {
+        DeviceGuard dg;
+        (void)dg.enter(c->device);
+        (void)rccl().CommDestroy(c->comm);
+    }
+    delete c;
+}
+
+// Every rank contributes counts[rank] elements (its shard) and receives all shards back to back, rank order, in `recv`.
+// Equal shards: one ncclAllGather.  Ragged shards (batch % world != 0): one grouped ncclBroadcast per rank, each into its slice.
+sgx_status sgx_gather(sgx_comm *c, const void *send, void *recv, size_t global_batch, size_t elems_per_item, int32_t dtype,
+                      void *hip_stream) {
+    if (!c) return SGX_INVALID_INPUT;
+    if (!send || !recv || global_batch == 0 || elems_per_item == 0) return comm_fail(c, SGX_INVALID_INPUT, "Invalid input: null or empty buffer");
+    if (dtype != SGX_F32 && dtype != SGX_F64) return comm_fail(c, SGX_INVALID_INPUT, "Invalid input: dtype must be f32 or f64");
+    const Rccl &r = rccl();
+    const ncclDataType_t nt = dtype == SGX_F64 ? ncclFloat64 : ncclFloat32;
+    const size_t elem = dtype == SGX_F64 ? 8 : 4;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    DeviceGuard dg;
+    if (dg.enter(c->device) != hipSuccess) return comm_fail(c, SGX_BACKEND, "hip -- FFT backend error: hipSetDevice failed");
+    size_t start = 0, count = 0;
+    (void)sgx_shard_range(global_batch, c->world, c->rank, &start, &count);
+    if (global_batch % size_t(c->world) == 0) {
+        SGX_NCCL(c, r.AllGather(send, recv, count * elems_per_item, nt, c->comm, s));
+        return SGX_OK;
+    }
+    SGX_NCCL(c, r.GroupStart());
+    for (int root = 0; root < c->world; ++root) {
+        size_t rs = 0, rc = 0;
+        (void)sgx_shard_range(global_batch, c->world, root, &rs, &rc);
+        if (rc == 0) continue;
+        void *slice = static_cast<char *>(recv) + rs * elems_per_item * elem;
+        ncclResult_t e = r.Broadcast(root == c->rank ? send : slice, slice, rc * elems_per_item, nt, root, c->comm, s);
+        if (e != ncclSuccess) { (void)r.GroupEnd(); return comm_fail(c, SGX_BACKEND, nccl_text(e)); }
+    }
+    SGX_NCCL(c, r.GroupEnd());
+    return SGX_OK;
+}
+
+sgx_status sgx_shard_execute(sgx_plan *plan, sgx_comm *c, const void *shard_samples, size_t global_batch, size_t n_samples,
+                             size_t sample_stride, void *shard_out, void *gathered_out, void *hip_stream) {
+    if (!plan || !c) return SGX_INVALID_INPUT;
+    size_t start = 0, count = 0;
+    if (sgx_shard_range(global_batch, c->world, c->rank, &start, &count) != SGX_OK) return comm_fail(c, SGX_INVALID_INPUT, "Invalid input: bad shard");
+    size_t nb = 0, nf = 0;
+    sgx_status st = sgx_output_shape(plan, n_samples, &nb, &nf);
+    if (st != SGX_OK) return comm_fail(c, st, sgx_last_error(plan));
+    const size_t per_item = nb * nf * (plan->out_mode == OUT_COMPLEX ? 2 : 1);
+    if (sgx_plan_device(plan) != c->device) return comm_fail(c, SGX_INVALID_INPUT, "Invalid input: plan and communicator are on different devices");
+    void *dst = shard_out;
+    if (!dst && gathered_out) dst = static_cast<char *>(gathered_out) + start * per_item * plan->elem;  // compute straight into this rank's slice
+    if (count > 0) {
+        if (!dst || !shard_samples) return comm_fail(c, SGX_INVALID_INPUT, "Invalid input: null buffer");
+        st = sgx_execute(plan, shard_samples, count, n_samples, sample_stride, dst, count * per_item, SGX_MEM_DEVICE, hip_stream);
+        if (st != SGX_OK) return comm_fail(c, st, sgx_last_error(plan));
+    }
+    if (!gathered_out) return SGX_OK;  // compute-only sharding: no data-path collective
+    return sgx_gather(c, dst ? dst : gathered_out, gathered_out, global_batch, per_item, plan->dtype, hip_stream);
+}
+
+}  // extern "C"

@@ -26,6 +26,25 @@ class Fft2dPlan:
         if st:
             raise _ffi._ERR.get(st, _ffi.InternalError)((self._lib.sgx_fft2d_last_error(None) or b"").decode())
         self._h = h
+        self._device = int(self._lib.sgx_fft2d_device(h))
+
+    @property
+    def device(self) -> int:
+        return self._device
+
+    def reserve(self, batch: int, host_staging: bool = True) -> None:
+        """Pre-size the plan-owned intermediates so that later calls of up to `batch` images do not allocate."""
+        self._check(self._lib.sgx_fft2d_reserve(self._h, int(batch), int(host_staging)))
+
+    def _device_images(self, t, what: str, shape_tail, tdt):
+        """A wrong shape, dtype, layout or device would make the kernels read or write out of bounds: check before the call."""
+        if not t.is_cuda or t.device.index != self._device:
+            raise ValueError(f"{what} is on {t.device}, the plan is bound to cuda:{self._device}")
+        if t.dtype != tdt or not t.is_contiguous():
+            raise ValueError(f"{what} must be a contiguous tensor of the plan's dtype")
+        if t.dim() != len(shape_tail) + 1 or tuple(t.shape[1:]) != tuple(shape_tail) or t.shape[0] == 0:
+            raise _ffi.DimensionMismatchError(f"Dimension mismatch: expected (batch, {', '.join(map(str, shape_tail))}), got {tuple(t.shape)}",
+                                              tuple(shape_tail), tuple(t.shape[1:]))
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -84,18 +103,47 @@ class Fft2dPlan:
     def forward_torch(self, x, out=None):
         import torch
         cdt = torch.float32 if self._dt == _ffi.F32 else torch.float64
+        self._device_images(x, "images", (self.nrows, self.ncols), cdt)
         b = x.shape[0]
         if out is None:
             out = torch.empty((b, self.nrows, self.ncols // 2 + 1, 2), dtype=cdt, device=x.device)
+        else:
+            self._device_images(out, "out", (self.nrows, self.ncols // 2 + 1, 2), cdt)
+            if out.shape[0] != b:
+                raise _ffi.DimensionMismatchError(f"Dimension mismatch: expected {b}, got {out.shape[0]}", b, out.shape[0])
         s = torch.cuda.current_stream(x.device).cuda_stream
         self._check(self._lib.sgx_fft2d_forward(self._h, x.data_ptr(), b, out.data_ptr(), _ffi.MEM_DEVICE, C.c_void_p(s)))
+        return out
+
+    def inverse_torch(self, spec, out=None):
+        """ifft2d of [B, nrows, ncols/2+1, 2] half spectra (interleaved re, im) -> [B, nrows, ncols], device resident."""
+        import torch
+        tdt = torch.float32 if self._dt == _ffi.F32 else torch.float64
+        self._device_images(spec, "spectra", (self.nrows, self.ncols // 2 + 1, 2), tdt)
+        b = spec.shape[0]
+        if out is None:
+            out = torch.empty((b, self.nrows, self.ncols), dtype=tdt, device=spec.device)
+        else:
+            self._device_images(out, "out", (self.nrows, self.ncols), tdt)
+            if out.shape[0] != b:
+                raise _ffi.DimensionMismatchError(f"Dimension mismatch: expected {b}, got {out.shape[0]}", b, out.shape[0])
+        s = torch.cuda.current_stream(spec.device).cuda_stream
+        self._check(self._lib.sgx_fft2d_inverse(self._h, spec.data_ptr(), b, out.data_ptr(), _ffi.MEM_DEVICE, C.c_void_p(s)))
         return out
 
     def convolve_torch(self, x, kernel, out=None):
         import torch
         k = np.ascontiguousarray(kernel, dtype=self._np)
+        if k.ndim != 2:
+            raise ValueError("kernel must be 2-D")
+        tdt = torch.float32 if self._dt == _ffi.F32 else torch.float64
+        self._device_images(x, "images", (self.nrows, self.ncols), tdt)
         if out is None:
             out = torch.empty_like(x)
+        else:
+            self._device_images(out, "out", (self.nrows, self.ncols), tdt)
+            if out.shape[0] != x.shape[0]:
+                raise _ffi.DimensionMismatchError(f"Dimension mismatch: expected {x.shape[0]}, got {out.shape[0]}", x.shape[0], out.shape[0])
         s = torch.cuda.current_stream(x.device).cuda_stream
         self._check(self._lib.sgx_fft2d_convolve(self._h, x.data_ptr(), x.shape[0], k.ctypes.data, k.shape[0], k.shape[1],
                                                  out.data_ptr(), _ffi.MEM_DEVICE, C.c_void_p(s)))

@@ -16,15 +16,30 @@ _PLAN_CACHE_MAX = 32
 
 
 def _key(obj):
+    """Hashable identity of a parameter object by VALUE: every field that reaches the plan, array contents included (two custom
+    windows of equal length must not share a plan).  Unknown types are an error — never repr(), which may omit fields or be an
+    address that a later object reuses."""
     if obj is None or isinstance(obj, (int, float, str, bool)):
         return obj
+    if isinstance(obj, np.generic):
+        return obj.item()
     if isinstance(obj, np.ndarray):
         return (obj.dtype.str, obj.shape, obj.tobytes())
     if isinstance(obj, (list, tuple)):
         return tuple(_key(v) for v in obj)
+    if isinstance(obj, dict):
+        return tuple(sorted((k, _key(v)) for k, v in obj.items()))
+    fields = {}
+    for klass in type(obj).__mro__:  # __slots__ classes have no __dict__: walk the declared slots of every base
+        slots = klass.__dict__.get("__slots__", ())
+        for name in ((slots,) if isinstance(slots, str) else slots):
+            if name not in ("__dict__", "__weakref__") and hasattr(obj, name):
+                fields[name] = getattr(obj, name)
     if hasattr(obj, "__dict__"):
-        return (type(obj).__name__,) + tuple((k, _key(v)) for k, v in sorted(vars(obj).items()))
-    return repr(obj)
+        fields.update(vars(obj))
+    if not fields and not hasattr(obj, "__dict__") and not any("__slots__" in k.__dict__ for k in type(obj).__mro__):
+        raise TypeError(f"cannot build a plan-cache key for {type(obj).__name__}")
+    return (type(obj).__module__, type(obj).__qualname__) + tuple((k, _key(v)) for k, v in sorted(fields.items()))
 
 
 def Plan(params, amp, mapping, db, dtype, mfcc=None, inverse=False):

@@ -223,6 +223,7 @@ class Plan:
         _ffi.raise_status(self._lib.sgx_plan_create(C.byref(p), C.byref(h)))
         self._h = h
         self.n_fft = st.n_fft
+        self._device = int(self._lib.sgx_plan_device(h))  # resolved ordinal (DEVICE_CURRENT was bound at creation); -2: host only
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -238,6 +239,20 @@ class Plan:
     @property
     def is_complex(self) -> bool:
         return self._amp == _ffi.AMP_COMPLEX
+
+    @property
+    def device(self) -> int:
+        """HIP device ordinal the plan's tables live on (-2: host-only plan)."""
+        return self._device
+
+    def reserve(self, batch: int, n_samples: int, host_staging: bool = True, inverse: bool = False) -> None:
+        """Pre-size the plan-owned scratch so that later calls of up to this size do not allocate (sgx_reserve)."""
+        _ffi.raise_status(self._lib.sgx_reserve(self._h, int(batch), int(n_samples), int(host_staging), int(inverse)), self._h)
+
+    def _check_device(self, t, what: str) -> None:
+        # the kernels run on the plan's device with the plan's tables: a tensor that lives elsewhere would be a wild pointer there
+        if not t.is_cuda or t.device.index != self._device:
+            raise ValueError(f"{what} is on {t.device}, the plan is bound to cuda:{self._device}")
 
     @property
     def kernel_name(self) -> str:
@@ -309,13 +324,18 @@ class Plan:
             raise ValueError("device path needs a 2-D CUDA tensor of the plan's dtype with unit inner stride")
         if x.numel() == 0:
             raise ValueError("samples must be non-empty")
+        self._check_device(x, "samples")
         b, n = x.shape
         nb, nf = self.output_shape(n)
         shape = (b, nb, nf, 2) if self.is_complex else (b, nb, nf)
         if out is None:
             out = torch.empty(shape, dtype=tdt, device=x.device)
-        elif tuple(out.shape) != shape or out.dtype != tdt or not out.is_contiguous():
-            raise _ffi.DimensionMismatchError(f"Dimension mismatch: expected {shape}, got {tuple(out.shape)}")
+        else:
+            if tuple(out.shape) != shape:
+                raise _ffi.DimensionMismatchError(f"Dimension mismatch: expected {shape}, got {tuple(out.shape)}", shape, tuple(out.shape))
+            if out.dtype != tdt or not out.is_contiguous():
+                raise ValueError("out must be a contiguous tensor of the plan's dtype")
+            self._check_device(out, "out")
         s = stream or torch.cuda.current_stream(x.device).cuda_stream
         _ffi.raise_status(self._lib.sgx_execute(self._h, x.data_ptr(), b, n, x.stride(0), out.data_ptr(), out.numel(),
                                                 _ffi.MEM_DEVICE, C.c_void_p(s)), self._h)
@@ -335,6 +355,8 @@ class Plan:
     def time_batch_torch(self, x, out, iters: int, stream: int = 0) -> float:
         """Mean device milliseconds per launch over `iters` back-to-back launches (hipEvents on the launch stream)."""
         import torch
+        self._check_device(x, "samples")
+        self._check_device(out, "out")
         s = stream or torch.cuda.current_stream(x.device).cuda_stream
         ms = C.c_float()
         b, n = x.shape
@@ -413,10 +435,16 @@ class Plan:
         want = torch.complex64 if self._dt == _ffi.F32 else torch.complex128
         if stft.dtype != want or not stft.is_contiguous() or stft.dim() != 3:
             raise ValueError("stft must be a contiguous 3-D tensor of the plan's complex dtype")
+        self._check_device(stft, "stft")
         b, nb, nf = stft.shape
+        rdt = torch.float32 if self._dt == _ffi.F32 else torch.float64
         if out is None:
             n_out = self.istft_length(nf) if nb == self.n_fft // 2 + 1 else 0
-            out = torch.empty((b, n_out), dtype=torch.float32 if self._dt == _ffi.F32 else torch.float64, device=stft.device)
+            out = torch.empty((b, n_out), dtype=rdt, device=stft.device)
+        else:
+            if out.dtype != rdt or not out.is_contiguous() or out.dim() != 2 or out.shape[0] != b:
+                raise ValueError("out must be a contiguous (batch, n_samples) tensor of the plan's real dtype")
+            self._check_device(out, "out")
         s = stream or torch.cuda.current_stream(stft.device).cuda_stream
         _ffi.raise_status(self._lib.sgx_istft(self._h, stft.data_ptr(), b, nb, nf, out.data_ptr(), out.numel(), _ffi.MEM_DEVICE,
                                               C.c_void_p(s)), self._h)

@@ -67,6 +67,38 @@ int main(void) {
     printf("linear power: max abs err %.3e (peak %.3e)\n", worst, peak);
     CHECK(worst <= 1e-4 * peak);
     CHECK(strcmp(sgx_kernel_name(plan), "r32x16_f32") == 0);
+    CHECK(sgx_plan_device(plan) >= 0);
+    CHECK(sgx_reserve(plan, B, N, 1, 0) == SGX_OK); /* host staging sized ahead: the host-pointer call below does not allocate */
+    {
+        float *hout = (float *)malloc(B * nb * nf * sizeof(float));
+        CHECK(sgx_execute(plan, x, B, N, N, hout, B * nb * nf, SGX_MEM_HOST, NULL) == SGX_OK);
+        CHECK(memcmp(hout, out, B * nb * nf * sizeof(float)) == 0); /* host path == device path, bit for bit */
+        free(hout);
+    }
+    /* multi-GPU entry points with a world of one rank: unique id, communicator, sharded execute + RCCL gather */
+    {
+        unsigned char id[SGX_COMM_ID_BYTES];
+        sgx_comm *comm = NULL;
+        CHECK(sgx_comm_unique_id(id) == SGX_OK);
+        CHECK(sgx_comm_create(id, 1, 0, -1, &comm) == SGX_OK && comm != NULL);
+        float *dg = NULL;
+        CHECK(hipMalloc((void **)&dg, B * nb * nf * sizeof(float)) == hipSuccess);
+        CHECK(hipMemset(dg, 0, B * nb * nf * sizeof(float)) == hipSuccess);
+        CHECK(sgx_shard_execute(plan, comm, dx, B, N, N, NULL, dg, NULL) == SGX_OK);
+        CHECK(hipDeviceSynchronize() == hipSuccess);
+        float *g = (float *)malloc(B * nb * nf * sizeof(float));
+        CHECK(hipMemcpy(g, dg, B * nb * nf * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess);
+        CHECK(memcmp(g, out, B * nb * nf * sizeof(float)) == 0);
+        /* a separate shard buffer gathered into the full one */
+        CHECK(hipMemset(dg, 0, B * nb * nf * sizeof(float)) == hipSuccess);
+        CHECK(sgx_shard_execute(plan, comm, dx, B, N, N, dout, dg, NULL) == SGX_OK);
+        CHECK(hipDeviceSynchronize() == hipSuccess);
+        CHECK(hipMemcpy(g, dg, B * nb * nf * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess);
+        CHECK(memcmp(g, out, B * nb * nf * sizeof(float)) == 0);
+        free(g);
+        (void)hipFree(dg);
+        sgx_comm_destroy(comm);
+    }
     /* wrong output size -> DimensionMismatch, and the message says so */
     CHECK(sgx_execute(plan, dx, B, N, N, dout, B * nb * nf - 1, SGX_MEM_DEVICE, NULL) == SGX_DIM_MISMATCH);
     CHECK(strstr(sgx_last_error(plan), "Dimension mismatch") != NULL);

@@ -36,6 +36,10 @@ int main(void) {
     /* no CPU fallback: compute on a host-only plan is a backend error with a message */
     float x[8] = {0}, y[8];
     CHECK(sgx_execute(plan, x, 1, 8, 8, y, 8, SGX_MEM_HOST, NULL) == SGX_DIM_MISMATCH);
+    size_t want = 0, got = 0; /* DimensionMismatch { expected, got } (src/error.rs:19-21) as numbers, not only as text */
+    CHECK(sgx_last_dim_mismatch(plan, &want, &got) == SGX_OK && want == 80 && got == 8);
+    CHECK(sgx_plan_device(plan) == -2);
+    CHECK(sgx_reserve(plan, 4, 16000, 1, 0) == SGX_BACKEND); /* host-only plan: nothing to reserve on */
     float big[80];
     CHECK(sgx_execute(plan, x, 1, 8, 8, big, 80, SGX_MEM_HOST, NULL) == SGX_BACKEND);
     CHECK(strstr(sgx_last_error(plan), "hip") != NULL);
@@ -47,9 +51,20 @@ int main(void) {
     size_t start = 0, count = 0;
     CHECK(sgx_shard_range(8192, 8, 3, &start, &count) == SGX_OK && start == 3072 && count == 1024);
     CHECK(sgx_shard_range(10, 4, 1, &start, &count) == SGX_OK && start == 3 && count == 3);
+    /* the multi-GPU entry points fail cleanly without a device / communicator */
+    sgx_comm *comm = NULL;
+    unsigned char id[SGX_COMM_ID_BYTES];
+    memset(id, 0, sizeof id);
+    CHECK(sgx_comm_create(id, 0, 0, -1, &comm) == SGX_INVALID_INPUT && comm == NULL);
+    CHECK(sgx_comm_adopt(NULL, 2, 0, -1, &comm) == SGX_INVALID_INPUT && comm == NULL);
+    CHECK(strlen(sgx_comm_last_error(NULL)) > 0);
+    CHECK(sgx_gather(NULL, x, y, 8, 1, SGX_F32, NULL) == SGX_INVALID_INPUT);
+    CHECK(sgx_shard_execute(NULL, NULL, x, 8, 8, 8, y, NULL, NULL) == SGX_INVALID_INPUT);
+    sgx_comm_destroy(NULL);
     sgx_fft2d *f2 = NULL;
     CHECK(sgx_fft2d_create(0, 8, SGX_F32, -2, &f2) == SGX_INVALID_INPUT && f2 == NULL);
     CHECK(sgx_fft2d_create(16, 16, SGX_F32, -2, &f2) == SGX_OK && f2 != NULL);
+    CHECK(sgx_fft2d_device(f2) == -2);
     sgx_fft2d_destroy(f2);
     printf("c_abi host-only checks passed\n");
     return 0;

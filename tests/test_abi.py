@@ -24,12 +24,12 @@ def host_plan(n_fft=512, hop=256, window=None, centre=True, sr=16000.0, mel=None
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "spectro_hip.h")).read()
     declared = set(re.findall(r"\b(sgx_[a-z0-9_]+)\s*\(", hdr))
-    declared -= {"sgx_plan"}
+    declared -= {"sgx_plan", "sgx_comm", "sgx_fft2d"}
     assert declared == set(_ffi.SYMBOLS), declared ^ set(_ffi.SYMBOLS)
     L = C.CDLL(_ffi.LIB_PATH)
     for s in declared:
         assert hasattr(L, s), s
-    assert _ffi.lib().sgx_abi_version() == 4
+    assert _ffi.lib().sgx_abi_version() == 5
 
 
 def test_params_struct_layout_matches_header():
@@ -176,3 +176,30 @@ def test_shard_range_partitions_batch():
             assert max(c for _, c in seen) - min(c for _, c in seen) <= 1
     s, c = C.c_size_t(), C.c_size_t()
     assert L.sgx_shard_range(8, 0, 0, C.byref(s), C.byref(c)) == _ffi.SGX_INVALID_INPUT
+
+
+def test_plan_cache_key_sees_custom_window_coefficients():
+    """two custom windows of equal length must not share a cached plan (the key is built from every field by value)."""
+    from spectrograms_amd.functions import _key
+    a = sg.WindowType.custom(np.hamming(64))
+    b = sg.WindowType.custom(np.hanning(64) + 0.1)
+    pa = sg.SpectrogramParams(sg.StftParams(64, 16, a, True), 16000.0)
+    pb = sg.SpectrogramParams(sg.StftParams(64, 16, b, True), 16000.0)
+    assert _key(a) != _key(b) and _key(pa) != _key(pb)
+    assert _key(pa) == _key(sg.SpectrogramParams(sg.StftParams(64, 16, sg.WindowType.custom(np.hamming(64)), True), 16000.0))
+    assert _key(sg.WindowType.kaiser(5.0)) != _key(sg.WindowType.kaiser(6.0))
+    assert _key(sg.MelParams(80, 0.0, 8000.0)) != _key(sg.MelParams(80, 0.0, 7999.0))
+    hash(_key(pa))  # usable as a dict key
+    with pytest.raises(TypeError):
+        _key(object())
+
+
+def test_dimension_mismatch_carries_expected_and_got():
+    """DimensionMismatch { expected, got } (src/error.rs:19-21) reaches Python as numbers, not only as message text."""
+    plan = host_plan(512, 256)
+    x = np.zeros((1, 4000))
+    with pytest.raises(sg.DimensionMismatchError) as ei:
+        plan.compute_batch(x, out=np.empty((1, 257, 3)))
+    nb, nf = plan.output_shape(4000)
+    assert ei.value.expected == nb * nf and ei.value.got == 257 * 3 and "Dimension mismatch" in str(ei.value)
+    assert plan.device == -2

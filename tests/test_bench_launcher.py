@@ -1,0 +1,34 @@
+"""bench.py's own multi-rank launcher (no GPU): `python bench.py --gpus 2 --dry-run` must start two fresh ranks, rendezvous over
+gloo, time K steps between barriers, take the max over ranks and print ONE JSON line from rank 0; a WORLD_SIZE that disagrees
+with --gpus is an error."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env=None):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          text=True, env=e, timeout=300)
+
+
+def test_direct_multi_rank_run_spawns_its_ranks():
+    r = _run(["--gpus", "2", "--steps", "5", "--warmup", "1", "--workload", "config4", "--gather", "overlap", "--dry-run"])
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]  # gloo may print a connection notice of its own
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak" and d["config"]["batch_per_gpu"] == 1024
+    assert d["config"]["gather"] == "overlap" and d["ms_per_step"] > 0
+
+
+def test_single_rank_dry_run_and_world_size_mismatch():
+    r = _run(["--gpus", "1", "--steps", "3", "--dry-run"])
+    assert r.returncode == 0 and json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["n_gpus"] == 1
+    r = _run(["--gpus", "4", "--dry-run"], env={"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
+                                                 "MASTER_PORT": "29999"})
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr

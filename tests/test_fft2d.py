@@ -163,6 +163,40 @@ def test_gpu_fft2d_batched_config5_subset():
 
 
 @pytest.mark.gpu
+def test_gpu_fft2d_config5_full_batch_properties():
+    """BASELINE configs[4] at its full size: 512 x 1024 x 1024 f32 in one call per op (the XCD-aware batch mapping at B = 512).
+    The oracle covers 4 images elsewhere; here every image is checked through size-independent properties: Parseval with the
+    half spectrum's Hermitian weights, ifft2d(fft2d(x)) = x, convolution with a delta = identity, and two images against the
+    oracle (first and last)."""
+    torch = pytest.importorskip("torch")
+    B, R, Cn = 512, 1024, 1024
+    g = torch.Generator(device="cuda").manual_seed(7)
+    r = torch.arange(R, device="cuda", dtype=torch.float32)[:, None]
+    c = torch.arange(Cn, device="cuda", dtype=torch.float32)[None, :]
+    x = (torch.sin(0.01 * r) + torch.cos(0.02 * c))[None] + 0.05 * torch.randn((B, R, Cn), generator=g, device="cuda", dtype=torch.float32)
+    x *= 1.0 + 0.001 * torch.arange(B, device="cuda", dtype=torch.float32)[:, None, None]  # no two images alike
+    plan = sg.Fft2dPlan(R, Cn, "float32")
+    plan.reserve(B, host_staging=False)
+    S = plan.forward_torch(x)
+    torch.cuda.synchronize()
+    assert tuple(S.shape) == (B, R, Cn // 2 + 1, 2) and bool(torch.isfinite(S).all())
+    p = (S.double() ** 2).sum(dim=3)                      # |S|^2, [B, R, 513]
+    w = torch.full((Cn // 2 + 1,), 2.0, device="cuda", dtype=torch.float64)
+    w[0] = w[-1] = 1.0                                   # columns 0 and N/2 have no mirror
+    lhs = (p * w).sum(dim=(1, 2))
+    rhs = (x.double() ** 2).sum(dim=(1, 2)) * (R * Cn)
+    assert float(((lhs - rhs).abs() / rhs).max()) < 1e-5
+    y = plan.inverse_torch(S)
+    assert float((y - x).abs().max()) <= 2e-5 * float(x.abs().max())
+    z = plan.convolve_torch(x, np.ones((1, 1), np.float32))
+    assert float((z - x).abs().max()) <= 2e-5 * float(x.abs().max())
+    for i in (0, B - 1):
+        ref = orc.fft2d(x[i].cpu().numpy().astype(np.float64))
+        got = torch.view_as_complex(S[i]).cpu().numpy()
+        assert np.max(np.abs(got - ref)) <= 2e-5 * np.max(np.abs(ref))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(1024, 1024), (1024, 64), (1024, 100), (1024, 7)])
 def test_gpu_fused_column_stage_1024_rows(shape):
     """f32 images with 1024 rows take the fused column kernel (forward FFT x kernel spectrum / mask x inverse FFT in one

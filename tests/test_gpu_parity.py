@@ -273,16 +273,19 @@ def test_strided_rows_and_device_path_match_host_path():
     dev = plan.compute_batch(big[:, :7000])  # row stride 7424 != n_samples
     torch.cuda.synchronize()
     assert np.array_equal(dev.cpu().numpy(), host)
-    # odd row stride / misaligned base -> falls back to the generic kernel, same numbers within f32 tolerance
-    odd = torch.zeros((5, 7001), dtype=torch.float32, device="cuda")
+    # odd row stride and a base that is only 4-byte aligned: the same kernel (its buffer loads need no more), the same bits
+    odd = torch.zeros((5 * 7001 + 1,), dtype=torch.float32, device="cuda")[1:].view(5, 7001)
     odd[:, :7000] = torch.from_numpy(x).cuda()
     dev2 = plan.compute_batch(odd[:, :7000]).cpu().numpy()
+    assert np.array_equal(dev2, host)
     ref = orc.spectrogram_batch(op, x.astype(np.float64))
-    assert np.max(np.abs(dev2 - ref)) < 1e-2  # dB units
+    pw = orc.spectrogram_batch(orc.Params(n_fft=1024, hop=256, n_mels=80), x.astype(np.float64))
+    near = pw > 1e-4 * pw.max()
+    assert np.max(np.abs(dev2 - ref)[near]) < 1e-3  # dB, the normal bound within 40 dB of the peak
     sp, _ = make(1024, 256, amp="complex")
     a = sp.compute_batch(big[:, :7000]).cpu().numpy()
     b = sp.compute_batch(odd[:, :7000]).cpu().numpy()
-    assert np.max(np.abs(a - b)) <= GUARD32 * np.max(np.abs(a))
+    assert np.array_equal(a, b)
 
 
 def test_dimension_mismatch_and_r2c():
@@ -430,3 +433,33 @@ def test_fuzz_shapes():
         plan, _ = run_case(n=n, batch=int(rng.integers(1, 4)), seed=case, **kw)
         seen.add(plan.kernel_name)
     assert {"reg_radix", "two_factor_dft", "direct_dft", "lds_radix2"} <= seen, seen
+
+
+def test_config4_shard_full_size_mel_power():
+    """BASELINE configs[3], one GPU's shard: 1024 x 10 s utterances, Mel-80 power, ONE launch (40 960 tiles: a different
+    persistent-grid regime from configs 2/3).  Oracle on eight rows including the last; over the whole output: finite,
+    non-negative, and every utterance equal — bit for bit — to its own B = 1 launch (the result of an utterance must not depend
+    on where it sits in the batch or on what its neighbours are)."""
+    torch = pytest.importorskip("torch")
+    B = 1024
+    base = H.cfg2_batch(256)
+    x = torch.from_numpy(base).cuda().repeat(4, 1)
+    x[256:] += 1e-3 * torch.arange(B - 256, device="cuda", dtype=torch.float32)[:, None] / B  # the repeats are not copies
+    params = sg.SpectrogramParams(sg.StftParams(1024, 256, sg.WindowType.hanning, True), 16000.0)
+    plan = sg.SpectrogramPlanner().mel_power_plan(params, sg.MelParams(80, 0.0, 8000.0), dtype="float32")
+    out = plan.compute_batch(x)
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == (B, 80, 626)
+    assert bool(torch.isfinite(out).all()) and float(out.min()) >= 0.0
+    rows = [0, 1, 255, 256, 511, 777, 1022, 1023]
+    ref = orc.spectrogram_batch(orc.Params(n_fft=1024, hop=256, n_mels=80), x[rows].cpu().numpy().astype(np.float64))
+    got = out[rows].cpu().numpy()
+    assert np.max(np.abs(got - ref)) <= 1e-4 * ref.max()
+    near = ref > 1e-4 * ref.max()
+    assert np.max(np.abs(got - ref)[near] / ref[near]) <= 1e-4
+    for r in (0, 313, 1023):
+        one = plan.compute_batch(x[r:r + 1])
+        assert torch.equal(one[0], out[r])
+    # sharding is by utterance with no halo: two half batches give the same bits as the whole
+    lo, hi = plan.compute_batch(x[:512]), plan.compute_batch(x[512:])
+    assert torch.equal(torch.cat([lo, hi]), out)

@@ -1,4 +1,4 @@
-"""PyTorch interop layer (python/spectrograms/torch.py): DLPack export, to_torch, batch, and the device-resident batch."""
+"""PyTorch interop: DLPack export of the result classes and the device-resident batch (spectrograms_amd/torch.py)."""
 import numpy as np
 import pytest
 import torch
@@ -18,27 +18,15 @@ def _spec(n_frames, seed=0):
     return Spectrogram(data, np.arange(5.0), np.arange(n_frames) * 0.1, params, None)
 
 
-def test_dlpack_and_to_torch_are_zero_copy_on_host():
+def test_host_results_export_dlpack_without_a_copy():
     s = _spec(7)
     t = torch.from_dlpack(s)
     assert t.shape == (5, 7) and t.dtype == torch.float64 and t.data_ptr() == s.data.ctypes.data
-    r = s.to_torch(with_metadata=True)
-    assert isinstance(r, sgt.TorchSpectrogram) and r.shape == (5, 7) and r.times.shape == (7,) and r.db_range is None
-    assert s.to_torch(dtype=torch.float32).dtype == torch.float32
 
 
-def test_batch_semantics_match_reference():
-    a, b, c = _spec(7, 1), _spec(7, 2), _spec(9, 3)
-    out = sgt.batch([a, b])
-    assert out.shape == (2, 5, 7) and torch.equal(out[1], torch.from_numpy(b.data))
-    with pytest.raises(ValueError, match="same shape"):
-        sgt.batch([a, c])
-    with pytest.raises(ValueError, match="empty"):
-        sgt.batch([])
-    p = sgt.batch([a, c], pad=True)
-    assert p.shape == (2, 5, 9) and torch.all(p[0, :, 7:] == 0)
-    t, meta = sgt.batch_with_metadata([a, b], dtype=torch.float32)
-    assert t.dtype == torch.float32 and len(meta) == 2 and meta[0]["shape"] == (5, 7)
+def test_batch_takes_resident_batches_only():
+    with pytest.raises(TypeError, match="SpectrogramBatch"):
+        sgt.batch([_spec(7, 1), _spec(7, 2)])
 
 
 @pytest.mark.gpu
@@ -56,8 +44,12 @@ def test_resident_batch_is_zero_copy_and_matches_oracle():
     assert np.max(np.abs(t.cpu().numpy() - ref)[near]) < 1e-3
     one = sb[2]
     assert one.shape == (80, 626) and len(one.times) == 626 and one.db_range() is not None
-    host, meta = sgt.batch_with_metadata(sb)
-    assert not host.is_cuda and len(meta) == 4
+    host, axes = sgt.batch_with_axes(sb, device="cpu")
+    assert not host.is_cuda and axes.item_shape == (80, 626) and axes.times.shape == (626,) and axes.frequencies.shape == (80,)
+    assert sgt.batch(sb, dtype=torch.float64).dtype == torch.float64
+    # tensors on another device than the plan's are refused before they reach the kernels
+    with pytest.raises(ValueError, match="CUDA tensor|plan is bound"):
+        plan.compute_batch(torch.zeros((2, 4000), dtype=torch.float32))
 
 
 def test_shift_helpers_and_plan_aliases():
