@@ -17,7 +17,7 @@ import spectrograms_amd as sg
 def main():
     workload = sys.argv[1] if len(sys.argv) > 1 else "linear_power"
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-    batch = int(sys.argv[3]) if len(sys.argv) > 3 else bench.BATCH
+    batch = int(sys.argv[3]) if len(sys.argv) > 3 else 256
     # SGX_PROF_NFFT / SGX_PROF_HOP / SGX_PROF_DTYPE: profile the shape-generic kernels on the same signals
     n_fft = int(os.environ.get("SGX_PROF_NFFT", bench.N_FFT))
     hop = int(os.environ.get("SGX_PROF_HOP", n_fft // 4))
