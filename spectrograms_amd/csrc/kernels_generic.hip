@@ -739,7 +739,10 @@ static size_t reg_radix_bytes(const StftArgs &a, unsigned ft, unsigned fa, unsig
     return (bytes + 15) & ~size_t(15);
 }
 
-static const size_t kRegBudget = 72 * 1024;  // two persistent workgroups per CU at the least
+// Tile + tables of one of the two persistent workgroups of a CU.  Per-bin outputs may take half of the CU's 160 KiB each: the
+// f64 n_fft = 1024 / 512 and f32 2048 tiles then hold 8 frames instead of 4 (64-byte store runs): 758 -> 606, 685 -> 527 and
+// 413 -> 363 us per 256 x 10 s.  Filterbank outputs keep the smaller budget (their |X|^2 rows come on top; 4096 / Mel lost 14 %).
+static const size_t kRegBudget = 72 * 1024, kRegBudgetBins = 80 * 1024;
 static const size_t kRegHardLimit = 144 * 1024;  // a single frame of the largest sizes may take most of the CU
 
 static unsigned reg_radix_ft_max(unsigned fbc) {
@@ -755,7 +758,8 @@ bool plan_geometry_reg_radix(StftArgs &a, int dtype) {
     if (!reg_radix_split(a, dtype, &fa, &fb, &fc)) return false;
     const size_t es = elem_size(dtype);
     // instances that run one workgroup per CU anyway (rr_waves == 1: f64 with a 16-point or longer pass) may use most of its LDS
-    const size_t budget = (dtype == SGX_F64 && fa >= 16) ? std::max(kRegBudget, kRegHardLimit - 16 * 1024) : kRegBudget;
+    const size_t base = a.out_mode == OUT_MEL ? kRegBudget : kRegBudgetBins;
+    const size_t budget = (dtype == SGX_F64 && fa >= 16) ? std::max(base, kRegHardLimit - 16 * 1024) : base;
     for (unsigned ft = reg_radix_ft_max(fb * fc); ft >= 1; ft >>= 1)
         if (reg_radix_bytes(a, ft, fa, fb * fc, es) <= budget) {
             a.ft = ft;
