@@ -236,6 +236,16 @@ sgx_status sgx_fft2d_reserve(sgx_fft2d *plan, size_t batch, int32_t host_staging
 int32_t sgx_fft2d_device(const sgx_fft2d *plan); /* the HIP device ordinal the plan is bound to */
 const char *sgx_fft2d_last_error(const sgx_fft2d *plan);
 
+/* ---- 1-D complex-to-complex plan: C2cPlan<T> (src/fft_backend.rs:113-137; `Sample::plan_c2c`, src/sample.rs:61-66).  In
+ * place, UNNORMALISED in both directions (the caller divides by n after an inverse, as the trait says), host pointers, `len`
+ * complex values of T = n else SGX_DIM_MISMATCH.  Everything is allocated at creation. */
+typedef struct sgx_c2c sgx_c2c; /* opaque; same single-caller rule as sgx_plan */
+sgx_status sgx_c2c_create(size_t n, int32_t dtype, int32_t device, sgx_c2c **out);
+void sgx_c2c_destroy(sgx_c2c *plan);
+sgx_status sgx_c2c_forward(sgx_c2c *plan, void *buf, size_t len);
+sgx_status sgx_c2c_inverse(sgx_c2c *plan, void *buf, size_t len);
+const char *sgx_c2c_last_error(const sgx_c2c *plan);
+
 const char *sgx_last_error(const sgx_plan *plan);
 const char *sgx_last_create_error(void);
 /* Name of the kernel variant the plan dispatches to ("r32x16_f32", "reg_radix", "lds_radix2", "two_factor_dft", "direct_dft"). */

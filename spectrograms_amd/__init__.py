@@ -6,7 +6,7 @@ include/spectro_hip.h.  There is no CPU fallback: if the library is not built, o
 compute calls raise FFTBackendError.
 """
 from ._ffi import DimensionMismatchError, FFTBackendError, InternalError, InvalidInputError, SpectrogramError
-from .fft2d import (Fft2dPlan, Fft2dPlanner, bandpass_filter, convolve_fft, detect_edges_fft, fft2d, fftfreq, fftshift,
+from .fft2d import (C2cPlan, Fft2dPlan, Fft2dPlanner, bandpass_filter, convolve_fft, detect_edges_fft, fft2d, fftfreq, fftshift,
                     fftshift_1d, gaussian_kernel_2d, highpass_filter, ifft2d, ifftshift, ifftshift_1d, lowpass_filter,
                     magnitude_spectrum_2d, power_spectrum_2d, rfftfreq, sharpen_fft)
 from .functions import (clear_fft_plan_cache, compute_chromagram, compute_erb_db_spectrogram,
@@ -39,7 +39,7 @@ __all__ = [
     "compute_istft", "ErbParams", "GammatoneParams", "compute_erb_power_spectrogram",
     "compute_erb_magnitude_spectrogram", "compute_erb_db_spectrogram", "LogHzParams",
     "compute_loghz_power_spectrogram", "compute_loghz_magnitude_spectrogram", "compute_loghz_db_spectrogram",
-    "fft2d", "ifft2d", "Fft2dPlan", "Fft2dPlanner", "convolve_fft", "gaussian_kernel_2d", "lowpass_filter",
+    "fft2d", "ifft2d", "C2cPlan", "Fft2dPlan", "Fft2dPlanner", "convolve_fft", "gaussian_kernel_2d", "lowpass_filter",
     "highpass_filter", "bandpass_filter", "detect_edges_fft", "sharpen_fft", "power_spectrum_2d",
     "magnitude_spectrum_2d", "fftshift", "ifftshift", "fftfreq", "rfftfreq", "fftshift_1d", "ifftshift_1d",
     "LinearPowerPlan", "LinearMagnitudePlan", "LinearDbPlan", "MelPowerPlan", "MelMagnitudePlan", "MelDbPlan",

@@ -29,6 +29,7 @@ SYMBOLS = [
     "sgx_fft2d_create", "sgx_fft2d_destroy", "sgx_fft2d_forward", "sgx_fft2d_inverse", "sgx_fft2d_convolve",
     "sgx_fft2d_filter", "sgx_fft2d_last_error", "sgx_fft2d_reserve", "sgx_fft2d_device",
     "sgx_reserve", "sgx_plan_device", "sgx_last_dim_mismatch",
+    "sgx_c2c_create", "sgx_c2c_destroy", "sgx_c2c_forward", "sgx_c2c_inverse", "sgx_c2c_last_error",
     "sgx_comm_unique_id", "sgx_comm_create", "sgx_comm_adopt", "sgx_comm_destroy", "sgx_comm_last_error", "sgx_gather", "sgx_shard_execute",
 ]
 
@@ -128,6 +129,13 @@ def lib() -> C.CDLL:
     L.sgx_plan_device.argtypes = [vp]
     L.sgx_plan_device.restype = C.c_int32
     L.sgx_last_dim_mismatch.argtypes = [vp, C.POINTER(sz), C.POINTER(sz)]
+    L.sgx_c2c_create.argtypes = [sz, C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.sgx_c2c_destroy.argtypes = [vp]
+    L.sgx_c2c_destroy.restype = None
+    L.sgx_c2c_forward.argtypes = [vp, vp, sz]
+    L.sgx_c2c_inverse.argtypes = [vp, vp, sz]
+    L.sgx_c2c_last_error.argtypes = [vp]
+    L.sgx_c2c_last_error.restype = C.c_char_p
     L.sgx_comm_unique_id.argtypes = [vp]
     L.sgx_comm_create.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
     L.sgx_comm_adopt.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]

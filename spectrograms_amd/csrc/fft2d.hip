@@ -423,3 +423,100 @@ sgx_status sgx_fft2d_filter(sgx_fft2d *p, const void *images, size_t batch, int3
 }
 
 }  // extern "C"
+
+// ---- 1-D complex-to-complex plan: C2cPlan<T> (src/fft_backend.rs:113-137), the third plan type `Sample` names --------------
+// In place, unnormalised in both directions, host pointers, one sequence of n per call: the column kernels of the 2-D path with
+// one sequence.  Off the batched hot path (the reference's callers are single transforms); everything is allocated at creation.
+struct sgx_c2c {
+    size_t n = 0;
+    int dtype = SGX_F32, device = -1;
+    size_t elem = 4;
+    unsigned log2n = 0, tile = 0;
+    void *d_tw = nullptr, *d_buf = nullptr, *d_out = nullptr;
+    mutable std::string err;
+};
+
+namespace {
+sgx_status fail1(const sgx_c2c *p, sgx_status st, const std::string &m) {
+    if (p) p->err = m; else g_err2d = m;
+    return st;
+}
+sgx_status c2c_run(sgx_c2c *p, void *buf, size_t len, int inverse) {
+    if (!p) return SGX_INVALID_INPUT;
+    if (!buf) return fail1(p, SGX_INVALID_INPUT, "Invalid input: null buffer");
+    if (len != p->n)  // dimension_mismatch(n_fft, buf.len())
+        return fail1(p, SGX_DIM_MISMATCH, "Dimension mismatch: expected " + std::to_string(p->n) + ", got " + std::to_string(len));
+    if (p->device < 0) return fail1(p, SGX_BACKEND, "hip -- FFT backend error: plan has no HIP device (host-only plan)");
+    DeviceGuard dg;
+    if (dg.enter(p->device) != hipSuccess) return fail1(p, SGX_BACKEND, "hip -- FFT backend error: hipSetDevice failed");
+    const size_t bytes = 2 * p->n * p->elem;
+    if (hipMemcpy(p->d_buf, buf, bytes, hipMemcpyHostToDevice) != hipSuccess) return fail1(p, SGX_BACKEND, "hip -- FFT backend error: copy in");
+    C2cArgs a{};
+    a.in = p->d_buf; a.out = p->d_out;
+    a.n = unsigned(p->n); a.log2n = p->log2n; a.nseq = 1; a.batch = 1;
+    a.in_img = p->n; a.out_img = p->n;
+    a.in_ss = p->n; a.in_is = 1; a.out_ss = p->n; a.out_is = 1;
+    a.tile = p->tile; a.tiles = 1;
+    a.tw = p->d_tw; a.inverse = inverse; a.in_seq_fast = 0; a.out_seq_fast = 0; a.scale = 1.0;
+    hipError_t e = launch_c2c_any(a, p->dtype, nullptr);
+    if (e != hipSuccess) return fail1(p, SGX_BACKEND, std::string("hip -- FFT backend error: ") + hipGetErrorString(e));
+    if (hipMemcpy(buf, p->d_out, bytes, hipMemcpyDeviceToHost) != hipSuccess) return fail1(p, SGX_BACKEND, "hip -- FFT backend error: copy out");
+    return SGX_OK;
+}
+}  // namespace
+
+extern "C" {
+sgx_status sgx_c2c_create(size_t n, int32_t dtype, int32_t device, sgx_c2c **out) {
+    if (out) *out = nullptr;
+    if (!out || n == 0) return fail1(nullptr, SGX_INVALID_INPUT, "Invalid input: n must be > 0");
+    if (dtype != SGX_F32 && dtype != SGX_F64) return fail1(nullptr, SGX_INVALID_INPUT, "Invalid input: dtype must be f32 or f64");
+    if (n > 0x7fffffffull) return fail1(nullptr, SGX_INVALID_INPUT, "Invalid input: n too large");
+    sgx_c2c *p = new (std::nothrow) sgx_c2c();
+    if (!p) return fail1(nullptr, SGX_INTERNAL, "Internal error: out of memory");
+    p->n = n; p->dtype = dtype; p->elem = dtype == SGX_F64 ? 8 : 4; p->device = device; p->log2n = ilog2_pow2(n);
+    if (device == -2) { *out = p; return SGX_OK; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { delete p; return fail1(nullptr, SGX_BACKEND, "hip -- FFT backend error: no HIP device available"); }
+    int dev = device;
+    if (dev == -1 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (dev < 0 || dev >= ndev) { delete p; return fail1(nullptr, SGX_INVALID_INPUT, "Invalid input: device ordinal out of range"); }
+    p->device = dev;
+    p->tile = fft2d_tile_for(unsigned(n), dtype);
+    DeviceGuard dg;
+    std::vector<double> tw(2 * n);
+    for (size_t k = 0; k < n; ++k) {
+        const double a = -2.0 * kPi2 * double(k) / double(n);
+        tw[2 * k] = std::cos(a);
+        tw[2 * k + 1] = std::sin(a);
+    }
+    bool ok = p->tile > 0 && dg.enter(dev) == hipSuccess && hipMalloc(&p->d_tw, 2 * n * p->elem) == hipSuccess &&
+              hipMalloc(&p->d_buf, 2 * n * p->elem) == hipSuccess && hipMalloc(&p->d_out, 2 * n * p->elem) == hipSuccess;
+    if (ok) {
+        if (dtype == SGX_F64) {
+            ok = hipMemcpy(p->d_tw, tw.data(), 2 * n * 8, hipMemcpyHostToDevice) == hipSuccess;
+        } else {
+            std::vector<float> t32(tw.begin(), tw.end());
+            ok = hipMemcpy(p->d_tw, t32.data(), 2 * n * 4, hipMemcpyHostToDevice) == hipSuccess;
+        }
+    }
+    if (!ok) {
+        for (void *b : {p->d_tw, p->d_buf, p->d_out}) if (b) (void)hipFree(b);
+        delete p;
+        return fail1(nullptr, SGX_BACKEND, "hip -- FFT backend error: could not set up the C2C plan (length too large for the on-chip tile, or allocation failed)");
+    }
+    *out = p;
+    return SGX_OK;
+}
+void sgx_c2c_destroy(sgx_c2c *p) {
+    if (!p) return;
+    if (p->device >= 0) {
+        DeviceGuard dg;
+        (void)dg.enter(p->device);
+        for (void *b : {p->d_tw, p->d_buf, p->d_out}) if (b) (void)hipFree(b);
+    }
+    delete p;
+}
+sgx_status sgx_c2c_forward(sgx_c2c *p, void *buf, size_t len) { return c2c_run(p, buf, len, 0); }
+sgx_status sgx_c2c_inverse(sgx_c2c *p, void *buf, size_t len) { return c2c_run(p, buf, len, 1); }
+const char *sgx_c2c_last_error(const sgx_c2c *p) { return p ? p->err.c_str() : g_err2d.c_str(); }
+}  // extern "C"

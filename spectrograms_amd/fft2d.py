@@ -150,6 +150,44 @@ class Fft2dPlan:
         return out
 
 
+class C2cPlan:
+    """1-D complex-to-complex plan: C2cPlan<T> of the reference (src/fft_backend.rs:113-137).  `forward` / `inverse` return a
+    new array; neither normalises (the caller divides by n after an inverse)."""
+
+    def __init__(self, n: int, dtype: Optional[str] = None, device: int = _ffi.DEVICE_CURRENT):
+        self._lib = _ffi.lib()
+        self.n = int(n)
+        self._dt = parse_dtype(dtype)
+        self._cnp = np.complex64 if self._dt == _ffi.F32 else np.complex128
+        h = C.c_void_p()
+        st = self._lib.sgx_c2c_create(self.n, self._dt, device, C.byref(h))
+        if st:
+            raise _ffi._ERR.get(st, _ffi.InternalError)((self._lib.sgx_c2c_last_error(None) or b"").decode())
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.sgx_c2c_destroy(h)
+            self._h = None
+
+    def _run(self, fn, x) -> np.ndarray:
+        buf = np.array(x, dtype=self._cnp, copy=True).ravel()
+        st = fn(self._h, buf.ctypes.data, buf.size)
+        if st:
+            msg = (self._lib.sgx_c2c_last_error(self._h) or b"").decode()
+            if st == _ffi.SGX_DIM_MISMATCH:
+                raise _ffi.DimensionMismatchError(msg, self.n, buf.size)
+            raise _ffi._ERR.get(st, _ffi.InternalError)(msg)
+        return buf
+
+    def forward(self, x) -> np.ndarray:
+        return self._run(self._lib.sgx_c2c_forward, x)
+
+    def inverse(self, x) -> np.ndarray:
+        return self._run(self._lib.sgx_c2c_inverse, x)
+
+
 class Fft2dPlanner:
     """Plan cache keyed by shape (src/fft2d.rs:491-657)."""
 

@@ -252,3 +252,32 @@ def test_gpu_fft2d_fuzz_shapes():
         got = sg.lowpass_filter(x, 0.4, dtype=dtype)
         reff = orc.filter2d(x.astype(np.float64), 0, 0.4)
         assert np.max(np.abs(got - reff)) <= (1e-9 if dtype == "float64" else 3e-5) * max(1.0, np.max(np.abs(reff))), (shape, dtype)
+
+
+def test_c2c_plan_host_validation():
+    p = sg.C2cPlan(16, "float32", device=_ffi.DEVICE_HOST_ONLY)
+    with pytest.raises(sg.DimensionMismatchError) as ei:
+        p.forward(np.zeros(15, np.complex64))
+    assert ei.value.expected == 16 and ei.value.got == 15
+    with pytest.raises(sg.FFTBackendError):  # no CPU fallback
+        p.forward(np.zeros(16, np.complex64))
+    with pytest.raises(sg.InvalidInputError):
+        sg.C2cPlan(0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,dtype,tol", [(8, "float64", 1e-12), (1024, "float32", 2e-6), (1000, "float64", 1e-11), (100, "float32", 2e-6),
+                                         (7, "float64", 1e-12), (4096, "float64", 1e-11)])
+def test_gpu_c2c_plan_matches_numpy(n, dtype, tol):
+    """C2cPlan<T>::forward / inverse (src/fft_backend.rs:113-137): unnormalised both ways; inverse(forward(x)) = n x
+    (the reference's own round-trip KAT, fft_backend.rs:1909-1927)."""
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    p = sg.C2cPlan(n, dtype)
+    X = p.forward(x)
+    ref = np.fft.fft(x)
+    assert np.max(np.abs(X - ref)) <= tol * np.max(np.abs(ref)) * max(1.0, np.log2(n))
+    y = p.inverse(X)
+    assert np.max(np.abs(y / n - x)) <= tol * np.max(np.abs(x)) * max(1.0, np.log2(n))
+    ones = p.forward(np.ones(n))
+    assert abs(ones[0] - n) <= tol * n and np.max(np.abs(ones[1:])) <= tol * n * max(1.0, np.log2(n))
