@@ -6,8 +6,6 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd $ROOT
 B=256 python tools/time_generic.py 2>&1 | grep -v amdgpu.ids > $OUT/generic_times.txt
-echo "--- SGX_GENERIC=lds (previous LDS radix-2 / two-factor kernels, same box)" >> $OUT/generic_times.txt
-SGX_GENERIC=lds B=256 python tools/time_generic.py 2>&1 | grep -v amdgpu.ids >> $OUT/generic_times.txt
 cd /tmp && export TMPDIR=/tmp
 for nf in 400 512; do
   export SGX_PROF_NFFT=$nf SGX_PROF_HOP=$((nf * 2 / 5))

@@ -1,15 +1,14 @@
 #!/bin/bash
-# MFMA utilisation of the matrix-core bank epilogue (ERB-64, and Mel-80 forced onto it with SGX_MEL=mfma): PMC pass only.
+# MFMA utilisation of the matrix-core bank epilogue (ERB-64): PMC pass only.  (Round 1 also forced Mel-80 onto it through a
+# switch the library no longer has: 11 % of the f32 matrix peak, profiles/r01_mfma_pmc.txt.)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 120 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma_erb -- python3 $ROOT/tools/prof_driver.py erb_power 4 > $OUT/mfma_erb.log 2>&1
-export SGX_MEL=mfma
-timeout 120 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma_mel -- python3 $ROOT/tools/prof_driver.py mel_power 4 > $OUT/mfma_mel.log 2>&1
 cd $ROOT
-for d in mfma_erb mfma_mel; do
+for d in mfma_erb; do
   f=$(find $OUT/$d -name '*counter_collection.csv' | head -1)
   echo "== $d"
   [ -n "$f" ] && python3 - "$f" <<'PY'
