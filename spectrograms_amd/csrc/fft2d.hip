@@ -458,7 +458,11 @@ sgx_status c2c_run(sgx_c2c *p, void *buf, size_t len, int inverse) {
     a.in_ss = p->n; a.in_is = 1; a.out_ss = p->n; a.out_is = 1;
     a.tile = p->tile; a.tiles = 1;
     a.tw = p->d_tw; a.inverse = inverse; a.in_seq_fast = 0; a.out_seq_fast = 0; a.scale = 1.0;
-    hipError_t e = launch_c2c_any(a, p->dtype, nullptr);
+    hipError_t e = launch_c2c_reg(a, p->dtype, nullptr);  // picks its own tile
+    if (e == hipErrorNotSupported) {
+        if (p->tile == 0) return fail1(p, SGX_BACKEND, "hip -- FFT backend error: length too large for the on-chip tile");
+        e = launch_c2c_tile(a, p->dtype, nullptr);
+    }
     if (e != hipSuccess) return fail1(p, SGX_BACKEND, std::string("hip -- FFT backend error: ") + hipGetErrorString(e));
     if (hipMemcpy(buf, p->d_out, bytes, hipMemcpyDeviceToHost) != hipSuccess) return fail1(p, SGX_BACKEND, "hip -- FFT backend error: copy out");
     return SGX_OK;
@@ -489,7 +493,7 @@ sgx_status sgx_c2c_create(size_t n, int32_t dtype, int32_t device, sgx_c2c **out
         tw[2 * k] = std::cos(a);
         tw[2 * k + 1] = std::sin(a);
     }
-    bool ok = p->tile > 0 && dg.enter(dev) == hipSuccess && hipMalloc(&p->d_tw, 2 * n * p->elem) == hipSuccess &&
+    bool ok = dg.enter(dev) == hipSuccess && hipMalloc(&p->d_tw, 2 * n * p->elem) == hipSuccess &&
               hipMalloc(&p->d_buf, 2 * n * p->elem) == hipSuccess && hipMalloc(&p->d_out, 2 * n * p->elem) == hipSuccess;
     if (ok) {
         if (dtype == SGX_F64) {
@@ -502,7 +506,7 @@ sgx_status sgx_c2c_create(size_t n, int32_t dtype, int32_t device, sgx_c2c **out
     if (!ok) {
         for (void *b : {p->d_tw, p->d_buf, p->d_out}) if (b) (void)hipFree(b);
         delete p;
-        return fail1(nullptr, SGX_BACKEND, "hip -- FFT backend error: could not set up the C2C plan (length too large for the on-chip tile, or allocation failed)");
+        return fail1(nullptr, SGX_BACKEND, "hip -- FFT backend error: could not set up the C2C plan (allocation failed)");
     }
     *out = p;
     return SGX_OK;
