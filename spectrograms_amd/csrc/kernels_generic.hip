@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_reg_radix(
     // Tables the tile loop needs come from LDS: a global load behind the split's stores would wait for all of them (loads
     // and stores retire through one in-order counter).  The workgroup is persistent: tiles blockIdx.x, + gridDim.x, ...
     for (unsigned i = tid; i <= M / 2; i += 256) stw[i] = tw[i];
-    for (unsigned i = tid; i < M; i += 256) sw[i] = ((const V *)a.window)[i];
+    for (unsigned i = tid; i < M; i += 256) sw[i] = ((const V *)a.window)[i] * (V){T(0.5), T(0.5)};  // halved (exact): the real split needs no 1/2
     MelCsr<T> csr{};
     typedef T V4 __attribute__((ext_vector_type(4)));
     const V4 *bw = nullptr;            // band table: 4 weights per group; row mm = groups [bptr[mm], bptr[mm+1]) from column bcol[mm]
@@ -383,34 +383,43 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_reg_radix(
             return fb[(k % A) * RS + (q % B) * C + q / B];
         };
         {
+            // Packed arithmetic on the pre-halved spectrum (window x 1/2 above): E = Z[k] + conj Z[m-k], D = (z.x - y.x, z.y + y.y),
+            // T = W (-i D) = D.y W + D.x (W.y, -W.x);  X[k] = E + T, X[m-k] = conj(E - T).  The output mode and the amplitude
+            // scale are uniform: they pick one of five specialised loops instead of being tested per bin.
             const unsigned f = tid & (a.ft - 1), kstep = 256u >> lft;  // a thread keeps its frame and walks the bins
             const V *fb = buf + (size_t)f * FS;
-            T *pf = pw + (size_t)f * pws;
-            auto emit = [&](unsigned k, T re, T im) {
-                if (a.out_mode == OUT_MEL) {
-                    const T p = re * re + im * im;
-                    pf[k] = a.amp == AMP_MAG_IN ? t_sqrt(p) : p;
-                } else {
-                    emit_bin<T>(a, b, f0 + f, f, k, re, im, pw, eps);
-                }
-            };
-            if (f < nf)
+            auto split_all = [&](auto &&put) {  // put(k, X): X[k] of frame f
+                if (f >= nf) return;
                 for (unsigned k = tid >> lft; k <= M / 2; k += kstep) {
                     if (k == 0) {  // DC and Nyquist bins: exactly real
                         const V z = fb[0];
-                        emit(0, z.x + z.y, T(0));
-                        emit(M, z.x - z.y, T(0));
+                        put(0u, (V){(z.x + z.y) * T(2), T(0)});
+                        put(M, (V){(z.x - z.y) * T(2), T(0)});
                         continue;
                     }
-                    const V z = at(fb, k), y = at(fb, M - k);
-                    const T half = T(0.5);
-                    const T er = (z.x + y.x) * half, ei = (z.y - y.y) * half;
-                    const T orr = (z.y + y.y) * half, oi = (y.x - z.x) * half;
-                    const V wv = stw[k];
-                    const T pr = orr * wv.x - oi * wv.y, pi = orr * wv.y + oi * wv.x;
-                    emit(k, er + pr, ei + pi);
-                    if (k != M - k) emit(M - k, er - pr, pi - ei);
+                    const V z = at(fb, k), y = at(fb, M - k), w = stw[k];
+                    const V E = inreg::pfma(y, (V){T(1), T(-1)}, z);
+                    const V D = inreg::pfma(y, (V){T(-1), T(1)}, z);
+                    const V Tt = inreg::pfma(inreg::hi2(D), w, inreg::lo2(D) * (V){w.y, -w.x});
+                    const V X = E + Tt, Y = E - Tt;
+                    put(k, X);
+                    if (k != M - k) put(M - k, (V){Y.x, -Y.y});
                 }
+            };
+            const size_t ob = ((size_t)b * a.n_out) * a.n_frames + f0 + f;
+            if (a.out_mode == OUT_MEL) {
+                T *pf = pw + (size_t)f * pws;
+                if (a.amp == AMP_MAG_IN) split_all([&](unsigned k, V X) { pf[k] = t_sqrt(X.x * X.x + X.y * X.y); });
+                else split_all([&](unsigned k, V X) { pf[k] = X.x * X.x + X.y * X.y; });
+            } else if (a.out_mode == OUT_COMPLEX) {
+                V *o = (V *)a.out + ob;
+                split_all([&](unsigned k, V X) { o[(size_t)k * a.n_frames] = X; });
+            } else {
+                T *o = (T *)a.out + ob;
+                if (a.amp == AMP_MAGNITUDE) split_all([&](unsigned k, V X) { o[(size_t)k * a.n_frames] = t_sqrt(X.x * X.x + X.y * X.y); });
+                else if (a.amp == AMP_DB) split_all([&](unsigned k, V X) { o[(size_t)k * a.n_frames] = T(10) * t_log10(t_max(X.x * X.x + X.y * X.y, eps)); });
+                else split_all([&](unsigned k, V X) { o[(size_t)k * a.n_frames] = X.x * X.x + X.y * X.y; });
+            }
         }
         if (a.out_mode == OUT_MEL) {
             __syncthreads();
