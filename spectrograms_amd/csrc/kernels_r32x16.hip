@@ -344,7 +344,7 @@ __device__ __forceinline__ v2f mul_add_unfused(float w, v2f p, v2f acc) {
 }
 template <int AMP>
 __device__ __forceinline__ void mel_tile_sched(const StftArgs &a, const float *pwT, const unsigned *sched, unsigned b, unsigned f0,
-                                               unsigned nf, float eps, unsigned tid) {
+                                               unsigned nf, float eps, unsigned tid SGX_STAMP_PARAMS) {
     const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u, slot = lane >> 3, fp = lane & 7u;
     // out[b][band][f0 + 2 fp ..]: one descriptor per tile; a lane without a frame or a slot without a band gets an offset past
     // its range and the hardware drops the store.  The stores are unconditional and the segment loop has a fixed trip count so
@@ -357,6 +357,7 @@ __device__ __forceinline__ void mel_tile_sched(const StftArgs &a, const float *p
     // one 16-byte record per (segment, wave, slot): {L of the wave, word offset of the slot's weight row, first bin, band}
     const uint4 *info = (const uint4 *)(sched + kSchedHdr) + wave * 8u + slot;
     uint4 cur = info[0];
+    SGX_STAMP(12);  // mel prologue
 #pragma unroll
     for (unsigned seg = 0; seg < (unsigned)kSchedSegs; ++seg) {
         const uint4 nxt = info[(seg + 1u) * 32u];  // fetched ahead; the table always holds kSchedSegs + 1 segments
@@ -371,6 +372,7 @@ __device__ __forceinline__ void mel_tile_sched(const StftArgs &a, const float *p
             acc = mul_add_unfused(w4.z, (v2f){q1.x, q1.y}, acc);
             acc = mul_add_unfused(w4.w, (v2f){q1.z, q1.w}, acc);
         }
+        SGX_STAMP(13);  // mel loops
         const bool have = cur.w != 0xffffffffu;
         const unsigned bo = cur.w * a.n_frames * 4u;
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, amp_f32<AMP>(acc.x, eps)), ro, (int)((have && fo0 != kDrop) ? bo + fo0 : kDrop), 0, 0);
@@ -435,7 +437,7 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
     constexpr int NCR = ROUNDS > 0 ? ROUNDS : 1;
     v4f creg[NCR];
     v2f xd[ROUNDS > 0 ? 1 : 32];
-    const unsigned chunks = XSPAD ? 1216u : (15u * a.hop + 1024u) >> 2;
+    const unsigned chunks = XSPAD ? 1216u : (15u * a.hop + 1024u + 3u) >> 2;
     const unsigned hop = XSPAD ? 256u : a.hop;
     const unsigned row_bytes = (unsigned)a.n_samples * 4u;  // host: n_samples < 2^29
     auto load_tile = [&](unsigned w) {
@@ -619,7 +621,7 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
 #ifdef SGX_ABL_NOMEL
             if (a.n_mels == 12345u)
 #endif
-            if constexpr (PWT) mel_tile_sched<AMP>(a, pwf, sched, b, f0, nf, eps, tid);
+            if constexpr (PWT) mel_tile_sched<AMP>(a, pwf, sched, b, f0, nf, eps, tid SGX_STAMP_ARGS);
             else if (a.mm_frag) map_tile_mfma<AMP>(a, pwf, b, f0, nf, eps, tid, 2u * half);
             else mel_tile_csr<AMP>(a, pwf, b, f0, nf, eps, tid, 256u);
             if constexpr (!PWT) __syncthreads();  // pw consumed before the next staging overwrites it
@@ -647,7 +649,7 @@ template <int MODE, int AMP>
 hipError_t launch_variant(const StftArgs &a, hipStream_t s) {
     const unsigned total = a.tiles * a.batch;
     const unsigned per_xcd = (total + 7) / 8;
-    const unsigned chunks = (15u * a.hop + 1024u) >> 2;
+    const unsigned chunks = (15u * a.hop + 1024u + 3u) >> 2;
     const unsigned pairs = (per_xcd + 1) / 2;
 #ifndef SGX_SLOTS
 #define SGX_SLOTS 32u

@@ -263,6 +263,14 @@ def test_hop_equals_n_fft_and_odd_hop():
     run_case(n=10001, n_fft=1024, hop=256, amp="complex")  # odd length: last float2 straddles the end
 
 
+@pytest.mark.parametrize("hop", [2, 66, 130, 258, 270, 272, 274, 510, 1022])
+def test_tuned_kernel_even_hops(hop):
+    """Every even hop runs on the tuned kernel: staged loads up to hop 272 (a tile of 15 hop + 1024 samples need not be a whole
+    number of 16-byte chunks), per-lane loads above; interior, edge and ragged last tiles."""
+    run_case(n=9000 + hop, batch=3, n_fft=1024, hop=hop, amp="complex")
+    run_case(n=5000, batch=2, n_fft=1024, hop=hop, n_mels=40, amp="power")
+
+
 def test_strided_rows_and_device_path_match_host_path():
     torch = pytest.importorskip("torch")
     plan, op = make(1024, 256, n_mels=80, amp="db", floor=-80.0)

@@ -33,8 +33,8 @@ o = torch.view_as_real(out) if out.is_complex() else out
 ms = plan.time_batch_torch(x, o, iters)
 L.sgx_debug_read_stamps(buf, 1)
 names = ["wait samples + stage writes", "barrier 1", "col/window reads + FFT32", "barrier 2", "twiddle + ex writes", "load issue",
-         "barrier 3", "row reads", "barrier 4", "FFT16 x2 (+ job-0 fixup)", "real split + stores / LDS writes", "barrier (|X|^2 tile complete)", "-", "drain (x4 stores)",
-         "filterbank stage (+ 2 barriers)"]
+         "barrier 3", "row reads", "barrier 4", "FFT16 x2 (+ job-0 fixup)", "real split + stores / LDS writes", "barrier (|X|^2 tile complete)", "band stage: prologue", "band stage: loops",
+         "band stage: epilogues + stores"]
 waves, rounds = buf[16], buf[15]
 tot = sum(buf[i] for i in range(15))
 print(f"workload={wl} kernel_ms(stamped)={ms:.4f} waves={waves} wave-rounds={rounds}")
