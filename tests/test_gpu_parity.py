@@ -237,6 +237,12 @@ def test_golden_config2_f32(golden_dir, b):
     P = sg.compute_linear_power_spectrogram(x, params, dtype="float32")
     rs = g[f"c2_b{b}_power_rowsum"]
     assert np.max(np.abs(P.data.astype(np.float64).sum(axis=1) - rs)) <= GUARD32 * rs.max()
+    # bin for bin on the stored frames: power = |stft|^2 of the reference's own complex values (S5)
+    pref = np.abs(ref) ** 2
+    got = P.data[:, g[f"c2_b{b}_frames"]].astype(np.float64)
+    assert np.max(np.abs(got - pref)) <= 1e-4 * pref.max()
+    near = pref > 1e-4 * pref.max()
+    assert np.max(np.abs(got - pref)[near] / pref[near]) <= 1e-4
 
 
 def test_golden_short_inputs(golden_dir):

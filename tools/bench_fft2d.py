@@ -20,8 +20,11 @@ def main():
     rng = np.random.default_rng(7)
     r, c = np.meshgrid(np.arange(R), np.arange(C), indexing="ij")
     base = (np.sin(0.01 * r) + np.cos(0.02 * c)).astype(np.float32)
-    x = torch.from_numpy(base).cuda()[None].repeat(batch, 1, 1).contiguous()
-    x += 0.05 * torch.randn(x.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(7))
+    # inputs are built on the host and uploaded with one copy, so a profile of this script holds the engine's kernels only
+    nz = min(batch, 32)
+    host = (base[None] + 0.05 * rng.standard_normal((nz, R, C), dtype=np.float32))
+    host = np.concatenate([host] * ((batch + nz - 1) // nz))[:batch]
+    x = torch.from_numpy(np.ascontiguousarray(host)).cuda()
     plan = sg.Fft2dPlan(R, C, "float32")
     k = sg.gaussian_kernel_2d(9, 2.0, dtype="float32")
     spec = plan.forward_torch(x)
