@@ -106,6 +106,10 @@ if __name__ == "__main__":
     if "--sources" in sys.argv:
         print(" ".join(os.path.join("spectrograms_amd", "csrc", s) for s in SOURCES))
     elif len(sys.argv) > 2 and sys.argv[1] == "--variant":
-        print(variant(sys.argv[2], sys.argv[3:]))
+        rest, srcs = sys.argv[3:], []
+        while len(rest) >= 2 and rest[0] == "--src":  # --variant NAME [--src file.hip]... flags...
+            srcs.append(rest[1])
+            rest = rest[2:]
+        print(variant(sys.argv[2], rest, tuple(srcs) or ("kernels_r32x16.hip",)))
     else:
         print(build(force="--force" in sys.argv, verbose=True))

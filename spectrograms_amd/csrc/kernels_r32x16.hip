@@ -36,6 +36,7 @@
 // :2068-2080; replaces the per-frame `R2cPlan::process` call at :1323 (fft_backend.rs:423-431).
 #include <utility>
 
+#include "buffer_ops.h"
 #include "fft_inreg.h"
 #include "r32x16_layout.h"
 #include "sgx_internal.h"
@@ -57,9 +58,6 @@ __device__ __forceinline__ float amp_f32(float p, float eps) {
 }
 __device__ __forceinline__ float power_of(v2f x) { return __builtin_fmaf(x.x, x.x, x.y * x.y); }
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
-}
 __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)p; }  // low half of a flat LDS address
 
 #ifdef SGX_STAMPS  // diagnostic build only (tools/stamps.py): a wave's cycles per phase

@@ -17,5 +17,5 @@ for dtype, n_fft, hop in (("float32", 256, 64), ("float32", 512, 128), ("float32
         nb, nf = plan.output_shape(x.shape[1])
         out = torch.empty((B, nb, nf), dtype=tdt, device="cuda")
         plan.time_batch_torch(x, out, 2)
-        ms = plan.time_batch_torch(x, out, 5)
+        ms = plan.time_batch_torch(x, out, int(os.environ.get("ITERS", 5)))
         print(f"{dtype} n_fft={n_fft:5d} hop={hop:4d} {name:8s} {plan.kernel_name:12s} {ms * 1e3:9.1f} us  {B * nf / ms / 1e3:8.1f} M frames/s", flush=True)
