@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void k_lds_radix2(StftArgs a) {
 // in-register transform is longer than 16 points, so f32 stays under 128 VGPRs (4 waves per SIMD).
 // A, B, C: lengths of the in-register passes (products of 2, 3, 5; C = 1: two passes), m = A B C
 template <typename T, int A_, int B_, int C_>
-__global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_reg_radix(StftArgs a, unsigned total_tiles, unsigned csr_lds, unsigned band_lds) {
+__global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_reg_radix(StftArgs a, unsigned total_tiles, unsigned csr_lds, unsigned band_lds, unsigned rot) {
     typedef typename PairOf<T>::type V;
     constexpr unsigned A = A_, B = B_, C = C_, BC = B * C, M = A * BC;
     constexpr unsigned NI = rr_items<B_, C_>();
@@ -338,7 +338,18 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_reg_radix(
             for (int j = 0; j < LB; ++j) asm volatile("" : "+v"(q2f[j]));
         }
     }
-    load_raw(blockIdx.x, raw);
+    // Tile order.  Round k covers tiles [k grid, (k + 1) grid); inside a round the workgroups of one XCD (blockIdx.x mod 8: the
+    // dispatcher deals workgroups to the XCDs in turn) take one contiguous eighth of it.  Neighbouring tiles of a signal write
+    // neighbouring ft-frame pieces of the same output rows — halves or quarters of the same 128-byte lines: in one XCD they
+    // meet in its L2 and leave as whole lines, spread over the XCDs every L2 writes its piece on its own (measured on the f64
+    // n_fft 1024 tiles of 8 frames = 64 bytes: 58 % of the write requests to memory were 32-byte ones).  Each round the
+    // positions move on by `rot`, chosen by the host so that a workgroup meets every tile index of a signal in turn (the first
+    // and last tile of a signal are the slower, bounds-checked ones: without that they pile up on a few workgroups).
+    // rot = ~0: plain order (grids that are not a multiple of 8: a single round of a small problem).
+    const unsigned grid = gridDim.x;
+    const unsigned pos0 = rot == ~0u ? blockIdx.x : (blockIdx.x & 7u) * (grid >> 3) + (blockIdx.x >> 3);
+    auto tile_of = [&](unsigned k) { return k * grid + (rot == ~0u ? pos0 : (pos0 + k * rot) % grid); };  // >= total_tiles: nothing this round
+    load_raw(min(tile_of(0), total_tiles - 1), raw);
     // landed before the loop as well: with loads still pending on entry the first use of `raw` inside the loop gets a
     // vmcnt(0), which from the second tile on waits for the previous tile's stores
 #pragma unroll
@@ -347,7 +358,10 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_reg_radix(
         for (unsigned n1 = 0; n1 < A; ++n1) asm volatile("" : "+v"(raw[j][n1]));
     __syncthreads();
     const unsigned lft = __ffs(a.ft) - 1u;
-    for (unsigned t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+    for (unsigned rnd = 0;; ++rnd) {
+        const unsigned t = tile_of(rnd);
+        if (t >= total_tiles) break;  // only the last round is partial
+        const unsigned t_next = tile_of(rnd + 1);
         const unsigned tile = t % a.tiles, b = t / a.tiles;
         const unsigned f0 = tile * a.ft, nf = min(a.ft, a.n_frames - f0);
         // the twiddle powers are opaque per tile: their products (rr_twiddle) are then rebuilt where they are used instead of
@@ -375,7 +389,7 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_reg_radix(
 #pragma unroll
             for (unsigned k1 = 1; k1 < A; ++k1) dst[k1 * RS + (pp ^ k1_mask(k1))] = inreg::cmulv(v[k1], rr_twiddle<LA>(pw2, k1));
         }
-        if (t + gridDim.x < total_tiles) load_raw(t + gridDim.x, raw);  // in flight behind passes 2 and 3
+        if (t_next < total_tiles) load_raw(t_next, raw);  // in flight behind passes 2 and 3
         __syncthreads();
         // the thread index is opaque from here on: the element addresses of passes 2, 3 and the split are recomputed per tile
         // (a few integer operations) instead of being carried through the whole loop in registers
@@ -469,7 +483,12 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_reg_radix(
                 T *o = (T *)a.out + ob;
                 if (a.amp == AMP_MAGNITUDE) split_all([&](unsigned k, V X) { o[(size_t)k * a.n_frames] = t_sqrt(X.x * X.x + X.y * X.y); });
                 else if (a.amp == AMP_DB) split_all([&](unsigned k, V X) { o[(size_t)k * a.n_frames] = T(10) * t_log10(t_max(X.x * X.x + X.y * X.y, eps)); });
-                else split_all([&](unsigned k, V X) { o[(size_t)k * a.n_frames] = X.x * X.x + X.y * X.y; });
+                else
+#ifdef SGX_ABL_NOSTORE
+                    split_all([&](unsigned k, V X) { if (X.x == T(1.2345e300)) o[(size_t)k * a.n_frames] = X.x * X.x + X.y * X.y; });
+#else
+                    split_all([&](unsigned k, V X) { o[(size_t)k * a.n_frames] = X.x * X.x + X.y * X.y; });
+#endif
             }
         }
         if (a.out_mode == OUT_MEL) {
@@ -846,14 +865,18 @@ static hipError_t launch_reg_radix_t(const StftArgs &a, unsigned total, size_t l
     const unsigned by_regs = rr_waves<T, A, B, C>();
     const unsigned by_lds = (unsigned)std::max<size_t>(1, (160 * 1024) / (lds + 512));
     unsigned grid = std::min(total, cus * std::min(by_regs, by_lds));
-    // A workgroup walks tiles blockIdx.x + k * grid, i.e. tile indices (blockIdx.x + k * grid) mod a.tiles of successive
-    // signals: with a common factor g it only ever sees the indices of its residue class mod g, so the first and last tile of
-    // every signal (the slower, bounds-checked ones) pile up on 2 / g of the workgroups and the rest wait for them at the end
-    // (measured: f32 n_fft 400, 32 tiles per signal on 512 workgroups, 192 vs 154 us).  A grid coprime to the tile count
-    // deals every workgroup every tile index in turn.
-    if (total > grid)
-        while (grid > 1 && std::gcd(grid, a.tiles) > 1) --grid;
-    hipLaunchKernelGGL((k_reg_radix<T, A, B, C>), dim3(grid), dim3(256), lds, s, a, total, csr_lds, band_lds);
+    // tile order (see the kernel): XCD-contiguous rounds need a grid that is a multiple of 8; the per-round shift `rot` makes
+    // (grid + rot) coprime to the tiles per signal, so that a workgroup walks through all tile indices of a signal instead of
+    // staying on one residue class — with 32 tiles per signal on 512 workgroups the two bounds-checked edge tiles of every
+    // signal would otherwise all land on 32 of them and the rest would wait (measured: f32 n_fft 400, 192 vs 154 us)
+    unsigned rot = ~0u;
+    if (total > grid) grid &= ~7u;
+    if (grid % 8 == 0) {
+        rot = 0;
+        if (total > grid)
+            while (rot < a.tiles && std::gcd(grid + rot, a.tiles) > 1) ++rot;
+    }
+    hipLaunchKernelGGL((k_reg_radix<T, A, B, C>), dim3(grid), dim3(256), lds, s, a, total, csr_lds, band_lds, rot);
     return hipGetLastError();
 }
 
