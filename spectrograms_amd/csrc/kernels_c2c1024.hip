@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include "fft_inreg.h"
 #include "sgx_internal.h"
+#include "xcd_map.h"
 
 namespace sgx {
 namespace {
@@ -18,14 +19,6 @@ namespace {
 using namespace inreg;
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-// Workgroups are dispatched round-robin over the 8 XCDs, each with its own L2.  Neighbouring tiles share cache lines (a
-// 16-sequence store segment is 128 bytes at a 4104-byte row pitch, an inverse-STFT tile re-reads 3 halo frames), so XCD x
-// takes the contiguous range [x * per, (x + 1) * per) of the logical tile space; the grid is rounded up to a multiple of 8.
-__device__ __forceinline__ unsigned xcd_logical_block(unsigned nblocks) {
-    const unsigned per = (nblocks + 7u) >> 3;
-    return (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-}
-static inline unsigned xcd_grid(unsigned long long nblocks) { return (unsigned)(((nblocks + 7ull) >> 3) << 3); }
 
 constexpr int kCFS = 8192 + 16;     // LDS bytes per sequence (odd multiple of 16: conflict-free b128 row reads)
 constexpr int kCLds = 16 * kCFS;    // 131328 B -> one workgroup per CU

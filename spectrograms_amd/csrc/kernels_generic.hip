@@ -241,11 +241,10 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_reg_radix(
     constexpr bool P2 = ct_is_pow2(M);        // power-of-two n_fft: table indices wrap with a mask instead of a remainder
     // where element (k1, p = hi C + lo) of a frame lives in LDS: rr_layout.h (three-pass splits: XOR swizzle, no bank conflicts
     // in any pass; two passes: rows of B + 1).  index = k1 RS + (lane part ^ instruction-stream part), see the helpers below.
-    constexpr RrSwz Z = RrLayout<sizeof(V), A_, B_, C_>::Z;
-    constexpr unsigned RS = Z.rs;                   // row stride (complex elements)
-    constexpr unsigned FS = rr_frame_stride(A, RS); // frame stride, odd: lanes over frames are conflict-free in the split
-    auto k1_mask = [Z](unsigned k1) { return (rr_hx(Z, B, k1) * C) | ((k1 * Z.ml) & (C - 1)); };   // the part of the swizzle that depends on the row
-    auto hi_part = [Z](unsigned hi) { return (hi * C) | ((hi >> Z.sh) & (C - 1)); };                // ... on hi (XORed with lo and k1_mask)
+    typedef RrLayout<sizeof(V), A_, B_, C_> L;
+    constexpr unsigned RS = L::RS, FS = L::FS;
+    auto k1_mask = [](unsigned k1) { return L::k1_mask(k1); };
+    auto hi_part = [](unsigned hi) { return L::hi_part(hi); };
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     V *buf = (V *)smem;                          // [ft][FS]
     V *stw = buf + (size_t)a.ft * FS;            // [M/2 + 1] split twiddles W_n^k
@@ -443,10 +442,7 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_reg_radix(
             for (unsigned n1 = 0; n1 < A; ++n1) asm volatile("" : "+v"(raw[j][n1]));
         // real split, frame index fastest across threads (a.ft is a power of two).  One work item per pair (k, m - k):
         // with E = (Z[k] + conj Z[m-k]) / 2, P = W_n^k (Z[k] - conj Z[m-k]) / (2i):  X[k] = E + P,  X[m-k] = conj(E - P).
-        auto at = [Z](const V *fb, unsigned k) -> V {  // Z[k]: row k mod A, position C k2 + k3 with k / A = k2 + B k3
-            const unsigned q = k / A;
-            return fb[rr_index(Z, B, C, k % A, q % B, q / B)];
-        };
+        auto at = [](const V *fb, unsigned k) -> V { return fb[L::of_output(k)]; };  // Z[k]: row k mod A, position (hi, lo) with k / A = hi + B lo
         {
             // Packed arithmetic on the pre-halved spectrum (window x 1/2 above): E = Z[k] + conj Z[m-k], D = (z.x - y.x, z.y + y.y),
             // T = W (-i D) = D.y W + D.x (W.y, -W.x);  X[k] = E + T, X[m-k] = conj(E - T).  The output mode and the amplitude

@@ -15,6 +15,8 @@
 #include <cstdlib>
 
 #include "reg_radix.h"
+#include "rr_layout.h"
+#include "xcd_map.h"
 
 namespace sgx {
 namespace {
@@ -28,11 +30,14 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_c2c_reg(C2
     constexpr unsigned A = A_, B = B_, C = C_, BC = B * C, N = A * BC;
     constexpr int LA = ct_log2_ceil(A), LB = ct_log2_ceil(B);
     constexpr bool P2 = ct_is_pow2(N);
-    constexpr unsigned RS = BC + 1, FS = (A * RS) | 1u;
+    typedef RrLayout<sizeof(V), A_, B_, C_> L;  // where element (k1, hi C + lo) of a sequence lives in LDS (rr_layout.h)
+    constexpr unsigned RS = L::RS, FS = L::FS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     V *buf = (V *)smem;  // [tile][FS]
     const unsigned tid = threadIdx.x, tile = 1u << ltile;
-    const unsigned t = blockIdx.x % a.tiles, b = blockIdx.x / a.tiles;
+    const unsigned lb = xcd_logical_block(a.tiles * a.batch);  // neighbouring tiles share cache lines: keep them in one XCD
+    if (lb >= a.tiles * a.batch) return;
+    const unsigned t = lb % a.tiles, b = lb / a.tiles;
     const unsigned s0 = t * tile;
     const unsigned ns = min(tile, a.nseq - s0);
     const V *in = (const V *)a.in + (size_t)b * a.in_img;
@@ -69,42 +74,45 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_c2c_reg(C2
         V pw2[LA];
 #pragma unroll
         for (int j = 0; j < LA; ++j) pw2[j] = tw[wrap((1u << j) * r)];
-        V *dst = buf + (size_t)s * FS + r;
-        dst[0] = v[0];
+        V *dst = buf + (size_t)s * FS;
+        const unsigned pp = L::hi_part(r / C) ^ (r % C);
+        dst[pp ^ L::k1_mask(0)] = v[0];
 #pragma unroll
-        for (unsigned k1 = 1; k1 < A; ++k1) dst[k1 * RS] = inreg::cmulv(v[k1], rr_twiddle<LA>(pw2, k1));
+        for (unsigned k1 = 1; k1 < A; ++k1) dst[k1 * RS + (pp ^ L::k1_mask(k1))] = inreg::cmulv(v[k1], rr_twiddle<LA>(pw2, k1));
     }
     __syncthreads();
     for (unsigned idx = tid; idx < ns * A * C; idx += 256) {
         const unsigned s = idx / (A * C), q = idx % (A * C), k1 = q / C, n3 = q % C;
-        V *row = buf + (size_t)s * FS + k1 * RS + n3;
+        V *row = buf + (size_t)s * FS + k1 * RS;
+        const unsigned lp = n3 ^ L::k1_mask(k1);  // point n2 sits at lp ^ hi_part(n2)
         V x[B];
 #pragma unroll
-        for (unsigned n2 = 0; n2 < B; ++n2) x[n2] = row[n2 * C];
+        for (unsigned n2 = 0; n2 < B; ++n2) x[n2] = row[lp ^ L::hi_part(n2)];
         inreg::MixFft<B, V>::run(x);
-        row[0] = x[0];
+        row[lp ^ L::hi_part(0)] = x[0];
         if constexpr (C > 1) {  // W_(BC)^(k2 n3) = W_N^(A k2 n3)
             V q2[LB];
 #pragma unroll
             for (int j = 0; j < LB; ++j) q2[j] = tw[wrap((A << j) * n3)];
 #pragma unroll
-            for (unsigned k2 = 1; k2 < B; ++k2) row[k2 * C] = inreg::cmulv(x[k2], rr_twiddle<LB>(q2, k2));
+            for (unsigned k2 = 1; k2 < B; ++k2) row[lp ^ L::hi_part(k2)] = inreg::cmulv(x[k2], rr_twiddle<LB>(q2, k2));
         } else {
 #pragma unroll
-            for (unsigned k2 = 1; k2 < B; ++k2) row[k2] = x[k2];
+            for (unsigned k2 = 1; k2 < B; ++k2) row[lp ^ L::hi_part(k2)] = x[k2];
         }
     }
     __syncthreads();
     if constexpr (C > 1) {
         for (unsigned idx = tid; idx < ns * A * B; idx += 256) {
             const unsigned s = idx / (A * B), q = idx % (A * B), k1 = q / B, k2 = q % B;
-            V *row = buf + (size_t)s * FS + k1 * RS + k2 * C;
+            V *row = buf + (size_t)s * FS + k1 * RS;
+            const unsigned lp = L::hi_part(k2) ^ L::k1_mask(k1);  // point n3 sits at lp ^ n3
             V x[C];
 #pragma unroll
-            for (unsigned n3 = 0; n3 < C; ++n3) x[n3] = row[n3];
+            for (unsigned n3 = 0; n3 < C; ++n3) x[n3] = row[lp ^ n3];
             inreg::MixFft<C, V>::run(x);
 #pragma unroll
-            for (unsigned k3 = 0; k3 < C; ++k3) row[k3] = x[k3];
+            for (unsigned k3 = 0; k3 < C; ++k3) row[lp ^ k3] = x[k3];
         }
         __syncthreads();
     }
@@ -114,8 +122,7 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_c2c_reg(C2
         unsigned s, k;
         if (a.out_seq_fast) { s = idx & (tile - 1); k = idx >> ltile; } else { k = idx % N; s = idx / N; }
         if (s >= ns) continue;
-        const unsigned q = k / A;
-        V v = buf[(size_t)s * FS + (k % A) * RS + (q % B) * C + q / B] * (V){sc, cj * sc};
+        V v = buf[(size_t)s * FS + L::of_output(k)] * (V){sc, cj * sc};
         if (a.mul) {  // fused spectrum product (uniform branch)
             const size_t mi = (size_t)k * a.mul_ks + (s0 + s);
             if (a.mul_real) {
@@ -136,13 +143,16 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_c2r_reg(C2
     constexpr unsigned A = A_, B = B_, C = C_, BC = B * C, M = A * BC, CN = 2 * M;
     constexpr int LA = ct_log2_ceil(A), LB = ct_log2_ceil(B);
     constexpr bool P2 = ct_is_pow2(M);
-    constexpr unsigned RS = BC + 1, FS = (A * RS) | 1u;
+    typedef RrLayout<sizeof(V), A_, B_, C_> L;
+    constexpr unsigned RS = L::RS, FS = L::FS;
     constexpr unsigned SXS = (M + 1) | 1u;  // row stride of the staged half spectrum (odd)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned tid = threadIdx.x, tile = 1u << ltile;
     V *sx = (V *)smem;                    // [tile][SXS] bins 0 .. M
     V *buf = sx + (size_t)tile * SXS;     // [tile][FS]
-    const unsigned t = blockIdx.x % a.tiles, b = blockIdx.x / a.tiles;
+    const unsigned lb = xcd_logical_block(a.tiles * a.batch);
+    if (lb >= a.tiles * a.batch) return;
+    const unsigned t = lb % a.tiles, b = lb / a.tiles;
     const unsigned r0 = t * tile;
     const unsigned nr = min(tile, a.nrows - r0);
     const V *in = (const V *)a.in + (size_t)b * a.in_img;
@@ -189,42 +199,45 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_c2r_reg(C2
         V pw2[LA];
 #pragma unroll
         for (int j = 0; j < LA; ++j) pw2[j] = tw[wrap((2u << j) * r)];  // W_m^e = W_CN^(2e)
-        V *dst = buf + (size_t)rr * FS + r;
-        dst[0] = v[0];
+        V *dst = buf + (size_t)rr * FS;
+        const unsigned pp = L::hi_part(r / C) ^ (r % C);
+        dst[pp ^ L::k1_mask(0)] = v[0];
 #pragma unroll
-        for (unsigned k1 = 1; k1 < A; ++k1) dst[k1 * RS] = inreg::cmulv(v[k1], rr_twiddle<LA>(pw2, k1));
+        for (unsigned k1 = 1; k1 < A; ++k1) dst[k1 * RS + (pp ^ L::k1_mask(k1))] = inreg::cmulv(v[k1], rr_twiddle<LA>(pw2, k1));
     }
     __syncthreads();
     for (unsigned idx = tid; idx < nr * A * C; idx += 256) {
         const unsigned rr = idx / (A * C), q = idx % (A * C), k1 = q / C, n3 = q % C;
-        V *row = buf + (size_t)rr * FS + k1 * RS + n3;
+        V *row = buf + (size_t)rr * FS + k1 * RS;
+        const unsigned lp = n3 ^ L::k1_mask(k1);
         V x[B];
 #pragma unroll
-        for (unsigned n2 = 0; n2 < B; ++n2) x[n2] = row[n2 * C];
+        for (unsigned n2 = 0; n2 < B; ++n2) x[n2] = row[lp ^ L::hi_part(n2)];
         inreg::MixFft<B, V>::run(x);
-        row[0] = x[0];
+        row[lp ^ L::hi_part(0)] = x[0];
         if constexpr (C > 1) {
             V q2[LB];
 #pragma unroll
             for (int j = 0; j < LB; ++j) q2[j] = tw[wrap((2u * A << j) * n3)];
 #pragma unroll
-            for (unsigned k2 = 1; k2 < B; ++k2) row[k2 * C] = inreg::cmulv(x[k2], rr_twiddle<LB>(q2, k2));
+            for (unsigned k2 = 1; k2 < B; ++k2) row[lp ^ L::hi_part(k2)] = inreg::cmulv(x[k2], rr_twiddle<LB>(q2, k2));
         } else {
 #pragma unroll
-            for (unsigned k2 = 1; k2 < B; ++k2) row[k2] = x[k2];
+            for (unsigned k2 = 1; k2 < B; ++k2) row[lp ^ L::hi_part(k2)] = x[k2];
         }
     }
     __syncthreads();
     if constexpr (C > 1) {
         for (unsigned idx = tid; idx < nr * A * B; idx += 256) {
             const unsigned rr = idx / (A * B), q = idx % (A * B), k1 = q / B, k2 = q % B;
-            V *row = buf + (size_t)rr * FS + k1 * RS + k2 * C;
+            V *row = buf + (size_t)rr * FS + k1 * RS;
+            const unsigned lp = L::hi_part(k2) ^ L::k1_mask(k1);
             V x[C];
 #pragma unroll
-            for (unsigned n3 = 0; n3 < C; ++n3) x[n3] = row[n3];
+            for (unsigned n3 = 0; n3 < C; ++n3) x[n3] = row[lp ^ n3];
             inreg::MixFft<C, V>::run(x);
 #pragma unroll
-            for (unsigned k3 = 0; k3 < C; ++k3) row[k3] = x[k3];
+            for (unsigned k3 = 0; k3 < C; ++k3) row[lp ^ k3] = x[k3];
         }
         __syncthreads();
     }
@@ -233,8 +246,7 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_c2r_reg(C2
     const V *win = (const V *)a.win;
     for (unsigned idx = tid; idx < nr * M; idx += 256) {
         const unsigned n = idx % M, rr = idx / M;
-        const unsigned q = n / A;
-        V v = buf[(size_t)rr * FS + (n % A) * RS + (q % B) * C + q / B] * (V){sc, -sc};
+        V v = buf[(size_t)rr * FS + L::of_output(n)] * (V){sc, -sc};
         if (win) v = v * win[n];
         *(V *)(out + (size_t)(r0 + rr) * CN + 2u * n) = v;
     }
@@ -246,7 +258,7 @@ hipError_t launch_c2c_t(const C2cArgs &a, unsigned ltile, size_t lds, hipStream_
         hipError_t e = set_max_dynamic_lds((const void *)k_c2c_reg<T, A, B, C>, (int)kR2Budget);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_c2c_reg<T, A, B, C>), dim3(a.tiles * a.batch), dim3(256), lds, s, a, ltile);
+    hipLaunchKernelGGL((k_c2c_reg<T, A, B, C>), dim3(xcd_grid((unsigned long long)a.tiles * a.batch)), dim3(256), lds, s, a, ltile);
     return hipGetLastError();
 }
 
@@ -256,7 +268,7 @@ hipError_t launch_c2r_t(const C2rArgs &a, unsigned ltile, size_t lds, hipStream_
         hipError_t e = set_max_dynamic_lds((const void *)k_c2r_reg<T, A, B, C>, (int)kR2Budget);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_c2r_reg<T, A, B, C>), dim3(a.tiles * a.batch), dim3(256), lds, s, a, ltile);
+    hipLaunchKernelGGL((k_c2r_reg<T, A, B, C>), dim3(xcd_grid((unsigned long long)a.tiles * a.batch)), dim3(256), lds, s, a, ltile);
     return hipGetLastError();
 }
 
@@ -270,7 +282,7 @@ hipError_t launch_c2c_reg(const C2cArgs &a0, int dtype, hipStream_t s) {
     if (kRegOff || !reg_split_len(a0.n, dtype, &fa, &fb, &fc)) return hipErrorNotSupported;
     const size_t es = elem_size(dtype);
     if (((size_t)a0.in | (size_t)a0.out) & (2 * es - 1)) return hipErrorNotSupported;
-    const size_t fs = ((size_t)fa * (fb * fc + 1)) | 1;
+    const size_t fs = rr_frame_stride(fa, rr_swizzle(2 * (unsigned)es, fa, fb, fc).rs);
     unsigned ltile = 5;  // up to 32 sequences per workgroup; no more than the job has
     while (ltile > 0 && ((size_t)(1u << ltile) * fs * 2 * es > kR2Budget || (1u << (ltile - 1)) >= a0.nseq)) --ltile;
     const size_t lds = (size_t)(1u << ltile) * fs * 2 * es;
@@ -300,7 +312,7 @@ hipError_t launch_c2r_reg(const C2rArgs &a0, int dtype, hipStream_t s) {
     const size_t es = elem_size(dtype);
     if (((size_t)a0.in | (size_t)a0.out | (size_t)a0.win) & (2 * es - 1)) return hipErrorNotSupported;
     const size_t m = a0.ncols / 2;
-    const size_t per = ((((size_t)fa * (fb * fc + 1)) | 1) + ((m + 1) | 1)) * 2 * es;
+    const size_t per = ((size_t)rr_frame_stride(fa, rr_swizzle(2 * (unsigned)es, fa, fb, fc).rs) + ((m + 1) | 1)) * 2 * es;
     unsigned ltile = 5;
     while (ltile > 0 && ((size_t)(1u << ltile) * per > kR2Budget || (1u << (ltile - 1)) >= a0.nrows)) --ltile;
     const size_t lds = (size_t)(1u << ltile) * per;

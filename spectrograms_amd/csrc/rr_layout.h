@@ -109,9 +109,17 @@ constexpr RrSwz rr_swizzle(unsigned elem_bytes, unsigned A, unsigned B, unsigned
     return RrSwz{B * C + 1, 0, 0, 0};
 }
 
+// The layout of one kernel instance.  index = k1 RS + (k1_mask(k1) ^ hi_part(hi) ^ lo): in each pass two of the three terms are
+// lane values built once per work item and the third is a compile-time constant of the unrolled loop.
 template <unsigned ElemBytes, int A, int B, int C>
 struct RrLayout {
     static constexpr RrSwz Z = rr_swizzle(ElemBytes, A, B, C);
+    static constexpr unsigned RS = Z.rs;                    // row stride (complex elements)
+    static constexpr unsigned FS = rr_frame_stride(A, RS);  // frame / sequence stride
+    static constexpr unsigned k1_mask(unsigned k1) { return (rr_hx(Z, B, k1) * C) | ((k1 * Z.ml) & (C - 1)); }  // the row's share of the swizzle
+    static constexpr unsigned hi_part(unsigned hi) { return (hi * C) | ((hi >> Z.sh) & (C - 1)); }
+    // element k = k1 + A (hi + B lo) of the finished transform
+    static constexpr unsigned of_output(unsigned k) { return (k % A) * RS + (k1_mask(k % A) ^ hi_part((k / A) % B) ^ (k / (A * B))); }
 };
 
 }  // namespace sgx
