@@ -249,7 +249,10 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_reg_radix(
     V *buf = (V *)smem;                          // [ft][FS]
     V *stw = buf + (size_t)a.ft * FS;            // [M/2 + 1] split twiddles W_n^k
     V *sw = stw + (M / 2 + 1);                   // [M] window pairs (w[2i], w[2i+1])
-    // [ft][pws] (Mel only, 32-byte aligned for the 4-element row reads), then the bank: padded band table or CSR arrays
+    // [sub][pws] (Mel only, 32-byte aligned for the 4-element row reads), then the bank: padded band table or CSR arrays.
+    // sub = a.mel_sub frames: the tile's |X|^2 rows are produced and reduced `sub` frames at a time, so that they do not
+    // limit the frames per tile (f32 n_fft 400 / Mel: 32 frames per tile instead of 16 — every thread has a pass-1 item)
+    const unsigned sub = a.mel_sub ? a.mel_sub : a.ft;
     T *pw = (T *)(smem + ((((size_t)a.ft * FS + M / 2 + 1 + M) * sizeof(V) + 31) & ~size_t(31)));
     const unsigned pws = 4u * (((a.nb_fft + 3u) >> 2) | 1u);  // row stride: 4-element groups, an odd number of them
     const V *tw = (const V *)a.tw;
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_reg_radix(
     const V4 *bw = nullptr;            // band table: 4 weights per group; row mm = groups [bptr[mm], bptr[mm+1]) from column bcol[mm]
     const unsigned *bptr = nullptr, *bcol = nullptr;
     if (a.out_mode == OUT_MEL) {
-        unsigned char *bank = (unsigned char *)(pw + (size_t)a.ft * pws);
+        unsigned char *bank = (unsigned char *)(pw + (size_t)sub * pws);
         if (band_lds) {  // uniform: rows are runs of consecutive columns and the padded table fits
             V4 *lw = (V4 *)bank;
             unsigned *lp = (unsigned *)(lw + a.mel_pchunks), *lc = lp + a.n_mels + 1;
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_reg_radix(
             for (unsigned i = tid; i <= a.n_mels; i += 256) lp[i] = a.mel_pptr[i];
             for (unsigned i = tid; i < a.n_mels; i += 256) lc[i] = a.mel_pcol[i];
             // columns nb_fft .. pws-1 of every row meet zero weights only, but must hold finite values
-            for (unsigned i = tid; i < a.ft * (pws - a.nb_fft); i += 256)
+            for (unsigned i = tid; i < sub * (pws - a.nb_fft); i += 256)
                 pw[(size_t)(i / (pws - a.nb_fft)) * pws + a.nb_fft + i % (pws - a.nb_fft)] = T(0);
             bw = lw; bptr = lp; bcol = lc;
         } else {
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_reg_radix(
             if constexpr (C > 1) asm volatile("" : "+v"(pp));  // the A swizzled addresses are rebuilt here (one XOR each), not kept across the loop
             dst[pp ^ k1_mask(0)] = v[0];
 #pragma unroll
-            for (unsigned k1 = 1; k1 < A; ++k1) dst[k1 * RS + (pp ^ k1_mask(k1))] = inreg::cmulv(v[k1], rr_twiddle<LA>(pw2, k1));
+            for (unsigned k1 = 1; k1 < A; ++k1) (dst + (pp ^ k1_mask(k1)))[k1 * RS] = inreg::cmulv(v[k1], rr_twiddle<LA>(pw2, k1));  // k1 RS: an immediate offset
         }
         if (t_next < total_tiles) load_raw(t_next, raw);  // in flight behind passes 2 and 3
         __syncthreads();
@@ -447,13 +450,13 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_reg_radix(
             // Packed arithmetic on the pre-halved spectrum (window x 1/2 above): E = Z[k] + conj Z[m-k], D = (z.x - y.x, z.y + y.y),
             // T = W (-i D) = D.y W + D.x (W.y, -W.x);  X[k] = E + T, X[m-k] = conj(E - T).  The output mode and the amplitude
             // scale are uniform: they pick one of five specialised loops instead of being tested per bin.
-            const unsigned f = tl & (a.ft - 1), kstep = 256u >> lft;  // a thread keeps its frame and walks the bins
-            const V *fb = buf + (size_t)f * FS;
-            auto split_all = [&](auto &&put) {  // put(k, X): X[k] of frame f
+            // a thread keeps its frame f and walks the bins k0, k0 + kstep, ...
+            auto split_frame = [&](unsigned f, unsigned k0, unsigned kstep, auto &&put) {  // put(k, X): X[k] of frame f
                 if (f >= nf) return;
-                for (unsigned k = tl >> lft; k <= M / 2; k += kstep) {
+                const V *fb = buf + (size_t)f * FS;
+                for (unsigned k = k0; k <= M / 2; k += kstep) {
                     if (k == 0) {  // DC and Nyquist bins: exactly real
-                        const V z = fb[0];
+                        const V z = fb[L::of_output(0)];
                         put(0u, (V){(z.x + z.y) * T(2), T(0)});
                         put(M, (V){(z.x - z.y) * T(2), T(0)});
                         continue;
@@ -467,53 +470,53 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_reg_radix(
                     if (k != M - k) put(M - k, (V){Y.x, -Y.y});
                 }
             };
-            const size_t ob = ((size_t)b * a.n_out) * a.n_frames + f0 + f;
-            if (a.out_mode == OUT_MEL) {
-                T *pf = pw + (size_t)f * pws;
-                if (a.amp == AMP_MAG_IN) split_all([&](unsigned k, V X) { pf[k] = t_sqrt(X.x * X.x + X.y * X.y); });
-                else split_all([&](unsigned k, V X) { pf[k] = X.x * X.x + X.y * X.y; });
-            } else if (a.out_mode == OUT_COMPLEX) {
-                V *o = (V *)a.out + ob;
-                split_all([&](unsigned k, V X) { o[(size_t)k * a.n_frames] = X; });
-            } else {
-                T *o = (T *)a.out + ob;
-                if (a.amp == AMP_MAGNITUDE) split_all([&](unsigned k, V X) { o[(size_t)k * a.n_frames] = t_sqrt(X.x * X.x + X.y * X.y); });
-                else if (a.amp == AMP_DB) split_all([&](unsigned k, V X) { o[(size_t)k * a.n_frames] = T(10) * t_log10(t_max(X.x * X.x + X.y * X.y, eps)); });
-                else
-#ifdef SGX_ABL_NOSTORE
-                    split_all([&](unsigned k, V X) { if (X.x == T(1.2345e300)) o[(size_t)k * a.n_frames] = X.x * X.x + X.y * X.y; });
-#else
-                    split_all([&](unsigned k, V X) { o[(size_t)k * a.n_frames] = X.x * X.x + X.y * X.y; });
-#endif
-            }
-        }
-        if (a.out_mode == OUT_MEL) {
-            __syncthreads();
-            // bank rows: thread = (frame, row) with the frame fastest; sequential un-fused accumulation in ascending column
-            // order (:102-117).  Rows that are one run of consecutive columns need no column look-up per term, so the LDS
-            // reads of a row are independent of each other and pipeline.
-            const unsigned f = tid & (a.ft - 1), mstep = 256u >> lft;
-            T *o = (T *)a.out + ((size_t)b * a.n_out) * a.n_frames + f0 + f;
-            const T *pf = pw + (size_t)f * pws;
-            if (f < nf)
-                for (unsigned mm = tid >> lft; mm < a.n_mels; mm += mstep) {
-                    T acc = T(0);
-                    if (bw) {  // 4 columns per step: one vector read of the weights, one of the row (zero weights pad the run)
-                        const unsigned c0 = bptr[mm], c1 = bptr[mm + 1];
-                        const V4 *xq = (const V4 *)(pf + bcol[mm]) - c0;
-                        for (unsigned c = c0; c < c1; ++c) {
-                            const V4 wq = bw[c], x = xq[c];
-                            acc = t_mul_add_unfused(wq.x, x.x, acc);
-                            acc = t_mul_add_unfused(wq.y, x.y, acc);
-                            acc = t_mul_add_unfused(wq.z, x.z, acc);
-                            acc = t_mul_add_unfused(wq.w, x.w, acc);
-                        }
-                    } else {
-                        const unsigned i0 = csr.ptr[mm], i1 = csr.ptr[mm + 1];
-                        for (unsigned i = i0; i < i1; ++i) acc = t_mul_add_unfused(csr.val[i], pf[csr.col[i]], acc);
-                    }
-                    o[(size_t)mm * a.n_frames] = amp_apply(acc, a.amp, eps);
+            if (a.out_mode != OUT_MEL) {
+                const unsigned f = tl & (a.ft - 1), k0 = tl >> lft, kstep = 256u >> lft;
+                const size_t ob = ((size_t)b * a.n_out) * a.n_frames + f0 + f;
+                if (a.out_mode == OUT_COMPLEX) {
+                    V *o = (V *)a.out + ob;
+                    split_frame(f, k0, kstep, [&](unsigned k, V X) { o[(size_t)k * a.n_frames] = X; });
+                } else {
+                    T *o = (T *)a.out + ob;
+                    if (a.amp == AMP_MAGNITUDE) split_frame(f, k0, kstep, [&](unsigned k, V X) { o[(size_t)k * a.n_frames] = t_sqrt(X.x * X.x + X.y * X.y); });
+                    else if (a.amp == AMP_DB) split_frame(f, k0, kstep, [&](unsigned k, V X) { o[(size_t)k * a.n_frames] = T(10) * t_log10(t_max(X.x * X.x + X.y * X.y, eps)); });
+                    else split_frame(f, k0, kstep, [&](unsigned k, V X) { o[(size_t)k * a.n_frames] = X.x * X.x + X.y * X.y; });
                 }
+            } else {
+                // filterbank outputs, `sub` frames at a time: |X|^2 (or |X|) rows to LDS, then the bank rows: thread = (frame, row)
+                // with the frame fastest; sequential un-fused accumulation in ascending column order (:102-117).  Rows that are
+                // one run of consecutive columns need no column look-up per term, so the LDS reads of a row are independent of
+                // each other and pipeline.
+                const unsigned lsub = __ffs(sub) - 1u, fl = tl & (sub - 1), q0 = tl >> lsub, qstep = 256u >> lsub;
+                T *pf = pw + (size_t)fl * pws;
+                for (unsigned part = 0; part < nf; part += sub) {
+                    const unsigned f = part + fl;
+                    if (a.amp == AMP_MAG_IN) split_frame(f, q0, qstep, [&](unsigned k, V X) { pf[k] = t_sqrt(X.x * X.x + X.y * X.y); });
+                    else split_frame(f, q0, qstep, [&](unsigned k, V X) { pf[k] = X.x * X.x + X.y * X.y; });
+                    __syncthreads();
+                    T *o = (T *)a.out + ((size_t)b * a.n_out) * a.n_frames + f0 + f;
+                    if (f < nf)
+                        for (unsigned mm = q0; mm < a.n_mels; mm += qstep) {
+                            T acc = T(0);
+                            if (bw) {  // 4 columns per step: one vector read of the weights, one of the row (zero weights pad the run)
+                                const unsigned c0 = bptr[mm], c1 = bptr[mm + 1];
+                                const V4 *xq = (const V4 *)(pf + bcol[mm]) - c0;
+                                for (unsigned c = c0; c < c1; ++c) {
+                                    const V4 wq = bw[c], x = xq[c];
+                                    acc = t_mul_add_unfused(wq.x, x.x, acc);
+                                    acc = t_mul_add_unfused(wq.y, x.y, acc);
+                                    acc = t_mul_add_unfused(wq.z, x.z, acc);
+                                    acc = t_mul_add_unfused(wq.w, x.w, acc);
+                                }
+                            } else {
+                                const unsigned i0 = csr.ptr[mm], i1 = csr.ptr[mm + 1];
+                                for (unsigned i = i0; i < i1; ++i) acc = t_mul_add_unfused(csr.val[i], pf[csr.col[i]], acc);
+                            }
+                            o[(size_t)mm * a.n_frames] = amp_apply(acc, a.amp, eps);
+                        }
+                    if (part + sub < nf) __syncthreads();  // the rows are rewritten by the next part
+                }
+            }
         }
         __syncthreads();  // the tile buffer (and pw) is free for the next tile
     }
@@ -805,12 +808,12 @@ static size_t reg_radix_csr_bytes(const StftArgs &a, size_t es) {
 }
 
 // LDS bytes of a tile of ft frames with its tables (without the bank)
-static size_t reg_radix_bytes(const StftArgs &a, unsigned ft, unsigned fa, unsigned fb, unsigned fc, size_t es) {
+static size_t reg_radix_bytes(const StftArgs &a, unsigned ft, unsigned sub, unsigned fa, unsigned fb, unsigned fc, size_t es) {
     const size_t fs = rr_frame_stride(fa, rr_swizzle(2 * (unsigned)es, fa, fb, fc).rs);
     const size_t m = (size_t)fa * fb * fc;
     const size_t pws = 4 * ((((size_t)a.nb_fft + 3) >> 2) | 1);
     size_t bytes = (ft * fs + m / 2 + 1 + m) * 2 * es;
-    if (a.out_mode == OUT_MEL) bytes = ((bytes + 31) & ~size_t(31)) + (size_t)ft * pws * es;
+    if (a.out_mode == OUT_MEL) bytes = ((bytes + 31) & ~size_t(31)) + (size_t)sub * pws * es;
     return (bytes + 15) & ~size_t(15);
 }
 
@@ -836,13 +839,17 @@ bool plan_geometry_reg_radix(StftArgs &a, int dtype) {
     // instances that run one workgroup per CU anyway (rr_waves == 1: f64 with a 16-point or longer pass) may use most of its LDS
     const size_t base = a.out_mode == OUT_MEL ? kRegBudget : kRegBudgetBins;
     const size_t budget = (dtype == SGX_F64 && fa >= 16) ? std::max(base, kRegHardLimit - 16 * 1024) : base;
+    // filterbank outputs: the |X|^2 rows may be produced in up to 4 parts of ft / parts frames (two barriers per part) when
+    // that buys a larger tile
     for (unsigned ft = reg_radix_ft_max(fb * fc); ft >= 1; ft >>= 1)
-        if (reg_radix_bytes(a, ft, fa, fb, fc, es) <= budget) {
-            a.ft = ft;
-            return true;
-        }
-    a.ft = 1;
-    return reg_radix_bytes(a, 1, fa, fb, fc, es) <= kRegHardLimit;
+        for (unsigned parts = 1; parts <= (a.out_mode == OUT_MEL ? 4u : 1u) && ft / parts >= std::min(ft, 4u); parts *= 2)
+            if (reg_radix_bytes(a, ft, ft / parts, fa, fb, fc, es) <= budget) {
+                a.ft = ft;
+                a.mel_sub = ft / parts;
+                return true;
+            }
+    a.ft = a.mel_sub = 1;
+    return reg_radix_bytes(a, 1, 1, fa, fb, fc, es) <= kRegHardLimit;
 }
 
 template <typename T, int A, int B, int C>
@@ -882,7 +889,9 @@ hipError_t launch_reg_radix(const StftArgs &a, int dtype, hipStream_t s) {
     if (!grid_ok(a, &g) || !reg_radix_split(a, dtype, &fa, &fb, &fc) || (a.ft & (a.ft - 1))) return hipErrorInvalidConfiguration;
     if (a.ft > reg_radix_ft_max(fb * fc)) return hipErrorInvalidConfiguration;
     const size_t es = elem_size(dtype);
-    size_t lds = reg_radix_bytes(a, a.ft, fa, fb, fc, es);
+    const unsigned sub = a.mel_sub ? a.mel_sub : a.ft;
+    if (sub > a.ft || (sub & (sub - 1))) return hipErrorInvalidConfiguration;
+    size_t lds = reg_radix_bytes(a, a.ft, sub, fa, fb, fc, es);
     if (lds > kRegHardLimit) return hipErrorInvalidConfiguration;
     // the bank stays in LDS for the life of the workgroup when it fits beside the tile: the padded band table if the rows
     // are runs of consecutive columns, else the CSR arrays (else CSR from global memory)

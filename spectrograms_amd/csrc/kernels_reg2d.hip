@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_c2c_reg(C2
         const unsigned pp = L::hi_part(r / C) ^ (r % C);
         dst[pp ^ L::k1_mask(0)] = v[0];
 #pragma unroll
-        for (unsigned k1 = 1; k1 < A; ++k1) dst[k1 * RS + (pp ^ L::k1_mask(k1))] = inreg::cmulv(v[k1], rr_twiddle<LA>(pw2, k1));
+        for (unsigned k1 = 1; k1 < A; ++k1) (dst + (pp ^ L::k1_mask(k1)))[k1 * RS] = inreg::cmulv(v[k1], rr_twiddle<LA>(pw2, k1));
     }
     __syncthreads();
     for (unsigned idx = tid; idx < ns * A * C; idx += 256) {
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_c2r_reg(C2
         const unsigned pp = L::hi_part(r / C) ^ (r % C);
         dst[pp ^ L::k1_mask(0)] = v[0];
 #pragma unroll
-        for (unsigned k1 = 1; k1 < A; ++k1) dst[k1 * RS + (pp ^ L::k1_mask(k1))] = inreg::cmulv(v[k1], rr_twiddle<LA>(pw2, k1));
+        for (unsigned k1 = 1; k1 < A; ++k1) (dst + (pp ^ L::k1_mask(k1)))[k1 * RS] = inreg::cmulv(v[k1], rr_twiddle<LA>(pw2, k1));
     }
     __syncthreads();
     for (unsigned idx = tid; idx < nr * A * C; idx += 256) {

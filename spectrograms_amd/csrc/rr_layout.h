@@ -113,13 +113,18 @@ constexpr RrSwz rr_swizzle(unsigned elem_bytes, unsigned A, unsigned B, unsigned
 // lane values built once per work item and the third is a compile-time constant of the unrolled loop.
 template <unsigned ElemBytes, int A, int B, int C>
 struct RrLayout {
-    static constexpr RrSwz Z = rr_swizzle(ElemBytes, A, B, C);
-    static constexpr unsigned RS = Z.rs;                    // row stride (complex elements)
-    static constexpr unsigned FS = rr_frame_stride(A, RS);  // frame / sequence stride
-    static constexpr unsigned k1_mask(unsigned k1) { return (rr_hx(Z, B, k1) * C) | ((k1 * Z.ml) & (C - 1)); }  // the row's share of the swizzle
-    static constexpr unsigned hi_part(unsigned hi) { return (hi * C) | ((hi >> Z.sh) & (C - 1)); }
+    // scalars, read by value: a struct member passed by reference would be an odr-use, and device code then loads the
+    // parameters from memory at run time instead of folding them
+    static constexpr unsigned RS = rr_swizzle(ElemBytes, A, B, C).rs;  // row stride (complex elements)
+    static constexpr unsigned MH = rr_swizzle(ElemBytes, A, B, C).mh, SH = rr_swizzle(ElemBytes, A, B, C).sh, ML = rr_swizzle(ElemBytes, A, B, C).ml;
+    static constexpr unsigned FS = rr_frame_stride(A, RS);             // frame / sequence stride
+    static constexpr unsigned k1_mask(unsigned k1) { return (((k1 * MH) & (B - 1)) * C) | ((k1 * ML) & (C - 1)); }  // the row's share of the swizzle
+    static constexpr unsigned hi_part(unsigned hi) { return (hi * C) | ((hi >> SH) & (C - 1)); }
     // element k = k1 + A (hi + B lo) of the finished transform
-    static constexpr unsigned of_output(unsigned k) { return (k % A) * RS + (k1_mask(k % A) ^ hi_part((k / A) % B) ^ (k / (A * B))); }
+    static constexpr unsigned of_output(unsigned k) {
+        if (C <= 1) return (k % A) * RS + k / A;  // two passes: plain rows
+        return (k % A) * RS + (k1_mask(k % A) ^ hi_part((k / A) % B) ^ (k / (A * B)));
+    }
 };
 
 }  // namespace sgx

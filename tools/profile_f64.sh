@@ -6,7 +6,7 @@ OUT=$ROOT/gpurun_out/f64prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export SGX_PROF_NFFT=${SGX_PROF_NFFT:-1024} SGX_PROF_HOP=${SGX_PROF_HOP:-256} SGX_PROF_DTYPE=${SGX_PROF_DTYPE:-float64}
-DRV="python3 $ROOT/tools/prof_driver.py linear_power 4"
+DRV="python3 $ROOT/tools/prof_driver.py ${SGX_PROF_WORKLOAD:-linear_power} 4"
 pmc() { name=$1; shift; timeout 120 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- $DRV > $OUT/$name.log 2>&1; }
 pmc sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE &&
 pmc sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT &&

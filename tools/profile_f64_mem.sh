@@ -6,7 +6,7 @@ OUT=$ROOT/gpurun_out/f64mem
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export SGX_PROF_NFFT=${SGX_PROF_NFFT:-1024} SGX_PROF_HOP=${SGX_PROF_HOP:-256} SGX_PROF_DTYPE=${SGX_PROF_DTYPE:-float64}
-DRV="python3 $ROOT/tools/prof_driver.py linear_power 4"
+DRV="python3 $ROOT/tools/prof_driver.py ${SGX_PROF_WORKLOAD:-linear_power} 4"
 pmc() { name=$1; shift; timeout 120 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- $DRV > $OUT/$name.log 2>&1; }
 pmc fetch FETCH_SIZE && pmc write WRITE_SIZE && pmc tcc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum TCC_MISS_sum
 python3 - <<PY
