@@ -307,6 +307,11 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_reg_radix(
     // the parity of hop and padding; frames past the end of a signal's last tile load (zeros or the row's tail) and are ignored.
     constexpr int kPair = 2 * BC * (int)sizeof(T);  // bytes from point n1 to point n1 + 1
     auto load_raw = [&](unsigned t, V (&raw)[NI][A]) {
+#ifdef SGX_ABL_NOGLOAD
+        for (unsigned j = 0; j < NI; ++j)
+            for (unsigned n1 = 0; n1 < A; ++n1) raw[j][n1] = (V){T(t), T(n1)};
+        return;
+#endif
         const unsigned tile = t % a.tiles, b = t / a.tiles;
         const unsigned f0 = tile * a.ft;
         const __amdgpu_buffer_rsrc_t rx = make_rsrc((const T *)a.x + (size_t)b * a.sample_stride, (unsigned)a.n_samples * (unsigned)sizeof(T));
@@ -454,18 +459,17 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_reg_radix(
             auto split_frame = [&](unsigned f, unsigned k0, unsigned kstep, auto &&put) {  // put(k, X): X[k] of frame f
                 if (f >= nf) return;
                 const V *fb = buf + (size_t)f * FS;
+                // k = 0 takes the same path with Z[m] := Z[0]: E = (2 z.x, 0), D = (0, 2 z.y), W^0 = (1, 0) give X[0] = (2 (z.x + z.y), 0)
+                // and X[m] = (2 (z.x - z.y), 0) with the same roundings as the closed form (the DC and Nyquist bins, exactly real);
+                // two bins per trip so that the LDS reads of one overlap the arithmetic of the other
+#pragma unroll 2
                 for (unsigned k = k0; k <= M / 2; k += kstep) {
-                    if (k == 0) {  // DC and Nyquist bins: exactly real
-                        const V z = fb[L::of_output(0)];
-                        put(0u, (V){(z.x + z.y) * T(2), T(0)});
-                        put(M, (V){(z.x - z.y) * T(2), T(0)});
-                        continue;
-                    }
-                    const V z = at(fb, k), y = at(fb, M - k), w = stw[k];
+                    const V z = at(fb, k), y = at(fb, k ? M - k : 0u), w = stw[k];
                     const V E = inreg::pfma(y, (V){T(1), T(-1)}, z);
                     const V D = inreg::pfma(y, (V){T(-1), T(1)}, z);
                     const V Tt = inreg::pfma(inreg::hi2(D), w, inreg::lo2(D) * (V){w.y, -w.x});
-                    const V X = E + Tt, Y = E - Tt;
+                    V X = E + Tt, Y = E - Tt;
+                    if (k == 0) X.y = Y.y = T(0);  // (+0, not the -0 the general path can leave)
                     put(k, X);
                     if (k != M - k) put(M - k, (V){Y.x, -Y.y});
                 }
@@ -480,7 +484,12 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_reg_radix(
                     T *o = (T *)a.out + ob;
                     if (a.amp == AMP_MAGNITUDE) split_frame(f, k0, kstep, [&](unsigned k, V X) { o[(size_t)k * a.n_frames] = t_sqrt(X.x * X.x + X.y * X.y); });
                     else if (a.amp == AMP_DB) split_frame(f, k0, kstep, [&](unsigned k, V X) { o[(size_t)k * a.n_frames] = T(10) * t_log10(t_max(X.x * X.x + X.y * X.y, eps)); });
-                    else split_frame(f, k0, kstep, [&](unsigned k, V X) { o[(size_t)k * a.n_frames] = X.x * X.x + X.y * X.y; });
+                    else
+#ifdef SGX_ABL_NOSTORE
+                        split_frame(f, k0, kstep, [&](unsigned k, V X) { if (X.x == T(1.2345e30)) o[(size_t)k * a.n_frames] = X.x * X.x + X.y * X.y; });
+#else
+                        split_frame(f, k0, kstep, [&](unsigned k, V X) { o[(size_t)k * a.n_frames] = X.x * X.x + X.y * X.y; });
+#endif
                 }
             } else {
                 // filterbank outputs, `sub` frames at a time: |X|^2 (or |X|) rows to LDS, then the bank rows: thread = (frame, row)

@@ -394,7 +394,8 @@ def test_linearity_full_size(cfg2_x):
     assert np.max(np.abs(Sab - ref)) <= GUARD32 * np.max(np.abs(ref))
 
 
-@pytest.mark.parametrize("n_fft,hop,dtype", [(400, 160, "float32"), (512, 128, "float32"), (400, 160, "float64"), (2048, 512, "float32")])
+@pytest.mark.parametrize("n_fft,hop,dtype", [(400, 160, "float32"), (512, 128, "float32"), (400, 160, "float64"), (2048, 512, "float32"),
+                                             (1024, 256, "float64")])
 def test_full_size_register_tiled_kernel(cfg2_x, n_fft, hop, dtype):
     """256 x 10 s through the persistent register-tiled kernel (more tiles than resident workgroups): whole-output parity with
     the CPU restatement in the same precision, plus Parseval per frame."""
@@ -413,6 +414,22 @@ def test_full_size_register_tiled_kernel(cfg2_x, n_fft, hop, dtype):
         lhs = 2.0 * got[b].astype(np.float64).sum(axis=0) - got[b, 0] - got[b, n_fft // 2]
         rhs = float(n_fft) * (fr ** 2).sum(axis=1)
         assert np.max(np.abs(lhs - rhs)) <= (1e-4 if dtype == "float32" else 1e-10) * rhs.max()
+
+
+@pytest.mark.parametrize("n_fft,hop,dtype,batch", [(400, 160, "float32", 37), (1024, 256, "float64", 19), (512, 128, "float64", 23)])
+def test_register_tiled_mel_in_parts_ragged_rounds(cfg2_x, n_fft, hop, dtype, batch):
+    """Filterbank outputs of the register-tiled kernel: the |X|^2 rows of a tile are produced in parts (f32 n_fft 400: 32-frame
+    tiles, two parts), and a batch whose tile count is not a multiple of the grid ends in a partial round of the XCD-ordered
+    tile walk.  Whole-output parity with the CPU restatement, and every utterance equals its own single-utterance launch."""
+    plan, op = make(n_fft, hop, dtype=dtype, n_mels=80, fmin=0.0, fmax=8000.0, amp="db", floor=-80.0)
+    x = cfg2_x[:batch] if dtype == "float32" else cfg2_x[:batch].astype(np.float64)
+    got = plan.compute_batch(x)
+    assert plan.kernel_name == "reg_radix"
+    ref = orc.spectrogram_batch(op, x.astype(np.float64), nthreads=orc.max_threads())
+    pop = orc.Params(**{**op.__dict__, "amp": "power", "floor_db": None, "_keep": []})
+    check(got, ref, "db", dtype, -80.0, orc.spectrogram_batch(pop, x.astype(np.float64), nthreads=orc.max_threads()))
+    for b in (0, batch // 2, batch - 1):
+        assert np.array_equal(plan.compute_batch(x[b:b + 1])[0], got[b])
 
 
 def test_fuzz_shapes():
