@@ -22,6 +22,10 @@
 #include "reg_radix.h"
 #include "rr_layout.h"
 
+#ifndef SGX_RR_LOADPOS
+#define SGX_RR_LOADPOS 1  // staged samples: 0 = the next tile is requested at the top of the tile, 1 = after pass 1
+#endif
+
 namespace sgx {
 
 template <typename T>
@@ -232,8 +236,8 @@ __global__ __launch_bounds__(256) void k_lds_radix2(StftArgs a) {
 // 3-4 barriers per tile instead of log2(m)/2 + 2, and 2-3 LDS round trips per point instead of log2(m)/2 + 1; no
 // in-register transform is longer than 16 points, so f32 stays under 128 VGPRs (4 waves per SIMD).
 // A, B, C: lengths of the in-register passes (products of 2, 3, 5; C = 1: two passes), m = A B C
-template <typename T, int A_, int B_, int C_>
-__global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_reg_radix(StftArgs a, unsigned total_tiles, unsigned csr_lds, unsigned band_lds, unsigned rot) {
+template <typename T, int A_, int B_, int C_, bool STAGED_>
+__global__ __launch_bounds__(256, (rr_stft_waves<T, A_, B_, C_, STAGED_>())) void k_reg_radix(StftArgs a, unsigned total_tiles, unsigned csr_lds, unsigned band_lds, unsigned rot) {
     typedef typename PairOf<T>::type V;
     constexpr unsigned A = A_, B = B_, C = C_, BC = B * C, M = A * BC;
     constexpr unsigned NI = rr_items<B_, C_>();
@@ -295,16 +299,48 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_reg_radix(
     // loop they would sit behind the previous tile's stores (one in-order counter) and wait for all of them.
     constexpr bool Q2_FIXED = C > 1 && 256u % (A * C) == 0;
     // instances short of registers (f64; f32 with 16-point passes in three-pass splits) rebuild the twiddle products per tile
-    constexpr bool TW_OPAQUE = sizeof(T) == 8 || (C > 1 && A >= 16);
+    constexpr bool TW_OPAQUE = true;
     V q2f[LB];
     if constexpr (Q2_FIXED) {
         const unsigned n3 = (tid % (A * C)) % C;
 #pragma unroll
         for (int j = 0; j < LB; ++j) q2f[j] = tw[P2 ? (((2u * A << j) * n3) & (a.n_fft - 1)) : (((2u * A << j) * n3) % a.n_fft)];
     }
-    // raw (unwindowed) samples of one tile's work items -> registers; issued one tile ahead.  Buffer loads: the hardware returns
-    // 0 outside the signal's row (S1: zero padding), so there is one straight-line path whatever the alignment of the row and
-    // the parity of hop and padding; frames past the end of a signal's last tile load (zeros or the row's tail) and are ignored.
+    // Staged samples (the default): the tile's (ft - 1) hop + n_fft samples are loaded once, as 16-byte chunks (chunk c = tid +
+    // 256 i) one tile ahead into registers, written over the (dead) tile buffer at the top of the tile and picked up from there
+    // by the pass-1 items — instead of every frame loading its own copy of the overlapping samples (n_fft / hop loads per
+    // sample, issued after pass 1 and waited for two passes later: measured 40 of 209 us for f32 n_fft 512).  Buffer loads: the
+    // hardware returns 0 outside the signal's row (S1: zero padding).
+    constexpr bool STAGED = STAGED_;
+    constexpr unsigned EPC = 16 / sizeof(T), R_MAX = rr_stage_rounds(M, sizeof(T));  // elements per chunk, chunk rounds per thread
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const unsigned xs_len = (a.ft - 1) * a.hop + a.n_fft, chunks = (xs_len + EPC - 1) / EPC;  // host: chunks <= 256 R_MAX, fits the tile buffer
+    v4u creg[R_MAX];
+    auto load_tile = [&](unsigned t) {
+        const unsigned tile = t % a.tiles, b = t / a.tiles;
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc((const T *)a.x + (size_t)b * a.sample_stride, (unsigned)a.n_samples * (unsigned)sizeof(T));
+        const int lo = (int)(tile * a.ft * a.hop) - (int)a.pad;  // host: n_samples * sizeof(T) < 2^31
+        const bool interior = lo >= 0 && (unsigned long long)lo + (unsigned long long)chunks * EPC <= a.n_samples;  // uniform
+        const int vo = (lo + (int)(EPC * tid)) * (int)sizeof(T);
+#pragma unroll
+        for (unsigned i = 0; i < R_MAX; ++i) {
+#ifdef SGX_ABL_NOGLOAD
+            creg[i] = (v4u){t, i, 0u, 0u};
+            continue;
+#endif
+            if (i * 256u + tid >= chunks) continue;
+            if (interior) {
+                creg[i] = __builtin_bit_cast(v4u, __builtin_amdgcn_raw_buffer_load_b128(rx, vo + (int)(i * 4096u), 0, 0));
+            } else {  // a chunk may straddle an end of the row: one access per sample, each checked on its own (offsets may be negative)
+                T e[EPC];
+#pragma unroll
+                for (unsigned q = 0; q < EPC; ++q) e[q] = BufLd<T>::template one<true>(rx, vo + (int)(i * 4096u + q * sizeof(T)));
+                creg[i] = __builtin_bit_cast(v4u, e);
+            }
+        }
+    };
+    // Direct loads (SGX_RR_STAGED=0, kept for A/B): raw (unwindowed) samples of one tile's work items -> registers, one tile
+    // ahead; frames past the end of a signal's last tile load (zeros or the row's tail) and are ignored.
     constexpr int kPair = 2 * BC * (int)sizeof(T);  // bytes from point n1 to point n1 + 1
     auto load_raw = [&](unsigned t, V (&raw)[NI][A]) {
 #ifdef SGX_ABL_NOGLOAD
@@ -333,10 +369,15 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_reg_radix(
     };
 
     V raw[NI][A];
+    if constexpr (!STAGED) {
 #pragma unroll
-    for (unsigned j = 0; j < NI; ++j)
+        for (unsigned j = 0; j < NI; ++j)
 #pragma unroll
-        for (unsigned n1 = 0; n1 < A; ++n1) raw[j][n1] = (V){T(0), T(0)};
+            for (unsigned n1 = 0; n1 < A; ++n1) raw[j][n1] = (V){T(0), T(0)};
+    } else {
+#pragma unroll
+        for (unsigned i = 0; i < R_MAX; ++i) creg[i] = (v4u){0u, 0u, 0u, 0u};
+    }
     if constexpr (TW_OPAQUE) {  // landed before the loop: inside it nothing but the sample prefetch is ever waited for
 #pragma unroll
         for (int j = 0; j < LA; ++j) asm volatile("" : "+v"(pw2[j]));
@@ -356,13 +397,19 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_reg_radix(
     const unsigned grid = gridDim.x;
     const unsigned pos0 = rot == ~0u ? blockIdx.x : (blockIdx.x & 7u) * (grid >> 3) + (blockIdx.x >> 3);
     auto tile_of = [&](unsigned k) { return k * grid + (rot == ~0u ? pos0 : (pos0 + k * rot) % grid); };  // >= total_tiles: nothing this round
-    load_raw(min(tile_of(0), total_tiles - 1), raw);
-    // landed before the loop as well: with loads still pending on entry the first use of `raw` inside the loop gets a
-    // vmcnt(0), which from the second tile on waits for the previous tile's stores
+    // the first tile's samples have landed before the loop: with loads still pending on entry their first use inside the loop
+    // gets a vmcnt(0), which from the second tile on waits for the previous tile's stores
+    if constexpr (STAGED) {
+        load_tile(min(tile_of(0), total_tiles - 1));
 #pragma unroll
-    for (unsigned j = 0; j < NI; ++j)
+        for (unsigned i = 0; i < R_MAX; ++i) asm volatile("" : "+v"(creg[i]));
+    } else {
+        load_raw(min(tile_of(0), total_tiles - 1), raw);
 #pragma unroll
-        for (unsigned n1 = 0; n1 < A; ++n1) asm volatile("" : "+v"(raw[j][n1]));
+        for (unsigned j = 0; j < NI; ++j)
+#pragma unroll
+            for (unsigned n1 = 0; n1 < A; ++n1) asm volatile("" : "+v"(raw[j][n1]));
+    }
     __syncthreads();
     const unsigned lft = __ffs(a.ft) - 1u;
     for (unsigned rnd = 0;; ++rnd) {
@@ -381,22 +428,62 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_reg_radix(
                 for (int j = 0; j < LB; ++j) asm volatile("" : "+v"(q2f[j]));
             }
         }
-#pragma unroll
-        for (unsigned j = 0; j < NI; ++j) {
-            const unsigned f = p1f + j * (256u / BC);
-            if (f >= nf) continue;
-            V v[A];
-#pragma unroll
-            for (unsigned n1 = 0; n1 < A; ++n1) v[n1] = raw[j][n1] * sw[BC * n1 + r];
-            inreg::MixFft<A, V>::run(v);
+        auto pass1_store = [&](unsigned f, V (&v)[A]) {  // times W_m^(k1 r), to row k1 of frame f
             V *dst = buf + (size_t)f * FS;
             unsigned pp = p1pos;
             if constexpr (C > 1) asm volatile("" : "+v"(pp));  // the A swizzled addresses are rebuilt here (one XOR each), not kept across the loop
             dst[pp ^ k1_mask(0)] = v[0];
 #pragma unroll
             for (unsigned k1 = 1; k1 < A; ++k1) (dst + (pp ^ k1_mask(k1)))[k1 * RS] = inreg::cmulv(v[k1], rr_twiddle<LA>(pw2, k1));  // k1 RS: an immediate offset
+        };
+        if constexpr (STAGED) {
+            // samples over the tile buffer (free since the previous tile's last barrier), then every item reads its points and
+            // transforms them in registers; the results go back to the buffer once every wave has read (r32x16's barrier 2)
+#pragma unroll
+            for (unsigned i = 0; i < R_MAX; ++i)
+                if (i * 256u + tid < chunks) ((v4u *)smem)[i * 256u + tid] = creg[i];
+#if SGX_RR_LOADPOS == 0
+            if (t_next < total_tiles) load_tile(t_next);  // a whole tile ahead of its use
+#endif
+            __syncthreads();
+            V v[NI][A];
+            const T *xs = (const T *)smem;
+#pragma unroll
+            for (unsigned j = 0; j < NI; ++j) {
+                const unsigned f = p1f + j * (256u / BC);
+                if (f >= nf) continue;
+                const T *xp = xs + f * a.hop + 2u * r;
+                if (!(a.hop & 1u)) {  // even hop: every frame starts on a pair boundary of the tile
+#pragma unroll
+                    for (unsigned n1 = 0; n1 < A; ++n1) v[j][n1] = *(const V *)(xp + 2u * BC * n1) * sw[BC * n1 + r];
+                } else {
+#pragma unroll
+                    for (unsigned n1 = 0; n1 < A; ++n1) v[j][n1] = (V){xp[2u * BC * n1], xp[2u * BC * n1 + 1u]} * sw[BC * n1 + r];
+                }
+                inreg::MixFft<A, V>::run(v[j]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (unsigned j = 0; j < NI; ++j) {
+                const unsigned f = p1f + j * (256u / BC);
+                if (f < nf) pass1_store(f, v[j]);
+            }
+#if SGX_RR_LOADPOS != 0
+            if (t_next < total_tiles) load_tile(t_next);  // in flight behind passes 2 and 3
+#endif
+        } else {
+#pragma unroll
+            for (unsigned j = 0; j < NI; ++j) {
+                const unsigned f = p1f + j * (256u / BC);
+                if (f >= nf) continue;
+                V v[A];
+#pragma unroll
+                for (unsigned n1 = 0; n1 < A; ++n1) v[n1] = raw[j][n1] * sw[BC * n1 + r];
+                inreg::MixFft<A, V>::run(v);
+                pass1_store(f, v);
+            }
+            if (t_next < total_tiles) load_raw(t_next, raw);  // in flight behind passes 2 and 3
         }
-        if (t_next < total_tiles) load_raw(t_next, raw);  // in flight behind passes 2 and 3
         __syncthreads();
         // the thread index is opaque from here on: the element addresses of passes 2, 3 and the split are recomputed per tile
         // (a few integer operations) instead of being carried through the whole loop in registers
@@ -444,10 +531,15 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_reg_radix(
         }
         // The next tile's samples have had passes 2 and 3 to arrive: collect them here, before the first store of the split,
         // so that nothing issued after this point ever has to be waited for.
+        if constexpr (STAGED) {
 #pragma unroll
-        for (unsigned j = 0; j < NI; ++j)
+            for (unsigned i = 0; i < R_MAX; ++i) asm volatile("" : "+v"(creg[i]));
+        } else {
 #pragma unroll
-            for (unsigned n1 = 0; n1 < A; ++n1) asm volatile("" : "+v"(raw[j][n1]));
+            for (unsigned j = 0; j < NI; ++j)
+#pragma unroll
+                for (unsigned n1 = 0; n1 < A; ++n1) asm volatile("" : "+v"(raw[j][n1]));
+        }
         // real split, frame index fastest across threads (a.ft is a power of two).  One work item per pair (k, m - k):
         // with E = (Z[k] + conj Z[m-k]) / 2, P = W_n^k (Z[k] - conj Z[m-k]) / (2i):  X[k] = E + P,  X[m-k] = conj(E - P).
         auto at = [](const V *fb, unsigned k) -> V { return fb[L::of_output(k)]; };  // Z[k]: row k mod A, position (hi, lo) with k / A = hi + B lo
@@ -832,6 +924,21 @@ static size_t reg_radix_bytes(const StftArgs &a, unsigned ft, unsigned sub, unsi
 static const size_t kRegBudget = 72 * 1024, kRegBudgetBins = 80 * 1024;
 static const size_t kRegHardLimit = 144 * 1024;  // a single frame of the largest sizes may take most of the CU
 
+// staged samples: the tile's (ft - 1) hop + n_fft samples must fit the chunk registers (256 threads x R rounds x 16 bytes) and the
+// tile buffer they are written over
+// the staged variant is the one to use (see rr_can_stage): per-bin outputs, f32 or the long f64 transforms
+static bool reg_radix_want_staged(const StftArgs &a, unsigned fa, unsigned fc, size_t es) {
+    return SGX_RR_STAGED && a.out_mode != OUT_MEL && (es == 4 || (fa >= 16 && fc > 1));
+}
+
+static bool reg_radix_stage_ok(const StftArgs &a, unsigned ft, unsigned fa, unsigned fb, unsigned fc, size_t es) {
+    if (!reg_radix_want_staged(a, fa, fc, es)) return true;
+    const unsigned long long len = (unsigned long long)(ft - 1) * a.hop + a.n_fft, epc = 16 / es;
+    const unsigned long long chunks = (len + epc - 1) / epc;
+    const size_t fs = rr_frame_stride(fa, rr_swizzle(2 * (unsigned)es, fa, fb, fc).rs);
+    return chunks <= 256ull * rr_stage_rounds(fa * fb * fc, (unsigned)es) && chunks * 16 <= (unsigned long long)ft * fs * 2 * es;
+}
+
 static unsigned reg_radix_ft_max(unsigned fbc) {
     const bool p2 = (fbc & (fbc - 1)) == 0;
     const unsigned ni = (p2 && fbc >= SGX_RR_NI2_MIN) ? 2 : 1;  // rr_items
@@ -850,21 +957,25 @@ bool plan_geometry_reg_radix(StftArgs &a, int dtype) {
     const size_t budget = (dtype == SGX_F64 && fa >= 16) ? std::max(base, kRegHardLimit - 16 * 1024) : base;
     // filterbank outputs: the |X|^2 rows may be produced in up to 4 parts of ft / parts frames (two barriers per part) when
     // that buys a larger tile
-    for (unsigned ft = reg_radix_ft_max(fb * fc); ft >= 1; ft >>= 1)
+    for (unsigned ft = reg_radix_ft_max(fb * fc); ft >= 1; ft >>= 1) {
+        if (!reg_radix_stage_ok(a, ft, fa, fb, fc, es)) continue;
         for (unsigned parts = 1; parts <= (a.out_mode == OUT_MEL ? 4u : 1u) && ft / parts >= std::min(ft, 4u); parts *= 2)
             if (reg_radix_bytes(a, ft, ft / parts, fa, fb, fc, es) <= budget) {
                 a.ft = ft;
                 a.mel_sub = ft / parts;
                 return true;
             }
+    }
     a.ft = a.mel_sub = 1;
-    return reg_radix_bytes(a, 1, 1, fa, fb, fc, es) <= kRegHardLimit;
+    return reg_radix_stage_ok(a, 1, fa, fb, fc, es) && reg_radix_bytes(a, 1, 1, fa, fb, fc, es) <= kRegHardLimit;
 }
 
 template <typename T, int A, int B, int C>
-static hipError_t launch_reg_radix_t(const StftArgs &a, unsigned total, size_t lds, unsigned csr_lds, unsigned band_lds, hipStream_t s) {
+static hipError_t launch_reg_radix_t(const StftArgs &a, unsigned total, size_t lds, unsigned csr_lds, unsigned band_lds, bool staged, hipStream_t s) {
     if (lds > 64 * 1024) {
-        hipError_t e = set_max_dynamic_lds((const void *)k_reg_radix<T, A, B, C>, (int)kRegHardLimit);
+        hipError_t e = set_max_dynamic_lds((const void *)k_reg_radix<T, A, B, C, false>, (int)kRegHardLimit);
+        if constexpr (rr_can_stage<T, A, C>())
+            if (e == hipSuccess) e = set_max_dynamic_lds((const void *)k_reg_radix<T, A, B, C, true>, (int)kRegHardLimit);
         if (e != hipSuccess) return e;
     }
     // persistent workgroups: as many as are resident at once (registers: rr_waves per SIMD = workgroups per CU; LDS: 160 KB
@@ -874,7 +985,7 @@ static hipError_t launch_reg_radix_t(const StftArgs &a, unsigned total, size_t l
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         return (unsigned)n;
     }();
-    const unsigned by_regs = rr_waves<T, A, B, C>();
+    const unsigned by_regs = staged && rr_can_stage<T, A, C>() ? rr_stft_waves<T, A, B, C, true>() : rr_stft_waves<T, A, B, C, false>();
     const unsigned by_lds = (unsigned)std::max<size_t>(1, (160 * 1024) / (lds + 512));
     unsigned grid = std::min(total, cus * std::min(by_regs, by_lds));
     // tile order (see the kernel): XCD-contiguous rounds need a grid that is a multiple of 8; the per-round shift `rot` makes
@@ -888,7 +999,13 @@ static hipError_t launch_reg_radix_t(const StftArgs &a, unsigned total, size_t l
         if (total > grid)
             while (rot < a.tiles && std::gcd(grid + rot, a.tiles) > 1) ++rot;
     }
-    hipLaunchKernelGGL((k_reg_radix<T, A, B, C>), dim3(grid), dim3(256), lds, s, a, total, csr_lds, band_lds, rot);
+    if constexpr (rr_can_stage<T, A, C>()) {
+        if (staged) {
+            hipLaunchKernelGGL((k_reg_radix<T, A, B, C, true>), dim3(grid), dim3(256), lds, s, a, total, csr_lds, band_lds, rot);
+            return hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL((k_reg_radix<T, A, B, C, false>), dim3(grid), dim3(256), lds, s, a, total, csr_lds, band_lds, rot);
     return hipGetLastError();
 }
 
@@ -899,7 +1016,8 @@ hipError_t launch_reg_radix(const StftArgs &a, int dtype, hipStream_t s) {
     if (a.ft > reg_radix_ft_max(fb * fc)) return hipErrorInvalidConfiguration;
     const size_t es = elem_size(dtype);
     const unsigned sub = a.mel_sub ? a.mel_sub : a.ft;
-    if (sub > a.ft || (sub & (sub - 1))) return hipErrorInvalidConfiguration;
+    if (sub > a.ft || (sub & (sub - 1)) || !reg_radix_stage_ok(a, a.ft, fa, fb, fc, es)) return hipErrorInvalidConfiguration;
+    const bool staged = reg_radix_want_staged(a, fa, fc, es);
     size_t lds = reg_radix_bytes(a, a.ft, sub, fa, fb, fc, es);
     if (lds > kRegHardLimit) return hipErrorInvalidConfiguration;
     // the bank stays in LDS for the life of the workgroup when it fits beside the tile: the padded band table if the rows
@@ -915,9 +1033,9 @@ hipError_t launch_reg_radix(const StftArgs &a, int dtype, hipStream_t s) {
         lds += csr;
     }
 #define SGX_RR_F32(A, B, C) \
-    if (fa == A && fb == B && fc == C) return launch_reg_radix_t<float, A, B, C>(a, (unsigned)g, lds, csr_lds, band_lds, s);
+    if (fa == A && fb == B && fc == C) return launch_reg_radix_t<float, A, B, C>(a, (unsigned)g, lds, csr_lds, band_lds, staged, s);
 #define SGX_RR_F64(A, B, C) \
-    if (fa == A && fb == B && fc == C) return launch_reg_radix_t<double, A, B, C>(a, (unsigned)g, lds, csr_lds, band_lds, s);
+    if (fa == A && fb == B && fc == C) return launch_reg_radix_t<double, A, B, C>(a, (unsigned)g, lds, csr_lds, band_lds, staged, s);
     if (dtype == SGX_F64) {
         SGX_RR_SPLITS_F64(SGX_RR_F64)
         SGX_RR_SPLITS_MIXED(SGX_RR_F64)

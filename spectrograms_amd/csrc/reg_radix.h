@@ -42,6 +42,30 @@ constexpr bool ct_is_pow2(unsigned n) { return n && !(n & (n - 1)); }
 template <int B, int C>
 constexpr unsigned rr_items() { return (ct_is_pow2(B * C) && B * C >= SGX_RR_NI2_MIN) ? 2 : 1; }
 
+// Sample staging (k_reg_radix): a tile's samples travel global -> registers (16-byte chunks, chunk c = tid + 256 i, one tile
+// ahead) -> LDS, where the pass-1 work items pick their points.  Rounds of 256 chunks a thread holds in registers: 24 KiB of
+// samples, 32 KiB for the transforms whose single frame needs that much.
+#ifndef SGX_RR_STAGED
+#define SGX_RR_STAGED 1
+#endif
+constexpr unsigned rr_stage_rounds(unsigned m, unsigned elem) { return 2u * m * elem >= 16384u ? 8u : 6u; }
+// Instances that have a staged variant (the host picks it for per-bin outputs: measured faster there — f32 n_fft 512 201 -> 180,
+// 2048 276 -> 244 us — and slower for filterbank outputs, whose kernels wait for no stores, and for f64 below n_fft 2048,
+// where two pass-1 items per thread held across a barrier spill)
+template <typename T, int A, int C>
+constexpr bool rr_can_stage() { return SGX_RR_STAGED && (sizeof(T) == 4 || (A >= 16 && C > 1)); }
+
+// k_reg_radix: waves per SIMD (= resident workgroups per CU) the register allocation aims at.  With the twiddle products rebuilt
+// per tile the two-pass f32 instances up to 16-point passes stay under 128 registers.
+// per tile the two-pass f32 instances up to 16-point passes stay under 128 registers; the longer ones do with staged samples
+// (the direct variant carries a frame's A sample pairs per thread across the whole tile)
+template <typename T, int A, int B, int C, bool STAGED>
+constexpr unsigned rr_stft_waves() {
+    if (sizeof(T) == 8) return A >= 16 ? 1 : SGX_RRW64;
+    if (C > 1) return A <= 8 ? 3 : 2;
+    return A <= 16 ? 4 : (STAGED && A <= 30) ? 3 : 2;
+}
+
 // waves per SIMD (= resident workgroups per CU) the register allocation of an instance aims at: the largest transforms
 // (16-point and longer passes in f64, the three-pass f32 sizes with a 16-point first pass) would spill at the default
 template <typename T, int A, int B, int C>
