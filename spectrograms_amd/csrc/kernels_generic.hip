@@ -926,6 +926,13 @@ static const size_t kRegHardLimit = 144 * 1024;  // a single frame of the larges
 
 // staged samples: the tile's (ft - 1) hop + n_fft samples must fit the chunk registers (256 threads x R rounds x 16 bytes) and the
 // tile buffer they are written over
+// rr_stft_waves for the host
+static unsigned reg_radix_waves(size_t es, unsigned fa, unsigned fc, bool staged) {
+    if (es == 8) return fa >= 16 ? 1 : SGX_RRW64;
+    if (fc > 1) return fa <= 8 ? 3 : 2;
+    return fa <= 16 ? 4 : (staged && fa <= 30) ? 3 : 2;
+}
+
 // the staged variant is the one to use (see rr_can_stage): per-bin outputs, f32 or the long f64 transforms
 static bool reg_radix_want_staged(const StftArgs &a, unsigned fa, unsigned fc, size_t es) {
     return SGX_RR_STAGED && a.out_mode != OUT_MEL && (es == 4 || (fa >= 16 && fc > 1));
@@ -955,14 +962,30 @@ bool plan_geometry_reg_radix(StftArgs &a, int dtype) {
     // instances that run one workgroup per CU anyway (rr_waves == 1: f64 with a 16-point or longer pass) may use most of its LDS
     const size_t base = a.out_mode == OUT_MEL ? kRegBudget : kRegBudgetBins;
     const size_t budget = (dtype == SGX_F64 && fa >= 16) ? std::max(base, kRegHardLimit - 16 * 1024) : base;
-    // filterbank outputs: the |X|^2 rows may be produced in up to 4 parts of ft / parts frames (two barriers per part) when
-    // that buys a larger tile
-    for (unsigned ft = reg_radix_ft_max(fb * fc); ft >= 1; ft >>= 1) {
-        if (!reg_radix_stage_ok(a, ft, fa, fb, fc, es)) continue;
-        for (unsigned parts = 1; parts <= (a.out_mode == OUT_MEL ? 4u : 1u) && ft / parts >= std::min(ft, 4u); parts *= 2)
-            if (reg_radix_bytes(a, ft, ft / parts, fa, fb, fc, es) <= budget) {
-                a.ft = ft;
-                a.mel_sub = ft / parts;
+    if (a.out_mode == OUT_MEL) {
+        // Filterbank outputs write little, so what counts is how many frames a CU keeps in flight: workgroups per CU (registers,
+        // LDS with the bank beside the tile) times frames per tile.  The |X|^2 rows may be produced in up to 4 parts of
+        // ft / parts frames (two barriers per part) when that buys a larger tile or one more workgroup per CU (f32 n_fft 512:
+        // 16-frame tiles in two parts run three workgroups per CU instead of two).  Ties: larger tile, then fewer parts.
+        const unsigned by_regs = reg_radix_waves(es, fa, fc, false);
+        const size_t bank = std::max(reg_radix_band_bytes(a, es), (size_t)0);
+        unsigned best = 0;
+        for (unsigned ft = reg_radix_ft_max(fb * fc); ft >= 1; ft >>= 1)
+            for (unsigned parts = 1; parts <= 4u && ft / parts >= std::min(ft, 4u); parts *= 2) {
+                const size_t lds = reg_radix_bytes(a, ft, ft / parts, fa, fb, fc, es);
+                if (lds > budget) continue;
+                const unsigned wgs = std::min<unsigned>(by_regs, (unsigned)std::max<size_t>(1, (160 * 1024) / (lds + bank + 512)));
+                if (wgs * ft > best) {
+                    best = wgs * ft;
+                    a.ft = ft;
+                    a.mel_sub = ft / parts;
+                }
+            }
+        if (best) return true;
+    } else {
+        for (unsigned ft = reg_radix_ft_max(fb * fc); ft >= 1; ft >>= 1)
+            if (reg_radix_stage_ok(a, ft, fa, fb, fc, es) && reg_radix_bytes(a, ft, ft, fa, fb, fc, es) <= budget) {
+                a.ft = a.mel_sub = ft;
                 return true;
             }
     }
