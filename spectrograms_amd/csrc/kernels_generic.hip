@@ -939,7 +939,6 @@ static bool reg_radix_want_staged(const StftArgs &a, unsigned fa, unsigned fc, s
 }
 
 static bool reg_radix_stage_ok(const StftArgs &a, unsigned ft, unsigned fa, unsigned fb, unsigned fc, size_t es) {
-    if (!reg_radix_want_staged(a, fa, fc, es)) return true;
     const unsigned long long len = (unsigned long long)(ft - 1) * a.hop + a.n_fft, epc = 16 / es;
     const unsigned long long chunks = (len + epc - 1) / epc;
     const size_t fs = rr_frame_stride(fa, rr_swizzle(2 * (unsigned)es, fa, fb, fc).rs);
@@ -983,14 +982,18 @@ bool plan_geometry_reg_radix(StftArgs &a, int dtype) {
             }
         if (best) return true;
     } else {
+        // staged samples where frames overlap by at least half and the samples of the tile the budget allows fit the chunk
+        // registers (hop = n_fft — the 2-D path's row pass — shares nothing between frames and would only lose tile size)
         for (unsigned ft = reg_radix_ft_max(fb * fc); ft >= 1; ft >>= 1)
-            if (reg_radix_stage_ok(a, ft, fa, fb, fc, es) && reg_radix_bytes(a, ft, ft, fa, fb, fc, es) <= budget) {
+            if (reg_radix_bytes(a, ft, ft, fa, fb, fc, es) <= budget) {
                 a.ft = a.mel_sub = ft;
+                a.staged = reg_radix_want_staged(a, fa, fc, es) && 2 * a.hop <= a.n_fft && reg_radix_stage_ok(a, ft, fa, fb, fc, es);
                 return true;
             }
     }
     a.ft = a.mel_sub = 1;
-    return reg_radix_stage_ok(a, 1, fa, fb, fc, es) && reg_radix_bytes(a, 1, 1, fa, fb, fc, es) <= kRegHardLimit;
+    a.staged = 0;
+    return reg_radix_bytes(a, 1, 1, fa, fb, fc, es) <= kRegHardLimit;
 }
 
 template <typename T, int A, int B, int C>
@@ -1039,8 +1042,9 @@ hipError_t launch_reg_radix(const StftArgs &a, int dtype, hipStream_t s) {
     if (a.ft > reg_radix_ft_max(fb * fc)) return hipErrorInvalidConfiguration;
     const size_t es = elem_size(dtype);
     const unsigned sub = a.mel_sub ? a.mel_sub : a.ft;
-    if (sub > a.ft || (sub & (sub - 1)) || !reg_radix_stage_ok(a, a.ft, fa, fb, fc, es)) return hipErrorInvalidConfiguration;
-    const bool staged = reg_radix_want_staged(a, fa, fc, es);
+    const bool staged = a.staged != 0;
+    if (sub > a.ft || (sub & (sub - 1))) return hipErrorInvalidConfiguration;
+    if (staged && !(reg_radix_want_staged(a, fa, fc, es) && reg_radix_stage_ok(a, a.ft, fa, fb, fc, es))) return hipErrorInvalidConfiguration;
     size_t lds = reg_radix_bytes(a, a.ft, sub, fa, fb, fc, es);
     if (lds > kRegHardLimit) return hipErrorInvalidConfiguration;
     // the bank stays in LDS for the life of the workgroup when it fits beside the tile: the padded band table if the rows

@@ -36,6 +36,7 @@ struct StftArgs {
     unsigned n_frames, nb_fft, n_out;
     unsigned ft, tiles;  // frames per workgroup tile, tiles per signal
     unsigned mel_sub;    // k_reg_radix, filterbank outputs: frames per |X|^2 part (a power of two dividing ft; 0 = ft)
+    unsigned staged;     // k_reg_radix: the tile's samples go through LDS (overlapping frames, per-bin outputs: plan_geometry_reg_radix)
     unsigned tw_lds;        // K_LDS_RADIX2: the first n_fft/2 twiddles are copied to LDS behind the tile (set by the geometry)
     unsigned fac_a, fac_b;  // K_TWO_FACTOR: n_fft = fac_a * fac_b, fac_a = largest divisor <= sqrt(n_fft)
     const void *window;
