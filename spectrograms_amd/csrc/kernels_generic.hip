@@ -28,6 +28,21 @@
 
 namespace sgx {
 
+#ifdef SGX_RR_STAMPS  // diagnostic build only (tools/stamps_generic.py): a wave's cycles per phase of k_reg_radix
+__device__ unsigned long long g_rr_stamps[32];
+#define RR_STAMP(i)                                                                         \
+    do {                                                                                    \
+        unsigned long long t_;                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        st_acc[i] += t_ - st_prev;                                                          \
+        st_prev = t_;                                                                       \
+    } while (0)
+#else
+#define RR_STAMP(i)
+#endif
+
 template <typename T>
 struct Cx {
     T re, im;
@@ -412,6 +427,10 @@ __global__ __launch_bounds__(256, (rr_stft_waves<T, A_, B_, C_, STAGED_>())) voi
     }
     __syncthreads();
     const unsigned lft = __ffs(a.ft) - 1u;
+#ifdef SGX_RR_STAMPS
+    unsigned long long st_acc[16] = {0}, st_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+#endif
     for (unsigned rnd = 0;; ++rnd) {
         const unsigned t = tile_of(rnd);
         if (t >= total_tiles) break;  // only the last round is partial
@@ -445,7 +464,9 @@ __global__ __launch_bounds__(256, (rr_stft_waves<T, A_, B_, C_, STAGED_>())) voi
 #if SGX_RR_LOADPOS == 0
             if (t_next < total_tiles) load_tile(t_next);  // a whole tile ahead of its use
 #endif
+            RR_STAMP(0);  // staging writes
             __syncthreads();
+            RR_STAMP(1);  // barrier
             V v[NI][A];
             const T *xs = (const T *)smem;
 #pragma unroll
@@ -462,15 +483,19 @@ __global__ __launch_bounds__(256, (rr_stft_waves<T, A_, B_, C_, STAGED_>())) voi
                 }
                 inreg::MixFft<A, V>::run(v[j]);
             }
+            RR_STAMP(2);  // pass 1: sample / window reads + transform
             __syncthreads();
+            RR_STAMP(3);  // barrier
 #pragma unroll
             for (unsigned j = 0; j < NI; ++j) {
                 const unsigned f = p1f + j * (256u / BC);
                 if (f < nf) pass1_store(f, v[j]);
             }
+            RR_STAMP(4);  // pass 1: twiddles + tile writes
 #if SGX_RR_LOADPOS != 0
             if (t_next < total_tiles) load_tile(t_next);  // in flight behind passes 2 and 3
 #endif
+            RR_STAMP(5);  // load issue
         } else {
 #pragma unroll
             for (unsigned j = 0; j < NI; ++j) {
@@ -482,9 +507,12 @@ __global__ __launch_bounds__(256, (rr_stft_waves<T, A_, B_, C_, STAGED_>())) voi
                 inreg::MixFft<A, V>::run(v);
                 pass1_store(f, v);
             }
+            RR_STAMP(2);  // direct: pass 1 complete (window reads, transform, twiddles, tile writes)
             if (t_next < total_tiles) load_raw(t_next, raw);  // in flight behind passes 2 and 3
+            RR_STAMP(5);  // load issue
         }
         __syncthreads();
+        RR_STAMP(6);  // barrier
         // the thread index is opaque from here on: the element addresses of passes 2, 3 and the split are recomputed per tile
         // (a few integer operations) instead of being carried through the whole loop in registers
         unsigned tl = tid;
@@ -514,7 +542,9 @@ __global__ __launch_bounds__(256, (rr_stft_waves<T, A_, B_, C_, STAGED_>())) voi
                 for (unsigned k2 = 1; k2 < B; ++k2) row[lp ^ hi_part(k2)] = x[k2];
             }
         }
+        RR_STAMP(7);  // pass 2
         __syncthreads();
+        RR_STAMP(8);  // barrier
         if constexpr (C > 1) {
             for (unsigned idx = tl; idx < nf * A * B; idx += 256) {
                 const unsigned f = idx / (A * B), q = idx % (A * B), k1 = q / B, k2 = q % B;
@@ -527,7 +557,9 @@ __global__ __launch_bounds__(256, (rr_stft_waves<T, A_, B_, C_, STAGED_>())) voi
 #pragma unroll
                 for (unsigned k3 = 0; k3 < C; ++k3) row[lp ^ k3] = x[k3];
             }
+            RR_STAMP(9);  // pass 3
             __syncthreads();
+            RR_STAMP(10);  // barrier
         }
         // The next tile's samples have had passes 2 and 3 to arrive: collect them here, before the first store of the split,
         // so that nothing issued after this point ever has to be waited for.
@@ -540,6 +572,7 @@ __global__ __launch_bounds__(256, (rr_stft_waves<T, A_, B_, C_, STAGED_>())) voi
 #pragma unroll
                 for (unsigned n1 = 0; n1 < A; ++n1) asm volatile("" : "+v"(raw[j][n1]));
         }
+        RR_STAMP(11);  // wait for the next tile's samples
         // real split, frame index fastest across threads (a.ft is a power of two).  One work item per pair (k, m - k):
         // with E = (Z[k] + conj Z[m-k]) / 2, P = W_n^k (Z[k] - conj Z[m-k]) / (2i):  X[k] = E + P,  X[m-k] = conj(E - P).
         auto at = [](const V *fb, unsigned k) -> V { return fb[L::of_output(k)]; };  // Z[k]: row k mod A, position (hi, lo) with k / A = hi + B lo
@@ -619,8 +652,19 @@ __global__ __launch_bounds__(256, (rr_stft_waves<T, A_, B_, C_, STAGED_>())) voi
                 }
             }
         }
+        RR_STAMP(12);  // split + stores (+ filterbank stage)
         __syncthreads();  // the tile buffer (and pw) is free for the next tile
+        RR_STAMP(13);  // barrier
+#ifdef SGX_RR_STAMPS
+        st_acc[15] += 1;
+#endif
     }
+#ifdef SGX_RR_STAMPS
+    if ((tid & 63u) == 0) {
+        for (int q = 0; q < 16; ++q) atomicAdd(&g_rr_stamps[q], st_acc[q]);
+        atomicAdd(&g_rr_stamps[16], 1ull);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1140,3 +1184,14 @@ hipError_t launch_mfcc(const void *mel, void *out, const void *basis, const void
 }
 
 }  // namespace sgx
+
+#ifdef SGX_RR_STAMPS
+extern "C" int sgx_debug_read_rr_stamps(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sgx::g_rr_stamps), sizeof(sgx::g_rr_stamps)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[32] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(sgx::g_rr_stamps), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
