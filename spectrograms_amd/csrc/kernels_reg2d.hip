@@ -137,7 +137,45 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_c2c_reg(C2
     }
 }
 
-template <typename T, int A_, int B_, int C_>
+// Overlap-add of a tile's windowed real frames fr[tile][frs] (LDS) into one signal's output (src/spectrogram.rs:4906-4930): one
+// thread per offset `off` inside a hop block, walking the tile's nbk hop blocks.  Position pos = (h0 + hb) hop + off receives
+// frames f in [fh - q + 1, fh] (fh = h0 + hb, q = ceil((n - off) / hop)) clipped to [0, n_frames), in ascending f as the reference
+// adds them, frame sample j = (fh - f) hop + off; norm = sum of w[j]^2 (each product rounded, then added), divide where > 1e-10.
+template <typename T>
+__device__ __forceinline__ void ola_tile(const T *fr, unsigned frs, unsigned n, const T *w, T *o, const C2rArgs &a, long long h0, long long fbase,
+                                         unsigned tid) {
+    const unsigned long long p0 = (unsigned long long)h0 * a.hop;
+    const long long last = (long long)a.nrows - 1;
+    auto sq_add = [](T acc, T wj) {
+        if constexpr (sizeof(T) == 4) return __fadd_rn(acc, __fmul_rn(wj, wj));
+        else return __dadd_rn(acc, __dmul_rn(wj, wj));
+    };
+    for (unsigned off = tid; off < a.hop; off += 256) {
+        const unsigned q = off < n ? (n - off + a.hop - 1u) / a.hop : 0u;  // frames overlapping this offset (hop > n: none past n)
+        T nrm_full = T(0);  // every interior position's norm
+        for (unsigned i = q; i-- > 0;) nrm_full = sq_add(nrm_full, w[i * a.hop + off]);
+        for (unsigned hb = 0; hb < a.nbk; ++hb) {
+            const unsigned long long pos = p0 + (unsigned long long)hb * a.hop + off;
+            if (pos < a.start || pos - a.start >= a.out_len) continue;
+            const long long fh = h0 + hb;
+            const long long f_lo = max(fh - (long long)q + 1, 0ll), f_hi = min(fh, last);
+            const unsigned cnt = f_hi >= f_lo ? (unsigned)(f_hi - f_lo + 1) : 0u;
+            T acc = T(0), nrm = nrm_full;
+            if (cnt) {
+                const T *src = fr + (size_t)(unsigned)(f_lo - fbase) * frs + (unsigned)(fh - f_lo) * a.hop + off;
+                for (unsigned i = 0; i < cnt; ++i) acc += src[(long long)i * ((long long)frs - (long long)a.hop)];  // next frame: row + 1, j - hop
+            }
+            if (cnt != q) {  // signal edges: fewer frames
+                nrm = T(0);
+                for (long long f = f_lo; f <= f_hi; ++f) nrm = sq_add(nrm, w[(unsigned)(fh - f) * a.hop + off]);
+            }
+            if (nrm > T(1e-10)) acc /= nrm;
+            o[pos - a.start] = acc;
+        }
+    }
+}
+
+template <typename T, int A_, int B_, int C_, bool OLA>
 __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_c2r_reg(C2rArgs a, unsigned ltile) {
     typedef typename PairOf<T>::type V;
     constexpr unsigned A = A_, B = B_, C = C_, BC = B * C, M = A * BC, CN = 2 * M;
@@ -153,8 +191,11 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_c2r_reg(C2
     const unsigned lb = xcd_logical_block(a.tiles * a.batch);
     if (lb >= a.tiles * a.batch) return;
     const unsigned t = lb % a.tiles, b = lb / a.tiles;
-    const unsigned r0 = t * tile;
-    const unsigned nr = min(tile, a.nrows - r0);
+    // OLA: row rr of the tile is frame fbase + rr (the first a.ov rows are the halo); frames outside the signal are zero rows
+    const long long h0 = (long long)t * a.nbk, fbase = OLA ? h0 - (long long)a.ov : (long long)t * tile;
+    const unsigned r0 = (unsigned)fbase;  // (!OLA)
+    const unsigned nr = OLA ? tile : min(tile, a.nrows - r0);
+    auto row_ok = [&](unsigned rr) { return OLA ? (fbase + rr >= 0 && fbase + rr < (long long)a.nrows) : rr < nr; };
     const V *in = (const V *)a.in + (size_t)b * a.in_img;
     T *out = (T *)a.out + (size_t)b * a.nrows * CN;
     const V *tw = (const V *)a.tw;  // W_CN^k, CN entries
@@ -168,13 +209,13 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_c2r_reg(C2
         for (int u = 0; u < 8; ++u) {
             const unsigned idx = base + u * 256u + tid;
             if (a.k_fast) { k[u] = idx % (M + 1); rr[u] = idx / (M + 1); } else { rr[u] = idx & (tile - 1); k[u] = idx >> ltile; }
-            if (idx >= tile * (M + 1)) rr[u] = nr;  // past the tile: skipped below
-            v[u] = rr[u] < nr ? in[(size_t)k[u] * a.in_ks + (size_t)(r0 + rr[u]) * a.in_rs] : (V){T(0), T(0)};
+            if (idx >= tile * (M + 1)) rr[u] = tile;  // past the tile: skipped below
+            v[u] = rr[u] < tile && row_ok(rr[u]) ? in[(size_t)k[u] * a.in_ks + (size_t)(fbase + rr[u]) * a.in_rs] : (V){T(0), T(0)};
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (rr[u] >= nr) continue;
-            if (k[u] == 0 || k[u] == M) {  // DC / Nyquist columns forced real; realfft reports a non-zero imaginary part
+            if (row_ok(rr[u]) && (k[u] == 0 || k[u] == M)) {  // DC / Nyquist columns forced real; realfft reports a non-zero imaginary part
                 if (a.bad_flag && v[u].y != T(0)) atomicOr(a.bad_flag, 1u);
                 v[u].y = T(0);
             }
@@ -244,11 +285,26 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_c2r_reg(C2
     // z[n] = conj(result[n]) * scale = (x[2n], x[2n+1]); lanes over n: contiguous row stores
     const T sc = (T)a.scale;
     const V *win = (const V *)a.win;
-    for (unsigned idx = tid; idx < nr * M; idx += 256) {
-        const unsigned n = idx % M, rr = idx / M;
-        V v = buf[(size_t)rr * FS + L::of_output(n)] * (V){sc, -sc};
-        if (win) v = v * win[n];
-        *(V *)(out + (size_t)(r0 + rr) * CN + 2u * n) = v;
+    if constexpr (OLA) {
+        // the windowed frames stay on chip: real rows over the (dead) staged spectrum, then the overlap-add
+        V *fr = sx;  // [tile][SXS] pairs = rows of 2 SXS reals
+        for (unsigned idx = tid; idx < tile * M; idx += 256) {
+            const unsigned n = idx % M, rr = idx / M;
+            V v = buf[(size_t)rr * FS + L::of_output(n)] * (V){sc, -sc};
+            const V w2 = win[n];
+            if constexpr (sizeof(T) == 4) v = (V){__fmul_rn(v.x, w2.x), __fmul_rn(v.y, w2.y)};
+            else v = (V){__dmul_rn(v.x, w2.x), __dmul_rn(v.y, w2.y)};
+            fr[(size_t)rr * SXS + n] = v;
+        }
+        __syncthreads();
+        ola_tile<T>((const T *)fr, 2u * SXS, CN, (const T *)a.win, (T *)a.out + (size_t)b * a.out_len, a, h0, fbase, tid);
+    } else {
+        for (unsigned idx = tid; idx < nr * M; idx += 256) {
+            const unsigned n = idx % M, rr = idx / M;
+            V v = buf[(size_t)rr * FS + L::of_output(n)] * (V){sc, -sc};
+            if (win) v = v * win[n];
+            *(V *)(out + (size_t)(r0 + rr) * CN + 2u * n) = v;
+        }
     }
 }
 
@@ -264,11 +320,15 @@ hipError_t launch_c2c_t(const C2cArgs &a, unsigned ltile, size_t lds, hipStream_
 
 template <typename T, int A, int B, int C>
 hipError_t launch_c2r_t(const C2rArgs &a, unsigned ltile, size_t lds, hipStream_t s) {
+    const bool ola = a.nbk != 0;
     if (lds > 64 * 1024) {
-        hipError_t e = set_max_dynamic_lds((const void *)k_c2r_reg<T, A, B, C>, (int)kR2Budget);
+        hipError_t e = ola ? set_max_dynamic_lds((const void *)k_c2r_reg<T, A, B, C, true>, (int)kR2Budget)
+                           : set_max_dynamic_lds((const void *)k_c2r_reg<T, A, B, C, false>, (int)kR2Budget);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_c2r_reg<T, A, B, C>), dim3(xcd_grid((unsigned long long)a.tiles * a.batch)), dim3(256), lds, s, a, ltile);
+    const dim3 grid(xcd_grid((unsigned long long)a.tiles * a.batch));
+    if (ola) hipLaunchKernelGGL((k_c2r_reg<T, A, B, C, true>), grid, dim3(256), lds, s, a, ltile);
+    else hipLaunchKernelGGL((k_c2r_reg<T, A, B, C, false>), grid, dim3(256), lds, s, a, ltile);
     return hipGetLastError();
 }
 
@@ -313,13 +373,26 @@ hipError_t launch_c2r_reg(const C2rArgs &a0, int dtype, hipStream_t s) {
     if (((size_t)a0.in | (size_t)a0.out | (size_t)a0.win) & (2 * es - 1)) return hipErrorNotSupported;
     const size_t m = a0.ncols / 2;
     const size_t per = ((size_t)rr_frame_stride(fa, rr_swizzle(2 * (unsigned)es, fa, fb, fc).rs) + ((m + 1) | 1)) * 2 * es;
+    const bool ola = a0.hop != 0;  // fused inverse STFT (launch_istft_reg)
     unsigned ltile = 5;
-    while (ltile > 0 && ((size_t)(1u << ltile) * per > kR2Budget || (1u << (ltile - 1)) >= a0.nrows)) --ltile;
+    while (ltile > 0 && ((size_t)(1u << ltile) * per > kR2Budget || (!ola && (1u << (ltile - 1)) >= a0.nrows))) --ltile;
     const size_t lds = (size_t)(1u << ltile) * per;
     if (lds > kR2Budget) return hipErrorNotSupported;
     C2rArgs a = a0;
     a.tile = 1u << ltile;
     a.tiles = (a.nrows + a.tile - 1) / a.tile;
+    a.nbk = 0;
+    if (ola) {
+        // `ov` halo frames per tile are transformed twice: fused only while at least three quarters of a tile's frames are its
+        // own, and in f32 (measured, 256 x 10 s: f32 n_fft 512 / hop 128 0.90 -> 0.81 ms, 400 / 160 0.75 -> 0.71 ms; f64 tiles hold
+        // half as many frames and lose: 1024 / 256 1.18 -> 1.20 ms, 400 / 160 1.47 -> 1.85 ms)
+        a.ov = (a.ncols - 1u) / a.hop;
+        if (a.hop > a.ncols || !a.win || 4 * a.ov > a.tile || dtype != SGX_F32) return hipErrorNotSupported;
+        a.nbk = a.tile - a.ov;
+        const unsigned long long full = (unsigned long long)(a.nrows - 1) * a.hop + a.ncols;
+        const unsigned long long blocks = (full + a.hop - 1) / a.hop;
+        a.tiles = (unsigned)((blocks + a.nbk - 1) / a.nbk);
+    }
     const unsigned long long g = (unsigned long long)a.tiles * a.batch;
     if (g == 0 || g >= 0x7fffffffull) return hipErrorInvalidConfiguration;
 #define SGX_C2R_F32(A, B, C) if (fa == A && fb == B && fc == C) return launch_c2r_t<float, A, B, C>(a, ltile, lds, s);
@@ -334,6 +407,20 @@ hipError_t launch_c2r_reg(const C2rArgs &a0, int dtype, hipStream_t s) {
 #undef SGX_C2R_F32
 #undef SGX_C2R_F64
     return hipErrorNotSupported;
+}
+
+hipError_t launch_istft_reg(const void *spec, void *out, const void *win, const void *tw, unsigned n, unsigned n_frames, unsigned hop,
+                            unsigned batch, unsigned long long start, unsigned long long out_len, double scale, unsigned *bad_flag,
+                            int dtype, hipStream_t s) {
+    if (hop == 0 || n_frames == 0) return hipErrorNotSupported;
+    C2rArgs c{};
+    c.in = spec; c.out = out;
+    c.nrows = n_frames; c.ncols = n; c.batch = batch;
+    c.in_img = (unsigned long long)(n / 2 + 1) * n_frames;
+    c.in_ks = n_frames; c.in_rs = 1; c.k_fast = 0;  // [bin][frame] (StftResult layout, S9)
+    c.tw = tw; c.scale = scale; c.win = win; c.bad_flag = bad_flag;
+    c.hop = hop; c.start = start; c.out_len = out_len;
+    return launch_c2r_reg(c, dtype, s);
 }
 
 }  // namespace sgx

@@ -817,11 +817,20 @@ sgx_status run_istft(sgx_plan *pl, const void *spec, size_t batch, size_t n_fram
                                      pl->d_itw1, s));
         return SGX_OK;
     }
-    if ((st = grow(pl, &pl->d_frames, &pl->d_frames_bytes, batch * n_frames * n * pl->elem)) != SGX_OK) return st;
-    if ((st = launch_c2r_frames(pl, spec, pl->d_frames, batch, n_frames, true, pl->d_window, s)) != SGX_OK) return st;
     const size_t pad = pl->p.centre ? n / 2 : 0;
     const size_t full = (n_frames - 1) * size_t(pl->p.hop_size) + n;
     const size_t start = out_len == full ? 0 : pad;  // untrimmed when the centred signal would be empty (:4933)
+    // fused register-tiled kernel (every length with a pass split, hop <= n_fft, at most half a tile of halo frames): the windowed
+    // frames never leave the chip
+    if (n_frames <= 0xffffffffull && batch <= 0xffffffffull) {
+        const hipError_t e = launch_istft_reg(spec, out, pl->d_window, pl->d_itw, unsigned(n), unsigned(n_frames), pl->p.hop_size, unsigned(batch),
+                                              start, out_len, pl->dtype == SGX_F64 ? 1.0 / double(n) : double(1.0f / float(n)),
+                                              (unsigned *)pl->d_flag, pl->dtype, s);
+        if (e == hipSuccess) return SGX_OK;
+        if (e != hipErrorNotSupported) SGX_HIP(pl, e);
+    }
+    if ((st = grow(pl, &pl->d_frames, &pl->d_frames_bytes, batch * n_frames * n * pl->elem)) != SGX_OK) return st;
+    if ((st = launch_c2r_frames(pl, spec, pl->d_frames, batch, n_frames, true, pl->d_window, s)) != SGX_OK) return st;
     SGX_HIP(pl, launch_istft_ola(pl->d_frames, pl->d_window, out, unsigned(n), pl->p.hop_size, unsigned(n_frames), start, out_len,
                                  unsigned(batch), pl->dtype, s));
     return SGX_OK;

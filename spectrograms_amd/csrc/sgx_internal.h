@@ -120,6 +120,11 @@ struct C2rArgs {
     // Nyquist bin carries a non-zero imaginary part (realfft's C2R reports FftError::InputValues for that)
     const void *win;
     unsigned *bad_flag;
+    // fused inverse STFT (k_c2r_reg<..., OLA = true>, launch_istft_reg): rows are the frames of one signal, a tile is `tile`
+    // consecutive frames of which the first `ov` are halo (recomputed by the previous tile), the windowed frames stay in LDS and
+    // are overlap-added into out[batch][out_len] (the padded signal from `start`); nrows = n_frames
+    unsigned hop, nbk, ov;
+    unsigned long long start, out_len;
 };
 unsigned fft2d_tile_for(unsigned n, int dtype);
 unsigned c2r_tile_for(unsigned n, int dtype, size_t lds_budget);
@@ -132,6 +137,11 @@ hipError_t launch_c2r_rows(const C2rArgs &a, int dtype, hipStream_t s);
 // or layout — use the LDS-tile kernels above.
 hipError_t launch_c2c_reg(const C2cArgs &a, int dtype, hipStream_t s);
 hipError_t launch_c2r_reg(const C2rArgs &a, int dtype, hipStream_t s);
+// fused inverse STFT for every length with a pass split: spec [batch][n/2+1][n_frames] -> out [batch][out_len]; hipErrorNotSupported:
+// use launch_c2r_reg / launch_c2r_rows into a frame scratch + launch_istft_ola
+hipError_t launch_istft_reg(const void *spec, void *out, const void *win, const void *tw, unsigned n, unsigned n_frames, unsigned hop,
+                            unsigned batch, unsigned long long start, unsigned long long out_len, double scale, unsigned *bad_flag,
+                            int dtype, hipStream_t s);
 inline hipError_t launch_c2c_any(const C2cArgs &a, int dtype, hipStream_t s) {
     const hipError_t e = launch_c2c_reg(a, dtype, s);
     return e == hipErrorNotSupported ? launch_c2c_tile(a, dtype, s) : e;

@@ -124,6 +124,34 @@ def test_gpu_istft_fused_1024_kernel(hop, centre, window, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_fft,hop,centre,window,n", [(512, 128, True, "hanning", 20000), (512, 100, True, "hamming", 20000),
+                                                       (512, 171, False, "hanning", 20000), (512, 512, True, "rectangular", 9000),
+                                                       (400, 160, True, "hanning", 30000), (400, 133, False, "blackman", 9000),
+                                                       (256, 64, True, "hanning", 40000), (128, 32, True, "hanning", 300),
+                                                       (512, 64, True, "hanning", 9000)])
+def test_gpu_istft_fused_register_tiled_kernel(n_fft, hop, centre, window, n):
+    """f32, lengths with a pass split: the fused register-tiled kernel (windowed frames kept in LDS, halo frames recomputed per
+    tile) over many tiles, hops that do not divide n_fft, a signal shorter than one tile, both output windows; hop = n_fft / 8
+    (more halo than a quarter of a tile) takes the frame-scratch path."""
+    x = np.random.default_rng(12).standard_normal((4, n)).astype(np.float32)
+    wt = getattr(sg.WindowType, window)
+    plan = sg.Plan(sg.SpectrogramParams(sg.StftParams(n_fft, hop, wt, centre), 16000.0), _ffi.AMP_COMPLEX, None, None, "float32")
+    S = np.stack([orc.stft(orc.Params(n_fft=n_fft, hop=hop, centre=centre, window=window), r) for r in x])
+    got = plan.istft_batch(S)
+    ref = np.stack([orc.istft(s, n_fft, hop, window, centre) for s in S])
+    assert got.shape == ref.shape
+    w = orc.make_window(window, n_fft)
+    nf = S.shape[2]
+    nrm = np.zeros((nf - 1) * hop + n_fft)
+    for f in range(nf):
+        nrm[f * hop:f * hop + n_fft] += w * w
+    nrm = nrm[n_fft // 2:n_fft // 2 + ref.shape[1]] if centre and ref.shape[1] != nrm.size else nrm
+    scale = np.minimum(1.0, np.sqrt(nrm))[None, :]  # see test_gpu_istft_fused_1024_kernel
+    assert np.max(np.abs(got - ref) * scale) < 2e-5 * max(1.0, np.max(np.abs(ref)))
+    assert np.array_equal(plan.istft_batch(S[2:3])[0], got[2])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype,tol", [("float32", 3e-6), ("float64", 1e-12)])
 def test_gpu_stft_istft_roundtrip_device(dtype, tol):
     """forward on the GPU, inverse on the GPU, device-resident end to end (config-2 shaped rows)."""
