@@ -137,13 +137,13 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_c2c_reg(C2
     }
 }
 
-// Overlap-add of a tile's windowed real frames fr[tile][frs] (LDS) into one signal's output (src/spectrogram.rs:4906-4930): one
-// thread per offset `off` inside a hop block, walking the tile's nbk hop blocks.  Position pos = (h0 + hb) hop + off receives
+// Overlap-add of a tile's frames, read straight from the transform buffer, into one signal's output (src/spectrogram.rs:4906-4930):
+// one thread per offset `off` inside a hop block, walking the tile's nbk hop blocks.  Position pos = (h0 + hb) hop + off receives
 // frames f in [fh - q + 1, fh] (fh = h0 + hb, q = ceil((n - off) / hop)) clipped to [0, n_frames), in ascending f as the reference
 // adds them, frame sample j = (fh - f) hop + off; norm = sum of w[j]^2 (each product rounded, then added), divide where > 1e-10.
-template <typename T>
-__device__ __forceinline__ void ola_tile(const T *fr, unsigned frs, unsigned n, const T *w, T *o, const C2rArgs &a, long long h0, long long fbase,
-                                         unsigned tid) {
+// sample(rr, j): sample j of the tile's row rr, scaled and windowed ((x / n) w, each product rounded as the unfused path rounds it)
+template <typename T, typename F>
+__device__ __forceinline__ void ola_tile(F &&sample, unsigned n, const T *w, T *o, const C2rArgs &a, long long h0, long long fbase, unsigned tid) {
     const unsigned long long p0 = (unsigned long long)h0 * a.hop;
     const long long last = (long long)a.nrows - 1;
     auto sq_add = [](T acc, T wj) {
@@ -159,13 +159,9 @@ __device__ __forceinline__ void ola_tile(const T *fr, unsigned frs, unsigned n, 
             if (pos < a.start || pos - a.start >= a.out_len) continue;
             const long long fh = h0 + hb;
             const long long f_lo = max(fh - (long long)q + 1, 0ll), f_hi = min(fh, last);
-            const unsigned cnt = f_hi >= f_lo ? (unsigned)(f_hi - f_lo + 1) : 0u;
             T acc = T(0), nrm = nrm_full;
-            if (cnt) {
-                const T *src = fr + (size_t)(unsigned)(f_lo - fbase) * frs + (unsigned)(fh - f_lo) * a.hop + off;
-                for (unsigned i = 0; i < cnt; ++i) acc += src[(long long)i * ((long long)frs - (long long)a.hop)];  // next frame: row + 1, j - hop
-            }
-            if (cnt != q) {  // signal edges: fewer frames
+            for (long long f = f_lo; f <= f_hi; ++f) acc += sample((unsigned)(f - fbase), (unsigned)(fh - f) * a.hop + off);
+            if (f_hi - f_lo + 1 != (long long)q) {  // signal edges: fewer frames
                 nrm = T(0);
                 for (long long f = f_lo; f <= f_hi; ++f) nrm = sq_add(nrm, w[(unsigned)(fh - f) * a.hop + off]);
             }
@@ -183,11 +179,9 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_c2r_reg(C2
     constexpr bool P2 = ct_is_pow2(M);
     typedef RrLayout<sizeof(V), A_, B_, C_> L;
     constexpr unsigned RS = L::RS, FS = L::FS;
-    constexpr unsigned SXS = (M + 1) | 1u;  // row stride of the staged half spectrum (odd)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned tid = threadIdx.x, tile = 1u << ltile;
-    V *sx = (V *)smem;                    // [tile][SXS] bins 0 .. M
-    V *buf = sx + (size_t)tile * SXS;     // [tile][FS]
+    V *buf = (V *)smem;                   // [tile][FS]
     const unsigned lb = xcd_logical_block(a.tiles * a.batch);
     if (lb >= a.tiles * a.batch) return;
     const unsigned t = lb % a.tiles, b = lb / a.tiles;
@@ -201,38 +195,31 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_c2r_reg(C2
     const V *tw = (const V *)a.tw;  // W_CN^k, CN entries
     auto wrap = [](unsigned e) { return P2 ? (e & (CN - 1)) : (e % CN); };
 
-    // stage the half spectrum, 8 loads in flight per thread
-    for (unsigned base = 0; base < tile * (M + 1); base += 8u * 256u) {
-        V v[8];
-        unsigned rr[8], k[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const unsigned idx = base + u * 256u + tid;
-            if (a.k_fast) { k[u] = idx % (M + 1); rr[u] = idx / (M + 1); } else { rr[u] = idx & (tile - 1); k[u] = idx >> ltile; }
-            if (idx >= tile * (M + 1)) rr[u] = tile;  // past the tile: skipped below
-            v[u] = rr[u] < tile && row_ok(rr[u]) ? in[(size_t)k[u] * a.in_ks + (size_t)(fbase + rr[u]) * a.in_rs] : (V){T(0), T(0)};
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (rr[u] >= nr) continue;
-            if (row_ok(rr[u]) && (k[u] == 0 || k[u] == M)) {  // DC / Nyquist columns forced real; realfft reports a non-zero imaginary part
-                if (a.bad_flag && v[u].y != T(0)) atomicOr(a.bad_flag, 1u);
-                v[u].y = T(0);
-            }
-            sx[(size_t)rr[u] * SXS + k[u]] = v[u];
-        }
-    }
-    __syncthreads();
-    for (unsigned idx = tid; idx < nr * BC; idx += 256) {
-        const unsigned r = idx % BC, rr = idx / BC;
-        const V *xr = sx + (size_t)rr * SXS;
-        V v[A];
+    // pass 1: every item loads its A pairs (X[k], X[m - k]) itself — lanes run along the contiguous axis of the input (rows for
+    // the [bin][frame] spectra of the inverse STFT, bins for the [row][bin] spectra of the 2-D path), 2 A loads in flight a thread
+    for (unsigned idx = tid; idx < tile * BC; idx += 256) {
+        unsigned r, rr;
+        if (a.k_fast) { r = idx % BC; rr = idx / BC; } else { rr = idx & (tile - 1); r = idx >> ltile; }
+        const bool ok = row_ok(rr);  // rows past the image / frames outside the signal transform zeros
+        const V *xp = in + (ok ? (size_t)(fbase + rr) * a.in_rs : 0);
+        V Xa[A], Yb[A];
 #pragma unroll
         for (unsigned n1 = 0; n1 < A; ++n1) {
             const unsigned k = BC * n1 + r;
-            const V Xa = xr[k], Yb = xr[M - k], w = tw[k];
+            Xa[n1] = ok ? xp[(size_t)k * a.in_ks] : (V){T(0), T(0)};
+            Yb[n1] = ok ? xp[(size_t)(M - k) * a.in_ks] : (V){T(0), T(0)};
+        }
+        if (r == 0) {  // k = 0: DC and Nyquist bins forced real; realfft reports a non-zero imaginary part
+            if (a.bad_flag && (Xa[0].y != T(0) || Yb[0].y != T(0))) atomicOr(a.bad_flag, 1u);
+            Xa[0].y = T(0);
+            Yb[0].y = T(0);
+        }
+        V v[A];
+#pragma unroll
+        for (unsigned n1 = 0; n1 < A; ++n1) {
+            const V w = tw[BC * n1 + r];
             // S = X[k] + conj X[m-k], D = X[k] - conj X[m-k], T = conj(W^k) D; the forward-transform trick wants conj(S + i T)
-            const V S = inreg::pfma(Yb, (V){T(1), T(-1)}, Xa), D = inreg::pfma(Yb, (V){T(-1), T(1)}, Xa);
+            const V S = inreg::pfma(Yb[n1], (V){T(1), T(-1)}, Xa[n1]), D = inreg::pfma(Yb[n1], (V){T(-1), T(1)}, Xa[n1]);
             const V Tt = inreg::cmulv(D, (V){w.x, -w.y});
             v[n1] = inreg::pfma(inreg::swp(Tt), (V){T(-1), T(-1)}, S * (V){T(1), T(-1)});
         }
@@ -247,7 +234,7 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_c2r_reg(C2
         for (unsigned k1 = 1; k1 < A; ++k1) (dst + (pp ^ L::k1_mask(k1)))[k1 * RS] = inreg::cmulv(v[k1], rr_twiddle<LA>(pw2, k1));
     }
     __syncthreads();
-    for (unsigned idx = tid; idx < nr * A * C; idx += 256) {
+    for (unsigned idx = tid; idx < tile * A * C; idx += 256) {
         const unsigned rr = idx / (A * C), q = idx % (A * C), k1 = q / C, n3 = q % C;
         V *row = buf + (size_t)rr * FS + k1 * RS;
         const unsigned lp = n3 ^ L::k1_mask(k1);
@@ -269,7 +256,7 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_c2r_reg(C2
     }
     __syncthreads();
     if constexpr (C > 1) {
-        for (unsigned idx = tid; idx < nr * A * B; idx += 256) {
+        for (unsigned idx = tid; idx < tile * A * B; idx += 256) {
             const unsigned rr = idx / (A * B), q = idx % (A * B), k1 = q / B, k2 = q % B;
             V *row = buf + (size_t)rr * FS + k1 * RS;
             const unsigned lp = L::hi_part(k2) ^ L::k1_mask(k1);
@@ -286,18 +273,15 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_c2r_reg(C2
     const T sc = (T)a.scale;
     const V *win = (const V *)a.win;
     if constexpr (OLA) {
-        // the windowed frames stay on chip: real rows over the (dead) staged spectrum, then the overlap-add
-        V *fr = sx;  // [tile][SXS] pairs = rows of 2 SXS reals
-        for (unsigned idx = tid; idx < tile * M; idx += 256) {
-            const unsigned n = idx % M, rr = idx / M;
-            V v = buf[(size_t)rr * FS + L::of_output(n)] * (V){sc, -sc};
-            const V w2 = win[n];
-            if constexpr (sizeof(T) == 4) v = (V){__fmul_rn(v.x, w2.x), __fmul_rn(v.y, w2.y)};
-            else v = (V){__dmul_rn(v.x, w2.x), __dmul_rn(v.y, w2.y)};
-            fr[(size_t)rr * SXS + n] = v;
-        }
-        __syncthreads();
-        ola_tile<T>((const T *)fr, 2u * SXS, CN, (const T *)a.win, (T *)a.out + (size_t)b * a.out_len, a, h0, fbase, tid);
+        // the frames stay on chip: the overlap-add picks sample j of row rr out of the transform buffer (pair j / 2, real part
+        // for even j, minus the imaginary part for odd j), scales and windows it as the unfused path does
+        const T *w = (const T *)a.win;
+        ola_tile<T>([&](unsigned rr, unsigned j) {
+            const V z = buf[(size_t)rr * FS + L::of_output(j >> 1)];
+            const T x = ((j & 1u) ? -z.y : z.x) * sc;
+            if constexpr (sizeof(T) == 4) return __fmul_rn(x, w[j]);
+            else return __dmul_rn(x, w[j]);
+        }, CN, w, (T *)a.out + (size_t)b * a.out_len, a, h0, fbase, tid);
     } else {
         for (unsigned idx = tid; idx < nr * M; idx += 256) {
             const unsigned n = idx % M, rr = idx / M;
@@ -372,10 +356,17 @@ hipError_t launch_c2r_reg(const C2rArgs &a0, int dtype, hipStream_t s) {
     const size_t es = elem_size(dtype);
     if (((size_t)a0.in | (size_t)a0.out | (size_t)a0.win) & (2 * es - 1)) return hipErrorNotSupported;
     const size_t m = a0.ncols / 2;
-    const size_t per = ((size_t)rr_frame_stride(fa, rr_swizzle(2 * (unsigned)es, fa, fb, fc).rs) + ((m + 1) | 1)) * 2 * es;
+    const size_t per = (size_t)rr_frame_stride(fa, rr_swizzle(2 * (unsigned)es, fa, fb, fc).rs) * 2 * es;
+    (void)m;
     const bool ola = a0.hop != 0;  // fused inverse STFT (launch_istft_reg)
+#ifndef SGX_C2R_KB
+#define SGX_C2R_KB 40
+#endif
+    // rows per workgroup: up to 32, within a quarter of a CU's LDS — four workgroups per CU overlap their load, transform and
+    // store phases (measured: f32 n_fft 512 inverse STFT 0.65 ms with 32-frame tiles at two per CU, 0.49 ms with 16-frame tiles)
+    const size_t c2r_budget = dtype == SGX_F64 ? kR2Budget : (size_t)SGX_C2R_KB * 1024;  // (f64: n_fft 400 0.90 vs 1.14 ms with the larger tile)
     unsigned ltile = 5;
-    while (ltile > 0 && ((size_t)(1u << ltile) * per > kR2Budget || (!ola && (1u << (ltile - 1)) >= a0.nrows))) --ltile;
+    while (ltile > 0 && ((size_t)(1u << ltile) * per > c2r_budget || (!ola && (1u << (ltile - 1)) >= a0.nrows))) --ltile;
     const size_t lds = (size_t)(1u << ltile) * per;
     if (lds > kR2Budget) return hipErrorNotSupported;
     C2rArgs a = a0;
@@ -384,8 +375,9 @@ hipError_t launch_c2r_reg(const C2rArgs &a0, int dtype, hipStream_t s) {
     a.nbk = 0;
     if (ola) {
         // `ov` halo frames per tile are transformed twice: fused only while at least three quarters of a tile's frames are its
-        // own, and in f32 (measured, 256 x 10 s: f32 n_fft 512 / hop 128 0.90 -> 0.81 ms, 400 / 160 0.75 -> 0.71 ms; f64 tiles hold
-        // half as many frames and lose: 1024 / 256 1.18 -> 1.20 ms, 400 / 160 1.47 -> 1.85 ms)
+        // own, and in f32 (measured, 256 x 10 s, against rows into a frame scratch + k_istft_ola: f32 n_fft 512 / hop 128 0.90 ->
+        // 0.81 ms with the spectrum staged through LDS, 0.49 ms with the direct loads; f64, whose tiles hold half as many frames:
+        // 512 / 128 1.03 -> 0.95 ms but 400 / 160 0.89 -> 0.96 ms and 256 / 64 1.00 -> 1.19 ms: not fused)
         a.ov = (a.ncols - 1u) / a.hop;
         if (a.hop > a.ncols || !a.win || 4 * a.ov > a.tile || dtype != SGX_F32) return hipErrorNotSupported;
         a.nbk = a.tile - a.ov;
