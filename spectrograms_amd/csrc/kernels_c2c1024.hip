@@ -23,19 +23,25 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int kCFS = 8192 + 16;     // LDS bytes per sequence (odd multiple of 16: conflict-free b128 row reads)
 constexpr int kCLds = 16 * kCFS;    // 131328 B -> one workgroup per CU
 
-template <bool IN_SEQ_FAST, bool INVERSE>
-__global__ __launch_bounds__(512, 2) void k_c2c1024(C2cArgs a, const v2f *tw1c) {
+// NS sequences per workgroup of 32 NS threads: 16 -> 131 KB, one workgroup of 8 waves per CU; 8 -> 66 KB, two independent
+// workgroups per CU whose load / transform / store phases could overlap, but with 64-byte instead of 128-byte segments on both
+// sides — measured slower (config 5 fft2d 1.78 vs 1.63 ms), so 16 it is
+#ifndef SGX_C2C1024_NS
+#define SGX_C2C1024_NS 16
+#endif
+template <bool IN_SEQ_FAST, bool INVERSE, unsigned NS>
+__global__ __launch_bounds__(32 * NS, 2) void k_c2c1024(C2cArgs a, const v2f *tw1c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned tid = threadIdx.x;
     const unsigned lb = xcd_logical_block(a.tiles * a.batch);
     if (lb >= a.tiles * a.batch) return;
     const unsigned t = lb % a.tiles, b = lb / a.tiles;
-    const unsigned s0 = t * 16u;
+    const unsigned s0 = t * NS;
     const v2f *in = (const v2f *)a.in + (size_t)b * a.in_img;
     v2f *out = (v2f *)a.out + (size_t)b * a.out_img;
     // ------------------------------------------------------------------ pass 1
     {
-        const unsigned s = IN_SEQ_FAST ? (tid & 15u) : (tid >> 5), n2 = IN_SEQ_FAST ? (tid >> 4) : (tid & 31u);
+        const unsigned s = IN_SEQ_FAST ? (tid & (NS - 1u)) : (tid >> 5), n2 = IN_SEQ_FAST ? (tid / NS) : (tid & 31u);
         const bool valid = s0 + s < a.nseq;
         v2f v[32];
         const v2f *p = in + (size_t)(s0 + s) * a.in_ss + (size_t)n2 * a.in_is;
@@ -64,8 +70,8 @@ __global__ __launch_bounds__(512, 2) void k_c2c1024(C2cArgs a, const v2f *tw1c) 
     __syncthreads();
     // ------------------------------------------------------------------ pass 2
     {
-        const unsigned w = tid >> 6, l = tid & 63u, jq = l >> 4, s = l & 15u;
-        const unsigned k1 = w * 4u + jq;
+        const unsigned w = tid >> 6, l = tid & 63u, jq = l / NS, s = l & (NS - 1u);
+        const unsigned k1 = w * (64u / NS) + jq;
         v2f x[32];
         const v4f *row = (const v4f *)(smem + s * kCFS + k1 * 256);
 #pragma unroll
@@ -568,23 +574,29 @@ hipError_t launch_c2r1024(const C2rArgs &a, const void *twr, const void *tw1, hi
     return hipGetLastError();
 }
 
-hipError_t launch_c2c1024(const C2cArgs &a, const void *tw1c, hipStream_t s) {
+hipError_t launch_c2c1024(const C2cArgs &a0, const void *tw1c, hipStream_t s) {
+    constexpr unsigned NS = SGX_C2C1024_NS;
+    constexpr int lds = (int)NS * kCFS;
+    C2cArgs a = a0;
+    a.tile = NS;
+    a.tiles = (a.nseq + NS - 1) / NS;
     const unsigned long long g = (unsigned long long)a.tiles * a.batch;
     if (g == 0 || g >= 0x7fffffffull || a.n != 1024) return hipErrorInvalidConfiguration;
     {
         hipError_t e;
-        if ((e = set_max_dynamic_lds((const void *)k_c2c1024<false, false>, kCLds)) != hipSuccess) return e;
-        if ((e = set_max_dynamic_lds((const void *)k_c2c1024<false, true>, kCLds)) != hipSuccess) return e;
-        if ((e = set_max_dynamic_lds((const void *)k_c2c1024<true, false>, kCLds)) != hipSuccess) return e;
-        if ((e = set_max_dynamic_lds((const void *)k_c2c1024<true, true>, kCLds)) != hipSuccess) return e;
+        if ((e = set_max_dynamic_lds((const void *)k_c2c1024<false, false, NS>, lds)) != hipSuccess) return e;
+        if ((e = set_max_dynamic_lds((const void *)k_c2c1024<false, true, NS>, lds)) != hipSuccess) return e;
+        if ((e = set_max_dynamic_lds((const void *)k_c2c1024<true, false, NS>, lds)) != hipSuccess) return e;
+        if ((e = set_max_dynamic_lds((const void *)k_c2c1024<true, true, NS>, lds)) != hipSuccess) return e;
     }
     const v2f *tw = (const v2f *)tw1c;
+    const dim3 grid(xcd_grid(g)), block(32 * NS);
     if (a.in_seq_fast) {
-        if (a.inverse) hipLaunchKernelGGL((k_c2c1024<true, true>), dim3(xcd_grid(g)), dim3(512), kCLds, s, a, tw);
-        else hipLaunchKernelGGL((k_c2c1024<true, false>), dim3(xcd_grid(g)), dim3(512), kCLds, s, a, tw);
+        if (a.inverse) hipLaunchKernelGGL((k_c2c1024<true, true, NS>), grid, block, lds, s, a, tw);
+        else hipLaunchKernelGGL((k_c2c1024<true, false, NS>), grid, block, lds, s, a, tw);
     } else {
-        if (a.inverse) hipLaunchKernelGGL((k_c2c1024<false, true>), dim3(xcd_grid(g)), dim3(512), kCLds, s, a, tw);
-        else hipLaunchKernelGGL((k_c2c1024<false, false>), dim3(xcd_grid(g)), dim3(512), kCLds, s, a, tw);
+        if (a.inverse) hipLaunchKernelGGL((k_c2c1024<false, true, NS>), grid, block, lds, s, a, tw);
+        else hipLaunchKernelGGL((k_c2c1024<false, false, NS>), grid, block, lds, s, a, tw);
     }
     return hipGetLastError();
 }
