@@ -516,9 +516,7 @@ __global__ __launch_bounds__(256, (rr_stft_waves<T, A_, B_, C_, STAGED_>())) voi
         // the thread index is opaque from here on: the element addresses of passes 2, 3 and the split are recomputed per tile
         // (a few integer operations) instead of being carried through the whole loop in registers
         unsigned tl = tid;
-#ifndef SGX_NO_TL
         asm volatile("" : "+v"(tl));
-#endif
         for (unsigned idx = tl; idx < nf * A * C; idx += 256) {
             const unsigned f = idx / (A * C), q = idx % (A * C), k1 = q / C, n3 = q % C;
             V *row = buf + (size_t)f * FS + k1 * RS;
