@@ -50,8 +50,10 @@ struct Cx {
 
 __device__ inline float t_sqrt(float v) { return sqrtf(v); }
 __device__ inline double t_sqrt(double v) { return sqrt(v); }
-__device__ inline float t_log10(float v) { return log10f(v); }
-__device__ inline double t_log10(double v) { return log10(v); }
+// 10 log10(v).  f32: (10 log10 2) log2(v) — the hardware's log2 and one multiply instead of log10f's extra-precision product
+// (< 2e-5 dB off at |dB| <= 100); f64: 10 log10(v)
+__device__ inline float t_db(float v) { return __builtin_log2f(v) * 3.01029995663981195f; }
+__device__ inline double t_db(double v) { return 10.0 * log10(v); }
 __device__ inline float t_max(float a, float b) { return fmaxf(a, b); }
 __device__ inline double t_max(double a, double b) { return fmax(a, b); }
 // un-fused multiply-add: the reference's `acc += T::from_f64(w) * x` is two roundings (rustc never contracts)
@@ -61,7 +63,7 @@ __device__ inline double t_mul_add_unfused(double a, double b, double c) { retur
 template <typename T>
 __device__ inline T amp_apply(T p, int amp, T eps) {
     if (amp == AMP_MAGNITUDE) return t_sqrt(p);
-    if (amp == AMP_DB) return T(10) * t_log10(t_max(p, eps));
+    if (amp == AMP_DB) return t_db(t_max(p, eps));
     return p;
 }
 
@@ -606,7 +608,7 @@ __global__ __launch_bounds__(256, (rr_stft_waves<T, A_, B_, C_, STAGED_>())) voi
                 } else {
                     T *o = (T *)a.out + ob;
                     if (a.amp == AMP_MAGNITUDE) split_frame(f, k0, kstep, [&](unsigned k, V X) { o[(size_t)k * a.n_frames] = t_sqrt(X.x * X.x + X.y * X.y); });
-                    else if (a.amp == AMP_DB) split_frame(f, k0, kstep, [&](unsigned k, V X) { o[(size_t)k * a.n_frames] = T(10) * t_log10(t_max(X.x * X.x + X.y * X.y, eps)); });
+                    else if (a.amp == AMP_DB) split_frame(f, k0, kstep, [&](unsigned k, V X) { o[(size_t)k * a.n_frames] = t_db(t_max(X.x * X.x + X.y * X.y, eps)); });
                     else
 #ifdef SGX_ABL_NOSTORE
                         split_frame(f, k0, kstep, [&](unsigned k, V X) { if (X.x == T(1.2345e30)) o[(size_t)k * a.n_frames] = X.x * X.x + X.y * X.y; });
