@@ -307,7 +307,7 @@ def main() -> int:
             # is algorithmic bytes / kernel time.  The kernel is bounded by its arithmetic + LDS work next to the HBM stream, not by
             # HBM alone: `valu_frac` is its share of the FP32 vector peak, `hbm_read_frac` north_star's read-only line.
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(kernel_wl), "kernel_ms": kernel_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(kernel_wl) if batch == 256 else None, "kernel_ms": kernel_ms,
                          "kernel_ms_scope": "HIP events over the timed region" if (gathered is None and overlap is None) else "compute only (separate back-to-back launches, no gather)", "algorithmic_bytes_per_frame": rd + wr,
                          "frames_per_launch": frames_per_launch, "hbm_read_frac": rd * kernel_fps / 1e9 / HBM_PEAK_GBS,
                          "valu_frac": valu_frac, "flops_per_frame": FLOPS_PER_FRAME[kernel_wl],
