@@ -823,11 +823,20 @@ __global__ __launch_bounds__(256) void k_mfcc_acc(const T *mel, T *out, const T 
     T acc[NC];
 #pragma unroll
     for (int k = 0; k < NC; ++k) acc[k] = T(0);
-    for (unsigned i = 0; i < n_mels; ++i) {
-        const T v = m[(size_t)i * n_frames];
-        const T *bi = sb + i * NC;
+    // 16 bands at a time: their Mel values are requested together (one memory round trip per 16 bands instead of one per band),
+    // then folded in ascending band order as before
+    for (unsigned i0 = 0; i0 < n_mels; i0 += 16) {
+        T v[16];
 #pragma unroll
-        for (int k = 0; k < NC; ++k) acc[k] = fma(v, bi[k], acc[k]);
+        for (int u = 0; u < 16; ++u) v[u] = i0 + u < n_mels ? m[(size_t)(i0 + u) * n_frames] : T(0);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (i0 + u < n_mels) {
+                const T *bi = sb + (i0 + u) * NC;
+#pragma unroll
+                for (int k = 0; k < NC; ++k) acc[k] = fma(v[u], bi[k], acc[k]);
+            }
+        }
     }
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
