@@ -118,6 +118,23 @@ __device__ __forceinline__ void read_cols(v2f (&x)[16], v2f (&w)[16], unsigned x
     ((ds_read64<col_off<XSPAD, 2 * K + PAR>()>(x[K], xaddr), ds_read64<(2 * K + PAR) * 128>(w[K], waddr)), ...);
 }
 
+// P512: z[n] = (a[n], b[n]) with n = 16 n1 + n2 — sample n of frame 2 p and of frame 2 p + 1, one hop (512 B) apart — as ONE
+// ds_read2_b32 into the register pair.  Byte offset of sample s of a slot = 4 s + 64 per KiB crossed (the slot base sits on a KiB
+// boundary of the padded staging buffer); a base address per four n1 keeps both 8-bit dword offsets in range.
+constexpr int p512_off_a(int n1) { return 64 * n1 + (n1 >> 4) * 64; }
+constexpr int p512_off_b(int n1) { return 64 * n1 + 512 + ((n1 + 8) >> 4) * 64; }
+template <int O0, int O1>
+__device__ __forceinline__ void ds_read2x32(v2f &d, unsigned addr) {
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(d) : "v"(addr), "n"(O0), "n"(O1));
+}
+template <int PAR, int... K>
+__device__ __forceinline__ void read_cols512(v2f (&x)[16], v2f (&w)[16], const unsigned (&base)[8], unsigned waddr, std::integer_sequence<int, K...>) {
+    ((ds_read2x32<(p512_off_a(2 * K + PAR) - p512_off_a((2 * K + PAR) & ~3)) / 4, (p512_off_b(2 * K + PAR) - p512_off_a((2 * K + PAR) & ~3)) / 4>(
+          x[K], base[(2 * K + PAR) >> 2]),
+      ds_read64<(2 * K + PAR) * 128>(w[K], waddr)),
+     ...);
+}
+
 // per-lane pass-1 twiddle tables: W_512^(k1*n2) = twa[k1>>3] * twb[k1&7]
 __device__ __forceinline__ void load_tw1(const StftArgs &a, unsigned n2, v2f (&twa)[4], v2f (&twb)[8]) {
     const v2f *t1 = (const v2f *)a.tw1 + n2;
@@ -243,6 +260,64 @@ __device__ __forceinline__ void pass2_compute(v2f (&A)[16], v2f (&B)[16], bool j
     }
     if (j0) emit(omid, 0u, pw_mid, a8 * (v2f){2.f, -2.f}, false);  // X[256] = 2 conj(Z[256]) (row 0, k2 = 8)
     SGX_STAMP(10);  // real split (+ direct stores / LDS writes)
+}
+
+// n_fft = 512, two frames per transform (P512): the slot's 512-point complex sequence is z[n] = a[n] + i b[n] of two consecutive
+// frames a, b (windowed, pre-halved), so the pair (P, Q) = (Z[k], Z[512-k]) gives both frames' bin k without a twiddle:
+//   A[k] = P + conj Q = E,   B[k] = -i (P - conj Q) = (D.y, -D.x)
+// — one 8-byte (power / magnitude / dB) or 16-byte (complex) store per pair: bin k of frames 2 p and 2 p + 1, which are adjacent
+// in memory.  Pairs with k > 256 (the second loop of every job but job 0) are the conjugates of bin 512 - k.  `vfull` is the
+// lane's byte offset when both frames exist, `vhalf` when only the first does (the other being out of range: dropped).
+template <int MODE, int AMP>
+__device__ __forceinline__ void pass2_pair512(v2f (&A)[16], v2f (&B)[16], bool j0, float eps, __amdgpu_buffer_rsrc_t ro, unsigned vfull1,
+                                              unsigned vhalf1, unsigned vfull2, unsigned vhalf2, unsigned vfullm, unsigned vhalfm, unsigned step) {
+    Fft<16, false>::run(A, A);
+    Fft<16, false>::run(B, B);
+    const v2f a8 = A[8];
+    if (j0) {  // as pass2_compute: job 0's two self-paired rows rearranged into the general pairing
+        v2f nA[16], nB[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { nA[i] = B[i]; nA[8 + i] = A[i]; }
+        nB[7] = A[0];
+#pragma unroll
+        for (int t = 1; t < 8; ++t) nB[7 - t] = A[16 - t];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) A[i] = nA[i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) B[i] = nB[i];
+        asm volatile("" ::: "memory");
+    }
+    auto emit = [&](unsigned vfull, unsigned vhalf, int soff, v2f Xa, v2f Xb, bool conj) {
+        if constexpr (MODE == OUT_COMPLEX) {
+            const float sg = conj ? -1.f : 1.f;
+            const v4f V = (v4f){Xa.x, sg * Xa.y, Xb.x, sg * Xb.y};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, V), ro, (int)vfull, soff, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, (v2f){V.x, V.y}), ro, (int)vhalf, soff, 0);
+        } else {
+            const v2f V = (v2f){amp_f32<AMP>(power_of(Xa), eps), amp_f32<AMP>(power_of(Xb), eps)};
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, V), ro, (int)vfull, soff, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, V.x), ro, (int)vhalf, soff, 0);
+        }
+    };
+    auto pair = [&](v2f P, v2f Q, v2f &Xa, v2f &Xb) {
+        Xa = pfma(Q, (v2f){1.f, -1.f}, P);                 // E
+        const v2f D = pfma(Q, (v2f){-1.f, 1.f}, P);
+        Xb = (v2f){D.y, -D.x};
+    };
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // k = c1 + 32 i < 256: rows ascending
+        v2f Xa, Xb;
+        pair(A[i], B[15 - i], Xa, Xb);
+        emit(vfull1, vhalf1, i * (int)step, Xa, Xb, false);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {  // job 0: k = 32 t (rows ascending); other jobs: k = j + 256 + 32 t -> row 256 - j - 32 t, conjugated
+        v2f Xa, Xb;
+        pair(A[8 + t], B[7 - t], Xa, Xb);
+        if (j0) emit(vfull2 + t * step, vhalf2 + t * step, 0, Xa, Xb, false);
+        else emit(vfull2 + (7 - t) * step, vhalf2 + (7 - t) * step, 0, Xa, Xb, true);
+    }
+    if (j0) emit(vfullm, vhalfm, 0, (v2f){2.f * a8.x, 0.f}, (v2f){2.f * a8.y, 0.f}, false);  // bin 256: Z[256] pairs with itself
 }
 
 // ---- filterbank stage, generic forms (|X|^2 tile stored pw[f][k], kPS floats per frame) -----------------------------------
@@ -397,10 +472,17 @@ __device__ __forceinline__ void mel_tile_sched(const StftArgs &a, const float *p
 // XSPAD (hop = 256): the staging buffer carries 128 B of padding per KiB, which keeps the 4 frames of a wave on distinct banks.
 // PWT (filterbank outputs): |X|^2 tile transposed + schedule (else pw[f][k] + matrix cores / CSR).
 // ====================================================================================================================
-template <int MODE, int AMP, int ROUNDS, bool WIDE, bool XSPAD, bool PWT>
+// P512 (n_fft = 512, hop = 128, per-bin outputs): a tile is 32 frames, a slot of the exchange buffer holds the 512-point complex
+// transform of TWO consecutive frames (real parts: frame 2 p, imaginary parts: frame 2 p + 1); passes 1 and 2 are unchanged (the
+// same 32 x 16 transform), the real split becomes the two-sequence split (pass2_pair512).  The staged samples carry 64 B of
+// padding per KiB: the four slots of a wave start 1 KiB apart and would otherwise read the same banks.
+template <int MODE, int AMP, int ROUNDS, bool WIDE, bool XSPAD, bool PWT, bool P512 = false>
 __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd, unsigned total, unsigned slots) {
     static_assert(!WIDE || MODE != OUT_MEL, "wide pass 2 needs a per-bin output");
     static_assert(!PWT || MODE == OUT_MEL, "PWT is a filterbank layout");
+    static_assert(!P512 || (!WIDE && !XSPAD && !PWT && MODE != OUT_MEL && ROUNDS > 0), "P512: per-bin outputs, staged samples");
+    constexpr unsigned FPT = P512 ? 32u : 16u;   // frames per tile
+    constexpr unsigned NB = P512 ? 257u : 513u;  // bins
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     const unsigned half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
     const unsigned tid = threadIdx.x & 255u;
@@ -440,27 +522,29 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
     constexpr int NCR = ROUNDS > 0 ? ROUNDS : 1;
     v4f creg[NCR];
     v2f xd[ROUNDS > 0 ? 1 : 32];
-    const unsigned chunks = XSPAD ? 1216u : (15u * a.hop + 1024u + 3u) >> 2;
-    const unsigned hop = XSPAD ? 256u : a.hop;
+    const unsigned chunks = XSPAD ? 1216u : P512 ? (31u * 128u + 512u + 3u) >> 2 : (15u * a.hop + 1024u + 3u) >> 2;
+    const unsigned hop = XSPAD ? 256u : P512 ? 128u : a.hop;
     const unsigned row_bytes = (unsigned)a.n_samples * 4u;  // host: n_samples < 2^29
     auto load_tile = [&](unsigned w) {
         const unsigned b = w / a.tiles, tile = w - b * a.tiles;
-        const unsigned f0 = tile * 16u;
+        const unsigned f0 = tile * FPT;
         const __amdgpu_buffer_rsrc_t rx = make_rsrc((const float *)a.x + (size_t)b * a.sample_stride, row_bytes);
         // first sample of the tile relative to the row; negative in the left padding: as an unsigned byte offset it is far out
         // of range, so the hardware returns 0 there as it does past the end of the row (S1: zero padding)
         const int tile_lo = (int)(f0 * hop) - (int)a.pad;
-        const bool interior = tile_lo >= 0 && (unsigned)tile_lo + 15u * hop + 1024u <= (unsigned)a.n_samples;  // wave-uniform
+        const bool interior = tile_lo >= 0 && (unsigned)tile_lo + (FPT - 1u) * hop + (P512 ? 512u : 1024u) <= (unsigned)a.n_samples;  // wave-uniform
         if constexpr (ROUNDS > 0) {
 #ifdef SGX_ABL_NOGLOAD
             for (int r = 0; r < ROUNDS; ++r) creg[r] = (v4f){(float)w, 1.f, 2.f, (float)r};
             return;
 #endif
             const int vo = (tile_lo + 4 * (int)tid) * 4;
-            if (interior) {  // reads up to 64 chunks past the tile (the next tile's samples: L2 hits, or 0 past the row)
+            // (P512: one path — the compiler merges the edge path's four dword loads into the same 16-byte load anyway, the range
+            // check being per dword, and two exclusive paths over the same registers cost the edge tiles a wait for the stores)
+            if (interior || P512) {  // reads up to 64 chunks past the tile (the next tile's samples: L2 hits, or 0 past the row)
 #pragma unroll
                 for (int r = 0; r < ROUNDS; ++r)
-                    if (XSPAD || r * 256u + tid < chunks) creg[r] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rx, vo + r * 4096, 0, 0));
+                    if (XSPAD || P512 || r * 256u + tid < chunks) creg[r] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rx, vo + r * 4096, 0, 0));
             } else {  // edge tile: dword loads, each bounds-checked on its own
 #pragma unroll
                 for (int r = 0; r < ROUNDS; ++r) {
@@ -517,8 +601,8 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
 #endif
     while (lead < hi) {
         const unsigned b = wid / a.tiles, tile = wid - b * a.tiles;
-        const unsigned f0 = tile * 16u;
-        const unsigned nf = min(16u, a.n_frames - f0);
+        const unsigned f0 = tile * FPT;
+        const unsigned nf = min(FPT, a.n_frames - f0);
         v2f xr[32];
         {
             v2f e[16], o[16], we[16], wo[16];
@@ -527,15 +611,25 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
 #pragma unroll
                 for (int r = 0; r < ROUNDS; ++r) {
                     const unsigned c = r * 256u + tid;
-                    if (XSPAD || c < chunks) *(v4f *)(smem + c * 16u + (XSPAD ? (c >> 6) * 128u : 0u)) = creg[r];
+                    if (XSPAD || P512 || c < chunks) *(v4f *)(smem + c * 16u + (XSPAD ? (c >> 6) * 128u : P512 ? (c >> 6) * 64u : 0u)) = creg[r];
                 }
                 SGX_STAMP(0);  // wait for the samples + staging writes
                 __syncthreads();  // barrier 1: xs complete
                 SGX_STAMP(1);
+                if constexpr (P512) {
+                    unsigned base[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) base[q] = lds_addr(smem) + p1f * (1024u + 64u) + n2 * 4u + (unsigned)p512_off_a(4 * q);
+                    read_cols512<0>(e, we, base, waddr, std::make_integer_sequence<int, 16>{});
+                    read_cols512<1>(o, wo, base, waddr, std::make_integer_sequence<int, 16>{});
+                    tie16<15>(e);
+                    tie16<-1>(we);
+                } else {
                 read_cols<XSPAD, 0>(e, we, xaddr, waddr, std::make_integer_sequence<int, 16>{});
                 read_cols<XSPAD, 1>(o, wo, xaddr, waddr, std::make_integer_sequence<int, 16>{});
                 tie16<15>(e);  // at most 15 of the 64 reads outstanding: the 32 of (e, we) have landed
                 tie16<-1>(we);
+                }
             } else {
                 const v2f *w2 = (const v2f *)(tabs + kWinOff) + n2;
 #pragma unroll
@@ -589,6 +683,9 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
             // (513 n_frames elements: the host guarantees 2 * 513 * n_frames * 8 < 2^32)
             p2ofs = (second ? f01 : f00) + fle + ((second && b1 != b0) ? 513u * a.n_frames : 0u);
             p2b = b0;
+        } else if constexpr (P512) {
+            p2ex = p2f;             // slot
+            p2ofs = f0 + 2u * p2f;  // its first frame
         } else {
             const unsigned p2f_eff = ALLSTORE ? min(p2f, nf - 1u) : p2f;
             p2ex = p2f_eff;
@@ -607,7 +704,16 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
                 if (tid < 48u) pwf[(tid / 3u) * kPS + 513u + tid % 3u] = 0.0f;
             }
         }
-        if (ALLSTORE || p2f < nf) {
+        if constexpr (P512) {
+            constexpr unsigned kDrop = 0x80000000u;  // out of the descriptor's range: the store is dropped
+            const __amdgpu_buffer_rsrc_t ro = make_rsrc((unsigned char *)a.out + (size_t)b * NB * a.n_frames * ES, NB * a.n_frames * ES);
+            // rows: first loop c1 + 32 i; second loop 32 t (job 0) or 256 - j - 32 t = (32 - j) + 32 (7 - t); bin 256
+            const unsigned c1 = j == 0 ? 16u : j, r2 = j == 0 ? 0u : 32u - j;
+            const unsigned nv = 2u * p2f + 1u < nf ? 2u : 2u * p2f < nf ? 1u : 0u;  // frames of this slot that exist
+            const unsigned o1 = (c1 * a.n_frames + p2ofs) * ES, o2 = (r2 * a.n_frames + p2ofs) * ES, om = (256u * a.n_frames + p2ofs) * ES;
+            pass2_pair512<MODE, AMP>(A, B, j == 0, eps, ro, nv == 2u ? o1 : kDrop, nv == 1u ? o1 : kDrop, nv == 2u ? o2 : kDrop,
+                                     nv == 1u ? o2 : kDrop, nv == 2u ? om : kDrop, nv == 1u ? om : kDrop, step);
+        } else if (ALLSTORE || p2f < nf) {
             const unsigned c1 = j == 0 ? 16u : j, c2 = j == 0 ? 0u : j + 256u;
             const unsigned long long obytes = (unsigned long long)min(2u, a.batch - p2b) * 513ull * a.n_frames * ES;
             const __amdgpu_buffer_rsrc_t ro = make_rsrc((unsigned char *)a.out + (size_t)p2b * 513u * a.n_frames * ES, (unsigned)obytes);
@@ -673,6 +779,10 @@ hipError_t launch_variant(const StftArgs &a, hipStream_t s) {
             return go(k_r32x16<MODE, AMP, 0, false, false, true>);
         }
     }
+    if constexpr (MODE != OUT_MEL) {
+        if (a.n_fft == 512u) return go(k_r32x16<MODE, AMP, 5, false, false, false, true>);  // two frames per transform (hop 128)
+    }
+    if (a.n_fft != 1024u) return hipErrorInvalidConfiguration;
     if (a.hop == 256u) return go(k_r32x16<MODE, AMP, 5, W, true, false>);
     if (chunks <= 5u * 256u) return go(k_r32x16<MODE, AMP, 5, W, false, false>);
     return go(k_r32x16<MODE, AMP, 0, W, false, false>);
@@ -692,6 +802,11 @@ extern "C" int sgx_debug_read_stamps(unsigned long long *out, int reset) {
 #endif
 
 bool plan_geometry_r32x16_f32(StftArgs &a) {
+    if (a.n_fft == 512 && a.hop == 128 && a.out_mode != OUT_MEL) {  // P512: two frames per transform, 32-frame tiles
+        if (a.n_samples >= (1ull << 29) || (unsigned long long)a.n_frames * 257ull * 8ull >= 0x7fffffffull) return false;
+        a.ft = 32;
+        return true;
+    }
     if (a.n_fft != 1024 || (a.hop & 1u)) return false;
     if (a.n_samples >= (1ull << 29)) return false;                                       // 32-bit byte offsets into a sample row
     if ((unsigned long long)a.n_frames * 513ull * 8ull >= 0x7fffffffull) return false;  // and into a pair of output signals

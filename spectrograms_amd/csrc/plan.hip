@@ -576,8 +576,12 @@ sgx_status build_device_tables(sgx_plan *pl) {
             }
         if ((st = upload<float>(pl, &pl->d_tw1, t1)) != SGX_OK) return st;
         if ((st = upload<float>(pl, &pl->d_tw2, t2)) != SGX_OK) return st;
-        std::vector<float> wh(n), oh(n, 0.5f);
-        for (unsigned i = 0; i < n; ++i) wh[i] = 0.5f * float(pl->window[i]);  // exact scaling of the f32 window
+        std::vector<float> wh(1024), oh(1024, 0.5f);
+        if (n == 1024) {
+            for (unsigned i = 0; i < n; ++i) wh[i] = 0.5f * float(pl->window[i]);  // exact scaling of the f32 window
+        } else {  // n_fft 512, two frames per transform: the pair (w[i], w[i]) multiplies z[i] = a[i] + i b[i]
+            for (unsigned i = 0; i < 512; ++i) wh[2 * i] = wh[2 * i + 1] = 0.5f * float(pl->window[i]);
+        }
         if ((st = upload<float>(pl, &pl->d_window_half, wh)) != SGX_OK) return st;
         if ((st = upload<float>(pl, &pl->d_ones_half, oh)) != SGX_OK) return st;
     }
@@ -910,6 +914,7 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
     // other composite lengths: two-factor DFT; primes fall through to the direct sum
     pl->kind = (pow2 || params->n_fft % 2 == 0) ? K_REG_RADIX : K_TWO_FACTOR;  // (even sizes outside the register-tiled list fall through)
     if (params->dtype == SGX_F32 && params->n_fft == 1024 && params->hop_size % 2 == 0) pl->kind = K_R32X16_F32;
+    if (params->dtype == SGX_F32 && params->n_fft == 512 && params->hop_size == 128) pl->kind = K_R32X16_F32;  // per-bin outputs (else falls back)
     {
         StftArgs probe;
         fill_args(pl, probe, nullptr, nullptr, 1, params->n_fft, params->n_fft, 1);

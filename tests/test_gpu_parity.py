@@ -269,6 +269,19 @@ def test_hop_equals_n_fft_and_odd_hop():
     run_case(n=10001, n_fft=1024, hop=256, amp="complex")  # odd length: last float2 straddles the end
 
 
+@pytest.mark.parametrize("amp,floor", [("power", None), ("magnitude", None), ("db", -80.0), ("complex", None)])
+@pytest.mark.parametrize("n,centre", [(1, True), (127, True), (128, True), (129, True), (512, False), (640, False), (4095, True), (4096, True),
+                                      (4224, True), (8321, False), (40000, True)])
+def test_tuned_kernel_512_two_frames_per_transform(n, centre, amp, floor):
+    """f32 n_fft 512 / hop 128, per-bin outputs: the tuned kernel packs two consecutive frames into one 512-point complex transform.
+    Odd and even frame counts (a slot whose second frame does not exist), signals shorter than a frame, exactly one and several
+    32-frame tiles, both centring modes, every amplitude scale and the complex STFT."""
+    plan, got = run_case(n=n, batch=3, n_fft=512, hop=128, centre=centre, amp=amp, floor=floor, dtype="float32")
+    assert plan.kernel_name == "r32x16_f32"
+    one = plan.compute_batch(signals(3, n, np.float32, 0)[1:2])
+    assert np.array_equal(np.asarray(one)[0], np.asarray(got)[1])
+
+
 @pytest.mark.parametrize("hop", [2, 66, 130, 258, 270, 272, 274, 510, 1022])
 def test_tuned_kernel_even_hops(hop):
     """Every even hop runs on the tuned kernel: staged loads up to hop 272 (a tile of 15 hop + 1024 samples need not be a whole
@@ -402,7 +415,8 @@ def test_full_size_register_tiled_kernel(cfg2_x, n_fft, hop, dtype):
     plan, op = make(n_fft, hop, dtype=dtype)
     x = cfg2_x if dtype == "float32" else cfg2_x.astype(np.float64)
     got = plan.compute_batch(x)
-    assert plan.kernel_name == "reg_radix"
+    # (f32 512 / 128 takes the tuned kernel's two-frames-per-transform mode)
+    assert plan.kernel_name == ("r32x16_f32" if (n_fft, hop, dtype) == (512, 128, "float32") else "reg_radix")
     nf = (160000 + 2 * (n_fft // 2) - n_fft) // hop + 1
     assert got.shape == (256, n_fft // 2 + 1, nf)
     ref = orc.spectrogram_batch(op, x, nthreads=orc.max_threads())
