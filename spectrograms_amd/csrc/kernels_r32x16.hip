@@ -268,9 +268,13 @@ __device__ __forceinline__ void pass2_compute(v2f (&A)[16], v2f (&B)[16], bool j
 // — one 8-byte (power / magnitude / dB) or 16-byte (complex) store per pair: bin k of frames 2 p and 2 p + 1, which are adjacent
 // in memory.  Pairs with k > 256 (the second loop of every job but job 0) are the conjugates of bin 512 - k.  `vfull` is the
 // lane's byte offset when both frames exist, `vhalf` when only the first does (the other being out of range: dropped).
+// Filterbank outputs: the pair's two powers go to the |X|^2 tile as one 8-byte LDS write (pw1 / pw2 / pwm: this lane's slots of the
+// rows the two loops and bin 256 start at; 32 bins further = kP512Step floats, see pwt512_index).
+constexpr unsigned kP512Step = 16u * 64u;
 template <int MODE, int AMP>
 __device__ __forceinline__ void pass2_pair512(v2f (&A)[16], v2f (&B)[16], bool j0, float eps, __amdgpu_buffer_rsrc_t ro, unsigned vfull1,
-                                              unsigned vhalf1, unsigned vfull2, unsigned vhalf2, unsigned vfullm, unsigned vhalfm, unsigned step) {
+                                              unsigned vhalf1, unsigned vfull2, unsigned vhalf2, unsigned vfullm, unsigned vhalfm, unsigned step,
+                                              float *pw1, float *pw2, float *pwm) {
     Fft<16, false>::run(A, A);
     Fft<16, false>::run(B, B);
     const v2f a8 = A[8];
@@ -287,8 +291,11 @@ __device__ __forceinline__ void pass2_pair512(v2f (&A)[16], v2f (&B)[16], bool j
         for (int i = 0; i < 8; ++i) B[i] = nB[i];
         asm volatile("" ::: "memory");
     }
-    auto emit = [&](unsigned vfull, unsigned vhalf, int soff, v2f Xa, v2f Xb, bool conj) {
-        if constexpr (MODE == OUT_COMPLEX) {
+    auto emit = [&](unsigned vfull, unsigned vhalf, int soff, v2f Xa, v2f Xb, bool conj, float *pwp) {
+        if constexpr (MODE == OUT_MEL) {
+            const float pa = power_of(Xa), pb = power_of(Xb);
+            *(v2f *)pwp = AMP == AMP_MAG_IN ? (v2f){sqrtf(pa), sqrtf(pb)} : (v2f){pa, pb};
+        } else if constexpr (MODE == OUT_COMPLEX) {
             const float sg = conj ? -1.f : 1.f;
             const v4f V = (v4f){Xa.x, sg * Xa.y, Xb.x, sg * Xb.y};
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, V), ro, (int)vfull, soff, 0);
@@ -308,16 +315,16 @@ __device__ __forceinline__ void pass2_pair512(v2f (&A)[16], v2f (&B)[16], bool j
     for (int i = 0; i < 8; ++i) {  // k = c1 + 32 i < 256: rows ascending
         v2f Xa, Xb;
         pair(A[i], B[15 - i], Xa, Xb);
-        emit(vfull1, vhalf1, i * (int)step, Xa, Xb, false);
+        emit(vfull1, vhalf1, i * (int)step, Xa, Xb, false, pw1 + i * kP512Step);
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {  // job 0: k = 32 t (rows ascending); other jobs: k = j + 256 + 32 t -> row 256 - j - 32 t, conjugated
         v2f Xa, Xb;
         pair(A[8 + t], B[7 - t], Xa, Xb);
-        if (j0) emit(vfull2 + t * step, vhalf2 + t * step, 0, Xa, Xb, false);
-        else emit(vfull2 + (7 - t) * step, vhalf2 + (7 - t) * step, 0, Xa, Xb, true);
+        if (j0) emit(vfull2 + t * step, vhalf2 + t * step, 0, Xa, Xb, false, pw2 + t * kP512Step);
+        else emit(vfull2 + (7 - t) * step, vhalf2 + (7 - t) * step, 0, Xa, Xb, true, pw2 + (7 - t) * kP512Step);
     }
-    if (j0) emit(vfullm, vhalfm, 0, (v2f){2.f * a8.x, 0.f}, (v2f){2.f * a8.y, 0.f}, false);  // bin 256: Z[256] pairs with itself
+    if (j0) emit(vfullm, vhalfm, 0, (v2f){2.f * a8.x, 0.f}, (v2f){2.f * a8.y, 0.f}, false, pwm);  // bin 256: Z[256] pairs with itself
 }
 
 // ---- filterbank stage, generic forms (|X|^2 tile stored pw[f][k], kPS floats per frame) -----------------------------------
@@ -459,6 +466,51 @@ __device__ __forceinline__ void mel_tile_sched(const StftArgs &a, const float *p
     }
 }
 
+// P512: |X|^2 tile of 32 frames: bin pair x frame pair = four floats, 16 frame pairs per bin pair
+__host__ __device__ constexpr unsigned pwt512_index(unsigned k, unsigned f) { return (k >> 1) * 64u + (f >> 1) * 4u + (k & 1u) * 2u + (f & 1u); }
+// The same schedule (records per segment, wave, 8 slots) walked by lanes (4 slots x 16 frame pairs): a lane takes slots s and s + 4
+// of every segment in turn.  A 16-lane read group is one slot's 16 frame pairs: 256 contiguous bytes.
+template <int AMP>
+__device__ __forceinline__ void mel_tile_sched512(const StftArgs &a, const float *pwT, const unsigned *sched, unsigned b, unsigned f0,
+                                                  unsigned nf, float eps, unsigned tid) {
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u, slot = lane >> 4, fp = lane & 15u;
+    const unsigned obytes = (a.n_out * a.n_frames - f0) * 4u;
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc((const float *)a.out + (size_t)b * a.n_out * a.n_frames + f0, obytes);
+    constexpr unsigned kDrop = 0x80000000u;
+    const unsigned fo0 = 2u * fp < nf ? 8u * fp : kDrop, fo1 = 2u * fp + 1u < nf ? 8u * fp + 4u : kDrop;
+    const uint4 *info = (const uint4 *)(sched + kSchedHdr) + wave * 8u + slot;
+    uint4 ca = info[0], cb = info[4];
+#pragma unroll
+    for (unsigned seg = 0; seg < (unsigned)kSchedSegs; ++seg) {
+        // slots s and s + 4 of the segment side by side: two independent sums per lane, their LDS reads in flight together
+        const uint4 na = info[(seg + 1u) * 32u], nb = info[(seg + 1u) * 32u + 4u];  // fetched ahead; the table holds kSchedSegs + 1 segments
+        const unsigned L = __builtin_amdgcn_readfirstlane(ca.x);
+        const v4f *wa = (const v4f *)((const float *)sched + ca.y), *wb = (const v4f *)((const float *)sched + cb.y);
+        const v4f *pa = (const v4f *)(pwT + (ca.z >> 1) * 64u) + fp, *pb = (const v4f *)(pwT + (cb.z >> 1) * 64u) + fp;  // kstart is even
+        v2f acca = {0.0f, 0.0f}, accb = {0.0f, 0.0f};
+        for (unsigned t = 0; t < L; t += 4u) {
+            const v4f w4a = wa[t >> 2], a0 = pa[(t >> 1) * 16u], a1 = pa[(t >> 1) * 16u + 16u];
+            const v4f w4b = wb[t >> 2], b0 = pb[(t >> 1) * 16u], b1 = pb[(t >> 1) * 16u + 16u];
+            acca = mul_add_unfused(w4a.x, (v2f){a0.x, a0.y}, acca);
+            accb = mul_add_unfused(w4b.x, (v2f){b0.x, b0.y}, accb);
+            acca = mul_add_unfused(w4a.y, (v2f){a0.z, a0.w}, acca);
+            accb = mul_add_unfused(w4b.y, (v2f){b0.z, b0.w}, accb);
+            acca = mul_add_unfused(w4a.z, (v2f){a1.x, a1.y}, acca);
+            accb = mul_add_unfused(w4b.z, (v2f){b1.x, b1.y}, accb);
+            acca = mul_add_unfused(w4a.w, (v2f){a1.z, a1.w}, acca);
+            accb = mul_add_unfused(w4b.w, (v2f){b1.z, b1.w}, accb);
+        }
+        const bool ha = ca.w != 0xffffffffu, hb = cb.w != 0xffffffffu;
+        const unsigned boa = ca.w * a.n_frames * 4u, bob = cb.w * a.n_frames * 4u;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, amp_f32<AMP>(acca.x, eps)), ro, (int)((ha && fo0 != kDrop) ? boa + fo0 : kDrop), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, amp_f32<AMP>(acca.y, eps)), ro, (int)((ha && fo1 != kDrop) ? boa + fo1 : kDrop), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, amp_f32<AMP>(accb.x, eps)), ro, (int)((hb && fo0 != kDrop) ? bob + fo0 : kDrop), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, amp_f32<AMP>(accb.y, eps)), ro, (int)((hb && fo1 != kDrop) ? bob + fo1 : kDrop), 0, 0);
+        ca = na;
+        cb = nb;
+    }
+}
+
 // ====================================================================================================================
 // k_r32x16: one persistent 512-thread workgroup per CU; its two halves each own a tile and an ex buffer and move through the
 // phases in lockstep (shared barriers) — measured 6-30 % faster than two independent 256-thread workgroups (round 1).
@@ -480,7 +532,7 @@ template <int MODE, int AMP, int ROUNDS, bool WIDE, bool XSPAD, bool PWT, bool P
 __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd, unsigned total, unsigned slots) {
     static_assert(!WIDE || MODE != OUT_MEL, "wide pass 2 needs a per-bin output");
     static_assert(!PWT || MODE == OUT_MEL, "PWT is a filterbank layout");
-    static_assert(!P512 || (!WIDE && !XSPAD && !PWT && MODE != OUT_MEL && ROUNDS > 0), "P512: per-bin outputs, staged samples");
+    static_assert(!P512 || (!WIDE && !XSPAD && ROUNDS > 0 && (PWT == (MODE == OUT_MEL))), "P512: staged samples, scheduled band stage");
     constexpr unsigned FPT = P512 ? 32u : 16u;   // frames per tile
     constexpr unsigned NB = P512 ? 257u : 513u;  // bins
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
@@ -698,7 +750,9 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
         SGX_STAMP(8);
         float *pwf = (float *)(smem + (PWT ? kOutOff : 0));  // PWT: above the staged samples, so the next staging does not wait for it
         if constexpr (MODE == OUT_MEL) {
-            if constexpr (PWT) {  // bins 513..523 are read with zero weights
+            if constexpr (P512) {  // bins 257..267 are read with zero weights
+                for (unsigned i = tid; i < 11u * 32u; i += 256u) pwf[pwt512_index(257u + (i >> 5), i & 31u)] = 0.0f;
+            } else if constexpr (PWT) {  // bins 513..523 are read with zero weights
                 if (tid < 176u) pwf[pwt_index(513u + (tid >> 4), tid & 15u)] = 0.0f;
             } else {
                 if (tid < 48u) pwf[(tid / 3u) * kPS + 513u + tid % 3u] = 0.0f;
@@ -711,8 +765,10 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
             const unsigned c1 = j == 0 ? 16u : j, r2 = j == 0 ? 0u : 32u - j;
             const unsigned nv = 2u * p2f + 1u < nf ? 2u : 2u * p2f < nf ? 1u : 0u;  // frames of this slot that exist
             const unsigned o1 = (c1 * a.n_frames + p2ofs) * ES, o2 = (r2 * a.n_frames + p2ofs) * ES, om = (256u * a.n_frames + p2ofs) * ES;
+            float *pws = pwf + 4u * p2f;  // this slot's frame pair
             pass2_pair512<MODE, AMP>(A, B, j == 0, eps, ro, nv == 2u ? o1 : kDrop, nv == 1u ? o1 : kDrop, nv == 2u ? o2 : kDrop,
-                                     nv == 1u ? o2 : kDrop, nv == 2u ? om : kDrop, nv == 1u ? om : kDrop, step);
+                                     nv == 1u ? o2 : kDrop, nv == 2u ? om : kDrop, nv == 1u ? om : kDrop, step, pws + pwt512_index(c1, 0u),
+                                     pws + pwt512_index(r2, 0u), pws + pwt512_index(256u, 0u));
         } else if (ALLSTORE || p2f < nf) {
             const unsigned c1 = j == 0 ? 16u : j, c2 = j == 0 ? 0u : j + 256u;
             const unsigned long long obytes = (unsigned long long)min(2u, a.batch - p2b) * 513ull * a.n_frames * ES;
@@ -730,7 +786,8 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
 #ifdef SGX_ABL_NOMEL
             if (a.n_mels == 12345u)
 #endif
-            if constexpr (PWT) mel_tile_sched<AMP>(a, pwf, sched, b, f0, nf, eps, tid SGX_STAMP_ARGS);
+            if constexpr (P512) mel_tile_sched512<AMP>(a, pwf, sched, b, f0, nf, eps, tid);
+            else if constexpr (PWT) mel_tile_sched<AMP>(a, pwf, sched, b, f0, nf, eps, tid SGX_STAMP_ARGS);
             else if (a.mm_frag) map_tile_mfma<AMP>(a, pwf, b, f0, nf, eps, tid, 2u * half);
             else mel_tile_csr<AMP>(a, pwf, b, f0, nf, eps, tid, 256u);
             if constexpr (!PWT) __syncthreads();  // pw consumed before the next staging overwrites it
@@ -774,6 +831,7 @@ hipError_t launch_variant(const StftArgs &a, hipStream_t s) {
     constexpr bool W = MODE != OUT_MEL;
     if constexpr (MODE == OUT_MEL) {
         if (pwt) {
+            if (a.n_fft == 512u) return go(k_r32x16<MODE, AMP, 5, false, false, true, true>);
             if (a.hop == 256u) return go(k_r32x16<MODE, AMP, 5, false, true, true>);
             if (chunks <= 5u * 256u) return go(k_r32x16<MODE, AMP, 5, false, false, true>);
             return go(k_r32x16<MODE, AMP, 0, false, false, true>);
@@ -802,7 +860,9 @@ extern "C" int sgx_debug_read_stamps(unsigned long long *out, int reset) {
 #endif
 
 bool plan_geometry_r32x16_f32(StftArgs &a) {
-    if (a.n_fft == 512 && a.hop == 128 && a.out_mode != OUT_MEL) {  // P512: two frames per transform, 32-frame tiles
+    // P512: two frames per transform, 32-frame tiles; filterbank outputs need the band schedule (a.x == nullptr: the plan's probe,
+    // made before the tables exist — a bank without a schedule falls back to the register-tiled kernel at the first call)
+    if (a.n_fft == 512 && a.hop == 128 && (a.out_mode != OUT_MEL || a.mel_sched || a.x == nullptr)) {
         if (a.n_samples >= (1ull << 29) || (unsigned long long)a.n_frames * 257ull * 8ull >= 0x7fffffffull) return false;
         a.ft = 32;
         return true;

@@ -515,8 +515,9 @@ sgx_status build_device_tables(sgx_plan *pl) {
                         Slot S = have ? G->s[q] : Slot{0xffffffffu, q, 0};
                         if (S.band != 0xffffffffu && S.steps > 0) {
                             const unsigned c1 = S.ks + S.steps - 1;
-                            if (c1 + (L - S.steps) > 523u) {  // would read past the zeroed rows: pad in front instead
-                                const unsigned d = (c1 + (L - S.steps) - 523u + 3u) / 4u;  // (keeps kstart = slot mod 4)
+                            const unsigned zlast = pl->nb_fft + 10u;  // the kernel zeroes the 11 rows behind the last bin (513..523; n_fft 512: 257..267)
+                            if (c1 + (L - S.steps) > zlast) {  // would read past the zeroed rows: pad in front instead
+                                const unsigned d = (c1 + (L - S.steps) - zlast + 3u) / 4u;  // (keeps kstart = slot mod 4)
                                 if (S.ks < 4 * d) { ok = false; break; }
                                 S.ks -= 4 * d;
                                 S.steps += 4 * d;

@@ -282,6 +282,18 @@ def test_tuned_kernel_512_two_frames_per_transform(n, centre, amp, floor):
     assert np.array_equal(np.asarray(one)[0], np.asarray(got)[1])
 
 
+@pytest.mark.parametrize("amp,floor", [("power", None), ("magnitude", None), ("db", -80.0)])
+@pytest.mark.parametrize("n,n_mels,fmin,fmax,norm", [(40000, 80, 0.0, 8000.0, None), (4100, 40, 20.0, 7600.0, "slaney"), (129, 128, 0.0, 8000.0, "l1"),
+                                                      (8321, 23, 100.0, 4000.0, None), (16000, 80, 0.0, 8000.0, "l2")])
+def test_tuned_kernel_512_mel(n, n_mels, fmin, fmax, norm, amp, floor):
+    """f32 n_fft 512 / hop 128 filterbank outputs: the two-frames-per-transform mode with the band schedule walked over 32-frame
+    tiles (|X|^2 of both frames of a slot written as one LDS pair)."""
+    plan, got = run_case(n=n, batch=3, n_fft=512, hop=128, n_mels=n_mels, fmin=fmin, fmax=fmax, norm=norm, amp=amp, floor=floor, dtype="float32")
+    assert plan.kernel_name == "r32x16_f32"
+    one = plan.compute_batch(signals(3, n, np.float32, 0)[2:3])
+    assert np.array_equal(np.asarray(one)[0], np.asarray(got)[2])
+
+
 @pytest.mark.parametrize("hop", [2, 66, 130, 258, 270, 272, 274, 510, 1022])
 def test_tuned_kernel_even_hops(hop):
     """Every even hop runs on the tuned kernel: staged loads up to hop 272 (a tile of 15 hop + 1024 samples need not be a whole
