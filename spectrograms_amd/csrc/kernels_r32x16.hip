@@ -591,12 +591,19 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
             return;
 #endif
             const int vo = (tile_lo + 4 * (int)tid) * 4;
-            // (P512: one path — the compiler merges the edge path's four dword loads into the same 16-byte load anyway, the range
-            // check being per dword, and two exclusive paths over the same registers cost the edge tiles a wait for the stores)
-            if (interior || P512) {  // reads up to 64 chunks past the tile (the next tile's samples: L2 hits, or 0 past the row)
+            // One straight-line path for every tile and every chunk round: the range check of a 16-byte buffer load is per dword (the
+            // compiler merged the edge tiles' four dword loads into this same instruction anyway) and a chunk never straddles the row
+            // start (the tile start and the padding are multiples of 4 samples).  Before: an interior and an edge path over the same
+            // registers, and rounds predicated on the tile's chunk count — the merged control flow made the compiler wait for the
+            // loads (and with them for the previous tile's stores) right after issuing them at every hop but 256.  Chunks past the
+            // tile read the following samples (L2 hits) or zeros and are staged into LDS the transforms never read.
+#ifndef SGX_ONEPATH
+#define SGX_ONEPATH 1
+#endif
+            if (SGX_ONEPATH || interior || P512) {
 #pragma unroll
                 for (int r = 0; r < ROUNDS; ++r)
-                    if (XSPAD || P512 || r * 256u + tid < chunks) creg[r] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rx, vo + r * 4096, 0, 0));
+                    if (SGX_ONEPATH || XSPAD || P512 || r * 256u + tid < chunks) creg[r] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rx, vo + r * 4096, 0, 0));
             } else {  // edge tile: dword loads, each bounds-checked on its own
 #pragma unroll
                 for (int r = 0; r < ROUNDS; ++r) {
@@ -663,7 +670,7 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
 #pragma unroll
                 for (int r = 0; r < ROUNDS; ++r) {
                     const unsigned c = r * 256u + tid;
-                    if (XSPAD || P512 || c < chunks) *(v4f *)(smem + c * 16u + (XSPAD ? (c >> 6) * 128u : P512 ? (c >> 6) * 64u : 0u)) = creg[r];
+                    if (SGX_ONEPATH || XSPAD || P512 || c < chunks) *(v4f *)(smem + c * 16u + (XSPAD ? (c >> 6) * 128u : P512 ? (c >> 6) * 64u : 0u)) = creg[r];
                 }
                 SGX_STAMP(0);  // wait for the samples + staging writes
                 __syncthreads();  // barrier 1: xs complete
