@@ -84,6 +84,10 @@ __device__ unsigned long long g_stamps[32];
 #define SGX_STAMP_ARGS
 #endif
 
+#ifndef SGX_ONEPATH
+#define SGX_ONEPATH 1  // 0: the interior / edge split and the per-round chunk predicates of the sample loads (A/B only)
+#endif
+
 // ---- single-issue LDS reads -------------------------------------------------------------------------------------------
 // hipcc fuses neighbouring 8-byte LDS reads into ds_read2_b64, which the LDS serves at 128 B/clk; a plain ds_read_b64 gets
 // 256 B/clk.  These reads are issued from inline asm (the compiler neither fuses nor counts them) and collected by an asm
@@ -597,9 +601,6 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
             // registers, and rounds predicated on the tile's chunk count — the merged control flow made the compiler wait for the
             // loads (and with them for the previous tile's stores) right after issuing them at every hop but 256.  Chunks past the
             // tile read the following samples (L2 hits) or zeros and are staged into LDS the transforms never read.
-#ifndef SGX_ONEPATH
-#define SGX_ONEPATH 1
-#endif
             if (SGX_ONEPATH || interior || P512) {
 #pragma unroll
                 for (int r = 0; r < ROUNDS; ++r)
@@ -615,7 +616,7 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
             }
         } else {
             const int vo = ((int)(p1f * hop) + tile_lo + 2 * (int)n2) * 4;
-            if (interior) {
+            if (SGX_ONEPATH || interior) {  // (one path here too: a pair never straddles the row start — hop and the padding are even)
 #pragma unroll
                 for (int n1 = 0; n1 < 32; ++n1) xd[n1] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rx, vo + n1 * 128, 0, 0));
             } else {
