@@ -302,9 +302,10 @@ def test_tuned_kernel_even_hops(hop):
     run_case(n=5000, batch=2, n_fft=1024, hop=hop, n_mels=40, amp="power")
 
 
-def test_strided_rows_and_device_path_match_host_path():
+@pytest.mark.parametrize("n_fft,hop", [(1024, 256), (512, 128), (1024, 160), (400, 160)])
+def test_strided_rows_and_device_path_match_host_path(n_fft, hop):
     torch = pytest.importorskip("torch")
-    plan, op = make(1024, 256, n_mels=80, amp="db", floor=-80.0)
+    plan, op = make(n_fft, hop, n_mels=80, amp="db", floor=-80.0)
     x = signals(5, 7000, np.float32, 3)
     host = plan.compute_batch(x)
     big = torch.zeros((5, 7424), dtype=torch.float32, device="cuda")
@@ -318,10 +319,10 @@ def test_strided_rows_and_device_path_match_host_path():
     dev2 = plan.compute_batch(odd[:, :7000]).cpu().numpy()
     assert np.array_equal(dev2, host)
     ref = orc.spectrogram_batch(op, x.astype(np.float64))
-    pw = orc.spectrogram_batch(orc.Params(n_fft=1024, hop=256, n_mels=80), x.astype(np.float64))
+    pw = orc.spectrogram_batch(orc.Params(n_fft=n_fft, hop=hop, n_mels=80), x.astype(np.float64))
     near = pw > 1e-4 * pw.max()
     assert np.max(np.abs(dev2 - ref)[near]) < 1e-3  # dB, the normal bound within 40 dB of the peak
-    sp, _ = make(1024, 256, amp="complex")
+    sp, _ = make(n_fft, hop, amp="complex")
     a = sp.compute_batch(big[:, :7000]).cpu().numpy()
     b = sp.compute_batch(odd[:, :7000]).cpu().numpy()
     assert np.array_equal(a, b)
