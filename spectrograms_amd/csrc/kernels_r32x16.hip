@@ -122,18 +122,22 @@ __device__ __forceinline__ void read_cols(v2f (&x)[16], v2f (&w)[16], unsigned x
     ((ds_read64<col_off<XSPAD, 2 * K + PAR>()>(x[K], xaddr), ds_read64<(2 * K + PAR) * 128>(w[K], waddr)), ...);
 }
 
-// P512: z[n] = (a[n], b[n]) with n = 16 n1 + n2 — sample n of frame 2 p and of frame 2 p + 1, one hop (512 B) apart — as ONE
-// ds_read2_b32 into the register pair.  Byte offset of sample s of a slot = 4 s + 64 per KiB crossed (the slot base sits on a KiB
-// boundary of the padded staging buffer); a base address per four n1 keeps both 8-bit dword offsets in range.
-constexpr int p512_off_a(int n1) { return 64 * n1 + (n1 >> 4) * 64; }
-constexpr int p512_off_b(int n1) { return 64 * n1 + 512 + ((n1 + 8) >> 4) * 64; }
+// P512: z[n] = (a[n], b[n]) with n = 16 n1 + n2 — sample n of frame 2 p and of frame 2 p + 1, one hop (4 HOP bytes) apart — as ONE
+// ds_read2_b32 into the register pair.  The staging buffer carries 64 B of padding per slot stride (two hops = 8 HOP bytes), so
+// the byte offset of sample s of a slot is 4 s + 64 per slot stride crossed (a slot starts right behind a pad); a base address
+// per four n1 keeps both 8-bit dword offsets in range (hop <= 160).
+template <int HOP>
+constexpr int p512_off_a(int n1) { return 64 * n1 + (64 * n1 / (8 * HOP)) * 64; }
+template <int HOP>
+constexpr int p512_off_b(int n1) { return 64 * n1 + 4 * HOP + ((64 * n1 + 4 * HOP) / (8 * HOP)) * 64; }
 template <int O0, int O1>
 __device__ __forceinline__ void ds_read2x32(v2f &d, unsigned addr) {
+    static_assert(O0 >= 0 && O0 < 256 && O1 >= 0 && O1 < 256, "ds_read2_b32: 8-bit dword offsets");
     asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(d) : "v"(addr), "n"(O0), "n"(O1));
 }
-template <int PAR, int... K>
+template <int HOP, int PAR, int... K>
 __device__ __forceinline__ void read_cols512(v2f (&x)[16], v2f (&w)[16], const unsigned (&base)[8], unsigned waddr, std::integer_sequence<int, K...>) {
-    ((ds_read2x32<(p512_off_a(2 * K + PAR) - p512_off_a((2 * K + PAR) & ~3)) / 4, (p512_off_b(2 * K + PAR) - p512_off_a((2 * K + PAR) & ~3)) / 4>(
+    ((ds_read2x32<(p512_off_a<HOP>(2 * K + PAR) - p512_off_a<HOP>((2 * K + PAR) & ~3)) / 4, (p512_off_b<HOP>(2 * K + PAR) - p512_off_a<HOP>((2 * K + PAR) & ~3)) / 4>(
           x[K], base[(2 * K + PAR) >> 2]),
       ds_read64<(2 * K + PAR) * 128>(w[K], waddr)),
      ...);
@@ -532,8 +536,11 @@ __device__ __forceinline__ void mel_tile_sched512(const StftArgs &a, const float
 // transform of TWO consecutive frames (real parts: frame 2 p, imaginary parts: frame 2 p + 1); passes 1 and 2 are unchanged (the
 // same 32 x 16 transform), the real split becomes the two-sequence split (pass2_pair512).  The staged samples carry 64 B of
 // padding per KiB: the four slots of a wave start 1 KiB apart and would otherwise read the same banks.
-template <int MODE, int AMP, int ROUNDS, bool WIDE, bool XSPAD, bool PWT, bool P512 = false>
+template <int MODE, int AMP, int ROUNDS, bool WIDE, bool XSPAD, bool PWT, int HOP512 = 0>
 __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd, unsigned total, unsigned slots) {
+    constexpr bool P512 = HOP512 != 0;           // n_fft 512 at hop HOP512
+    constexpr unsigned SS512 = 8u * HOP512;      // bytes from one slot's (frame pair's) first sample to the next slot's
+    static_assert(!P512 || (HOP512 % 4 == 0 && ROUNDS * 256 * 4 >= 31 * HOP512 + 512), "P512: 16-byte chunks, the whole tile staged");
     static_assert(!WIDE || MODE != OUT_MEL, "wide pass 2 needs a per-bin output");
     static_assert(!PWT || MODE == OUT_MEL, "PWT is a filterbank layout");
     static_assert(!P512 || (!WIDE && !XSPAD && ROUNDS > 0 && (PWT == (MODE == OUT_MEL))), "P512: staged samples, scheduled band stage");
@@ -578,8 +585,8 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
     constexpr int NCR = ROUNDS > 0 ? ROUNDS : 1;
     v4f creg[NCR];
     v2f xd[ROUNDS > 0 ? 1 : 32];
-    const unsigned chunks = XSPAD ? 1216u : P512 ? (31u * 128u + 512u + 3u) >> 2 : (15u * a.hop + 1024u + 3u) >> 2;
-    const unsigned hop = XSPAD ? 256u : P512 ? 128u : a.hop;
+    const unsigned chunks = XSPAD ? 1216u : P512 ? (31u * HOP512 + 512u + 3u) >> 2 : (15u * a.hop + 1024u + 3u) >> 2;
+    const unsigned hop = XSPAD ? 256u : P512 ? (unsigned)HOP512 : a.hop;
     const unsigned row_bytes = (unsigned)a.n_samples * 4u;  // host: n_samples < 2^29
     auto load_tile = [&](unsigned w) {
         const unsigned b = w / a.tiles, tile = w - b * a.tiles;
@@ -671,7 +678,7 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
 #pragma unroll
                 for (int r = 0; r < ROUNDS; ++r) {
                     const unsigned c = r * 256u + tid;
-                    if (SGX_ONEPATH || XSPAD || P512 || c < chunks) *(v4f *)(smem + c * 16u + (XSPAD ? (c >> 6) * 128u : P512 ? (c >> 6) * 64u : 0u)) = creg[r];
+                    if (SGX_ONEPATH || XSPAD || P512 || c < chunks) *(v4f *)(smem + c * 16u + (XSPAD ? (c >> 6) * 128u : P512 ? (c * 16u / (P512 ? SS512 : 1u)) * 64u : 0u)) = creg[r];
                 }
                 SGX_STAMP(0);  // wait for the samples + staging writes
                 __syncthreads();  // barrier 1: xs complete
@@ -679,9 +686,9 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
                 if constexpr (P512) {
                     unsigned base[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) base[q] = lds_addr(smem) + p1f * (1024u + 64u) + n2 * 4u + (unsigned)p512_off_a(4 * q);
-                    read_cols512<0>(e, we, base, waddr, std::make_integer_sequence<int, 16>{});
-                    read_cols512<1>(o, wo, base, waddr, std::make_integer_sequence<int, 16>{});
+                    for (int q = 0; q < 8; ++q) base[q] = lds_addr(smem) + p1f * (SS512 + 64u) + n2 * 4u + (unsigned)p512_off_a<P512 ? HOP512 : 128>(4 * q);
+                    read_cols512<P512 ? HOP512 : 128, 0>(e, we, base, waddr, std::make_integer_sequence<int, 16>{});
+                    read_cols512<P512 ? HOP512 : 128, 1>(o, wo, base, waddr, std::make_integer_sequence<int, 16>{});
                     tie16<15>(e);
                     tie16<-1>(we);
                 } else {
@@ -839,14 +846,24 @@ hipError_t launch_variant(const StftArgs &a, hipStream_t s) {
     constexpr bool W = MODE != OUT_MEL;
     if constexpr (MODE == OUT_MEL) {
         if (pwt) {
-            if (a.n_fft == 512u) return go(k_r32x16<MODE, AMP, 5, false, false, true, true>);
+            if (a.n_fft == 512u) {  // two frames per transform
+                if (a.hop == 64u) return go(k_r32x16<MODE, AMP, 3, false, false, true, 64>);
+                if (a.hop == 128u) return go(k_r32x16<MODE, AMP, 5, false, false, true, 128>);
+                if (a.hop == 160u) return go(k_r32x16<MODE, AMP, 6, false, false, true, 160>);
+                return hipErrorInvalidConfiguration;
+            }
             if (a.hop == 256u) return go(k_r32x16<MODE, AMP, 5, false, true, true>);
             if (chunks <= 5u * 256u) return go(k_r32x16<MODE, AMP, 5, false, false, true>);
             return go(k_r32x16<MODE, AMP, 0, false, false, true>);
         }
     }
     if constexpr (MODE != OUT_MEL) {
-        if (a.n_fft == 512u) return go(k_r32x16<MODE, AMP, 5, false, false, false, true>);  // two frames per transform (hop 128)
+        if (a.n_fft == 512u) {  // two frames per transform
+            if (a.hop == 64u) return go(k_r32x16<MODE, AMP, 3, false, false, false, 64>);
+            if (a.hop == 128u) return go(k_r32x16<MODE, AMP, 5, false, false, false, 128>);
+            if (a.hop == 160u) return go(k_r32x16<MODE, AMP, 6, false, false, false, 160>);
+            return hipErrorInvalidConfiguration;
+        }
     }
     if (a.n_fft != 1024u) return hipErrorInvalidConfiguration;
     if (a.hop == 256u) return go(k_r32x16<MODE, AMP, 5, W, true, false>);
@@ -870,7 +887,7 @@ extern "C" int sgx_debug_read_stamps(unsigned long long *out, int reset) {
 bool plan_geometry_r32x16_f32(StftArgs &a) {
     // P512: two frames per transform, 32-frame tiles; filterbank outputs need the band schedule (a.x == nullptr: the plan's probe,
     // made before the tables exist — a bank without a schedule falls back to the register-tiled kernel at the first call)
-    if (a.n_fft == 512 && a.hop == 128 && (a.out_mode != OUT_MEL || a.mel_sched || a.x == nullptr)) {
+    if (a.n_fft == 512 && (a.hop == 64 || a.hop == 128 || a.hop == 160) && (a.out_mode != OUT_MEL || a.mel_sched || a.x == nullptr)) {
         if (a.n_samples >= (1ull << 29) || (unsigned long long)a.n_frames * 257ull * 8ull >= 0x7fffffffull) return false;
         a.ft = 32;
         return true;

@@ -294,6 +294,27 @@ def test_tuned_kernel_512_mel(n, n_mels, fmin, fmax, norm, amp, floor):
     assert np.array_equal(np.asarray(one)[0], np.asarray(got)[2])
 
 
+@pytest.mark.parametrize("amp,floor", [("power", None), ("db", -80.0), ("complex", None)])
+@pytest.mark.parametrize("hop", [64, 160])
+@pytest.mark.parametrize("n,centre", [(1, True), (159, True), (160, True), (512, False), (703, False), (2047, True), (4960, True), (5121, True), (21000, False)])
+def test_tuned_kernel_512_other_hops(n, centre, hop, amp, floor):
+    """The two-frames-per-transform mode at hops 64 and 160 (the staging padding, the pass-1 read offsets and the number of chunk
+    rounds depend on the hop): odd / even frame counts, one and several 32-frame tiles, both centring modes."""
+    plan, got = run_case(n=n, batch=3, n_fft=512, hop=hop, centre=centre, amp=amp, floor=floor, dtype="float32")
+    assert plan.kernel_name == "r32x16_f32"
+    one = plan.compute_batch(signals(3, n, np.float32, 0)[1:2])
+    assert np.array_equal(np.asarray(one)[0], np.asarray(got)[1])
+
+
+@pytest.mark.parametrize("hop", [64, 160])
+@pytest.mark.parametrize("n,n_mels,norm,amp,floor", [(40000, 80, None, "db", -80.0), (4100, 40, "slaney", "power", None), (161, 128, "l1", "magnitude", None)])
+def test_tuned_kernel_512_mel_other_hops(n, n_mels, norm, amp, floor, hop):
+    plan, got = run_case(n=n, batch=3, n_fft=512, hop=hop, n_mels=n_mels, norm=norm, amp=amp, floor=floor, dtype="float32")
+    assert plan.kernel_name == "r32x16_f32"
+    one = plan.compute_batch(signals(3, n, np.float32, 0)[2:3])
+    assert np.array_equal(np.asarray(one)[0], np.asarray(got)[2])
+
+
 @pytest.mark.parametrize("hop", [2, 66, 130, 258, 270, 272, 274, 510, 1022])
 def test_tuned_kernel_even_hops(hop):
     """Every even hop runs on the tuned kernel: staged loads up to hop 272 (a tile of 15 hop + 1024 samples need not be a whole
@@ -302,7 +323,7 @@ def test_tuned_kernel_even_hops(hop):
     run_case(n=5000, batch=2, n_fft=1024, hop=hop, n_mels=40, amp="power")
 
 
-@pytest.mark.parametrize("n_fft,hop", [(1024, 256), (512, 128), (1024, 160), (400, 160)])
+@pytest.mark.parametrize("n_fft,hop", [(1024, 256), (512, 128), (512, 160), (1024, 160), (400, 160)])
 def test_strided_rows_and_device_path_match_host_path(n_fft, hop):
     torch = pytest.importorskip("torch")
     plan, op = make(n_fft, hop, n_mels=80, amp="db", floor=-80.0)
