@@ -137,37 +137,53 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_c2c_reg(C2
     }
 }
 
-// Overlap-add of a tile's frames, read straight from the transform buffer, into one signal's output (src/spectrogram.rs:4906-4930):
-// one thread per offset `off` inside a hop block, walking the tile's nbk hop blocks.  Position pos = (h0 + hb) hop + off receives
-// frames f in [fh - q + 1, fh] (fh = h0 + hb, q = ceil((n - off) / hop)) clipped to [0, n_frames), in ascending f as the reference
-// adds them, frame sample j = (fh - f) hop + off; norm = sum of w[j]^2 (each product rounded, then added), divide where > 1e-10.
+// Overlap-add of a tile's frames, read straight from the transform buffer, into one signal's output (src/spectrogram.rs:4906-4930).
+// The tile's nbk hop blocks are nbk * hop output positions, walked by all 256 threads (consecutive threads = consecutive
+// positions: contiguous stores).  Position pos = (h0 + hb) hop + off receives frames f in [fh - q + 1, fh] (fh = h0 + hb,
+// q = ceil((n - off) / hop)) clipped to [0, n_frames), in ascending f as the reference adds them, frame sample j = (fh - f) hop + off;
+// norm = sum of w[j]^2 (each product rounded, then added), divide where > 1e-10.  The interior norm of every offset is built
+// once per tile into `nrm_tab` (LDS, hop entries).  Requires hop <= n.
 // sample(rr, j): sample j of the tile's row rr, scaled and windowed ((x / n) w, each product rounded as the unfused path rounds it)
+// (Before: one thread per offset walking all nbk blocks — at hop 128 half the workgroup idled through the longest phase of the
+// kernel: f32 n_fft 512 / hop 128 inverse STFT 0.49 ms.)
 template <typename T, typename F>
-__device__ __forceinline__ void ola_tile(F &&sample, unsigned n, const T *w, T *o, const C2rArgs &a, long long h0, long long fbase, unsigned tid) {
+__device__ __forceinline__ void ola_tile(F &&sample, unsigned n, const T *w, T *o, const C2rArgs &a, long long h0, long long fbase, unsigned tid,
+                                         T *nrm_tab) {
     const unsigned long long p0 = (unsigned long long)h0 * a.hop;
     const long long last = (long long)a.nrows - 1;
     auto sq_add = [](T acc, T wj) {
         if constexpr (sizeof(T) == 4) return __fadd_rn(acc, __fmul_rn(wj, wj));
         else return __dadd_rn(acc, __dmul_rn(wj, wj));
     };
+    // frames overlapping offset off: q_hi below thr, q_hi - 1 from thr on (uniform values, no per-position division)
+    const unsigned q_hi = (n + a.hop - 1u) / a.hop, thr = n - (q_hi - 1u) * a.hop;
     for (unsigned off = tid; off < a.hop; off += 256) {
-        const unsigned q = off < n ? (n - off + a.hop - 1u) / a.hop : 0u;  // frames overlapping this offset (hop > n: none past n)
-        T nrm_full = T(0);  // every interior position's norm
+        const unsigned q = off < thr ? q_hi : q_hi - 1u;
+        T nrm_full = T(0);
         for (unsigned i = q; i-- > 0;) nrm_full = sq_add(nrm_full, w[i * a.hop + off]);
-        for (unsigned hb = 0; hb < a.nbk; ++hb) {
-            const unsigned long long pos = p0 + (unsigned long long)hb * a.hop + off;
-            if (pos < a.start || pos - a.start >= a.out_len) continue;
-            const long long fh = h0 + hb;
-            const long long f_lo = max(fh - (long long)q + 1, 0ll), f_hi = min(fh, last);
-            T acc = T(0), nrm = nrm_full;
-            for (long long f = f_lo; f <= f_hi; ++f) acc += sample((unsigned)(f - fbase), (unsigned)(fh - f) * a.hop + off);
-            if (f_hi - f_lo + 1 != (long long)q) {  // signal edges: fewer frames
-                nrm = T(0);
-                for (long long f = f_lo; f <= f_hi; ++f) nrm = sq_add(nrm, w[(unsigned)(fh - f) * a.hop + off]);
-            }
-            if (nrm > T(1e-10)) acc /= nrm;
-            o[pos - a.start] = acc;
+        nrm_tab[off] = nrm_full;
+    }
+    __syncthreads();
+    const unsigned dq = 256u / a.hop, dr = 256u - dq * a.hop;  // one step of 256 positions = dq blocks + dr offsets
+    unsigned hb = tid / a.hop, off = tid - hb * a.hop;
+    for (; hb < a.nbk; hb += dq, off += dr) {
+        if (off >= a.hop) {
+            off -= a.hop;
+            if (++hb >= a.nbk) break;
         }
+        const unsigned long long pos = p0 + (unsigned long long)hb * a.hop + off;
+        if (pos < a.start || pos - a.start >= a.out_len) continue;
+        const unsigned q = off < thr ? q_hi : q_hi - 1u;
+        const long long fh = h0 + hb;
+        const long long f_lo = max(fh - (long long)q + 1, 0ll), f_hi = min(fh, last);
+        T acc = T(0), nrm = nrm_tab[off];
+        for (long long f = f_lo; f <= f_hi; ++f) acc += sample((unsigned)(f - fbase), (unsigned)(fh - f) * a.hop + off);
+        if (f_hi - f_lo + 1 != (long long)q) {  // signal edges: fewer frames
+            nrm = T(0);
+            for (long long f = f_lo; f <= f_hi; ++f) nrm = sq_add(nrm, w[(unsigned)(fh - f) * a.hop + off]);
+        }
+        if (nrm > T(1e-10)) acc /= nrm;
+        o[pos - a.start] = acc;
     }
 }
 
@@ -194,6 +210,11 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_c2r_reg(C2
     T *out = (T *)a.out + (size_t)b * a.nrows * CN;
     const V *tw = (const V *)a.tw;  // W_CN^k, CN entries
     auto wrap = [](unsigned e) { return P2 ? (e & (CN - 1)) : (e % CN); };
+    // OLA: behind the tile sit the overlap-add's norm table (hop entries) and a copy of the window (CN entries; visible after the
+    // barriers of the passes): the walk reads the window four to eight times per output sample
+    T *nrm_tab = (T *)(buf + (size_t)tile * FS), *win_lds = nrm_tab + a.hop;
+    if constexpr (OLA)
+        for (unsigned i = tid; i < CN; i += 256) win_lds[i] = ((const T *)a.win)[i];
 
     // pass 1: every item loads its A pairs (X[k], X[m - k]) itself — lanes run along the contiguous axis of the input (rows for
     // the [bin][frame] spectra of the inverse STFT, bins for the [row][bin] spectra of the 2-D path), 2 A loads in flight a thread
@@ -275,13 +296,13 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_c2r_reg(C2
     if constexpr (OLA) {
         // the frames stay on chip: the overlap-add picks sample j of row rr out of the transform buffer (pair j / 2, real part
         // for even j, minus the imaginary part for odd j), scales and windows it as the unfused path does
-        const T *w = (const T *)a.win;
+        const T *w = win_lds;
         ola_tile<T>([&](unsigned rr, unsigned j) {
             const V z = buf[(size_t)rr * FS + L::of_output(j >> 1)];
             const T x = ((j & 1u) ? -z.y : z.x) * sc;
             if constexpr (sizeof(T) == 4) return __fmul_rn(x, w[j]);
             else return __dmul_rn(x, w[j]);
-        }, CN, w, (T *)a.out + (size_t)b * a.out_len, a, h0, fbase, tid);
+        }, CN, w, (T *)a.out + (size_t)b * a.out_len, a, h0, fbase, tid, nrm_tab);
     } else {
         for (unsigned idx = tid; idx < nr * M; idx += 256) {
             const unsigned n = idx % M, rr = idx / M;
@@ -374,8 +395,9 @@ hipError_t launch_c2r_reg(const C2rArgs &a0, int dtype, hipStream_t s) {
     // store phases (measured: f32 n_fft 512 inverse STFT 0.65 ms with 32-frame tiles at two per CU, 0.49 ms with 16-frame tiles)
     const size_t c2r_budget = dtype == SGX_F64 ? kR2Budget : (size_t)SGX_C2R_KB * 1024;  // (f64: n_fft 400 0.90 vs 1.14 ms with the larger tile)
     unsigned ltile = 5;
-    while (ltile > 0 && ((size_t)(1u << ltile) * per > c2r_budget || (!ola && (1u << (ltile - 1)) >= a0.nrows))) --ltile;
-    const size_t lds = (size_t)(1u << ltile) * per;
+    const size_t ola_tab = ola ? ((size_t)a0.hop + a0.ncols) * es : 0;  // the overlap-add's norm table and window copy behind the tile
+    while (ltile > 0 && ((size_t)(1u << ltile) * per + ola_tab > c2r_budget || (!ola && (1u << (ltile - 1)) >= a0.nrows))) --ltile;
+    const size_t lds = (size_t)(1u << ltile) * per + ola_tab;
     if (lds > kR2Budget) return hipErrorNotSupported;
     C2rArgs a = a0;
     a.tile = 1u << ltile;
@@ -387,7 +409,10 @@ hipError_t launch_c2r_reg(const C2rArgs &a0, int dtype, hipStream_t s) {
         // 0.81 ms with the spectrum staged through LDS, 0.49 ms with the direct loads; f64, whose tiles hold half as many frames:
         // 512 / 128 1.03 -> 0.95 ms but 400 / 160 0.89 -> 0.96 ms and 256 / 64 1.00 -> 1.19 ms: not fused)
         a.ov = (a.ncols - 1u) / a.hop;
-        if (a.hop > a.ncols || !a.win || 4 * a.ov > a.tile || dtype != SGX_F32) return hipErrorNotSupported;
+#ifndef SGX_OLA_HALO
+#define SGX_OLA_HALO 2
+#endif
+        if (a.hop > a.ncols || !a.win || SGX_OLA_HALO * a.ov > a.tile || dtype != SGX_F32) return hipErrorNotSupported;
         a.nbk = a.tile - a.ov;
         const unsigned long long full = (unsigned long long)(a.nrows - 1) * a.hop + a.ncols;
         const unsigned long long blocks = (full + a.hop - 1) / a.hop;

@@ -128,11 +128,15 @@ def test_gpu_istft_fused_1024_kernel(hop, centre, window, n):
                                                        (512, 171, False, "hanning", 20000), (512, 512, True, "rectangular", 9000),
                                                        (400, 160, True, "hanning", 30000), (400, 133, False, "blackman", 9000),
                                                        (256, 64, True, "hanning", 40000), (128, 32, True, "hanning", 300),
-                                                       (512, 64, True, "hanning", 9000)])
+                                                       (512, 64, True, "hanning", 9000), (512, 63, False, "hamming", 9000),
+                                                       (400, 50, True, "hanning", 9000), (512, 32, True, "hanning", 5000),
+                                                       (256, 255, False, "hanning", 5000), (256, 256, True, "hamming", 5000),
+                                                       (1000, 200, True, "hanning", 30000)])
 def test_gpu_istft_fused_register_tiled_kernel(n_fft, hop, centre, window, n):
     """f32, lengths with a pass split: the fused register-tiled kernel (windowed frames kept in LDS, halo frames recomputed per
-    tile) over many tiles, hops that do not divide n_fft, a signal shorter than one tile, both output windows; hop = n_fft / 8
-    (more halo than a quarter of a tile) takes the frame-scratch path."""
+    tile) over many tiles, hops that do not divide n_fft (and do or do not divide the workgroup's 256 threads: the overlap-add
+    walks the tile's positions with all threads), a signal shorter than one tile, both output windows; up to half a tile of halo
+    frames is fused (hop = n_fft / 8: 7 of 16), hop = n_fft / 16 takes the frame-scratch path."""
     x = np.random.default_rng(12).standard_normal((4, n)).astype(np.float32)
     wt = getattr(sg.WindowType, window)
     plan = sg.Plan(sg.SpectrogramParams(sg.StftParams(n_fft, hop, wt, centre), 16000.0), _ffi.AMP_COMPLEX, None, None, "float32")
