@@ -23,6 +23,15 @@ struct sgx_fft2d {
     void *d_inter = nullptr, *d_spec = nullptr, *d_kspec = nullptr, *d_mask = nullptr, *d_in = nullptr, *d_out = nullptr, *d_kimg = nullptr;
     size_t inter_bytes = 0, spec_bytes = 0, kspec_bytes = 0, mask_bytes = 0, in_bytes = 0, out_bytes = 0, kimg_bytes = 0;
     unsigned log2r = 0, log2c = 0, tile_r = 0, tile_c = 0;
+    // what d_kspec / d_mask currently hold, and the stream they were produced on: a plan that convolves or filters batch after
+    // batch with the same kernel / cut-offs (on the same stream, so the order is the stream's) prepares them once, not per call
+    std::vector<unsigned char> kspec_of;
+    size_t kspec_rows = 0, kspec_cols = 0;
+    hipStream_t kspec_stream = nullptr;
+    bool kspec_valid = false, mask_valid = false;
+    int mask_kind = -1;
+    double mask_lo = 0.0, mask_hi = 0.0;
+    hipStream_t mask_stream = nullptr;
     mutable std::string err;
 };
 
@@ -358,19 +367,30 @@ sgx_status sgx_fft2d_convolve(sgx_fft2d *p, const void *images, size_t batch, co
     const size_t R = p->nrows, C = p->ncols, Cb = p->cb;
     DeviceGuard dg;
     F2_HIP(p, dg.enter(p->device));
-    // pad_kernel_for_fft (image_ops.rs:123-152): kernel centre -> (0,0), wrapped
-    std::vector<unsigned char> padded(R * C * p->elem, 0);
-    const long cr = long(krows / 2), cc = long(kcols / 2);
-    for (size_t i = 0; i < krows; ++i)
-        for (size_t j = 0; j < kcols; ++j) {
-            const long tr = ((long(i) - cr) % long(R) + long(R)) % long(R), tc = ((long(j) - cc) % long(C) + long(C)) % long(C);
-            std::memcpy(&padded[(size_t(tr) * C + size_t(tc)) * p->elem], (const unsigned char *)kernel_host + (i * kcols + j) * p->elem, p->elem);
-        }
-    if ((st = grow2(p, &p->d_kimg, &p->kimg_bytes, padded.size())) != SGX_OK) return st;
-    if ((st = grow2(p, &p->d_kspec, &p->kspec_bytes, R * Cb * 2 * p->elem)) != SGX_OK) return st;
-    F2_HIP(p, hipMemcpyAsync(p->d_kimg, padded.data(), padded.size(), hipMemcpyHostToDevice, s));
-    F2_HIP(p, hipStreamSynchronize(s));  // `padded` goes out of scope
-    if ((st = forward_dev(p, p->d_kimg, 1, p->d_kspec, s)) != SGX_OK) return st;
+    const size_t kbytes = krows * kcols * p->elem;
+    const bool same_kernel = p->kspec_valid && p->kspec_rows == krows && p->kspec_cols == kcols && p->kspec_stream == s &&
+                             p->kspec_of.size() == kbytes && std::memcmp(p->kspec_of.data(), kernel_host, kbytes) == 0;
+    if (!same_kernel) {
+        p->kspec_valid = false;
+        // pad_kernel_for_fft (image_ops.rs:123-152): kernel centre -> (0,0), wrapped
+        std::vector<unsigned char> padded(R * C * p->elem, 0);
+        const long cr = long(krows / 2), cc = long(kcols / 2);
+        for (size_t i = 0; i < krows; ++i)
+            for (size_t j = 0; j < kcols; ++j) {
+                const long tr = ((long(i) - cr) % long(R) + long(R)) % long(R), tc = ((long(j) - cc) % long(C) + long(C)) % long(C);
+                std::memcpy(&padded[(size_t(tr) * C + size_t(tc)) * p->elem], (const unsigned char *)kernel_host + (i * kcols + j) * p->elem, p->elem);
+            }
+        if ((st = grow2(p, &p->d_kimg, &p->kimg_bytes, padded.size())) != SGX_OK) return st;
+        if ((st = grow2(p, &p->d_kspec, &p->kspec_bytes, R * Cb * 2 * p->elem)) != SGX_OK) return st;
+        F2_HIP(p, hipMemcpyAsync(p->d_kimg, padded.data(), padded.size(), hipMemcpyHostToDevice, s));
+        F2_HIP(p, hipStreamSynchronize(s));  // `padded` goes out of scope
+        if ((st = forward_dev(p, p->d_kimg, 1, p->d_kspec, s)) != SGX_OK) return st;
+        p->kspec_of.assign((const unsigned char *)kernel_host, (const unsigned char *)kernel_host + kbytes);
+        p->kspec_rows = krows;
+        p->kspec_cols = kcols;
+        p->kspec_stream = s;
+        p->kspec_valid = true;
+    }
     const size_t imgb = batch * R * C * p->elem;
     return with_staging(p, images, imgb, out, imgb, mem_kind, s, [&](const void *i, void *o) -> sgx_status {
         if (use_fused(p)) return fused_product_dev(p, i, batch, p->d_kspec, false, o, s);
@@ -398,20 +418,28 @@ sgx_status sgx_fft2d_filter(sgx_fft2d *p, const void *images, size_t batch, int3
     const size_t R = p->nrows, C = p->ncols, Cb = p->cb;
     DeviceGuard dg;
     F2_HIP(p, dg.enter(p->device));
-    std::vector<double> m, m2;
-    lowpass_mask(R, Cb, cut_lo, m);  // spectrum.dim() = (nrows, ncols/2+1): S14
-    if (kind == 1) for (double &v : m) v = 1.0 - v;
-    if (kind == 2) {
-        lowpass_mask(R, Cb, cut_hi, m2);
-        for (size_t i = 0; i < m.size(); ++i) m[i] = m2[i] - m[i];
+    if (!(p->mask_valid && p->mask_kind == kind && p->mask_lo == cut_lo && p->mask_hi == cut_hi && p->mask_stream == s)) {
+        p->mask_valid = false;
+        std::vector<double> m, m2;
+        lowpass_mask(R, Cb, cut_lo, m);  // spectrum.dim() = (nrows, ncols/2+1): S14
+        if (kind == 1) for (double &v : m) v = 1.0 - v;
+        if (kind == 2) {
+            lowpass_mask(R, Cb, cut_hi, m2);
+            for (size_t i = 0; i < m.size(); ++i) m[i] = m2[i] - m[i];
+        }
+        std::vector<unsigned char> mt(m.size() * p->elem);
+        for (size_t i = 0; i < m.size(); ++i) {
+            if (p->dtype == SGX_F64) ((double *)mt.data())[i] = m[i]; else ((float *)mt.data())[i] = float(m[i]);
+        }
+        if ((st = grow2(p, &p->d_mask, &p->mask_bytes, mt.size())) != SGX_OK) return st;
+        F2_HIP(p, hipMemcpyAsync(p->d_mask, mt.data(), mt.size(), hipMemcpyHostToDevice, s));
+        F2_HIP(p, hipStreamSynchronize(s));
+        p->mask_kind = kind;
+        p->mask_lo = cut_lo;
+        p->mask_hi = cut_hi;
+        p->mask_stream = s;
+        p->mask_valid = true;
     }
-    std::vector<unsigned char> mt(m.size() * p->elem);
-    for (size_t i = 0; i < m.size(); ++i) {
-        if (p->dtype == SGX_F64) ((double *)mt.data())[i] = m[i]; else ((float *)mt.data())[i] = float(m[i]);
-    }
-    if ((st = grow2(p, &p->d_mask, &p->mask_bytes, mt.size())) != SGX_OK) return st;
-    F2_HIP(p, hipMemcpyAsync(p->d_mask, mt.data(), mt.size(), hipMemcpyHostToDevice, s));
-    F2_HIP(p, hipStreamSynchronize(s));
     const size_t imgb = batch * R * C * p->elem;
     return with_staging(p, images, imgb, out, imgb, mem_kind, s, [&](const void *i, void *o) -> sgx_status {
         if (use_fused(p)) return fused_product_dev(p, i, batch, p->d_mask, true, o, s);

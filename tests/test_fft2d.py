@@ -217,6 +217,35 @@ def test_gpu_fused_column_stage_1024_rows(shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape,dtype", [((1024, 64), "float32"), ((64, 48), "float32"), ((40, 64), "float64")])
+def test_gpu_kernel_spectrum_and_mask_are_reused_only_when_unchanged(shape, dtype):
+    """A plan keeps the last kernel's spectrum / the last filter mask on the device and prepares them again only when the kernel
+    bytes, its shape, the cut-offs or the stream differ: every call must equal a fresh plan's answer bit for bit."""
+    torch = pytest.importorskip("torch")
+    npdt = np.float32 if dtype == "float32" else np.float64
+    x = np.stack([img(shape, 3 + k, npdt) for k in range(2)])
+    k1 = sg.gaussian_kernel_2d(5, 1.0, dtype=dtype)
+    k2 = sg.gaussian_kernel_2d(5, 2.5, dtype=dtype)       # same shape, other values
+    k3 = np.ascontiguousarray(k2[:3, :])                  # same leading bytes, other shape
+    fresh = lambda k: sg.Fft2dPlan(shape[0], shape[1], dtype).convolve(x, k)
+    plan = sg.Fft2dPlan(shape[0], shape[1], dtype)
+    for k in (k1, k1, k2, k2, k3, k1):
+        assert np.array_equal(plan.convolve(x, k), fresh(k))
+    fresh_f = lambda *a: sg.Fft2dPlan(shape[0], shape[1], dtype).filter(x, *a)
+    for a in ((0, 0.3, 0.0), (0, 0.3, 0.0), (1, 0.3, 0.0), (2, 0.3, 0.6), (2, 0.3, 0.7), (0, 0.3, 0.0)):
+        assert np.array_equal(plan.filter(x, *a), fresh_f(*a))
+    # the cached spectrum belongs to the stream that produced it: another stream prepares its own
+    xd = torch.from_numpy(x).cuda()
+    ref = fresh(k1)
+    a = plan.convolve_torch(xd, k1).cpu().numpy()
+    with torch.cuda.stream(torch.cuda.Stream()):
+        b = plan.convolve_torch(xd, k1)
+        torch.cuda.current_stream().synchronize()
+    c = plan.convolve_torch(xd, k1).cpu().numpy()
+    assert np.array_equal(a, ref) and np.array_equal(b.cpu().numpy(), ref) and np.array_equal(c, ref)
+
+
+@pytest.mark.gpu
 def test_gpu_planner_spectrum_helpers():
     pl = sg.Fft2dPlanner(dtype="float32")
     x = img((64, 48), 3, np.float32)
