@@ -223,7 +223,9 @@ sgx_status sgx_fft2d_forward(sgx_fft2d *plan, const void *images, size_t batch, 
 sgx_status sgx_fft2d_inverse(sgx_fft2d *plan, const void *spectrum, size_t batch, void *images, int32_t mem_kind,
                              void *hip_stream);
 /* convolve_fft(image, kernel): kernel (krows x kcols, host pointer, T) is wrapped so its centre sits at (0,0)
- * (pad_kernel_for_fft, image_ops.rs:123-152), transformed once and multiplied into every image's spectrum */
+ * (pad_kernel_for_fft, image_ops.rs:123-152), transformed once and multiplied into every image's spectrum.  The plan keeps
+ * that spectrum on the device: a later call with the same kernel bytes and shape on the same stream reuses it (the kernel is
+ * read from `kernel_host` during the call, never afterwards); sgx_fft2d_filter keeps its mask per (kind, cut-offs, stream). */
 sgx_status sgx_fft2d_convolve(sgx_fft2d *plan, const void *images, size_t batch, const void *kernel_host, size_t krows,
                               size_t kcols, void *out, int32_t mem_kind, void *hip_stream);
 /* lowpass (kind 0, cut_lo), highpass (1, cut_lo), bandpass (2, cut_lo..cut_hi): binary radial masks built on the HALF
