@@ -70,7 +70,8 @@ def test_chroma_params_validation_and_host_tables():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
-@pytest.mark.parametrize("n_fft,hop,norm", [(2048, 512, "l2"), (1024, 256, "l1"), (1024, 256, "max"), (1024, 256, "none"), (400, 160, "l2")])
+@pytest.mark.parametrize("n_fft,hop,norm", [(2048, 512, "l2"), (1024, 256, "l1"), (1024, 256, "max"), (1024, 256, "none"), (400, 160, "l2"), (512, 128, "l2"),
+                                            (512, 64, "max")])
 def test_gpu_chromagram_matches_oracle(n_fft, hop, norm, dtype):
     rdt = np.float32 if dtype == "float32" else np.float64
     rng = np.random.default_rng(4)

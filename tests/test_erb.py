@@ -59,7 +59,10 @@ def test_host_erb_tables_and_validation():
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
 @pytest.mark.parametrize("n_fft,hop,amp,floor,spacing", [(1024, 256, "power", None, "linear"), (512, 256, "magnitude", None, "apple_tr35"),
-                                                         (1024, 256, "db", -80.0, "linear"), (400, 160, "power", None, "linear")])
+                                                         (1024, 256, "db", -80.0, "linear"), (400, 160, "power", None, "linear"),
+                                                         # n_fft 512 at the tuned kernel's hops: a dense bank has no band schedule, so the
+                                                         # plan leaves the two-frames-per-transform mode for the generic kernel
+                                                         (512, 128, "power", None, "linear"), (512, 160, "db", -80.0, "linear")])
 def test_gpu_erb_matches_oracle(n_fft, hop, amp, floor, spacing, dtype):
     npdt = np.float32 if dtype == "float32" else np.float64
     x = (0.3 * np.random.default_rng(2).standard_normal((3, 7000))).astype(npdt)
