@@ -628,6 +628,7 @@ __global__ __launch_bounds__(256, (rr_stft_waves<T, A_, B_, C_, STAGED_>())) voi
                     if (a.amp == AMP_MAG_IN) split_frame(f, q0, qstep, [&](unsigned k, V X) { pf[k] = t_sqrt(X.x * X.x + X.y * X.y); });
                     else split_frame(f, q0, qstep, [&](unsigned k, V X) { pf[k] = X.x * X.x + X.y * X.y; });
                     __syncthreads();
+                    RR_STAMP(14);  // filterbank outputs: split + |X|^2 rows + barrier (12 is then the bank stage alone)
                     T *o = (T *)a.out + ((size_t)b * a.n_out) * a.n_frames + f0 + f;
                     if (f < nf)
                         for (unsigned mm = q0; mm < a.n_mels; mm += qstep) {

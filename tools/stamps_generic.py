@@ -29,9 +29,10 @@ L.sgx_debug_read_rr_stamps(buf, 1)
 ms = plan.time_batch_torch(x, out, 5)
 L.sgx_debug_read_rr_stamps(buf, 1)
 names = ["staging writes", "barrier", "pass 1: reads + transform", "barrier", "pass 1: twiddles + tile writes", "load issue", "barrier", "pass 2", "barrier",
-         "pass 3", "barrier", "wait for next samples", "split + stores (+ bank stage)", "barrier"]
+         "pass 3", "barrier", "wait for next samples", "split + stores (filterbank outputs: bank stage)", "barrier",
+         "filterbank outputs: split + |X|^2 rows + barrier"]
 waves, rounds = buf[16], buf[15]
-tot = sum(buf[i] for i in range(14))
+tot = sum(buf[i] for i in range(15))
 print(f"n_fft={n_fft} hop={hop} {dt} {wl} kernel={plan.kernel_name} kernel_ms(stamped)={ms:.4f} waves={waves} wave-tiles={rounds}")
 for i, n in enumerate(names):
     print(f"  {n:34s} {buf[i] / max(rounds, 1):9.0f} cyc/wave/tile  {100.0 * buf[i] / max(tot, 1):5.1f} %")
