@@ -354,6 +354,37 @@ __device__ __forceinline__ void istft_ola(const IstftArgs &a, const unsigned cha
         // edge normalisation — same sums in the same (ascending-frame) order.
         const bool interior = fbase >= 0 && fbase + (long long)(NF - 1u) <= last && p0 >= a.start &&
                               p0 + (unsigned long long)a.nbk * a.hop <= a.start + a.out_len && (1024u % a.hop) == 0u;
+        if (interior && a.hop < NT) {
+            // fewer offsets than threads: all NT threads walk the tile's nbk * hop positions (consecutive threads = consecutive
+            // positions), the norm of an offset comes from a table built once per tile in the 2304 dead bytes between the real
+            // frames and the twiddle table (hop < 256 entries)
+            const unsigned q = 1024u / a.hop, fstride = 1024u - a.hop;
+            float *nt = (float *)(smem + NF * 4096u);
+            if (tid < a.hop) {
+                float nrm = 0.f;
+                for (unsigned i = q; i-- > 0;) {
+                    const float wj = w[i * a.hop + tid];
+                    nrm = __fadd_rn(nrm, __fmul_rn(wj, wj));
+                }
+                nt[tid] = nrm;
+            }
+            __syncthreads();
+            const unsigned dq = NT / a.hop, dr = NT - dq * a.hop;
+            unsigned hb = tid / a.hop, off = tid - hb * a.hop;
+            for (; hb < a.nbk; hb += dq, off += dr) {
+                if (off >= a.hop) {
+                    off -= a.hop;
+                    if (++hb >= a.nbk) break;
+                }
+                const float *src = fr + (a.ov + 1u - q + hb) * 1024u + (q - 1u) * a.hop + off;  // frame fh - q + 1, sample j
+                float acc = 0.f;
+                for (unsigned i = 0; i < q; ++i) acc += src[i * fstride];
+                const float nrm = nt[off];
+                if (nrm > 1e-10f) acc /= nrm;
+                o[(p0 - a.start) + (size_t)hb * a.hop + off] = acc;
+            }
+            return;
+        }
         if (interior) {
             const unsigned q = 1024u / a.hop, fstride = 1024u - a.hop;
             for (unsigned off = tid; off < a.hop; off += NT) {

@@ -768,7 +768,13 @@ sgx_status inverse_tables(sgx_plan *pl) {
     }
     sgx_status st = upload<T>(pl, &pl->d_itw, tw);
     if (st != SGX_OK) return st;
-    if (std::is_same<T, float>::value && n == 1024 && pl->p.hop_size >= 64) {  // tables of the fused tuned kernel
+    // The fused tuned kernel recomputes ov = floor(1023 / hop) halo frames per 16-frame tile.  Up to ov = 10 (hop >= 94) that beats
+    // the register-tiled rows + overlap-add through a frame scratch; below, the halo wins (256 x 10 s: hop 100 1.62 vs 1.68 ms,
+    // hop 80 2.93 vs 2.04 ms, hop 64 — one new hop block per tile — 11.3 vs 2.5 ms).
+#ifndef SGX_ISTFT1024_MIN_HOP
+#define SGX_ISTFT1024_MIN_HOP 94
+#endif
+    if (std::is_same<T, float>::value && n == 1024 && pl->p.hop_size >= SGX_ISTFT1024_MIN_HOP) {  // tables of the fused tuned kernel
         std::vector<float> tr(2 * 32 * 16), t1(2 * 32 * 16);
         for (unsigned n1 = 0; n1 < 32; ++n1)
             for (unsigned n2 = 0; n2 < 16; ++n2) {

@@ -98,12 +98,14 @@ def test_gpu_istft_matches_oracle(n_fft, hop, centre, window, dtype):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hop,centre,window,n", [(64, True, "hanning", 9000), (100, True, "hamming", 9000), (256, False, "hanning", 20000),
+@pytest.mark.parametrize("hop,centre,window,n", [(64, True, "hanning", 9000), (93, True, "hanning", 9000), (94, False, "hanning", 9000),
+                                                 (100, True, "hamming", 9000), (128, True, "hanning", 20000), (256, False, "hanning", 20000),
                                                  (300, True, "blackman", 20000), (512, True, "hanning", 20000),
                                                  (1024, True, "rectangular", 20000), (256, True, "hanning", 700)])
 def test_gpu_istft_fused_1024_kernel(hop, centre, window, n):
     """f32, n_fft = 1024: the fused tuned kernel (halo frames recomputed per tile) for hops that do and do not divide n_fft,
-    with tile edges, a single-tile signal and the untrimmed / trimmed output windows."""
+    with tile edges, a single-tile signal and the untrimmed / trimmed output windows; below hop 94 (more than 10 halo frames of
+    16) the plan takes the register-tiled rows + overlap-add instead (hop 64 here)."""
     x = np.random.default_rng(11).standard_normal((5, n)).astype(np.float32)
     wt = getattr(sg.WindowType, window)
     plan = sg.Plan(sg.SpectrogramParams(sg.StftParams(1024, hop, wt, centre), 16000.0), _ffi.AMP_COMPLEX, None, None, "float32")
