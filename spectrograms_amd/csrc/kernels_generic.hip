@@ -1165,6 +1165,37 @@ hipError_t launch_two_factor(const StftArgs &a, int dtype, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Filterbank rows over a [batch][nb][n_frames] power (or magnitude) tensor in HBM -> [batch][n_mels][n_frames]: the second launch
+// of the split filterbank path (long frames, see run_device in plan.hip).  One wave = one bank row x 64 consecutive frames: the
+// row's CSR terms are wave-uniform (scalar loads), every term reads 64 consecutive frames of one bin (contiguous), and the sum
+// runs in ascending column order, un-fused, exactly as SparseMatrix::multiply_vec does (spectrogram.rs:102-117).
+template <typename T>
+__global__ __launch_bounds__(64) void k_bank_rows(const T *pw, T *out, const unsigned *ptr, const unsigned *col, const T *val, unsigned nb,
+                                                  unsigned n_mels, unsigned n_frames, unsigned fblocks, int amp, T eps) {
+    const unsigned b = blockIdx.x / fblocks, f = (blockIdx.x - b * fblocks) * 64u + threadIdx.x, mm = blockIdx.y;
+    if (f >= n_frames) return;
+    const T *p = pw + (size_t)b * nb * n_frames + f;
+    const unsigned i0 = ptr[mm], i1 = ptr[mm + 1];
+    T acc = T(0);
+#pragma unroll 4
+    for (unsigned i = i0; i < i1; ++i) acc = t_mul_add_unfused(val[i], p[(size_t)col[i] * n_frames], acc);
+    out[((size_t)b * n_mels + mm) * n_frames + f] = amp_apply(acc, amp, eps);
+}
+
+hipError_t launch_bank_rows(const void *pw, void *out, const StftArgs &a, int dtype, hipStream_t s) {
+    const unsigned fblocks = (a.n_frames + 63u) / 64u;
+    const unsigned long long gx = (unsigned long long)fblocks * a.batch;
+    if (gx == 0 || gx >= 0x7fffffffull || a.n_mels == 0 || a.n_mels > 65535u) return hipErrorInvalidConfiguration;
+    const dim3 grid((unsigned)gx, a.n_mels);
+    if (dtype == SGX_F64)
+        hipLaunchKernelGGL(k_bank_rows<double>, grid, dim3(64), 0, s, (const double *)pw, (double *)out, a.mel_ptr, a.mel_col,
+                           (const double *)a.mel_val, a.nb_fft, a.n_mels, a.n_frames, fblocks, a.amp, (double)a.eps);
+    else
+        hipLaunchKernelGGL(k_bank_rows<float>, grid, dim3(64), 0, s, (const float *)pw, (float *)out, a.mel_ptr, a.mel_col,
+                           (const float *)a.mel_val, a.nb_fft, a.n_mels, a.n_frames, fblocks, a.amp, (float)a.eps);
+    return hipGetLastError();
+}
+
 hipError_t launch_mfcc(const void *mel, void *out, const void *basis, const void *lifter, unsigned batch, unsigned n_mels,
                        unsigned n_frames, unsigned n_mfcc, unsigned skip, int has_lifter, int dtype, hipStream_t s) {
     const unsigned long long n = (unsigned long long)batch * n_frames;

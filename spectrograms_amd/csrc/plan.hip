@@ -680,6 +680,14 @@ sgx_status check_call(sgx_plan *pl, const void *samples, size_t batch, size_t n_
 
 sgx_status grow(sgx_plan *pl, void **buf, size_t *have, size_t need);
 
+#ifndef SGX_SPLIT_BANK_BYTES
+#define SGX_SPLIT_BANK_BYTES 16384  // n_fft * sizeof(T) from which the filterbank runs as a second launch (f32 4096, f64 2048)
+#endif
+bool split_filterbank(const sgx_plan *pl, const StftArgs &a, KernelKind kind) {
+    return kind == K_REG_RADIX && a.out_mode == OUT_MEL && size_t(a.n_fft) * pl->elem >= SGX_SPLIT_BANK_BYTES && pl->d_mel_ptr &&
+           pl->d_mel_col && pl->d_mel_val;
+}
+
 sgx_status run_device(sgx_plan *pl, const void *x, size_t batch, size_t n_samples, size_t stride, void *out,
                       size_t n_frames, hipStream_t s, int iters, float *ms) {
     StftArgs a;
@@ -704,10 +712,27 @@ sgx_status run_device(sgx_plan *pl, const void *x, size_t batch, size_t n_sample
             return set_err(pl, SGX_BACKEND, "hip -- FFT backend error: n_fft too large for the on-chip frame tile");
     }
     if (kind == K_R32X16_F32) a.window = pl->d_window_half;
+    // Long frames on the register-tiled kernel with a filterbank output: a tile holds one or two frames, so the fused bank stage has
+    // (frames x rows) = 80-160 work items for 256 threads and its longest rows (hundreds of sequentially added terms) set the time
+    // (256 x 10 s, f64 n_fft 4096 Mel-80 dB: 1.93 ms per 64 signals against 0.32 ms for the per-bin output).  There the per-bin power
+    // (magnitude for the magnitude-domain banks) goes to a plan-owned tensor and a second launch reduces it with one wave per
+    // (row, 64 frames): the same terms in the same order, so the same bits.
+    StftArgs a1 = a;  // the first launch
+    const bool split_bank = split_filterbank(pl, a, kind);
+    if (split_bank) {
+        sgx_status st = grow(pl, &pl->d_pwbuf, &pl->d_pwbuf_bytes, batch * size_t(pl->nb_fft) * n_frames * pl->elem);
+        if (st != SGX_OK) return st;
+        a1.out_mode = OUT_LINEAR;
+        a1.amp = a.amp == AMP_MAG_IN ? AMP_MAGNITUDE : AMP_POWER;
+        a1.out = pl->d_pwbuf;
+        a1.n_out = pl->nb_fft;
+        if (!set_geometry(pl, a1, kind)) return set_err(pl, SGX_BACKEND, "hip -- FFT backend error: n_fft too large for the on-chip frame tile");
+    }
     if (ms) SGX_HIP(pl, hipEventRecord(pl->ev0, s));
     const unsigned skip = pl->p.n_mfcc - pl->n_final * (mfcc ? 1u : 0u);
     for (int i = 0; i < iters; ++i) {
-        SGX_HIP(pl, launch(pl, a, kind, s));
+        SGX_HIP(pl, launch(pl, a1, kind, s));
+        if (split_bank) SGX_HIP(pl, launch_bank_rows(pl->d_pwbuf, stage_out, a, pl->dtype, s));
         if (pl->p.freq_scale == SGX_FREQ_CHROMA)
             SGX_HIP(pl, launch_chroma_norm(out, unsigned(batch), unsigned(n_frames), pl->p.chroma_norm, pl->dtype, s));
         if (mfcc)
@@ -736,7 +761,7 @@ sgx_status grow(sgx_plan *pl, void **buf, size_t *have, size_t need) {
 
 void free_device(sgx_plan *pl) {
     void **bufs[] = {&pl->d_window, &pl->d_tw, &pl->d_tw1, &pl->d_tw2, &pl->d_mel_ptr, &pl->d_mel_col,
-                     &pl->d_mel_val, &pl->d_dct, &pl->d_lifter, &pl->d_melbuf, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_mm_frag, &pl->d_mm_blk, &pl->d_mel_sched, &pl->d_itw, &pl->d_itwr, &pl->d_itw1, &pl->d_frames, &pl->d_flag, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half};
+                     &pl->d_mel_val, &pl->d_dct, &pl->d_lifter, &pl->d_melbuf, &pl->d_pwbuf, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_mm_frag, &pl->d_mm_blk, &pl->d_mel_sched, &pl->d_itw, &pl->d_itwr, &pl->d_itw1, &pl->d_frames, &pl->d_flag, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half};
     for (void **b : bufs)
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
@@ -1174,6 +1199,14 @@ sgx_status sgx_reserve(sgx_plan *plan, size_t batch, size_t n_samples, int32_t h
     if (plan->p.n_mfcc > 0 &&
         (st = grow(plan, &plan->d_melbuf, &plan->d_melbuf_bytes, batch * size_t(plan->n_out) * nf * plan->elem)) != SGX_OK)
         return st;
+    {
+        StftArgs probe{};
+        probe.out_mode = plan->out_mode;
+        probe.n_fft = plan->p.n_fft;
+        if (!inverse && split_filterbank(plan, probe, plan->kind) &&
+            (st = grow(plan, &plan->d_pwbuf, &plan->d_pwbuf_bytes, batch * size_t(plan->nb_fft) * nf * plan->elem)) != SGX_OK)
+            return st;
+    }
     if (inverse) {  // sgx_istft of `batch` spectra whose frame count is that of n_samples-long signals
         const bool fused = plan->d_itwr && nf * 513ull * 8ull < 0x7fffffffull;
         if (!fused && (st = grow(plan, &plan->d_frames, &plan->d_frames_bytes, batch * nf * plan->p.n_fft * plan->elem)) != SGX_OK) return st;

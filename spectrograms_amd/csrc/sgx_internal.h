@@ -86,6 +86,8 @@ hipError_t launch_two_factor(const StftArgs &a, int dtype, hipStream_t s);
 bool plan_geometry_lds_radix2(StftArgs &a, int dtype);
 bool plan_geometry_reg_radix(StftArgs &a, int dtype);
 hipError_t launch_reg_radix(const StftArgs &a, int dtype, hipStream_t s);
+// filterbank rows over a [batch][nb_fft][n_frames] power / magnitude tensor (split filterbank path): CSR bank, amp and eps from `a`
+hipError_t launch_bank_rows(const void *pw, void *out, const StftArgs &a, int dtype, hipStream_t s);
 bool plan_geometry_r32x16_f32(StftArgs &a);
 
 // ---- 2-D FFT path (kernels_fft2d.hip)
@@ -233,6 +235,9 @@ struct sgx_plan {
     // MFCC epilogue: DCT-II basis [n_mfcc][n_mels] and lifter [n_mfcc] in T; Mel-dB scratch (grown on demand)
     void *d_dct = nullptr, *d_lifter = nullptr, *d_melbuf = nullptr;
     size_t d_melbuf_bytes = 0;
+    // split filterbank path (long frames): the per-bin power / magnitude tensor between the two launches (grown on demand)
+    void *d_pwbuf = nullptr;
+    size_t d_pwbuf_bytes = 0;
     unsigned n_final = 0;  // rows of the final output (n_out, or the MFCC row count)
     void *d_window_half = nullptr, *d_ones_half = nullptr;  // 0.5*window (exact) for the tuned kernel's real split
     // inverse path (sgx_istft / sgx_c2r), created on first use: full twiddle table e^{-2 pi i k/n}, frame scratch, flag

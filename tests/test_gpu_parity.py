@@ -137,6 +137,21 @@ def test_pow2_sizes(n_fft, hop, amp, dtype):
         assert plan.kernel_name == "reg_radix"
 
 
+@pytest.mark.parametrize("amp,floor", [("power", None), ("magnitude", None), ("db", -80.0)])
+@pytest.mark.parametrize("n_fft,hop,dtype,n_mels,norm", [(4096, 1024, "float32", 80, None), (8192, 2048, "float32", 128, "slaney"),
+                                                         (2048, 512, "float64", 80, None), (4096, 1000, "float64", 40, "l1"),
+                                                         (1920, 480, "float64", 64, None)])
+def test_long_frames_filterbank_in_a_second_launch(n_fft, hop, dtype, n_mels, norm, amp, floor):
+    """Filterbank outputs at n_fft * sizeof(T) >= 16 KiB on the register-tiled kernel run as two launches (per-bin power to a
+    plan-owned tensor, then one wave per (band, 64 frames)): the same terms in the reference's order; frame counts that are not
+    multiples of 64, one signal vs the batch, and a second call on the same plan (the tensor is reused)."""
+    plan, got = run_case(n=5 * n_fft + 123, batch=3, n_fft=n_fft, hop=hop, n_mels=n_mels, norm=norm, amp=amp, floor=floor, dtype=dtype)
+    assert plan.kernel_name == "reg_radix"
+    x = signals(3, 5 * n_fft + 123, np.float32 if dtype == "float32" else np.float64, 0)
+    assert np.array_equal(np.asarray(plan.compute_batch(x[1:2]))[0], np.asarray(got)[1])
+    assert np.array_equal(np.asarray(plan.compute_batch(x)), np.asarray(got))
+
+
 MIXED = [80, 120, 160, 200, 240, 320, 400, 480, 600, 640, 800, 960, 1000, 1200, 1440, 1600, 1920]
 
 
