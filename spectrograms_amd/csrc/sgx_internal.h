@@ -94,7 +94,8 @@ bool plan_geometry_r32x16_f32(StftArgs &a);
 struct C2cArgs {
     const void *in;
     void *out;
-    unsigned n, log2n;  // log2n == 0: not a power of two (direct DFT)
+    unsigned n, log2n;  // log2n == 0: not a power of two (two-factor or direct DFT)
+    unsigned n1;        // k_c2c_tile, set by its launcher: n = n1 * n2 two-factor transform through a second LDS buffer (0: direct sum)
     unsigned nseq, batch;
     unsigned long long in_img, out_img;              // elements between images
     unsigned long long in_ss, in_is, out_ss, out_is;  // sequence / index strides (elements)
@@ -115,6 +116,7 @@ struct C2rArgs {
     unsigned nrows, ncols, log2c, batch;
     unsigned long long in_img, in_ks, in_rs;
     int k_fast;  // input is [r][k]-major (in_ks == 1): map threads with k fastest
+    unsigned n1;  // k_c2r_rows, set by its launcher: ncols = n1 * n2 two-factor transform (0: direct sum)
     unsigned tile, tiles;
     const void *tw;  // e^{-2 pi i k / ncols}, ncols entries
     double scale;

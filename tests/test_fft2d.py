@@ -111,7 +111,11 @@ def test_host_validation():
 # ------------------------------------------------------------------ GPU parity
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
-@pytest.mark.parametrize("shape", SHAPES + [(256, 256), (1024, 1024), (512, 1024), (1024, 64), (100, 1024), (37, 1024)])
+@pytest.mark.parametrize("shape", SHAPES + [(256, 256), (1024, 1024), (512, 1024), (1024, 64), (100, 1024), (37, 1024), (4096, 8), (8, 4096),
+                                            (8192, 4),
+                                            # lengths without a register-tiled split: two-factor transform in LDS (1000 = 25 x 40, 1023 = 31 x 33,
+                                            # 1001 = 13 x 77), the direct sum where its two buffers do not fit (6000 in f64) or the length is prime
+                                            (1000, 6), (6, 1023), (63, 35), (1001, 4), (6000, 2), (509, 3)])
 def test_gpu_fft2d_matches_oracle(shape, dtype):
     npdt = np.float32 if dtype == "float32" else np.float64
     x = img(shape, 5, npdt)
