@@ -308,7 +308,7 @@ hipError_t launch_c2c_tile(const C2cArgs &a0, int dtype, hipStream_t s) {
     if (g == 0 || g >= 0x7fffffffull || a.tile == 0) return hipErrorInvalidConfiguration;
     const size_t lds = (size_t)a.tile * (a.n + 1) * 2 * esz(dtype) + extra;
     if (lds > 64 * 1024) {
-        hipError_t e = set_max_dynamic_lds(dtype == SGX_F64 ? (const void *)k_c2c_tile<double> : (const void *)k_c2c_tile<float>, (int)lds);
+        hipError_t e = set_max_dynamic_lds(dtype == SGX_F64 ? (const void *)k_c2c_tile<double> : (const void *)k_c2c_tile<float>, 144 * 1024);  // (set once)
         if (e != hipSuccess) return e;
     }
     if (dtype == SGX_F64) hipLaunchKernelGGL(k_c2c_tile<double>, dim3((unsigned)g), dim3(256), lds, s, a);

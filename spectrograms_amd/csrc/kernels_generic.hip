@@ -884,7 +884,13 @@ hipError_t launch_chroma_norm(void *data, unsigned batch, unsigned n_frames, int
 // the sizes in tools/time_generic.py: shorter store segments, but more waves to hide the LDS / barrier latency
 static const size_t kLdsBudget = 32 * 1024;
 
-static const size_t kLdsHardLimit = 64 * 1024;  // static + dynamic LDS a kernel gets without the large-LDS opt-in
+// a single frame may take the large-LDS window (the launchers opt in above 64 KiB): with the 64 KiB default a 6000-point f32
+// two-factor tile (120 KB) did not fit and the plan fell through to the O(n^2) direct sum — 320 ms per 64 x 10 s, slower than a CPU
+static const size_t kLdsHardLimit = 144 * 1024;
+template <typename K>
+static hipError_t lds_opt_in(K kernel, size_t lds) {
+    return lds > 64 * 1024 ? set_max_dynamic_lds((const void *)kernel, (int)kLdsHardLimit) : hipSuccess;  // (set once per kernel and device)
+}
 
 static size_t elem_size(int dtype) { return dtype == SGX_F64 ? 8 : 4; }
 
@@ -1135,6 +1141,7 @@ hipError_t launch_lds_radix2(const StftArgs &a, int dtype, hipStream_t s) {
     size_t es = elem_size(dtype);
     size_t lds = (size_t)a.ft * (a.m + 1) * 2 * es + (a.out_mode == OUT_MEL ? (size_t)a.ft * a.nb_fft * es : 0);
     if (a.tw_lds) lds = (size_t)a.tw_lds + (size_t)a.m * 2 * es;
+    if (hipError_t e = dtype == SGX_F64 ? lds_opt_in(k_lds_radix2<double>, lds) : lds_opt_in(k_lds_radix2<float>, lds); e != hipSuccess) return e;
     if (dtype == SGX_F64)
         hipLaunchKernelGGL(k_lds_radix2<double>, dim3((unsigned)g), dim3(256), lds, s, a);
     else
@@ -1147,6 +1154,7 @@ hipError_t launch_direct_dft(const StftArgs &a, int dtype, hipStream_t s) {
     if (!grid_ok(a, &g)) return hipErrorInvalidConfiguration;
     size_t es = elem_size(dtype);
     size_t lds = (size_t)a.ft * a.n_fft * es + (a.out_mode == OUT_MEL ? (size_t)a.ft * a.nb_fft * es : 0);
+    if (hipError_t e = dtype == SGX_F64 ? lds_opt_in(k_direct_dft<double>, lds) : lds_opt_in(k_direct_dft<float>, lds); e != hipSuccess) return e;
     if (dtype == SGX_F64)
         hipLaunchKernelGGL(k_direct_dft<double>, dim3((unsigned)g), dim3(256), lds, s, a);
     else
@@ -1158,6 +1166,7 @@ hipError_t launch_two_factor(const StftArgs &a, int dtype, hipStream_t s) {
     unsigned long long g;
     if (!grid_ok(a, &g) || a.fac_a < 2 || a.fac_a * a.fac_b != a.n_fft) return hipErrorInvalidConfiguration;
     const size_t lds = two_factor_bytes(a, a.ft, elem_size(dtype));
+    if (hipError_t e = dtype == SGX_F64 ? lds_opt_in(k_two_factor<double>, lds) : lds_opt_in(k_two_factor<float>, lds); e != hipSuccess) return e;
     if (dtype == SGX_F64)
         hipLaunchKernelGGL(k_two_factor<double>, dim3((unsigned)g), dim3(256), lds, s, a);
     else

@@ -683,10 +683,24 @@ sgx_status grow(sgx_plan *pl, void **buf, size_t *have, size_t need);
 #ifndef SGX_SPLIT_BANK_BYTES
 #define SGX_SPLIT_BANK_BYTES 16384  // n_fft * sizeof(T) from which the filterbank runs as a second launch (f32 4096, f64 2048)
 #endif
-bool split_filterbank(const sgx_plan *pl, const StftArgs &a, KernelKind kind) {
-    return kind == K_REG_RADIX && a.out_mode == OUT_MEL && size_t(a.n_fft) * pl->elem >= SGX_SPLIT_BANK_BYTES && pl->d_mel_ptr &&
-           pl->d_mel_col && pl->d_mel_val;
+// the first launch of the split filterbank path: per-bin power (magnitude for the magnitude-domain banks) instead of the bank's rows
+void per_bin_args(const sgx_plan *pl, StftArgs &a) {
+    a.amp = a.amp == AMP_MAG_IN ? AMP_MAGNITUDE : AMP_POWER;
+    a.out_mode = OUT_LINEAR;
+    a.n_out = pl->nb_fft;
 }
+// geometry for `kind`, else down the chain: tuned -> register-tiled -> LDS radix-2 / two factors -> direct sum
+bool resolve_geometry(const sgx_plan *pl, StftArgs &a, KernelKind &kind) {
+    if (set_geometry(pl, a, kind)) return true;
+    const bool p2 = (a.n_fft & (a.n_fft - 1)) == 0;
+    bool ok = false;
+    if (kind == K_R32X16_F32) ok = set_geometry(pl, a, kind = K_REG_RADIX);
+    if (!ok && p2 && kind != K_LDS_RADIX2) ok = set_geometry(pl, a, kind = K_LDS_RADIX2);
+    if (!ok && !p2 && kind == K_REG_RADIX) ok = set_geometry(pl, a, kind = K_TWO_FACTOR);
+    if (!ok) ok = set_geometry(pl, a, kind = K_DIRECT_DFT);
+    return ok;
+}
+int chain_pos(KernelKind k) { return k == K_R32X16_F32 ? 0 : k == K_REG_RADIX ? 1 : k == K_DIRECT_DFT ? 3 : 2; }
 
 sgx_status run_device(sgx_plan *pl, const void *x, size_t batch, size_t n_samples, size_t stride, void *out,
                       size_t n_frames, hipStream_t s, int iters, float *ms) {
@@ -700,34 +714,23 @@ sgx_status run_device(sgx_plan *pl, const void *x, size_t batch, size_t n_sample
     }
     fill_args(pl, a, x, stage_out, batch, n_samples, stride, n_frames);
     KernelKind kind = pick_kernel(pl, x, stride);
-    if (!set_geometry(pl, a, kind)) {
-        // fallback chain: tuned -> register-tiled -> LDS radix-2 -> direct sum (a two-factor plan that no longer fits goes direct)
-        const bool p2 = (a.n_fft & (a.n_fft - 1)) == 0;
-        bool ok = false;
-        if (kind == K_R32X16_F32) ok = set_geometry(pl, a, kind = K_REG_RADIX);
-        if (!ok && p2 && kind != K_LDS_RADIX2) ok = set_geometry(pl, a, kind = K_LDS_RADIX2);
-        if (!ok && !p2 && kind == K_REG_RADIX) ok = set_geometry(pl, a, kind = K_TWO_FACTOR);
-        if (!ok) ok = set_geometry(pl, a, kind = K_DIRECT_DFT);
-        if (!ok)
-            return set_err(pl, SGX_BACKEND, "hip -- FFT backend error: n_fft too large for the on-chip frame tile");
-    }
-    if (kind == K_R32X16_F32) a.window = pl->d_window_half;
-    // Long frames on the register-tiled kernel with a filterbank output: a tile holds one or two frames, so the fused bank stage has
-    // (frames x rows) = 80-160 work items for 256 threads and its longest rows (hundreds of sequentially added terms) set the time
-    // (256 x 10 s, f64 n_fft 4096 Mel-80 dB: 1.93 ms per 64 signals against 0.32 ms for the per-bin output).  There the per-bin power
-    // (magnitude for the magnitude-domain banks) goes to a plan-owned tensor and a second launch reduces it with one wave per
-    // (row, 64 frames): the same terms in the same order, so the same bits.
-    StftArgs a1 = a;  // the first launch
-    const bool split_bank = split_filterbank(pl, a, kind);
+    // Split filterbank path (decided at plan creation, `split_bank`): the per-bin power goes to a plan-owned tensor and a second
+    // launch reduces it with one wave per (row, 64 frames) — the same terms in the same order, so the same bits.  Taken (i) for long
+    // frames on the register-tiled kernel, where a tile holds one or two frames, the fused bank stage has 80-160 (frame, row) items
+    // for 256 threads and its longest rows set the time (64 x 10 s, f64 n_fft 4096 Mel-80 dB: 1.93 ms against 0.32 ms for the
+    // per-bin output), and (ii) where the tile with its |X|^2 rows no longer fits the kernel the per-bin output runs on (n_fft 3000
+    // Mel fell from the two-factor kernel to the direct sum: 130 ms against 5.3 ms).
+    StftArgs a1 = a;  // the first (or only) launch
+    const bool split_bank = pl->split_bank;
     if (split_bank) {
         sgx_status st = grow(pl, &pl->d_pwbuf, &pl->d_pwbuf_bytes, batch * size_t(pl->nb_fft) * n_frames * pl->elem);
         if (st != SGX_OK) return st;
-        a1.out_mode = OUT_LINEAR;
-        a1.amp = a.amp == AMP_MAG_IN ? AMP_MAGNITUDE : AMP_POWER;
+        per_bin_args(pl, a1);
         a1.out = pl->d_pwbuf;
-        a1.n_out = pl->nb_fft;
-        if (!set_geometry(pl, a1, kind)) return set_err(pl, SGX_BACKEND, "hip -- FFT backend error: n_fft too large for the on-chip frame tile");
     }
+    if (!resolve_geometry(pl, a1, kind))
+        return set_err(pl, SGX_BACKEND, "hip -- FFT backend error: n_fft too large for the on-chip frame tile");
+    if (kind == K_R32X16_F32) a1.window = pl->d_window_half;
     if (ms) SGX_HIP(pl, hipEventRecord(pl->ev0, s));
     const unsigned skip = pl->p.n_mfcc - pl->n_final * (mfcc ? 1u : 0u);
     for (int i = 0; i < iters; ++i) {
@@ -950,16 +953,27 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
     {
         StftArgs probe;
         fill_args(pl, probe, nullptr, nullptr, 1, params->n_fft, params->n_fft, 1);
-        bool ok = set_geometry(pl, probe, pl->kind);
-        while (!ok && pl->kind != K_DIRECT_DFT) {
-            pl->kind = (pl->kind == K_R32X16_F32) ? K_REG_RADIX
-                       : (pl->kind == K_REG_RADIX) ? (pow2 ? K_LDS_RADIX2 : K_TWO_FACTOR) : K_DIRECT_DFT;
-            ok = set_geometry(pl, probe, pl->kind);
+        KernelKind kind = pl->kind;
+        bool ok = resolve_geometry(pl, probe, kind);
+        if (pl->out_mode == OUT_MEL) {  // would the per-bin output run further up the chain?  (see run_device)
+            StftArgs lin;
+            fill_args(pl, lin, nullptr, nullptr, 1, params->n_fft, params->n_fft, 1);
+            per_bin_args(pl, lin);
+            KernelKind kind_lin = pl->kind;
+            const bool ok_lin = resolve_geometry(pl, lin, kind_lin);
+            const bool long_frames = ok && kind != K_R32X16_F32 && size_t(params->n_fft) * pl->elem >= SGX_SPLIT_BANK_BYTES;
+            const bool further_up = ok_lin && kind_lin != K_R32X16_F32 && (!ok || chain_pos(kind_lin) < chain_pos(kind));
+            if (ok_lin && (long_frames || further_up)) {
+                pl->split_bank = true;
+                kind = kind_lin;
+                ok = true;
+            }
         }
         if (!ok) {
             delete pl;
             return create_fail(SGX_BACKEND, "hip -- FFT backend error: n_fft too large for the on-chip frame tile");
         }
+        pl->kind = kind;
     }
 
     pl->device = params->device;
@@ -1199,14 +1213,9 @@ sgx_status sgx_reserve(sgx_plan *plan, size_t batch, size_t n_samples, int32_t h
     if (plan->p.n_mfcc > 0 &&
         (st = grow(plan, &plan->d_melbuf, &plan->d_melbuf_bytes, batch * size_t(plan->n_out) * nf * plan->elem)) != SGX_OK)
         return st;
-    {
-        StftArgs probe{};
-        probe.out_mode = plan->out_mode;
-        probe.n_fft = plan->p.n_fft;
-        if (!inverse && split_filterbank(plan, probe, plan->kind) &&
-            (st = grow(plan, &plan->d_pwbuf, &plan->d_pwbuf_bytes, batch * size_t(plan->nb_fft) * nf * plan->elem)) != SGX_OK)
-            return st;
-    }
+    if (!inverse && plan->split_bank &&
+        (st = grow(plan, &plan->d_pwbuf, &plan->d_pwbuf_bytes, batch * size_t(plan->nb_fft) * nf * plan->elem)) != SGX_OK)
+        return st;
     if (inverse) {  // sgx_istft of `batch` spectra whose frame count is that of n_samples-long signals
         const bool fused = plan->d_itwr && nf * 513ull * 8ull < 0x7fffffffull;
         if (!fused && (st = grow(plan, &plan->d_frames, &plan->d_frames_bytes, batch * nf * plan->p.n_fft * plan->elem)) != SGX_OK) return st;

@@ -240,6 +240,7 @@ struct sgx_plan {
     // split filterbank path (long frames): the per-bin power / magnitude tensor between the two launches (grown on demand)
     void *d_pwbuf = nullptr;
     size_t d_pwbuf_bytes = 0;
+    bool split_bank = false;  // decided at plan creation (plan.hip)
     unsigned n_final = 0;  // rows of the final output (n_out, or the MFCC row count)
     void *d_window_half = nullptr, *d_ones_half = nullptr;  // 0.5*window (exact) for the tuned kernel's real split
     // inverse path (sgx_istft / sgx_c2r), created on first use: full twiddle table e^{-2 pi i k/n}, frame scratch, flag

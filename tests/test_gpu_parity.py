@@ -140,13 +140,18 @@ def test_pow2_sizes(n_fft, hop, amp, dtype):
 @pytest.mark.parametrize("amp,floor", [("power", None), ("magnitude", None), ("db", -80.0)])
 @pytest.mark.parametrize("n_fft,hop,dtype,n_mels,norm", [(4096, 1024, "float32", 80, None), (8192, 2048, "float32", 128, "slaney"),
                                                          (2048, 512, "float64", 80, None), (4096, 1000, "float64", 40, "l1"),
-                                                         (1920, 480, "float64", 64, None)])
+                                                         (1920, 480, "float64", 64, None),
+                                                         # other kernels: LDS radix-2 (beyond the register-tiled sizes), two factors (its tile
+                                                         # with the |X|^2 rows would not fit: the plan used to fall to the direct sum)
+                                                         (16384, 4096, "float32", 80, None), (8192, 2048, "float64", 80, None),
+                                                         (3000, 750, "float32", 40, None), (6000, 1500, "float32", 40, None)])
 def test_long_frames_filterbank_in_a_second_launch(n_fft, hop, dtype, n_mels, norm, amp, floor):
     """Filterbank outputs at n_fft * sizeof(T) >= 16 KiB on the register-tiled kernel run as two launches (per-bin power to a
     plan-owned tensor, then one wave per (band, 64 frames)): the same terms in the reference's order; frame counts that are not
     multiples of 64, one signal vs the batch, and a second call on the same plan (the tensor is reused)."""
     plan, got = run_case(n=5 * n_fft + 123, batch=3, n_fft=n_fft, hop=hop, n_mels=n_mels, norm=norm, amp=amp, floor=floor, dtype=dtype)
-    assert plan.kernel_name == "reg_radix"
+    assert plan.kernel_name == {(16384, "float32"): "lds_radix2", (8192, "float64"): "lds_radix2", (3000, "float32"): "two_factor_dft",
+                                (6000, "float32"): "two_factor_dft"}.get((n_fft, dtype), "reg_radix")
     x = signals(3, 5 * n_fft + 123, np.float32 if dtype == "float32" else np.float64, 0)
     assert np.array_equal(np.asarray(plan.compute_batch(x[1:2]))[0], np.asarray(got)[1])
     assert np.array_equal(np.asarray(plan.compute_batch(x)), np.asarray(got))
