@@ -732,8 +732,10 @@ __global__ __launch_bounds__(256) void k_two_factor(StftArgs a) {
     const T *xb = (const T *)a.x + (size_t)b * a.sample_stride;
     const T *w = (const T *)a.window;
     const T eps = (T)a.eps;
-    for (unsigned i = threadIdx.x; i < n; i += 256) ltw[i] = ((const Cx<T> *)a.tw)[i];
-    const Cx<T> *tw = ltw;
+    // (a frame too long for the LDS copy — per-bin outputs only, a.tw_lds == 0 — gathers the twiddles from the table in memory)
+    if (a.tw_lds)
+        for (unsigned i = threadIdx.x; i < n; i += 256) ltw[i] = ((const Cx<T> *)a.tw)[i];
+    const Cx<T> *tw = a.tw_lds ? ltw : (const Cx<T> *)a.tw;
     for (unsigned idx = threadIdx.x; idx < nf * n; idx += 256) {
         const unsigned f = idx / n, i = idx % n;
         const long long s = (long long)(f0 + f) * a.hop + (long long)i - (long long)a.pad;
@@ -944,7 +946,15 @@ bool plan_geometry_two_factor(StftArgs &a, int dtype) {
     a.fac_a = best;
     a.fac_b = a.n_fft / best;
     const size_t es = elem_size(dtype);
-    return pick_frames_per_tile(a, [&](unsigned ft) { return two_factor_bytes(a, ft, es); });
+    a.tw_lds = 1;  // twiddle table copied to LDS
+    if (pick_frames_per_tile(a, [&](unsigned ft) { return two_factor_bytes(a, ft, es); })) return true;
+    // one frame without the LDS twiddle copy (f64 n_fft 6000: 144 KB instead of 240 KB — the direct sum took 312 ms per 64 x 10 s)
+    if (a.out_mode != OUT_MEL && (size_t)a.n_fft * 3 * es <= kLdsHardLimit) {
+        a.ft = 1;
+        a.tw_lds = 0;
+        return true;
+    }
+    return false;
 }
 
 static bool grid_ok(const StftArgs &a, unsigned long long *blocks) {
@@ -1165,7 +1175,7 @@ hipError_t launch_direct_dft(const StftArgs &a, int dtype, hipStream_t s) {
 hipError_t launch_two_factor(const StftArgs &a, int dtype, hipStream_t s) {
     unsigned long long g;
     if (!grid_ok(a, &g) || a.fac_a < 2 || a.fac_a * a.fac_b != a.n_fft) return hipErrorInvalidConfiguration;
-    const size_t lds = two_factor_bytes(a, a.ft, elem_size(dtype));
+    const size_t lds = two_factor_bytes(a, a.ft, elem_size(dtype)) - (a.tw_lds ? 0 : (size_t)a.n_fft * 2 * elem_size(dtype));
     if (hipError_t e = dtype == SGX_F64 ? lds_opt_in(k_two_factor<double>, lds) : lds_opt_in(k_two_factor<float>, lds); e != hipSuccess) return e;
     if (dtype == SGX_F64)
         hipLaunchKernelGGL(k_two_factor<double>, dim3((unsigned)g), dim3(256), lds, s, a);

@@ -157,6 +157,16 @@ def test_long_frames_filterbank_in_a_second_launch(n_fft, hop, dtype, n_mels, no
     assert np.array_equal(np.asarray(plan.compute_batch(x)), np.asarray(got))
 
 
+@pytest.mark.parametrize("n_fft,hop,dtype,kernel", [(6000, 1500, "float32", "two_factor_dft"), (6000, 2000, "float64", "two_factor_dft"),
+                                                    (3000, 700, "float64", "two_factor_dft"), (5003, 2000, "float32", "direct_dft")])
+@pytest.mark.parametrize("amp", ["complex", "power"])
+def test_long_composite_frames_stay_on_the_two_factor_kernel(n_fft, hop, dtype, kernel, amp):
+    """Composite lengths outside the register-tiled lists with tiles above 64 KiB (the large LDS window; f64 6000 without the LDS
+    twiddle copy) run the two-factor kernel, not the O(n^2) direct sum; a prime length has nothing else."""
+    plan, _ = run_case(n=3 * n_fft + 77, batch=2, n_fft=n_fft, hop=hop, amp=amp, dtype=dtype)
+    assert plan.kernel_name == kernel
+
+
 MIXED = [80, 120, 160, 200, 240, 320, 400, 480, 600, 640, 800, 960, 1000, 1200, 1440, 1600, 1920]
 
 
