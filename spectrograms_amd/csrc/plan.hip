@@ -681,7 +681,9 @@ sgx_status check_call(sgx_plan *pl, const void *samples, size_t batch, size_t n_
 sgx_status grow(sgx_plan *pl, void **buf, size_t *have, size_t need);
 
 #ifndef SGX_SPLIT_BANK_BYTES
-#define SGX_SPLIT_BANK_BYTES 16384  // n_fft * sizeof(T) from which the filterbank runs as a second launch (f32 4096, f64 2048)
+// n_fft * sizeof(T) from which the filterbank runs as a second launch (f64 from n_fft 1600, f32 from 4096): measured per 64 x 10 s,
+// fused vs split, f64 1024 (8 KiB) 126 vs 129 us, f64 1600 (12.5 KiB) 456 vs 348 us, f64 1920 707 vs 395 us, f64 2048 690 vs 364 us
+#define SGX_SPLIT_BANK_BYTES 12000
 #endif
 // the first launch of the split filterbank path: per-bin power (magnitude for the magnitude-domain banks) instead of the bank's rows
 void per_bin_args(const sgx_plan *pl, StftArgs &a) {
