@@ -99,7 +99,9 @@ static const RegSplit kMixedSplits[] = {
     {800, 32, 25},  // 1600 (50 ms @ 32 kHz)
     {960, 32, 30},  // 1920 (40 ms @ 48 kHz)
     // round numbers as image sides / column lengths of the 2-D path (and n_fft 2000, 2400, 2560): a 40-point second pass
+    {640, 16, 40},   // (rows of 1280-wide images: 720p)
     {1000, 25, 40},
+    {1080, 30, 36},  // (columns of 1920 x 1080 images)
     {1200, 30, 40},
     {1280, 32, 40},
 };
@@ -138,6 +140,6 @@ inline bool reg_split_len(unsigned len, int dtype, unsigned *pa, unsigned *pb, u
 #define SGX_RR_SPLITS_MIXED(X)                                                                                          \
     X(8, 5, 1) X(10, 6, 1) X(10, 8, 1) X(10, 10, 1) X(12, 10, 1) X(16, 10, 1) X(25, 8, 1) X(16, 15, 1) X(20, 15, 1)       \
     X(20, 16, 1) X(25, 16, 1) X(24, 20, 1) X(25, 20, 1) X(25, 24, 1) X(30, 24, 1) X(32, 25, 1) X(32, 30, 1)       \
-    X(25, 40, 1) X(30, 40, 1) X(32, 40, 1)
+    X(25, 40, 1) X(30, 40, 1) X(32, 40, 1) X(16, 40, 1) X(30, 36, 1)
 
 }  // namespace sgx

@@ -117,7 +117,7 @@ def test_host_validation():
                                             # 1001 = 13 x 77), the direct sum where its two buffers do not fit (6000 in f64) or the length is prime
                                             (1000, 6), (6, 1023), (63, 35), (1001, 4), (6000, 2), (509, 3),
                                             # 1000 / 1200 / 1280 as column lengths and as (halved) row lengths: register-tiled, 40-point second pass
-                                            (1200, 5), (1280, 3), (5, 2000), (3, 2400)])
+                                            (1200, 5), (1280, 3), (5, 2000), (3, 2400), (1080, 6), (6, 1280), (640, 4)])
 def test_gpu_fft2d_matches_oracle(shape, dtype):
     npdt = np.float32 if dtype == "float32" else np.float64
     x = img(shape, 5, npdt)

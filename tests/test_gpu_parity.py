@@ -167,7 +167,7 @@ def test_long_composite_frames_stay_on_the_two_factor_kernel(n_fft, hop, dtype, 
     assert plan.kernel_name == kernel
 
 
-MIXED = [80, 120, 160, 200, 240, 320, 400, 480, 600, 640, 800, 960, 1000, 1200, 1440, 1600, 1920, 2000, 2400, 2560]
+MIXED = [80, 120, 160, 200, 240, 320, 400, 480, 600, 640, 800, 960, 1000, 1200, 1440, 1600, 1280, 1920, 2000, 2160, 2400, 2560]
 
 
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
