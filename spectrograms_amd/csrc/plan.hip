@@ -964,8 +964,11 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
             KernelKind kind_lin = pl->kind;
             const bool ok_lin = resolve_geometry(pl, lin, kind_lin);
             const bool long_frames = ok && kind != K_R32X16_F32 && size_t(params->n_fft) * pl->elem >= SGX_SPLIT_BANK_BYTES;
+            // f64 at the composite sizes (25-, 30-, 32-point first passes at one wave per SIMD): the fused stage never wins there —
+            // 64 x 10 s, fused vs split: 400 198 vs 163 us, 800 193 vs 148, 1440 240 vs 173, ties at 240 / 480 / 960 / 1000 (f32: fused wins)
+            const bool f64_mixed = ok && kind == K_REG_RADIX && pl->dtype == SGX_F64 && !pow2;
             const bool further_up = ok_lin && kind_lin != K_R32X16_F32 && (!ok || chain_pos(kind_lin) < chain_pos(kind));
-            if (ok_lin && (long_frames || further_up)) {
+            if (ok_lin && (long_frames || f64_mixed || further_up)) {
                 pl->split_bank = true;
                 kind = kind_lin;
                 ok = true;
