@@ -142,6 +142,8 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--preheat-s", type=float, default=0.3,
+                    help="seconds of untimed steps before the warmup steps, so that the timed steps run at steady clocks (0: none)")
     ap.add_argument("--workload", default="linear_power", choices=sorted(WORKLOADS))
     ap.add_argument("--gather", nargs="?", const="sync", default=None, choices=["sync", "overlap"],
                     help="RCCL all-gather of the output shards inside the timed region: 'sync' (default when given) gathers "
@@ -252,6 +254,24 @@ def main() -> int:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # Clock settling, before the W warmup steps: after the idle seconds of start-up (imports, plan creation, uploads) the GPU's power
+    # management needs about 300 launches (~35 ms) of this workload to reach its steady clocks — measured per block of 25 launches from
+    # idle: 132 152 137 131 126 124 121 121 121 118 116 ... 115 us — so without it the K timed steps sit on the ramp.  Same steps, same
+    # buffers, every rank the same count (from the slowest rank's step time); reported as `preheat_steps`.
+    preheat_steps = 0
+    if args.preheat_s > 0:
+        t_probe = time.perf_counter()
+        for i in range(10):
+            step(i)
+        fence()
+        tp = torch.tensor([(time.perf_counter() - t_probe) / 10], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+        preheat_steps = int(min(20000, max(0.0, args.preheat_s / max(float(tp.item()), 1e-6))))
+        for i in range(preheat_steps):
+            step(i)
+        fence()
+        preheat_steps += 10
     for i in range(args.warmup):
         step(i)
     fence()
@@ -296,6 +316,7 @@ def main() -> int:
         line = {
             "metric": "STFT frames/sec (f32, n_fft=1024 hop=256)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "preheat_steps": preheat_steps,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"configs[{cfg_idx}]: {batch} x 10 s 16 kHz f32 per GPU, {kernel_wl} n_fft=1024 hop=256 Hanning centre"
