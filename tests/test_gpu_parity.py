@@ -472,15 +472,15 @@ def test_linearity_full_size(cfg2_x):
 
 
 @pytest.mark.parametrize("n_fft,hop,dtype", [(400, 160, "float32"), (512, 128, "float32"), (400, 160, "float64"), (2048, 512, "float32"),
-                                             (1024, 256, "float64")])
+                                             (1024, 256, "float64"), (512, 160, "float32"), (2000, 500, "float32")])
 def test_full_size_register_tiled_kernel(cfg2_x, n_fft, hop, dtype):
     """256 x 10 s through the persistent register-tiled kernel (more tiles than resident workgroups): whole-output parity with
     the CPU restatement in the same precision, plus Parseval per frame."""
     plan, op = make(n_fft, hop, dtype=dtype)
     x = cfg2_x if dtype == "float32" else cfg2_x.astype(np.float64)
     got = plan.compute_batch(x)
-    # (f32 512 / 128 takes the tuned kernel's two-frames-per-transform mode)
-    assert plan.kernel_name == ("r32x16_f32" if (n_fft, hop, dtype) == (512, 128, "float32") else "reg_radix")
+    # (f32 512 at hops 64 / 128 / 160 takes the tuned kernel's two-frames-per-transform mode)
+    assert plan.kernel_name == ("r32x16_f32" if (n_fft, dtype) == (512, "float32") else "reg_radix")
     nf = (160000 + 2 * (n_fft // 2) - n_fft) // hop + 1
     assert got.shape == (256, n_fft // 2 + 1, nf)
     ref = orc.spectrogram_batch(op, x, nthreads=orc.max_threads())
