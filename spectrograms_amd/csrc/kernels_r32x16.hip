@@ -143,6 +143,11 @@ __device__ __forceinline__ void read_cols512(v2f (&x)[16], v2f (&w)[16], const u
      ...);
 }
 
+template <int PAR, int... K>
+__device__ __forceinline__ void read_win(v2f (&w)[16], unsigned waddr, std::integer_sequence<int, K...>) {
+    (ds_read64<(2 * K + PAR) * 128>(w[K], waddr), ...);
+}
+
 // per-lane pass-1 twiddle tables: W_512^(k1*n2) = twa[k1>>3] * twb[k1&7]
 __device__ __forceinline__ void load_tw1(const StftArgs &a, unsigned n2, v2f (&twa)[4], v2f (&twb)[8]) {
     const v2f *t1 = (const v2f *)a.tw1 + n2;
@@ -683,7 +688,23 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
                 SGX_STAMP(0);  // wait for the samples + staging writes
                 __syncthreads();  // barrier 1: xs complete
                 SGX_STAMP(1);
-                if constexpr (P512) {
+                if constexpr (HOP512 == 256) {
+                    // hop 256: frame 2 p + 1 starts 1024 (+ pad) bytes behind frame 2 p — out of reach of ds_read2_b32's 8-bit dword
+                    // offsets — so the pair is two 4-byte reads with 16-bit immediates off one base
+                    const float *pa = (const float *)(smem + p1f * (SS512 + 64u) + n2 * 4u);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        e[k] = (v2f){pa[p512_off_a<256>(2 * k) / 4], pa[p512_off_b<256>(2 * k) / 4]};
+                        o[k] = (v2f){pa[p512_off_a<256>(2 * k + 1) / 4], pa[p512_off_b<256>(2 * k + 1) / 4]};
+                    }
+                    read_win<0>(we, waddr, std::make_integer_sequence<int, 16>{});
+                    read_win<1>(wo, waddr, std::make_integer_sequence<int, 16>{});
+                    // (the window reads are asm and not counted by the compiler: everything is collected here)
+                    tie16<0>(e);
+                    tie16<-1>(o);
+                    tie16<-1>(we);
+                    tie16<-1>(wo);
+                } else if constexpr (P512) {
                     unsigned base[8];
 #pragma unroll
                     for (int q = 0; q < 8; ++q) base[q] = lds_addr(smem) + p1f * (SS512 + 64u) + n2 * 4u + (unsigned)p512_off_a<P512 ? HOP512 : 128>(4 * q);
@@ -862,6 +883,7 @@ hipError_t launch_variant(const StftArgs &a, hipStream_t s) {
             if (a.hop == 64u) return go(k_r32x16<MODE, AMP, 3, false, false, false, 64>);
             if (a.hop == 128u) return go(k_r32x16<MODE, AMP, 5, false, false, false, 128>);
             if (a.hop == 160u) return go(k_r32x16<MODE, AMP, 6, false, false, false, 160>);
+            if (a.hop == 256u) return go(k_r32x16<MODE, AMP, 9, false, false, false, 256>);  // (per-bin outputs only: 37 KB of staged samples)
             return hipErrorInvalidConfiguration;
         }
     }
@@ -887,7 +909,8 @@ extern "C" int sgx_debug_read_stamps(unsigned long long *out, int reset) {
 bool plan_geometry_r32x16_f32(StftArgs &a) {
     // P512: two frames per transform, 32-frame tiles; filterbank outputs need the band schedule (a.x == nullptr: the plan's probe,
     // made before the tables exist — a bank without a schedule falls back to the register-tiled kernel at the first call)
-    if (a.n_fft == 512 && (a.hop == 64 || a.hop == 128 || a.hop == 160) && (a.out_mode != OUT_MEL || a.mel_sched || a.x == nullptr)) {
+    if (a.n_fft == 512 && a.hop == 256 && a.out_mode == OUT_MEL) return false;  // (the staged tile would reach into the |X|^2 tile)
+    if (a.n_fft == 512 && (a.hop == 64 || a.hop == 128 || a.hop == 160 || a.hop == 256) && (a.out_mode != OUT_MEL || a.mel_sched || a.x == nullptr)) {
         if (a.n_samples >= (1ull << 29) || (unsigned long long)a.n_frames * 257ull * 8ull >= 0x7fffffffull) return false;
         a.ft = 32;
         return true;

@@ -133,7 +133,8 @@ def test_pow2_sizes(n_fft, hop, amp, dtype):
     (unaligned frames), the LDS radix-2 kernel below 32 points."""
     plan, _ = run_case(n=max(6000, 3 * n_fft), n_fft=n_fft, hop=hop, amp=amp, dtype=dtype)
     fits = n_fft <= (4096 if dtype == "float64" else 8192)  # an 8192-point f64 tile (164 KB with its tables) exceeds the CU's LDS
-    if 32 <= n_fft and fits and not (n_fft == 1024 and dtype == "float32" and hop % 2 == 0):
+    tuned = dtype == "float32" and ((n_fft == 1024 and hop % 2 == 0) or (n_fft == 512 and hop in (64, 128, 160, 256)))
+    if 32 <= n_fft and fits and not tuned:
         assert plan.kernel_name == "reg_radix"
 
 
@@ -325,7 +326,7 @@ def test_tuned_kernel_512_mel(n, n_mels, fmin, fmax, norm, amp, floor):
 
 
 @pytest.mark.parametrize("amp,floor", [("power", None), ("db", -80.0), ("complex", None)])
-@pytest.mark.parametrize("hop", [64, 160])
+@pytest.mark.parametrize("hop", [64, 160, 256])
 @pytest.mark.parametrize("n,centre", [(1, True), (159, True), (160, True), (512, False), (703, False), (2047, True), (4960, True), (5121, True), (21000, False)])
 def test_tuned_kernel_512_other_hops(n, centre, hop, amp, floor):
     """The two-frames-per-transform mode at hops 64 and 160 (the staging padding, the pass-1 read offsets and the number of chunk
