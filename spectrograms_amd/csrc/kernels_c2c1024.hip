@@ -622,11 +622,7 @@ hipError_t launch_colconv1024(const C2cArgs &a, const void *tw1c, const void *mu
         if ((e = set_max_dynamic_lds((const void *)k_colconv1024<false>, kCLdsP)) != hipSuccess) return e;
         if ((e = set_max_dynamic_lds((const void *)k_colconv1024<true>, kCLdsP)) != hipSuccess) return e;
     }
-    static const unsigned cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return (unsigned)n;
-    }();
+    const unsigned cus = device_cu_count();  // of the current device = the plan's (DeviceGuard)
     // persistent: one workgroup per CU; XCD x (blockIdx mod 8) walks the contiguous run [x per_xcd, (x + 1) per_xcd) of tiles
     const unsigned total = (unsigned)g, per_xcd = (total + 7u) / 8u;
     const unsigned slots = std::max(1u, std::min(cus / 8u, per_xcd));

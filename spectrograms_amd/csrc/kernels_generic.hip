@@ -1076,11 +1076,7 @@ static hipError_t launch_reg_radix_t(const StftArgs &a, unsigned total, size_t l
     }
     // persistent workgroups: as many as are resident at once (registers: rr_waves per SIMD = workgroups per CU; LDS: 160 KB
     // per CU), each walking tiles blockIdx.x, + gridDim.x, ...
-    static const unsigned cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return (unsigned)n;
-    }();
+    const unsigned cus = device_cu_count();  // of the current device = the plan's (DeviceGuard)
     const unsigned by_regs = staged && rr_can_stage<T, A, C>() ? rr_stft_waves<T, A, B, C, true>() : rr_stft_waves<T, A, B, C, false>();
     const unsigned by_lds = (unsigned)std::max<size_t>(1, (160 * 1024) / (lds + 512));
     unsigned grid = std::min(total, cus * std::min(by_regs, by_lds));

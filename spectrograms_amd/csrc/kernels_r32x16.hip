@@ -854,9 +854,10 @@ hipError_t launch_variant(const StftArgs &a, hipStream_t s) {
     const unsigned chunks = (15u * a.hop + 1024u + 3u) >> 2;
     const unsigned pairs = (per_xcd + 1) / 2;
 #ifndef SGX_SLOTS
-#define SGX_SLOTS 32u
+#define SGX_SLOTS 0u  // 0: the device's CU count / 8 (MI355X: 32); a number: A/B runs with fewer workgroups
 #endif
-    const unsigned nslots = pairs < SGX_SLOTS ? pairs : SGX_SLOTS;  // one 512-thread workgroup per CU
+    const unsigned cu_slots = SGX_SLOTS ? SGX_SLOTS : std::max(1u, device_cu_count() / 8u);
+    const unsigned nslots = pairs < cu_slots ? pairs : cu_slots;  // one 512-thread workgroup per CU
     const bool pwt = MODE == OUT_MEL && a.mel_sched != nullptr;
     auto go = [&](auto kernel) -> hipError_t {
         hipError_t e = set_max_dynamic_lds((const void *)kernel, kLdsBytes);
@@ -907,10 +908,11 @@ extern "C" int sgx_debug_read_stamps(unsigned long long *out, int reset) {
 #endif
 
 bool plan_geometry_r32x16_f32(StftArgs &a) {
-    // P512: two frames per transform, 32-frame tiles; filterbank outputs need the band schedule (a.x == nullptr: the plan's probe,
-    // made before the tables exist — a bank without a schedule falls back to the register-tiled kernel at the first call)
+    // P512: two frames per transform, 32-frame tiles; filterbank outputs need the band schedule (built on the host at plan creation,
+    // before this is asked: a bank without one resolves to the register-tiled kernel)
     if (a.n_fft == 512 && a.hop == 256 && a.out_mode == OUT_MEL) return false;  // (the staged tile would reach into the |X|^2 tile)
-    if (a.n_fft == 512 && (a.hop == 64 || a.hop == 128 || a.hop == 160 || a.hop == 256) && (a.out_mode != OUT_MEL || a.mel_sched || a.x == nullptr)) {
+    if (a.n_fft == 512 && a.out_mode == OUT_MEL && a.mel_sched_words == 0) return false;
+    if (a.n_fft == 512 && (a.hop == 64 || a.hop == 128 || a.hop == 160 || a.hop == 256)) {
         if (a.n_samples >= (1ull << 29) || (unsigned long long)a.n_frames * 257ull * 8ull >= 0x7fffffffull) return false;
         a.ft = 32;
         return true;

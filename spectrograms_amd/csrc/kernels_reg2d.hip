@@ -379,8 +379,9 @@ hipError_t launch_c2c_reg(const C2cArgs &a0, int dtype, hipStream_t s) {
     return hipErrorNotSupported;
 }
 
-hipError_t launch_c2r_reg(const C2rArgs &a0, int dtype, hipStream_t s) {
-    unsigned fa, fb, fc;
+// Geometry of launch_c2r_reg (pass split, rows per workgroup, LDS, halo of the fused inverse STFT) without the launch, so that
+// sgx_reserve can tell whether a call will run fused (no frame scratch) with the very test the launcher applies.
+static hipError_t c2r_reg_plan(const C2rArgs &a0, int dtype, C2rArgs &a, unsigned &ltile, size_t &lds, unsigned &fa, unsigned &fb, unsigned &fc) {
     if (kRegOff || (a0.ncols & 1u) || !reg_split_len(a0.ncols / 2, dtype, &fa, &fb, &fc)) return hipErrorNotSupported;
     const size_t es = elem_size(dtype);
     if (((size_t)a0.in | (size_t)a0.out | (size_t)a0.win) & (2 * es - 1)) return hipErrorNotSupported;
@@ -394,12 +395,12 @@ hipError_t launch_c2r_reg(const C2rArgs &a0, int dtype, hipStream_t s) {
     // rows per workgroup: up to 32, within a quarter of a CU's LDS — four workgroups per CU overlap their load, transform and
     // store phases (measured: f32 n_fft 512 inverse STFT 0.65 ms with 32-frame tiles at two per CU, 0.49 ms with 16-frame tiles)
     const size_t c2r_budget = dtype == SGX_F64 ? kR2Budget : (size_t)SGX_C2R_KB * 1024;  // (f64: n_fft 400 0.90 vs 1.14 ms with the larger tile)
-    unsigned ltile = 5;
+    ltile = 5;
     const size_t ola_tab = ola ? ((size_t)a0.hop + a0.ncols) * es : 0;  // the overlap-add's norm table and window copy behind the tile
     while (ltile > 0 && ((size_t)(1u << ltile) * per + ola_tab > c2r_budget || (!ola && (1u << (ltile - 1)) >= a0.nrows))) --ltile;
-    const size_t lds = (size_t)(1u << ltile) * per + ola_tab;
+    lds = (size_t)(1u << ltile) * per + ola_tab;
     if (lds > kR2Budget) return hipErrorNotSupported;
-    C2rArgs a = a0;
+    a = a0;
     a.tile = 1u << ltile;
     a.tiles = (a.nrows + a.tile - 1) / a.tile;
     a.nbk = 0;
@@ -418,6 +419,15 @@ hipError_t launch_c2r_reg(const C2rArgs &a0, int dtype, hipStream_t s) {
         const unsigned long long blocks = (full + a.hop - 1) / a.hop;
         a.tiles = (unsigned)((blocks + a.nbk - 1) / a.nbk);
     }
+    return hipSuccess;
+}
+
+hipError_t launch_c2r_reg(const C2rArgs &a0, int dtype, hipStream_t s) {
+    unsigned fa, fb, fc, ltile;
+    size_t lds;
+    C2rArgs a;
+    const hipError_t pe = c2r_reg_plan(a0, dtype, a, ltile, lds, fa, fb, fc);
+    if (pe != hipSuccess) return pe;
     const unsigned long long g = (unsigned long long)a.tiles * a.batch;
     if (g == 0 || g >= 0x7fffffffull) return hipErrorInvalidConfiguration;
 #define SGX_C2R_F32(A, B, C) if (fa == A && fb == B && fc == C) return launch_c2r_t<float, A, B, C>(a, ltile, lds, s);
@@ -434,10 +444,8 @@ hipError_t launch_c2r_reg(const C2rArgs &a0, int dtype, hipStream_t s) {
     return hipErrorNotSupported;
 }
 
-hipError_t launch_istft_reg(const void *spec, void *out, const void *win, const void *tw, unsigned n, unsigned n_frames, unsigned hop,
-                            unsigned batch, unsigned long long start, unsigned long long out_len, double scale, unsigned *bad_flag,
-                            int dtype, hipStream_t s) {
-    if (hop == 0 || n_frames == 0) return hipErrorNotSupported;
+static C2rArgs istft_reg_args(const void *spec, void *out, const void *win, const void *tw, unsigned n, unsigned n_frames, unsigned hop,
+                              unsigned batch, unsigned long long start, unsigned long long out_len, double scale, unsigned *bad_flag) {
     C2rArgs c{};
     c.in = spec; c.out = out;
     c.nrows = n_frames; c.ncols = n; c.batch = batch;
@@ -445,7 +453,26 @@ hipError_t launch_istft_reg(const void *spec, void *out, const void *win, const 
     c.in_ks = n_frames; c.in_rs = 1; c.k_fast = 0;  // [bin][frame] (StftResult layout, S9)
     c.tw = tw; c.scale = scale; c.win = win; c.bad_flag = bad_flag;
     c.hop = hop; c.start = start; c.out_len = out_len;
-    return launch_c2r_reg(c, dtype, s);
+    return c;
+}
+
+hipError_t launch_istft_reg(const void *spec, void *out, const void *win, const void *tw, unsigned n, unsigned n_frames, unsigned hop,
+                            unsigned batch, unsigned long long start, unsigned long long out_len, double scale, unsigned *bad_flag,
+                            int dtype, hipStream_t s) {
+    if (hop == 0 || n_frames == 0) return hipErrorNotSupported;
+    return launch_c2r_reg(istft_reg_args(spec, out, win, tw, n, n_frames, hop, batch, start, out_len, scale, bad_flag), dtype, s);
+}
+
+bool istft_reg_fuses(const void *win, unsigned n, unsigned n_frames, unsigned hop, unsigned batch, int dtype) {
+    if (hop == 0 || n_frames == 0 || batch == 0) return false;
+    // (the spectrum and output pointers of a real call are hipMalloc'ed or element-aligned: only `win` can fail the alignment test)
+    const C2rArgs c = istft_reg_args(nullptr, nullptr, win, nullptr, n, n_frames, hop, batch, 0, 0, 1.0, nullptr);
+    unsigned fa, fb, fc, ltile;
+    size_t lds;
+    C2rArgs a;
+    if (c2r_reg_plan(c, dtype, a, ltile, lds, fa, fb, fc) != hipSuccess) return false;
+    const unsigned long long g = (unsigned long long)a.tiles * a.batch;
+    return g != 0 && g < 0x7fffffffull;
 }
 
 }  // namespace sgx

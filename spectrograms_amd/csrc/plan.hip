@@ -362,6 +362,101 @@ sgx_status upload_cast(sgx_plan *pl, void **dst, const std::vector<double> &src)
     return upload<T>(pl, dst, tmp);
 }
 
+// Band schedule of the tuned f32 kernel (n_fft 1024, and 512 in its two-frames-per-transform mode), built on the HOST at plan
+// creation — before the kernel kind is resolved, so that a bank without a schedule (rows that are not runs of bins, too many
+// words) resolves to the kernel that will really run it, and the split-filterbank decision is made for that kernel.
+// A padding step has weight +0: it adds +0 to the running sum as long as |X|^2 of that bin is finite.  A non-finite |X|^2
+// (possible only with non-finite or > 1e19 samples, which poison the whole frame's spectrum anyway) within the padded cover
+// of a band — up to 11 bins past its last — makes that band NaN where the reference's CSR sum would not look at the bin.
+void build_band_schedule(sgx_plan *pl) {
+    pl->h_mel_sched.clear();
+    pl->mel_sched_words = 0;
+    if (pl->out_mode != OUT_MEL || pl->mel_ptr.size() != size_t(pl->p.n_mels) + 1) return;
+    for (size_t m = 0; m < pl->p.n_mels; ++m)
+        for (uint32_t i = pl->mel_ptr[m]; i + 1 < pl->mel_ptr[m + 1]; ++i)
+            if (pl->mel_col[i + 1] != pl->mel_col[i] + 1) return;  // rows must be runs of consecutive bins
+    if (pl->p.n_fft == 1024 && pl->mel_val.size() >= size_t(48) * pl->p.n_mels) return;  // wide rows: matrix-core epilogue
+    {
+        const unsigned nm = pl->p.n_mels;
+        std::vector<unsigned> order(nm);
+        for (unsigned m = 0; m < nm; ++m) order[m] = m;
+        auto len = [&](unsigned m) { return pl->mel_ptr[m + 1] - pl->mel_ptr[m]; };
+        std::stable_sort(order.begin(), order.end(), [&](unsigned x, unsigned y) { return len(x) > len(y); });
+        const unsigned ngroups = (nm + 7) / 8;
+        struct Slot { unsigned band, ks, steps; };
+        struct Group { unsigned L; Slot s[8]; };
+        std::vector<Group> groups(ngroups);
+        for (unsigned g = 0; g < ngroups; ++g) {
+            Group &G = groups[g];
+            G.L = 0;
+            for (unsigned q = 0; q < 8; ++q) {
+                Slot &S = G.s[q];
+                S = Slot{0xffffffffu, q, 0};
+                if (8 * g + q >= nm) continue;
+                S.band = order[8 * g + q];
+                if (len(S.band) == 0) continue;  // degenerate triangle: empty sum, still written
+                const unsigned c0 = pl->mel_col[pl->mel_ptr[S.band]], c1 = pl->mel_col[pl->mel_ptr[S.band + 1] - 1];
+                const unsigned want = (q & 2u) ? 2u : 0u;        // slots 0, 1 start at 0 mod 4, slots 2, 3 at 2 mod 4 (bank halves)
+                const unsigned back = (c0 + 4u - want) & 3u;      // (c0 - want) mod 4
+                S.ks = c0 >= back ? c0 - back : (c0 & ~1u);       // always even: the kernel reads bin pairs
+                S.steps = c1 - S.ks + 1;
+                G.L = std::max(G.L, (S.steps + 3u) & ~3u);  // the kernel takes 4 steps per trip
+            }
+        }
+        std::vector<std::vector<unsigned>> per_wave(4);
+        unsigned load[4] = {0, 0, 0, 0};
+        for (unsigned g = 0; g < ngroups; ++g) {  // groups are already in descending length order
+            unsigned best = 0;
+            for (unsigned w = 1; w < 4; ++w) if (load[w] < load[best]) best = w;
+            per_wave[best].push_back(g);
+            load[best] += groups[g].L + 8;  // + the per-segment epilogue
+        }
+        unsigned nseg = 0;
+        for (auto &v : per_wave) nseg = std::max<unsigned>(nseg, unsigned(v.size()));
+        const unsigned kSegs = r32x16::kSchedSegs;
+        std::vector<uint32_t> words(r32x16::kSchedHdr + (kSegs + 1) * 32 * 4, 0);
+        words[0] = nseg;
+        bool ok = nseg <= kSegs;
+        for (unsigned seg = 0; ok && seg <= kSegs; ++seg)
+            for (unsigned w = 0; w < 4; ++w) {
+                const size_t ro = r32x16::kSchedHdr + ((seg * 4 + w) * 8) * 4;
+                const bool have = seg < per_wave[w].size();
+                const Group *G = have ? &groups[per_wave[w][seg]] : nullptr;
+                const unsigned L = have ? G->L : 0, lpad = ((L / 4) & 1u) ? L : L + 4;  // lpad / 4 odd: the 8 slots' rows start on different banks
+                const unsigned woff = unsigned((words.size() + 3) & ~size_t(3));
+                words.resize(woff + 8 * size_t(lpad), 0);
+                for (unsigned q = 0; q < 8; ++q) {
+                    Slot S = have ? G->s[q] : Slot{0xffffffffu, q, 0};
+                    if (S.band != 0xffffffffu && S.steps > 0) {
+                        const unsigned c1 = S.ks + S.steps - 1;
+                        const unsigned zlast = pl->nb_fft + 10u;  // the kernel zeroes the 11 rows behind the last bin (513..523; n_fft 512: 257..267)
+                        if (c1 + (L - S.steps) > zlast) {  // would read past the zeroed rows: pad in front instead
+                            const unsigned d = (c1 + (L - S.steps) - zlast + 3u) / 4u;  // (keeps kstart = slot mod 4)
+                            if (S.ks < 4 * d) { ok = false; break; }
+                            S.ks -= 4 * d;
+                            S.steps += 4 * d;
+                        }
+                        const uint32_t p0 = pl->mel_ptr[S.band], c0 = pl->mel_col[p0];
+                        for (uint32_t i = p0; i < pl->mel_ptr[S.band + 1]; ++i) {
+                            const float wv = float(pl->mel_val[i]);
+                            uint32_t bits;
+                            std::memcpy(&bits, &wv, 4);
+                            words[woff + q * lpad + (c0 - S.ks) + (i - p0)] = bits;
+                        }
+                    }
+                    uint32_t *r = &words[ro + 4 * q];
+                    r[0] = L; r[1] = woff + q * lpad; r[2] = S.ks; r[3] = S.band;
+                }
+            }
+        words.resize(words.size() + 4, 0);
+        words[1] = uint32_t(words.size());
+        if (ok && words.size() <= size_t(r32x16::kMelMaxWords)) {
+            pl->mel_sched_words = unsigned(words.size());
+            pl->h_mel_sched = std::move(words);
+        }
+    }
+}
+
 template <typename T>
 sgx_status build_device_tables(sgx_plan *pl) {
     const unsigned n = pl->p.n_fft;
@@ -457,89 +552,9 @@ sgx_status build_device_tables(sgx_plan *pl) {
             if ((st = upload<float>(pl, &pl->d_mm_frag, frag)) != SGX_OK) return st;
             if ((st = upload<uint32_t>(pl, &pl->d_mm_blk, blk)) != SGX_OK) return st;
         }
-        // Band schedule of the tuned kernel (f32, n_fft = 1024; r32x16_layout.h): contiguous banks that do not go to the matrix
-        // cores.  Bands sorted by length, 8 consecutive ranks = one group = the 8 slots of a wave for one segment; groups dealt
-        // longest-first to the wave with the least work (LPT), so the four waves of a half finish together.  Slots start at an
-        // even bin, = 0 or 2 mod 4 by slot (zero weights in front), so the slots of a read group hit different banks; a slot shorter
-        // than its group is padded with zero weights behind — or in front, if it would run past the zeroed rows 513..523.
-        if (std::is_same<T, float>::value && pl->kind == K_R32X16_F32 && contig && !pl->d_mm_frag) {
-            const unsigned nm = pl->p.n_mels;
-            std::vector<unsigned> order(nm);
-            for (unsigned m = 0; m < nm; ++m) order[m] = m;
-            auto len = [&](unsigned m) { return pl->mel_ptr[m + 1] - pl->mel_ptr[m]; };
-            std::stable_sort(order.begin(), order.end(), [&](unsigned x, unsigned y) { return len(x) > len(y); });
-            const unsigned ngroups = (nm + 7) / 8;
-            struct Slot { unsigned band, ks, steps; };
-            struct Group { unsigned L; Slot s[8]; };
-            std::vector<Group> groups(ngroups);
-            for (unsigned g = 0; g < ngroups; ++g) {
-                Group &G = groups[g];
-                G.L = 0;
-                for (unsigned q = 0; q < 8; ++q) {
-                    Slot &S = G.s[q];
-                    S = Slot{0xffffffffu, q, 0};
-                    if (8 * g + q >= nm) continue;
-                    S.band = order[8 * g + q];
-                    if (len(S.band) == 0) continue;  // degenerate triangle: empty sum, still written
-                    const unsigned c0 = pl->mel_col[pl->mel_ptr[S.band]], c1 = pl->mel_col[pl->mel_ptr[S.band + 1] - 1];
-                    const unsigned want = (q & 2u) ? 2u : 0u;        // slots 0, 1 start at 0 mod 4, slots 2, 3 at 2 mod 4 (bank halves)
-                    const unsigned back = (c0 + 4u - want) & 3u;      // (c0 - want) mod 4
-                    S.ks = c0 >= back ? c0 - back : (c0 & ~1u);       // always even: the kernel reads bin pairs
-                    S.steps = c1 - S.ks + 1;
-                    G.L = std::max(G.L, (S.steps + 3u) & ~3u);  // the kernel takes 4 steps per trip
-                }
-            }
-            std::vector<std::vector<unsigned>> per_wave(4);
-            unsigned load[4] = {0, 0, 0, 0};
-            for (unsigned g = 0; g < ngroups; ++g) {  // groups are already in descending length order
-                unsigned best = 0;
-                for (unsigned w = 1; w < 4; ++w) if (load[w] < load[best]) best = w;
-                per_wave[best].push_back(g);
-                load[best] += groups[g].L + 8;  // + the per-segment epilogue
-            }
-            unsigned nseg = 0;
-            for (auto &v : per_wave) nseg = std::max<unsigned>(nseg, unsigned(v.size()));
-            const unsigned kSegs = r32x16::kSchedSegs;
-            std::vector<uint32_t> words(r32x16::kSchedHdr + (kSegs + 1) * 32 * 4, 0);
-            words[0] = nseg;
-            bool ok = nseg <= kSegs;
-            for (unsigned seg = 0; ok && seg <= kSegs; ++seg)
-                for (unsigned w = 0; w < 4; ++w) {
-                    const size_t ro = r32x16::kSchedHdr + ((seg * 4 + w) * 8) * 4;
-                    const bool have = seg < per_wave[w].size();
-                    const Group *G = have ? &groups[per_wave[w][seg]] : nullptr;
-                    const unsigned L = have ? G->L : 0, lpad = ((L / 4) & 1u) ? L : L + 4;  // lpad / 4 odd: the 8 slots' rows start on different banks
-                    const unsigned woff = unsigned((words.size() + 3) & ~size_t(3));
-                    words.resize(woff + 8 * size_t(lpad), 0);
-                    for (unsigned q = 0; q < 8; ++q) {
-                        Slot S = have ? G->s[q] : Slot{0xffffffffu, q, 0};
-                        if (S.band != 0xffffffffu && S.steps > 0) {
-                            const unsigned c1 = S.ks + S.steps - 1;
-                            const unsigned zlast = pl->nb_fft + 10u;  // the kernel zeroes the 11 rows behind the last bin (513..523; n_fft 512: 257..267)
-                            if (c1 + (L - S.steps) > zlast) {  // would read past the zeroed rows: pad in front instead
-                                const unsigned d = (c1 + (L - S.steps) - zlast + 3u) / 4u;  // (keeps kstart = slot mod 4)
-                                if (S.ks < 4 * d) { ok = false; break; }
-                                S.ks -= 4 * d;
-                                S.steps += 4 * d;
-                            }
-                            const uint32_t p0 = pl->mel_ptr[S.band], c0 = pl->mel_col[p0];
-                            for (uint32_t i = p0; i < pl->mel_ptr[S.band + 1]; ++i) {
-                                const float wv = float(pl->mel_val[i]);
-                                uint32_t bits;
-                                std::memcpy(&bits, &wv, 4);
-                                words[woff + q * lpad + (c0 - S.ks) + (i - p0)] = bits;
-                            }
-                        }
-                        uint32_t *r = &words[ro + 4 * q];
-                        r[0] = L; r[1] = woff + q * lpad; r[2] = S.ks; r[3] = S.band;
-                    }
-                }
-            words.resize(words.size() + 4, 0);
-            words[1] = uint32_t(words.size());
-            if (ok && words.size() <= size_t(r32x16::kMelMaxWords)) {
-                pl->mel_sched_words = unsigned(words.size());
-                if ((st = upload<uint32_t>(pl, &pl->d_mel_sched, words)) != SGX_OK) return st;
-            }
+        // Band schedule of the tuned kernel: built on the host at plan creation (build_band_schedule), uploaded here
+        if (std::is_same<T, float>::value && pl->kind == K_R32X16_F32 && !pl->h_mel_sched.empty() && !pl->d_mm_frag) {
+            if ((st = upload<uint32_t>(pl, &pl->d_mel_sched, pl->h_mel_sched)) != SGX_OK) return st;
         }
     }
     if (pl->p.n_mfcc > 0) {
@@ -952,6 +967,7 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
     pl->kind = (pow2 || params->n_fft % 2 == 0) ? K_REG_RADIX : K_TWO_FACTOR;  // (even sizes outside the register-tiled list fall through)
     if (params->dtype == SGX_F32 && params->n_fft == 1024 && params->hop_size % 2 == 0) pl->kind = K_R32X16_F32;
     if (params->dtype == SGX_F32 && params->n_fft == 512 && (params->hop_size == 64 || params->hop_size == 128 || params->hop_size == 160 || params->hop_size == 256)) pl->kind = K_R32X16_F32;  // per-bin outputs (else falls back)
+    if (pl->kind == K_R32X16_F32) build_band_schedule(pl);  // before the kind is resolved: plan_geometry_r32x16_f32 asks for it
     {
         StftArgs probe;
         fill_args(pl, probe, nullptr, nullptr, 1, params->n_fft, params->n_fft, 1);
@@ -1222,7 +1238,11 @@ sgx_status sgx_reserve(sgx_plan *plan, size_t batch, size_t n_samples, int32_t h
         (st = grow(plan, &plan->d_pwbuf, &plan->d_pwbuf_bytes, batch * size_t(plan->nb_fft) * nf * plan->elem)) != SGX_OK)
         return st;
     if (inverse) {  // sgx_istft of `batch` spectra whose frame count is that of n_samples-long signals
-        const bool fused = plan->d_itwr && nf * 513ull * 8ull < 0x7fffffffull;
+        // the same tests run_istft applies: tuned n_fft = 1024 kernel, else the fused register-tiled kernel; only the unfused
+        // fallback (rows + overlap-add) touches the frame scratch
+        const bool fused = (plan->d_itwr && nf * 513ull * 8ull < 0x7fffffffull) ||
+                           (nf <= 0xffffffffull && batch <= 0xffffffffull &&
+                            istft_reg_fuses(plan->d_window, plan->p.n_fft, unsigned(nf), plan->p.hop_size, unsigned(batch), plan->dtype));
         if (!fused && (st = grow(plan, &plan->d_frames, &plan->d_frames_bytes, batch * nf * plan->p.n_fft * plan->elem)) != SGX_OK) return st;
     }
     if (host_staging) {

@@ -146,6 +146,8 @@ hipError_t launch_c2r_reg(const C2rArgs &a, int dtype, hipStream_t s);
 hipError_t launch_istft_reg(const void *spec, void *out, const void *win, const void *tw, unsigned n, unsigned n_frames, unsigned hop,
                             unsigned batch, unsigned long long start, unsigned long long out_len, double scale, unsigned *bad_flag,
                             int dtype, hipStream_t s);
+// would launch_istft_reg run this shape fused (hipSuccess) — the launcher's own geometry test, for sgx_reserve
+bool istft_reg_fuses(const void *win, unsigned n, unsigned n_frames, unsigned hop, unsigned batch, int dtype);
 inline hipError_t launch_c2c_any(const C2cArgs &a, int dtype, hipStream_t s) {
     const hipError_t e = launch_c2c_reg(a, dtype, s);
     return e == hipErrorNotSupported ? launch_c2c_tile(a, dtype, s) : e;
@@ -186,6 +188,22 @@ inline hipError_t set_max_dynamic_lds(const void *fn, int bytes) {
     e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e == hipSuccess) done.insert({fn, dev});
     return e;
+}
+
+// Compute units of the CURRENT device (the entry points have made the plan's device current), looked up once per device: a
+// process may drive GPUs with different CU counts or partition modes, and the persistent grids are sized per device.
+inline unsigned device_cu_count() {
+    static std::mutex mu;
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256u;
+    std::lock_guard<std::mutex> guard(mu);
+    if (cached[dev] <= 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return (unsigned)cached[dev];
 }
 
 // Entry points run on the plan's device and leave the caller's current device as they found it.
@@ -230,6 +248,7 @@ struct sgx_plan {
     void *d_window = nullptr, *d_tw = nullptr, *d_tw1 = nullptr, *d_tw2 = nullptr;
     void *d_mel_ptr = nullptr, *d_mel_col = nullptr, *d_mel_val = nullptr, *d_mel_pptr = nullptr, *d_mel_pcol = nullptr, *d_mel_pw = nullptr, *d_mm_frag = nullptr, *d_mm_blk = nullptr, *d_mel_sched = nullptr;
     unsigned mel_sched_words = 0;
+    std::vector<uint32_t> h_mel_sched;  // the tuned kernel's band schedule as built on the host (plan.hip build_band_schedule)
     unsigned mm_nblk = 0;
     unsigned mel_pchunks = 0;
     unsigned mel_contig = 0;

@@ -45,12 +45,20 @@ const Rccl &rccl() {
     static std::once_flag once;
     std::call_once(once, [] {
         void *h = RTLD_DEFAULT;
-        if (!dlsym(RTLD_DEFAULT, "ncclAllGather")) {
+#ifdef SGX_NO_RCCL  // test build only (tests/test_abi.py): a host without any RCCL — every candidate name fails to load
+        constexpr bool probe_process = false;
+        const char *const names[] = {"librccl-absent-for-this-test.so.1"};
+#else
+        constexpr bool probe_process = true;
+        const char *const names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+#endif
+        if (!probe_process || !dlsym(RTLD_DEFAULT, "ncclAllGather")) {
             h = nullptr;
-            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            for (const char *name : names)
                 if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
             if (!h) {
-                r.why = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed");
+                const char *de = dlerror();  // one call: dlerror() clears the message it returns
+                r.why = std::string("RCCL not found: ") + (de ? de : "dlopen failed");
                 return;
             }
         }
@@ -135,8 +143,12 @@ sgx_status sgx_comm_adopt(void *nccl_comm, int32_t world_size, int32_t rank, int
         return comm_fail(nullptr, SGX_INVALID_INPUT, "Invalid input: bad communicator arguments");
     const Rccl &r = rccl();
     if (!r.ok) return comm_fail(nullptr, SGX_BACKEND, "hip -- FFT backend error: " + r.why);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return comm_fail(nullptr, SGX_BACKEND, "hip -- FFT backend error: no HIP device available");
     int dev = device;
     if (dev == -1 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (dev < 0 || dev >= ndev) return comm_fail(nullptr, SGX_INVALID_INPUT, "Invalid input: device ordinal out of range");
     sgx_comm *c = new (std::nothrow) sgx_comm();
     if (!c) return comm_fail(nullptr, SGX_INTERNAL, "Internal error: out of memory");
     c->comm = static_cast<ncclComm_t>(nccl_comm);
@@ -163,6 +175,8 @@ sgx_status sgx_gather(sgx_comm *c, const void *send, void *recv, size_t global_b
     if (!send || !recv || global_batch == 0 || elems_per_item == 0) return comm_fail(c, SGX_INVALID_INPUT, "Invalid input: null or empty buffer");
     if (dtype != SGX_F32 && dtype != SGX_F64) return comm_fail(c, SGX_INVALID_INPUT, "Invalid input: dtype must be f32 or f64");
     const Rccl &r = rccl();
+    if (!r.ok) return comm_fail(c, SGX_BACKEND, "hip -- FFT backend error: " + r.why);
+    if (!c->comm) return comm_fail(c, SGX_INVALID_INPUT, "Invalid input: communicator has no RCCL handle");
     const ncclDataType_t nt = dtype == SGX_F64 ? ncclFloat64 : ncclFloat32;
     const size_t elem = dtype == SGX_F64 ? 8 : 4;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);

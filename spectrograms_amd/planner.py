@@ -224,6 +224,7 @@ class Plan:
         self._h = h
         self.n_fft = st.n_fft
         self._device = int(self._lib.sgx_plan_device(h))  # resolved ordinal (DEVICE_CURRENT was bound at creation); -2: host only
+        self._frame_plan = None  # no-centre sibling for compute_frame, created on first use
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -378,18 +379,22 @@ class Plan:
         return Spectrogram(data, freqs, times, self._params, self._db.floor_db if self._db else None)
 
     def compute_frame(self, samples, frame_idx: int) -> np.ndarray:
-        """SpectrogramPlan::compute_frame (:335-372): one column.  Computed from the n_fft-sample span it covers."""
+        """SpectrogramPlan::compute_frame (:335-372): one column, computed from the n_fft-sample span it covers.  The reference
+        reuses the plan's FFT / window / mapping for this; here the one-frame launch runs on a no-centre sibling plan that is
+        created on first use and kept for the life of this plan (same device, same tables)."""
         x = self._host_samples(samples, 1)
         st = self._params.stft
         pad = st.n_fft // 2 if st.centre else 0
-        lo = frame_idx * st.hop_size - pad
+        lo = int(frame_idx) * st.hop_size - pad
         seg = np.zeros(st.n_fft, self._np)
         a, b = max(lo, 0), min(lo + st.n_fft, x.size)
         if b > a:
             seg[a - lo:b - lo] = x[a:b]
-        tmp = Plan(SpectrogramParams(type(st)(st.n_fft, st.hop_size, st.window, False), self._params.sample_rate),
-                   self._amp, self._mel, self._db, self.dtype)
-        return tmp.compute_batch(seg[None, :])[0][:, 0]
+        sib = self if not st.centre else self._frame_plan
+        if sib is None:
+            sib = self._frame_plan = Plan(SpectrogramParams(type(st)(st.n_fft, st.hop_size, st.window, False), self._params.sample_rate),
+                                          self._amp, self._mel, self._db, self.dtype, self._device, self._mfcc)
+        return sib.compute_batch(seg[None, :])[0][:, 0]
 
     def r2c(self, frame) -> np.ndarray:
         """Conforming R2cPlan::process (src/fft_backend.rs:423-431) on one frame of n_fft reals."""

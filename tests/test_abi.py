@@ -203,3 +203,46 @@ def test_dimension_mismatch_carries_expected_and_got():
     nb, nf = plan.output_shape(4000)
     assert ei.value.expected == nb * nf and ei.value.got == 257 * 3 and "Dimension mismatch" in str(ei.value)
     assert plan.device == -2
+
+
+def test_rccl_not_found_is_a_soft_failure():
+    """A host without any RCCL: sgx_comm_unique_id / create / adopt report SGX_BACKEND with a message (round 2's code called
+    dlerror() twice and built a std::string from NULL).  shard.hip is rebuilt with -DSGX_NO_RCCL (every library name fails to
+    load) into build/libsgx_norccl.so and driven through ctypes in a child process, so a crash would only kill the child."""
+    import subprocess
+    import sys
+
+    from spectrograms_amd import build as b
+
+    so = b.variant("norccl", ["-DSGX_NO_RCCL"], ("shard.hip",))
+    code = (
+        "import ctypes as C, sys\n"
+        f"L = C.CDLL({so!r})\n"
+        "L.sgx_comm_last_error.restype = C.c_char_p\n"
+        "L.sgx_comm_last_error.argtypes = [C.c_void_p]\n"
+        "buf = (C.c_char * 128)()\n"
+        "st = L.sgx_comm_unique_id(buf)\n"
+        "msg = L.sgx_comm_last_error(None).decode()\n"
+        "h = C.c_void_p()\n"
+        "st2 = L.sgx_comm_create(buf, 2, 0, -1, C.byref(h))\n"
+        "st3 = L.sgx_comm_adopt(C.c_void_p(0x1000), 2, 0, -1, C.byref(h))\n"
+        "print(st, st2, st3, msg)\n"
+    )
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    st, st2, st3, msg = r.stdout.strip().split(" ", 3)
+    assert (int(st), int(st2), int(st3)) == (_ffi.SGX_BACKEND,) * 3
+    assert "RCCL not found" in msg
+
+
+def test_kernel_kind_is_resolved_with_the_band_schedule_known():
+    """n_fft 512 filterbank plans take the tuned kernel's two-frames-per-transform mode only when the bank has a band schedule
+    (built on the host before the kind is resolved); other banks must report the kernel that will really run them."""
+    mel = host_plan(512, 128, mel=sg.MelParams(40, 0.0, 8000.0), dtype="float32")
+    assert mel.kernel_name == "r32x16_f32"
+    erb = sg.Plan(sg.SpectrogramParams(sg.StftParams(512, 128, sg.WindowType.hanning, True), 16000.0), _ffi.AMP_POWER,
+                  sg.ErbParams(64, 50.0, 8000.0), None, "float32", device=HOST)
+    assert erb.kernel_name == "reg_radix"  # 64 dense rows of 257 bins: too many words for the LDS schedule
+    lin = host_plan(512, 128, dtype="float32")
+    assert lin.kernel_name == "r32x16_f32"
+    assert host_plan(512, 256, mel=sg.MelParams(40, 0.0, 8000.0), dtype="float32").kernel_name == "reg_radix"
