@@ -9,6 +9,13 @@ signals that is already resident in HBM.  Workloads (BASELINE.json configs):
     stft           the same batch, complex STFT
     config4        configs[3]: 1024 utterances per GPU (8192 over 8 GPUs), Mel-80 power; `--gather` adds the RCCL all-gather
 
+The default run (what the driver records) carries, next to the headline line of `--workload` (default linear_power), a
+`workloads` object with short legs of the other BASELINE configurations — mel_power (north_star's target sentence), mel_db
+(configs[2]), config4's per-GPU shard (configs[3]) and configs[4]: fft2d / convolve_fft over 512 x 1024 x 1024 images — each
+with its own ms_per_step, value and roofline; `cold_ms_per_step` (the W + K steps from idle clocks, measured before anything
+else has run); `roofline.peak_measured` (sgx_membench: copy / read / write rates of this very device, in-process); and a
+NumPy / pocketfft datapoint inside `cpu_baseline`.  `--no-legs` switches the extra legs off.
+
 Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL).  Utterances shard by rank with no data-path
 collective (weak scaling: every rank owns a full batch); `--gather sync|overlap` adds the all-gather that reassembles the
 batched output on every rank inside the timed region.  `python bench.py --gpus N` run directly (no RANK/WORLD_SIZE in the
@@ -32,6 +39,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak is ~6290 GB/s
 VALU_PEAK_TFLOPS = 157.3   # FP32 vector peak (same guide)
 FLOPS_PER_FRAME = {"linear_power": 28.1e3, "stft": 26.6e3, "mel_power": 30.1e3, "mel_db": 30.1e3}  # FFT 25.6 k + window 1 k (+ |.|^2 1.5 k, Mel 2 k)
+LEGS = ("mel_power", "mel_db", "config4", "fft2d", "convolve_fft")  # the default run's extra legs (besides the headline workload)
+IMG_SIDE, IMG_BATCH = 1024, 512  # BASELINE configs[4]
 SR, N_FFT, HOP, N_SAMPLES = 16000.0, 1024, 256, 160000
 WORKLOADS = {  # name -> (kernel workload, utterances per GPU, BASELINE config index)
     "linear_power": ("linear_power", 256, 1), "mel_db": ("mel_db", 256, 2), "mel_power": ("mel_power", 256, 2),
@@ -75,7 +84,7 @@ def measured_traffic(kernel_wl: str):
     return t.get(kernel_wl)
 
 
-def cpu_baseline(kernel_wl: str, budget_s: float = 12.0):
+def cpu_baseline(kernel_wl: str, budget_s: float = 10.0):
     """Times the CPU restatement of the reference algorithm (oracle/, kind 'port': per-frame window -> real FFT ->
     |.|^2 -> [sparse Mel -> dB], one plan per thread over utterances — the reference's batch idiom, src/lib.rs:228-236)
     on this host's cores, into a preallocated output (the reference allocates per call; that is not charged here)."""
@@ -134,7 +143,58 @@ def cpu_baseline(kernel_wl: str, budget_s: float = 12.0):
     return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{reps} passes over a {nsig}-utterance batch ({frames} frames, {dt:.1f} s wall, one plan per "
                       f"thread, {cores} threads = the fastest of the thread counts tried); one thread alone: {single:.0f} frames/s",
-            "single_thread_value": single}
+            "single_thread_value": single, "pocketfft": cpu_pocketfft(kernel_wl, x[:16])}
+
+
+def cpu_pocketfft(kernel_wl: str, x: np.ndarray, budget_s: float = 3.0):
+    """Secondary CPU datapoint: the same pipeline written the NumPy way — zero-padded strided frames x window ->
+    numpy.fft.rfft (pocketfft, SIMD, f32 in / complex64 out) over all frames of an utterance at once -> |.|^2 [-> dense Mel
+    matmul -> 10 log10] — as python/examples/numpy_impls.py does it, one utterance per call, on ONE thread of this host.  An
+    optimised CPU FFT next to the scalar port above; neither is RustFFT (no Rust toolchain on either box)."""
+    from numpy.lib.stride_tricks import sliding_window_view
+
+    from oracle import oracle as orc
+
+    n = np.arange(N_FFT, dtype=np.float64)
+    w = (0.5 - 0.5 * np.cos(2.0 * np.pi * n / (N_FFT - 1))).astype(np.float32)  # symmetric Hann (S3)
+    melT = None
+    if kernel_wl in ("mel_power", "mel_db"):
+        ptr, col, val, _ = orc.mel_filterbank(SR, N_FFT, 80, 0.0, 8000.0, None)
+        m = np.zeros((80, N_FFT // 2 + 1), np.float32)
+        for r in range(80):
+            m[r, col[ptr[r]:ptr[r + 1]]] = val[ptr[r]:ptr[r + 1]]
+        melT = np.ascontiguousarray(m.T)
+    eps = np.float32(10.0 ** (-80.0 / 10.0))
+
+    def one(sig):
+        xp = np.pad(sig, N_FFT // 2)
+        fr = sliding_window_view(xp, N_FFT)[::HOP] * w
+        spec = np.fft.rfft(fr, axis=-1)
+        if kernel_wl == "stft":
+            return np.ascontiguousarray(spec.T)
+        p = spec.real * spec.real + spec.imag * spec.imag
+        if melT is not None:
+            p = p @ melT
+        if kernel_wl == "mel_db":
+            p = 10.0 * np.log10(np.maximum(p, eps))
+        return np.ascontiguousarray(p.T)  # (bins, frames), the reference's layout (S9)
+
+    try:  # one thread for the Mel matmul too (OpenBLAS' thread pool costs more than it gains on a 626 x 513 x 80 product)
+        import threadpoolctl
+        limit = threadpoolctl.threadpool_limits(1)
+    except Exception:
+        limit = None
+    o = one(x[0])
+    frames, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        for sig in x:
+            one(sig)
+            frames += o.shape[1]
+    dt = time.perf_counter() - t0
+    if limit is not None:
+        limit.restore_original_limits()
+    return {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "numpy-pocketfft",
+            "sample": f"{frames} frames in {dt:.1f} s: {x.shape[0]} utterances per pass, one numpy.fft.rfft call over the 626 frames of an utterance"}
 
 
 def parse_args(argv=None):
@@ -149,6 +209,9 @@ def parse_args(argv=None):
                     help="RCCL all-gather of the output shards inside the timed region: 'sync' (default when given) gathers "
                          "after every launch on the launch stream; 'overlap' gathers step i asynchronously while step i+1 computes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="headline workload only: skip the `workloads` legs, the cold-clock run and the measured HBM peak (A/B timing runs)")
+    ap.add_argument("--legs", default=",".join(LEGS), help="comma-separated legs of the default run (subset of %s)" % ",".join(LEGS))
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: the ranks rendezvous over gloo and time an empty step — exercises the launcher, the barrier / "
                          "max-over-ranks timing and the JSON line (tests/test_bench_launcher.py)")
@@ -177,6 +240,172 @@ def spawn_ranks(args) -> int:
     return rc
 
 
+def make_plan(sg, kernel_wl: str):
+    params = sg.SpectrogramParams(sg.StftParams(N_FFT, HOP, sg.WindowType.hanning, True), SR)
+    planner = sg.SpectrogramPlanner()
+    if kernel_wl == "linear_power":
+        return planner.linear_power_plan(params, dtype="float32")
+    if kernel_wl == "mel_power":
+        return planner.mel_power_plan(params, sg.MelParams(80, 0.0, 8000.0), dtype="float32")
+    if kernel_wl == "stft":
+        return planner.stft_plan(params, dtype="float32")
+    return planner.mel_db_plan(params, sg.MelParams(80, 0.0, 8000.0), sg.LogParams(-80.0), dtype="float32")
+
+
+def stft_roofline(kernel_wl: str, batch: int, n_frames: int, kernel_ms: float, peak_measured=None, scope="HIP events over the timed region", full_peak=False):
+    """The roofline object of one STFT-type launch: algorithmic bytes / launch time against the 8 TB/s line; `valu_frac` is its
+    share of the FP32 vector peak (the Mel workloads are bound by arithmetic + LDS, not by HBM), `hbm_read_frac`
+    north_star's read-only line."""
+    rd, wr = bytes_per_frame(kernel_wl, n_frames)
+    frames = batch * n_frames
+    fps = frames / (kernel_ms * 1e-3)
+    achieved = (rd + wr) * fps / 1e9
+    valu = FLOPS_PER_FRAME[kernel_wl] * fps / (VALU_PEAK_TFLOPS * 1e12)
+    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+         "traffic": measured_traffic(kernel_wl) if batch == 256 else None, "kernel_ms": kernel_ms, "kernel_ms_scope": scope,
+         "algorithmic_bytes_per_frame": rd + wr, "frames_per_launch": frames, "hbm_read_frac": rd * fps / 1e9 / HBM_PEAK_GBS,
+         "valu_frac": valu, "flops_per_frame": FLOPS_PER_FRAME[kernel_wl], "limiter": "valu+lds" if valu > achieved / HBM_PEAK_GBS else "hbm"}
+    if peak_measured:
+        if full_peak:
+            r["peak_measured"] = peak_measured
+        if peak_measured.get("copy"):
+            r["frac_of_measured_copy"] = achieved / peak_measured["copy"]
+    return r
+
+
+def timed_steps(torch, stream, step, steps: int, fence):
+    """K back-to-back steps between two events on the launch stream and two fences: (wall seconds, device ms per step)."""
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for i in range(steps):
+        step(i)
+    ev1.record(stream)
+    fence()
+    return time.perf_counter() - t0, ev0.elapsed_time(ev1) / steps
+
+
+def preheat(step, fence, seconds: float, reduce_max=None) -> int:
+    """Clock settling: after idle seconds (imports, plan creation, uploads) the GPU's power management needs about 300 launches
+    (~35 ms) of the STFT workload to reach its steady clocks — measured per block of 25 launches from idle: 132 152 137 131 126
+    124 121 121 121 118 116 ... 115 us — so without it the K timed steps sit on the ramp.  Same steps, same buffers, every rank
+    the same count (from the slowest rank's step time); the count is reported as `preheat_steps`."""
+    if seconds <= 0:
+        return 0
+    t_probe = time.perf_counter()
+    for i in range(10):
+        step(i)
+    fence()
+    per = (time.perf_counter() - t_probe) / 10
+    if reduce_max is not None:
+        per = reduce_max(per)
+    n = int(min(20000, max(0.0, seconds / max(per, 1e-6))))
+    for i in range(n):
+        step(i)
+    fence()
+    return n + 10
+
+
+def measured_peak(lib, device: int):
+    """HBM rates of this device from the library's own streaming kernels (sgx_membench: 1 GiB buffers, 16 B per lane, 5 passes)."""
+    import ctypes as C
+
+    out = {}
+    for mode, name in ((0, "copy"), (1, "read"), (2, "write")):
+        g = C.c_double()
+        st = lib.sgx_membench(device, 0, mode, 5, C.byref(g))
+        out[name] = float(g.value) if st == 0 else None
+    out["unit"] = "GB/s"
+    out["how"] = "sgx_membench in this process: 1 GiB per buffer (4x the Infinity Cache), 16 B per lane, mean of 5 passes; copy counts bytes read + written"
+    return out
+
+
+def stft_leg(torch, sg, dev, name: str, xs256, args, peak):
+    """One extra leg of the default run: BASELINE configs[2] (mel_db), north_star's Mel-power sentence, or configs[3]'s per-GPU
+    shard (1024 utterances, Mel-80 power; input = the 256-utterance batch four times)."""
+    kernel_wl, batch, cfg_idx = WORKLOADS[name]
+    plan = make_plan(sg, kernel_wl)
+    n_bins, n_frames = plan.output_shape(N_SAMPLES)
+    xs = xs256 if batch == 256 else [torch.cat([x] * (batch // 256)) for x in xs256]
+    outs = [torch.empty((batch, n_bins, n_frames), dtype=torch.float32, device=dev) for _ in xs]
+    stream = torch.cuda.current_stream(dev)
+
+    def step(i):
+        plan.compute_batch(xs[i % len(xs)], out=outs[i % len(xs)])
+
+    def fence():
+        torch.cuda.synchronize(dev)
+
+    ph = preheat(step, fence, args.preheat_s)
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    dt, kernel_ms = timed_steps(torch, stream, step, args.steps, fence)
+    frames = batch * n_frames
+    return {"config": f"configs[{cfg_idx}]: {batch} x 10 s 16 kHz f32, {kernel_wl} n_fft=1024 hop=256 Hanning centre",
+            "kernel": plan.kernel_name, "steps": args.steps, "warmup": args.warmup, "preheat_steps": ph,
+            "ms_per_step": dt / args.steps * 1e3, "value": frames * args.steps / dt, "unit": "frames/s",
+            "roofline": stft_roofline(kernel_wl, batch, n_frames, kernel_ms, peak)}
+
+
+def fft2d_legs(torch, sg, dev, which, args, peak):
+    """BASELINE configs[4]: 512 x 1024 x 1024 f32 images, img[r, c] = sin(0.01 r) + cos(0.02 c) + N(0, 0.05^2) (32 distinct noise
+    fields, tiled): `fft2d` alone and `convolve_fft` with gaussian_kernel_2d(9, 2.0).  Algorithmic bytes per image: fft2d 4 MiB
+    read + 1024 * 513 * 8 B written; convolve_fft 4 MiB read + 4 MiB written (kernel spectrum cached by the plan)."""
+    R = C = IMG_SIDE
+    rng = np.random.default_rng(7)
+    r, c = np.meshgrid(np.arange(R), np.arange(C), indexing="ij")
+    base = (np.sin(0.01 * r) + np.cos(0.02 * c)).astype(np.float32)
+    nz = 32
+    host = base[None] + 0.05 * rng.standard_normal((nz, R, C), dtype=np.float32)
+    x = torch.from_numpy(np.ascontiguousarray(host)).to(dev).repeat(IMG_BATCH // nz, 1, 1)
+    plan = sg.Fft2dPlan(R, C, "float32")
+    k = sg.gaussian_kernel_2d(9, 2.0, dtype="float32")
+    stream = torch.cuda.current_stream(dev)
+    res = {}
+    flops = {"fft2d": 2.5 * R * C * 20.0, "convolve_fft": 2 * 2.5 * R * C * 20.0 + 6.0 * R * (C // 2 + 1)}
+    for name in which:
+        if name == "fft2d":
+            buf = plan.forward_torch(x)
+            fn = lambda i: plan.forward_torch(x, buf)
+            bpi = R * C * 4 + R * (C // 2 + 1) * 8
+        else:
+            buf = plan.convolve_torch(x, k)
+            fn = lambda i: plan.convolve_torch(x, k, buf)
+            bpi = 2 * R * C * 4
+
+        def fence():
+            torch.cuda.synchronize(dev)
+
+        fence()
+        ph = preheat(fn, fence, args.preheat_s)
+        steps, warm = max(3, min(args.steps, 20)), max(1, min(args.warmup, 5))
+        for i in range(warm):
+            fn(i)
+        fence()
+        dt, ms = timed_steps(torch, stream, fn, steps, fence)
+        ips = IMG_BATCH / (ms * 1e-3)
+        achieved = ips * bpi / 1e9
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel_ms": ms, "kernel_ms_scope": "HIP events over the timed region (three launches per step)",
+                "algorithmic_bytes_per_image": bpi, "images_per_step": IMG_BATCH, "valu_frac": flops[name] * ips / (VALU_PEAK_TFLOPS * 1e12),
+                "limiter": "hbm"}
+        if peak and peak.get("copy"):
+            roof["frac_of_measured_copy"] = achieved / peak["copy"]
+        res[name] = {"config": f"configs[4]: {IMG_BATCH} x {R}x{C} f32 images, {name}" + (" with gaussian_kernel_2d(9, 2.0)" if name != "fft2d" else ""),
+                     "steps": steps, "warmup": warm, "preheat_steps": ph, "ms_per_step": dt / steps * 1e3, "value": IMG_BATCH * steps / dt,
+                     "unit": "images/s", "roofline": roof}
+        del buf
+    return res
+
+
+def device_identity(torch, dev) -> int:
+    """A number that is the same for two ranks exactly when they sit on the same physical GPU (uuid, else the PCI address)."""
+    p = torch.cuda.get_device_properties(dev)
+    ident = str(getattr(p, "uuid", "")) or "%s:%s:%s" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", dev.index), getattr(p, "pci_device_id", 0))
+    return int.from_bytes(hashlib.sha256(ident.encode()).digest()[:7], "little")
+
+
 def main() -> int:
     args = parse_args()
     if args.gpus < 1:
@@ -191,6 +420,10 @@ def main() -> int:
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU", file=sys.stderr)
         return 2
+    legs = [l for l in args.legs.split(",") if l]
+    if any(l not in LEGS for l in legs):
+        print(f"bench.py: --legs takes a subset of {','.join(LEGS)}", file=sys.stderr)
+        return 2
 
     import torch
     import torch.distributed as dist
@@ -203,29 +436,31 @@ def main() -> int:
         print("bench.py: no GPU visible — the product path has no CPU fallback", file=sys.stderr)
         return 2
     import spectrograms_amd as sg
+    from spectrograms_amd import _ffi
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rccl_ranks = 1
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        rccl_ranks = dist.get_world_size()
+        # one rank per GPU: two ranks on one device would report a scaling curve of a time-shared GPU
+        ids = torch.empty(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(ids, torch.tensor([device_identity(torch, dev)], dtype=torch.int64, device=dev))
+        if len(set(ids.tolist())) != world:
+            if rank == 0:
+                print(f"bench.py: {world} ranks but only {len(set(ids.tolist()))} distinct GPUs — a device ordinal repeats", file=sys.stderr)
+            dist.destroy_process_group()
+            return 3
 
     # ---- plan + synthetic device-resident batch (weak scaling: every rank owns `batch` utterances)
-    params = sg.SpectrogramParams(sg.StftParams(N_FFT, HOP, sg.WindowType.hanning, True), SR)
-    planner = sg.SpectrogramPlanner()
-    if kernel_wl == "linear_power":
-        plan = planner.linear_power_plan(params, dtype="float32")
-    elif kernel_wl == "mel_power":
-        plan = planner.mel_power_plan(params, sg.MelParams(80, 0.0, 8000.0), dtype="float32")
-    elif kernel_wl == "stft":
-        plan = planner.stft_plan(params, dtype="float32")
-    else:
-        plan = planner.mel_db_plan(params, sg.MelParams(80, 0.0, 8000.0), sg.LogParams(-80.0), dtype="float32")
+    plan = make_plan(sg, kernel_wl)
     n_bins, n_frames = plan.output_shape(N_SAMPLES)
     # the generator has 96 distinct rows (48 pitches + 48 noise seeds would repeat the sines); build 256 and tile for config 4
     base = np.stack([cfg_signal(rank * batch + b) for b in range(min(batch, 256))])
-    host = base if batch <= 256 else np.concatenate([base] * (batch // 256))
     nsets = 2  # rotate buffer sets so a step never re-reads its own input out of the 256 MiB Infinity Cache
-    xs = [torch.from_numpy(host).to(dev) for _ in range(nsets)]
+    xs256 = [torch.from_numpy(base).to(dev) for _ in range(nsets)]
+    xs = xs256 if batch <= 256 else [torch.cat([x] * (batch // 256)) for x in xs256]
     oshape = (batch, n_bins, n_frames, 2) if kernel_wl == "stft" else (batch, n_bins, n_frames)
     outs = [torch.empty(oshape, dtype=torch.float32, device=dev) for _ in range(nsets)]
     gathered = None
@@ -254,24 +489,20 @@ def main() -> int:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # Clock settling, before the W warmup steps: after the idle seconds of start-up (imports, plan creation, uploads) the GPU's power
-    # management needs about 300 launches (~35 ms) of this workload to reach its steady clocks — measured per block of 25 launches from
-    # idle: 132 152 137 131 126 124 121 121 121 118 116 ... 115 us — so without it the K timed steps sit on the ramp.  Same steps, same
-    # buffers, every rank the same count (from the slowest rank's step time); reported as `preheat_steps`.
-    preheat_steps = 0
-    if args.preheat_s > 0:
-        t_probe = time.perf_counter()
-        for i in range(10):
-            step(i)
-        fence()
-        tp = torch.tensor([(time.perf_counter() - t_probe) / 10], dtype=torch.float64, device=dev)
+    def reduce_max(v: float) -> float:
+        t = torch.tensor([v], dtype=torch.float64, device=dev)
         if world > 1:
-            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
-        preheat_steps = int(min(20000, max(0.0, args.preheat_s / max(float(tp.item()), 1e-6))))
-        for i in range(preheat_steps):
-            step(i)
-        fence()
-        preheat_steps += 10
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- cold clocks first: the W + K steps a caller gets who launches from an idle GPU (no preheat; nothing has run yet but the
+    # one launch that loads the code object)
+    step(0)
+    fence()
+    cold_dt, _ = timed_steps(torch, stream, step, args.warmup + args.steps, fence)
+    cold_ms = reduce_max(cold_dt) / (args.warmup + args.steps) * 1e3
+
+    preheat_steps = preheat(step, fence, args.preheat_s, reduce_max)
     for i in range(args.warmup):
         step(i)
     fence()
@@ -289,50 +520,42 @@ def main() -> int:
         fence()
         gather_ms = e0.elapsed_time(e1) / 5
     fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)  # the stream the kernels are launched on (the plan launches on torch's current stream)
-    for i in range(args.steps):
-        step(i)
-    ev1.record(stream)
-    fence()
-    dt = time.perf_counter() - t0
+    dt, ev_ms = timed_steps(torch, stream, step, args.steps, fence)  # the stream the kernels are launched on (torch's current stream)
     if gathered is None and overlap is None:
-        kernel_ms = ev0.elapsed_time(ev1) / args.steps  # mean launch duration over the timed region itself
-
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        kernel_ms = ev_ms  # mean launch duration over the timed region itself
+    dt = reduce_max(dt)
+    kmin = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+    kmax = kmin.clone()
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+        dist.all_reduce(kmin, op=dist.ReduceOp.MIN)
+        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
 
+    extra = world == 1 and not args.no_legs
+    peak = measured_peak(_ffi.lib(), local_rank) if extra else None  # right behind the timed steps: steady clocks
     frames_per_launch = batch * n_frames
     frames_per_step = frames_per_launch * world
     value = frames_per_step * args.steps / dt
-    rd, wr = bytes_per_frame(kernel_wl, n_frames)
     kernel_fps = frames_per_launch / (kernel_ms * 1e-3)
-    achieved = (rd + wr) * kernel_fps / 1e9
-    valu_frac = FLOPS_PER_FRAME[kernel_wl] * kernel_fps / (VALU_PEAK_TFLOPS * 1e12)
+    line = None
     if rank == 0:
+        scope = "HIP events over the timed region" if (gathered is None and overlap is None) else "compute only (separate back-to-back launches, no gather)"
         line = {
             "metric": "STFT frames/sec (f32, n_fft=1024 hop=256)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "preheat_steps": preheat_steps,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3,
+            # the same W + K steps launched from idle clocks, before anything else ran on the device (no preheat)
+            "cold_ms_per_step": cold_ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"configs[{cfg_idx}]: {batch} x 10 s 16 kHz f32 per GPU, {kernel_wl} n_fft=1024 hop=256 Hanning centre"
                                    + (" (8192 utterances over 8 GPUs)" if args.workload == "config4" else ""),
                        "batch_per_gpu": batch, "n_samples": N_SAMPLES, "frames_per_step": frames_per_step, "kernel": plan.kernel_name,
                        "gather": (args.gather if (gathered is not None or overlap is not None) else False),
                        "parallelism": f"utterance-shard x{world}"},
-            # the dominant kernel, measured live (hipEvents around back-to-back launches on the launch stream, no gather): `achieved`
-            # is algorithmic bytes / kernel time.  The kernel is bounded by its arithmetic + LDS work next to the HBM stream, not by
-            # HBM alone: `valu_frac` is its share of the FP32 vector peak, `hbm_read_frac` north_star's read-only line.
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(kernel_wl) if batch == 256 else None, "kernel_ms": kernel_ms,
-                         "kernel_ms_scope": "HIP events over the timed region" if (gathered is None and overlap is None) else "compute only (separate back-to-back launches, no gather)", "algorithmic_bytes_per_frame": rd + wr,
-                         "frames_per_launch": frames_per_launch, "hbm_read_frac": rd * kernel_fps / 1e9 / HBM_PEAK_GBS,
-                         "valu_frac": valu_frac, "flops_per_frame": FLOPS_PER_FRAME[kernel_wl],
-                         "limiter": "valu+lds" if valu_frac > achieved / HBM_PEAK_GBS else "hbm"},
+            "rccl_ranks": rccl_ranks, "kernel_ms_min": float(kmin.item()), "kernel_ms_max": float(kmax.item()),
+            # the dominant kernel, measured live (hipEvents around back-to-back launches on the launch stream, no gather)
+            "roofline": stft_roofline(kernel_wl, batch, n_frames, kernel_ms, peak, scope, full_peak=True),
         }
         if gathered is not None or overlap is not None:
             shard_bytes = float(np.prod(oshape)) * 4.0
@@ -340,6 +563,22 @@ def main() -> int:
                               "gather_ms": gather_ms,
                               # ring all-gather: every rank sends and receives (world - 1) shards over its links
                               "GBps_per_rank": None if not gather_ms else shard_bytes * (world - 1) / (gather_ms * 1e-3) / 1e9}
+    if extra:
+        del outs, xs
+        torch.cuda.empty_cache()
+        wl = {}
+        for name in legs:
+            if name in ("fft2d", "convolve_fft") or name == args.workload:
+                continue
+            wl[name] = stft_leg(torch, sg, dev, name, xs256, args, peak)
+            torch.cuda.empty_cache()
+        two_d = [l for l in legs if l in ("fft2d", "convolve_fft")]
+        if two_d:
+            del xs256
+            torch.cuda.empty_cache()
+            wl.update(fft2d_legs(torch, sg, dev, two_d, args, peak))
+        line["workloads"] = wl
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(kernel_wl)
         print(json.dumps(line))
@@ -350,26 +589,42 @@ def main() -> int:
 
 
 def dry_run(args, rank: int, world: int) -> int:
-    """The launcher / timing skeleton without a GPU: gloo rendezvous, barrier, K empty steps, max over ranks, one JSON line."""
+    """The launcher / timing skeleton without a GPU: gloo rendezvous, barrier, K empty steps, max over ranks, the per-rank
+    min / max reduction, the one-rank-per-device check (here: the rank number stands in for the device), one JSON line."""
     import torch
     import torch.distributed as dist
 
+    ranks = 1
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
+        ranks = dist.get_world_size()
+        ids = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        fake = int(os.environ.get("SGX_DRY_DEVICE", rank))  # tests: two ranks claiming one device must be refused
+        dist.all_gather(ids, torch.tensor([fake], dtype=torch.int64))
+        if len({int(t.item()) for t in ids}) != world:
+            if rank == 0:
+                print(f"bench.py: {world} ranks but only {len({int(t.item()) for t in ids})} distinct GPUs — a device ordinal repeats", file=sys.stderr)
+            dist.destroy_process_group()
+            return 3
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         time.sleep(1e-4)
     if world > 1:
         dist.barrier()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    el = time.perf_counter() - t0
+    dt = torch.tensor([el], dtype=torch.float64)
+    kmin, kmax = dt.clone() / args.steps * 1e3, dt.clone() / args.steps * 1e3
     if world > 1:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(kmin, op=dist.ReduceOp.MIN)
+        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
     _, batch, cfg_idx = WORKLOADS[args.workload]
     if rank == 0:
         print(json.dumps({"metric": "STFT frames/sec (f32, n_fft=1024 hop=256)", "value": 0.0, "unit": "frames/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(dt.item()) / args.steps * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "dry-run (no GPU work)",
+                          "rccl_ranks": ranks, "kernel_ms_min": float(kmin.item()), "kernel_ms_max": float(kmax.item()),
                           "config": {"workload": f"configs[{cfg_idx}] dry run", "batch_per_gpu": batch, "gather": args.gather or False,
                                      "parallelism": f"utterance-shard x{world}"}}))
     if world > 1:

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SGX_ABI_VERSION 5
+#define SGX_ABI_VERSION 6
 
 typedef struct sgx_plan sgx_plan; /* opaque */
 
@@ -247,6 +247,12 @@ void sgx_c2c_destroy(sgx_c2c *plan);
 sgx_status sgx_c2c_forward(sgx_c2c *plan, void *buf, size_t len);
 sgx_status sgx_c2c_inverse(sgx_c2c *plan, void *buf, size_t len);
 const char *sgx_c2c_last_error(const sgx_c2c *plan);
+
+/* ---- measurement utility ("verify the HBM peak on the box with a device memcpy / triad and quote the measured
+ * peak next to the nominal"): streams `bytes` (0 = 1 GiB, four times the Infinity Cache) `iters` times with 16-byte accesses
+ * from every CU and returns the rate in GB/s.  mode 0: copy (bytes read + bytes written per pass), 1: read only, 2: write only.
+ * Allocates and frees its own buffers on `device` (-1 = current); no plan involved, nothing on the transform path calls it. */
+sgx_status sgx_membench(int32_t device, size_t bytes, int32_t mode, int32_t iters, double *gb_per_s);
 
 const char *sgx_last_error(const sgx_plan *plan);
 const char *sgx_last_create_error(void);

@@ -31,6 +31,7 @@ SYMBOLS = [
     "sgx_reserve", "sgx_plan_device", "sgx_last_dim_mismatch",
     "sgx_c2c_create", "sgx_c2c_destroy", "sgx_c2c_forward", "sgx_c2c_inverse", "sgx_c2c_last_error",
     "sgx_comm_unique_id", "sgx_comm_create", "sgx_comm_adopt", "sgx_comm_destroy", "sgx_comm_last_error", "sgx_gather", "sgx_shard_execute",
+    "sgx_membench",
 ]
 
 
@@ -145,6 +146,7 @@ def lib() -> C.CDLL:
     L.sgx_comm_last_error.restype = C.c_char_p
     L.sgx_gather.argtypes = [vp, vp, vp, sz, sz, C.c_int32, vp]
     L.sgx_shard_execute.argtypes = [vp, vp, vp, sz, sz, sz, vp, vp, vp]
+    L.sgx_membench.argtypes = [C.c_int32, sz, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
     _lib = L
     return L
 

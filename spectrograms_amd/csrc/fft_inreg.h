@@ -4,6 +4,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#ifndef SGX_BFLY3
+#define SGX_BFLY3 1  // twiddled butterflies as three packed instructions (x1 = 2 e - x0); 0: four.  Measured on the tuned kernel: Mel-80 power
+                     // 115.8 -> 111.2 us, linear power 115.4 -> 113.0 us per 256 x 10 s (profiles/experiments_r03/bfly3_bandpf_abv.txt)
+#endif
+
 namespace sgx {
 namespace inreg {
 
@@ -51,7 +56,11 @@ __device__ __forceinline__ void bfly(V e, V o, V &x0, V &x1) {
         constexpr E wr = (E)kCos64[idx], wi = (E)(-kSin64[idx]);
         const V so = swp(o);
         x0 = pfma(so, (V){-wi, wi}, pfma(o, (V){wr, wr}, e));
+#if SGX_BFLY3  // x1 = 2 e - x0: three packed instructions per twiddled butterfly instead of four (one more rounding of x0 carried into x1)
+        x1 = pfma(e, (V){E(2), E(2)}, -x0);
+#else
         x1 = pfma(so, (V){wi, -wi}, pfma(o, (V){-wr, -wr}, e));
+#endif
     }
 }
 template <int N, int K, typename V>

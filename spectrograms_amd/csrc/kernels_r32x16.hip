@@ -84,6 +84,9 @@ __device__ unsigned long long g_stamps[32];
 #define SGX_STAMP_ARGS
 #endif
 
+#ifndef SGX_BANDPF
+#define SGX_BANDPF 0  // 1: the band reduction of the n_fft 1024 kernel reads one 8-step group ahead (plan.hip pads L to multiples of 8)
+#endif
 #ifndef SGX_ONEPATH
 #define SGX_ONEPATH 1  // 0: the interior / edge split and the per-round chunk predicates of the sample loads (A/B only)
 #endif
@@ -463,6 +466,41 @@ __device__ __forceinline__ void mel_tile_sched(const StftArgs &a, const float *p
         const v4f *wr = (const v4f *)((const float *)sched + cur.y);
         const v4f *pr = (const v4f *)(pwT + (cur.z >> 1) * 32u) + fp;  // kstart is even
         v2f acc = {0.0f, 0.0f};
+#if SGX_BANDPF
+        // Software pipeline, 8 steps (two weight quads, four bin pairs) per group, L a multiple of 8 (host): the operands of group
+        // g + 1 are requested before group g is summed, so a segment exposes the LDS latency once instead of once per 4 steps (the
+        // compiler's own loop waits for its three reads every trip unless L >= 32).  The read-ahead past the slot's last group hits the
+        // row's zero pad / the next row and bins behind the band: never summed.
+        auto ld8 = [&](v4f(&w)[2], v4f(&p)[4], unsigned t) {
+            w[0] = wr[t >> 2];
+            w[1] = wr[(t >> 2) + 1u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p[u] = pr[(t >> 1) * 8u + 8u * u];
+        };
+        auto sum8 = [&](const v4f(&w)[2], const v4f(&p)[4]) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                acc = mul_add_unfused(w[u].x, (v2f){p[2 * u].x, p[2 * u].y}, acc);
+                acc = mul_add_unfused(w[u].y, (v2f){p[2 * u].z, p[2 * u].w}, acc);
+                acc = mul_add_unfused(w[u].z, (v2f){p[2 * u + 1].x, p[2 * u + 1].y}, acc);
+                acc = mul_add_unfused(w[u].w, (v2f){p[2 * u + 1].z, p[2 * u + 1].w}, acc);
+            }
+        };
+        // (the scheduling barriers keep the machine scheduler from sinking the requests next to their uses, which it does to save
+        // registers — that is the exposed latency this loop exists to remove)
+        v4f wa[2], pa[4], wb[2], pb[4];
+        ld8(wa, pa, 0u);
+        __builtin_amdgcn_sched_barrier(0);
+        for (unsigned t = 0; t < L; t += 16u) {
+            ld8(wb, pb, t + 8u);
+            __builtin_amdgcn_sched_barrier(0);
+            sum8(wa, pa);
+            if (t + 8u >= L) break;
+            ld8(wa, pa, t + 16u);
+            __builtin_amdgcn_sched_barrier(0);
+            sum8(wb, pb);
+        }
+#else
         for (unsigned t = 0; t < L; t += 4u) {  // q0 = (bin t: frames f, f+1; bin t+1: frames f, f+1)
             const v4f w4 = wr[t >> 2], q0 = pr[(t >> 1) * 8u], q1 = pr[(t >> 1) * 8u + 8u];
             acc = mul_add_unfused(w4.x, (v2f){q0.x, q0.y}, acc);
@@ -470,6 +508,7 @@ __device__ __forceinline__ void mel_tile_sched(const StftArgs &a, const float *p
             acc = mul_add_unfused(w4.z, (v2f){q1.x, q1.y}, acc);
             acc = mul_add_unfused(w4.w, (v2f){q1.z, q1.w}, acc);
         }
+#endif
         SGX_STAMP(13);  // mel loops
         const bool have = cur.w != 0xffffffffu;
         const unsigned bo = cur.w * a.n_frames * 4u;

@@ -1,0 +1,103 @@
+// membench.hip — sgx_membench: the HBM rate this device really delivers to plain streaming kernels, measured in-process so that
+// bench.py can quote it next to the nominal 8 TB/s ("verify on the box with a device memcpy / triad and quote
+// the measured peak next to the nominal").  Measurement utility of the C ABI: it allocates its own buffers, runs, frees them; no
+// plan is involved and nothing on the transform path calls it.
+//
+// Three kernels, all 16 bytes per lane, grid-stride, one 256-thread workgroup per CU x 8: copy (read + write), read (sum kept
+// alive, nothing written), write (fill).  Buffers default to 1 GiB each — four times the 256 MiB Infinity Cache — so the rate is
+// the memory's, not the cache's (MI355X_MICROARCH.md §Infinity Cache).
+#include <algorithm>
+#include <new>
+#include <string>
+
+#include "sgx_internal.h"
+
+namespace sgx {
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_mb_copy(const v4f *__restrict__ src, v4f *__restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 256u * 4u;
+    for (size_t i = (size_t)blockIdx.x * 256u * 4u + threadIdx.x; i < n; i += stride) {
+        v4f r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = i + u * 256u < n ? src[i + u * 256u] : (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * 256u < n) dst[i + u * 256u] = r[u];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mb_read(const v4f *__restrict__ src, float *__restrict__ sink, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 256u * 4u;
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    for (size_t i = (size_t)blockIdx.x * 256u * 4u + threadIdx.x; i < n; i += stride) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * 256u < n) acc += src[i + u * 256u];
+    }
+    const float s = acc.x + acc.y + acc.z + acc.w;
+    if (s == 123456.789f) sink[0] = s;  // never true for the zero-filled source: keeps the loads alive without a write stream
+}
+
+__global__ __launch_bounds__(256) void k_mb_write(v4f *__restrict__ dst, size_t n, float v) {
+    const size_t stride = (size_t)gridDim.x * 256u * 4u;
+    const v4f val = {v, v + 1.f, v + 2.f, v + 3.f};
+    for (size_t i = (size_t)blockIdx.x * 256u * 4u + threadIdx.x; i < n; i += stride) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * 256u < n) dst[i + u * 256u] = val;
+    }
+}
+
+}  // namespace
+}  // namespace sgx
+
+using namespace sgx;
+
+extern "C" sgx_status sgx_membench(int32_t device, size_t bytes, int32_t mode, int32_t iters, double *gb_per_s) {
+    if (!gb_per_s || mode < 0 || mode > 2 || iters <= 0) return SGX_INVALID_INPUT;
+    *gb_per_s = 0.0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SGX_BACKEND;
+    int dev = device;
+    if (dev == -1 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (dev < 0 || dev >= ndev) return SGX_INVALID_INPUT;
+    DeviceGuard dg;
+    if (dg.enter(dev) != hipSuccess) return SGX_BACKEND;
+    if (bytes == 0) bytes = size_t(1) << 30;
+    bytes &= ~size_t(4095);
+    if (bytes < 4096) return SGX_INVALID_INPUT;
+    void *src = nullptr, *dst = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    sgx_status st = SGX_BACKEND;
+    float ms = 0.f;
+    const size_t n = bytes / 16;
+    const unsigned grid = (unsigned)std::min<size_t>((n + 1023) / 1024, size_t(device_cu_count()) * 8u);
+    auto run = [&]() {
+        if (mode == 0) hipLaunchKernelGGL(k_mb_copy, dim3(grid), dim3(256), 0, nullptr, (const v4f *)src, (v4f *)dst, n);
+        else if (mode == 1) hipLaunchKernelGGL(k_mb_read, dim3(grid), dim3(256), 0, nullptr, (const v4f *)src, (float *)dst, n);
+        else hipLaunchKernelGGL(k_mb_write, dim3(grid), dim3(256), 0, nullptr, (v4f *)dst, n, 1.0f);
+    };
+    do {
+        if (mode != 2 && hipMalloc(&src, bytes) != hipSuccess) break;
+        if (hipMalloc(&dst, mode == 1 ? 4096 : bytes) != hipSuccess) break;
+        if (src && hipMemsetAsync(src, 0, bytes, nullptr) != hipSuccess) break;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) break;
+        for (int w = 0; w < 3; ++w) run();
+        if (hipEventRecord(e0, nullptr) != hipSuccess) break;
+        for (int i = 0; i < iters; ++i) run();
+        if (hipEventRecord(e1, nullptr) != hipSuccess) break;
+        if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) break;
+        if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0.f) break;
+        const double moved = double(bytes) * (mode == 0 ? 2.0 : 1.0) * double(iters);
+        *gb_per_s = moved / (double(ms) * 1e-3) / 1e9;
+        st = SGX_OK;
+    } while (false);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (src) (void)hipFree(src);
+    if (dst) (void)hipFree(dst);
+    return st;
+}

@@ -16,6 +16,9 @@
 
 using namespace sgx;
 
+#ifndef SGX_BANDPF
+#define SGX_BANDPF 0  // must match kernels_r32x16.hip
+#endif
 namespace {
 
 thread_local std::string g_create_err;
@@ -400,7 +403,11 @@ void build_band_schedule(sgx_plan *pl) {
                 const unsigned back = (c0 + 4u - want) & 3u;      // (c0 - want) mod 4
                 S.ks = c0 >= back ? c0 - back : (c0 & ~1u);       // always even: the kernel reads bin pairs
                 S.steps = c1 - S.ks + 1;
+#if SGX_BANDPF
+                G.L = std::max(G.L, (S.steps + 7u) & ~7u);  // the kernel takes 8 steps per group (software pipeline)
+#else
                 G.L = std::max(G.L, (S.steps + 3u) & ~3u);  // the kernel takes 4 steps per trip
+#endif
             }
         }
         std::vector<std::vector<unsigned>> per_wave(4);
@@ -450,7 +457,7 @@ void build_band_schedule(sgx_plan *pl) {
             }
         words.resize(words.size() + 4, 0);
         words[1] = uint32_t(words.size());
-        if (ok && words.size() <= size_t(r32x16::kMelMaxWords)) {
+        if (ok && words.size() + 16 <= size_t(r32x16::kMelMaxWords)) {  // (+16: the kernel's read-ahead stays inside the LDS table)
             pl->mel_sched_words = unsigned(words.size());
             pl->h_mel_sched = std::move(words);
         }

@@ -24,6 +24,15 @@ def test_direct_multi_rank_run_spawns_its_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak" and d["config"]["batch_per_gpu"] == 1024
     assert d["config"]["gather"] == "overlap" and d["ms_per_step"] > 0
+    # what the multi-rank line must carry so that the driver's scaling records can be audited: how many ranks the process group
+    # really has, and the spread of the per-rank launch times
+    assert d["rccl_ranks"] == 2 and 0 < d["kernel_ms_min"] <= d["kernel_ms_max"]
+
+
+def test_two_ranks_on_one_device_are_refused():
+    r = _run(["--gpus", "2", "--steps", "2", "--dry-run"], env={"SGX_DRY_DEVICE": "0"})  # both ranks claim device 0
+    assert r.returncode == 3 and "device ordinal repeats" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
 def test_single_rank_dry_run_and_world_size_mismatch():

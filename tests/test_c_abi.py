@@ -43,3 +43,23 @@ def test_device_smoke(tmp_path):
     assert r.returncode == 0, r.stdout
     r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0 and "device smoke passed" in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
+def test_shard_execute_multi_rank(tmp_path):
+    """sgx_comm_create / sgx_shard_execute / sgx_gather with 2 and 3 ranks (host threads sharing the one GPU of the test box), equal
+    and ragged shards, in-place and separate shard buffers, against a single launch bit for bit.  The collectives are served by
+    tests/c_abi/fake_rccl.c, which the library finds through its own dlsym lookup because the executable exports it."""
+    lib = sgbuild.build()
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "shard_ranks")
+    srcs = [os.path.join(ROOT, "tests", "c_abi", f) for f in ("shard_ranks.c", "fake_rccl.c")]
+    libdir = os.path.dirname(lib)
+    r = subprocess.run([hipcc, "-x", "c", "-std=gnu99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"),
+                        "-I/opt/rocm/include", *srcs, "-o", exe, "-rdynamic", "-L" + libdir, "-lspectro_hip", "-L/opt/rocm/lib",
+                        "-lamdhip64", "-lm", "-lpthread", "-Wl,-rpath," + libdir + ":/opt/rocm/lib"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and "multi-rank shard test passed" in r.stdout, r.stdout
