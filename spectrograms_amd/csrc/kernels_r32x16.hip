@@ -87,6 +87,9 @@ __device__ unsigned long long g_stamps[32];
 #ifndef SGX_BANDPF
 #define SGX_BANDPF 0  // 1: the band reduction of the n_fft 1024 kernel reads one 8-step group ahead (plan.hip pads L to multiples of 8)
 #endif
+#ifndef SGX_DMA
+#define SGX_DMA 0  // 1: filterbank outputs at n_fft 1024: the next tile's samples go HBM -> LDS directly (buffer_load ... lds), issued behind barrier 4
+#endif
 #ifndef SGX_ONEPATH
 #define SGX_ONEPATH 1  // 0: the interior / edge split and the per-round chunk predicates of the sample loads (A/B only)
 #endif
@@ -149,6 +152,27 @@ __device__ __forceinline__ void read_cols512(v2f (&x)[16], v2f (&w)[16], const u
 template <int PAR, int... K>
 __device__ __forceinline__ void read_win(v2f (&w)[16], unsigned waddr, std::integer_sequence<int, K...>) {
     (ds_read64<(2 * K + PAR) * 128>(w[K], waddr), ...);
+}
+
+// LDS-DMA: 16 bytes per lane from the buffer (range-checked per dword: out-of-range dwords arrive as 0) straight into LDS at
+// lds_base + 16 * lane.  Issued from inline asm — for a compiler-visible LDS-DMA hipcc drains vmcnt(0) before the next LDS read
+// that may alias it and at every __syncthreads() (cdna_hip_programming.md §5, Pipelining across barriers), which would expose
+// the whole HBM latency right behind the request; completion is counted by hand (s_waitcnt vmcnt) where the samples are read.
+template <int OFF>
+__device__ __forceinline__ void dma16_to_lds(__amdgpu_buffer_rsrc_t r, int voff, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen offset:%4 lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(r), "s"(lds_base), "n"(OFF)
+                 : "memory");
+}
+template <bool XSPAD, int R, int ROUNDS>
+__device__ __forceinline__ void dma_rounds(__amdgpu_buffer_rsrc_t r, int voff, unsigned xs_base, unsigned wave) {
+    if constexpr (R < ROUNDS) {
+        const unsigned c0 = R * 256u + wave * 64u;  // the wave's first chunk of this round
+        dma16_to_lds<0>(r, voff + R * 4096, xs_base + c0 * 16u + (XSPAD ? (c0 >> 6) * 128u : 0u));
+        dma_rounds<XSPAD, R + 1, ROUNDS>(r, voff, xs_base, wave);
+    }
 }
 
 // per-lane pass-1 twiddle tables: W_512^(k1*n2) = twa[k1>>3] * twb[k1&7]
@@ -443,7 +467,7 @@ __device__ __forceinline__ v2f mul_add_unfused(float w, v2f p, v2f acc) {
     const v2f m = (v2f){w, w} * p;
     return m + acc;
 }
-template <int AMP>
+template <int AMP, bool PACK = false>
 __device__ __forceinline__ void mel_tile_sched(const StftArgs &a, const float *pwT, const unsigned *sched, unsigned b, unsigned f0,
                                                unsigned nf, float eps, unsigned tid SGX_STAMP_PARAMS) {
     const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u, slot = lane >> 3, fp = lane & 7u;
@@ -451,10 +475,22 @@ __device__ __forceinline__ void mel_tile_sched(const StftArgs &a, const float *p
     // its range and the hardware drops the store.  The stores are unconditional and the segment loop has a fixed trip count so
     // that the compiler can count them behind the next tile's sample loads (vmcnt(2 kSchedSegs), not vmcnt(0): the loop must
     // never wait for its own stores).
-    const unsigned obytes = (a.n_out * a.n_frames - f0) * 4u;
-    const __amdgpu_buffer_rsrc_t ro = make_rsrc((const float *)a.out + (size_t)b * a.n_out * a.n_frames + f0, obytes);
     constexpr unsigned kDrop = 0x80000000u;
-    const unsigned fo0 = 2u * fp < nf ? 8u * fp : kDrop, fo1 = 2u * fp + 1u < nf ? 8u * fp + 4u : kDrop;
+    unsigned obytes, fo0, fo1;
+    const float *obase;
+    if constexpr (PACK) {  // the tile's slots run on into the following signals: a slot's offset counts from signal b
+        obase = (const float *)a.out + (size_t)b * a.n_out * a.n_frames;
+        obytes = min(17u, a.batch - b) * a.n_out * a.n_frames * 4u;
+        const unsigned fl0 = f0 + 2u * fp, fl1 = fl0 + 1u, b0 = fl0 / a.n_frames, b1 = fl1 / a.n_frames;
+        fo0 = 2u * fp < nf ? (b0 * a.n_out * a.n_frames + (fl0 - b0 * a.n_frames)) * 4u : kDrop;
+        fo1 = 2u * fp + 1u < nf ? (b1 * a.n_out * a.n_frames + (fl1 - b1 * a.n_frames)) * 4u : kDrop;
+    } else {
+        obase = (const float *)a.out + (size_t)b * a.n_out * a.n_frames + f0;
+        obytes = (a.n_out * a.n_frames - f0) * 4u;
+        fo0 = 2u * fp < nf ? 8u * fp : kDrop;
+        fo1 = 2u * fp + 1u < nf ? 8u * fp + 4u : kDrop;
+    }
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(obase, obytes);
     // one 16-byte record per (segment, wave, slot): {L of the wave, word offset of the slot's weight row, first bin, band}
     const uint4 *info = (const uint4 *)(sched + kSchedHdr) + wave * 8u + slot;
     uint4 cur = info[0];
@@ -580,14 +616,22 @@ __device__ __forceinline__ void mel_tile_sched512(const StftArgs &a, const float
 // transform of TWO consecutive frames (real parts: frame 2 p, imaginary parts: frame 2 p + 1); passes 1 and 2 are unchanged (the
 // same 32 x 16 transform), the real split becomes the two-sequence split (pass2_pair512).  The staged samples carry 64 B of
 // padding per KiB: the four slots of a wave start 1 KiB apart and would otherwise read the same banks.
-template <int MODE, int AMP, int ROUNDS, bool WIDE, bool XSPAD, bool PWT, int HOP512 = 0>
+// PACK (n_fft = 1024, batches of short signals): a tile is 16 consecutive frames of the BATCH — global frame g = 16 tile + slot is
+// frame g mod n_frames of signal g / n_frames — so a signal of 4 frames fills a quarter of a tile and the next three signals fill
+// the rest (one-signal tiles left 3/4 of every tile empty: 0.44 G frames/s for 65 536 x 4 frames).  Samples come per lane (the
+// direct path, ROUNDS = 0) through one descriptor over the whole batch, each pair range-checked against its own row in the lane;
+// outputs through one descriptor from the tile's first signal.  The reference's per-frame loop costs the same per frame whatever
+// the signal length (src/spectrogram.rs:240-294).
+template <int MODE, int AMP, int ROUNDS, bool WIDE, bool XSPAD, bool PWT, int HOP512 = 0, bool PACK = false>
 __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd, unsigned total, unsigned slots) {
     constexpr bool P512 = HOP512 != 0;           // n_fft 512 at hop HOP512
+    static_assert(!PACK || (ROUNDS == 0 && !WIDE && !XSPAD && HOP512 == 0 && (MODE != OUT_MEL || PWT)), "PACK: direct loads, 16-frame tiles, scheduled band stage");
     constexpr unsigned SS512 = 8u * HOP512;      // bytes from one slot's (frame pair's) first sample to the next slot's
     static_assert(!P512 || (HOP512 % 4 == 0 && ROUNDS * 256 * 4 >= 31 * HOP512 + 512), "P512: 16-byte chunks, the whole tile staged");
     static_assert(!WIDE || MODE != OUT_MEL, "wide pass 2 needs a per-bin output");
     static_assert(!PWT || MODE == OUT_MEL, "PWT is a filterbank layout");
     static_assert(!P512 || (!WIDE && !XSPAD && ROUNDS > 0 && (PWT == (MODE == OUT_MEL))), "P512: staged samples, scheduled band stage");
+    constexpr bool DMA = SGX_DMA != 0 && PWT && ROUNDS > 0 && !P512;  // samples HBM -> LDS without registers (see dma16_to_lds)
     constexpr unsigned FPT = P512 ? 32u : 16u;   // frames per tile
     constexpr unsigned NB = P512 ? 257u : 513u;  // bins
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
@@ -646,6 +690,10 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
             return;
 #endif
             const int vo = (tile_lo + 4 * (int)tid) * 4;
+            if constexpr (DMA) {
+                dma_rounds<XSPAD, 0, ROUNDS>(rx, vo, lds_addr(smem), __builtin_amdgcn_readfirstlane(tid >> 6));
+                return;
+            }
             // One straight-line path for every tile and every chunk round: the range check of a 16-byte buffer load is per dword (the
             // compiler merged the edge tiles' four dword loads into this same instruction anyway) and a chunk never straddles the row
             // start (the tile start and the padding are multiples of 4 samples).  Before: an interior and an edge path over the same
@@ -664,6 +712,25 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
                     for (int e = 0; e < 4; ++e) c[e] = __builtin_amdgcn_raw_buffer_load_b32(rx, vo + r * 4096 + 4 * e, 0, 0);
                     creg[r] = __builtin_bit_cast(v4f, c);
                 }
+            }
+        } else if constexpr (PACK) {
+            // slot p1f of packed tile w = global frame g = frame fq of signal bq.  One descriptor over the whole batch (host: its bytes
+            // fit 32 bits): the row's own range is checked here — a pair is inside, outside (offset past the descriptor: reads 0, the
+            // zero padding S1), or, for an odd row length, straddles the row end (second sample cleared).
+            const unsigned g = w * 16u + p1f;
+            const bool live = g < a.gframes;
+            const unsigned bq = live ? g / a.n_frames : 0u, fq = g - bq * a.n_frames;
+            const __amdgpu_buffer_rsrc_t rall = make_rsrc(a.x, a.x_bytes);
+            const int s0 = (int)(fq * hop) - (int)a.pad + 2 * (int)n2;
+            const unsigned rowo = bq * (unsigned)a.sample_stride;
+            const unsigned ns = (unsigned)a.n_samples;
+#pragma unroll
+            for (int n1 = 0; n1 < 32; ++n1) {
+                const int sidx = s0 + 32 * n1;
+                const bool in0 = live && (unsigned)sidx < ns;
+                v2f v = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rall, in0 ? (int)((rowo + (unsigned)sidx) * 4u) : (int)0xfffffff0u, 0, 0));
+                if ((unsigned)(sidx + 1) >= ns) v.y = 0.0f;
+                xd[n1] = v;
             }
         } else {
             const int vo = ((int)(p1f * hop) + tile_lo + 2 * (int)n2) * 4;
@@ -686,6 +753,7 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
     // values to the same addresses — so both halves always run the same number of rounds and barriers
     if (wid >= hi) wid = lead;
     if (lead < hi) load_tile(wid);
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the first tile's samples are in LDS (nothing else is in flight yet)
     __syncthreads();  // tables visible
 
     const unsigned xaddr = lds_addr(smem) + p1f * hop * 4u + n2 * 8u + (XSPAD ? p1f * 128u : 0u);
@@ -706,23 +774,33 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
         for (unsigned q = 0; q < (blockIdx.x >> 3) * SGX_STAGGER; ++q) __builtin_amdgcn_s_sleep(1);
         __syncthreads();
     }
+#ifdef SGX_PRIO  // experiment: static priority for the younger half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+    if (half == SGX_PRIO - 1u) __builtin_amdgcn_s_setprio(1);
+#endif
 #ifdef SGX_STAMPS
     unsigned long long st_acc[16] = {0}, st_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
 #endif
     while (lead < hi) {
-        const unsigned b = wid / a.tiles, tile = wid - b * a.tiles;
-        const unsigned f0 = tile * FPT;
-        const unsigned nf = min(FPT, a.n_frames - f0);
+        // (PACK: b = the tile's first signal, f0 = its first frame's index in that signal, nf = the tile's live slots)
+        const unsigned b = PACK ? wid * 16u / a.n_frames : wid / a.tiles, tile = wid - b * a.tiles;
+        const unsigned f0 = PACK ? wid * 16u - b * a.n_frames : tile * FPT;
+        const unsigned nf = PACK ? min(16u, a.gframes - wid * 16u) : min(FPT, a.n_frames - f0);
         v2f xr[32];
         {
             v2f e[16], o[16], we[16], wo[16];
             if constexpr (ROUNDS > 0) {
                 // stage: chunk c of the tile -> xs (this half's ex is free: barrier 4 of the previous tile / the prologue)
+                if constexpr (DMA) {
+                    // this wave's requests have landed: they are older than the 2 kSchedSegs band-stage stores issued behind them (the
+                    // first tile's were collected before the loop); barrier 1 then covers the other waves' pieces
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kSchedSegs) : "memory");
+                } else {
 #pragma unroll
                 for (int r = 0; r < ROUNDS; ++r) {
                     const unsigned c = r * 256u + tid;
                     if (SGX_ONEPATH || XSPAD || P512 || c < chunks) *(v4f *)(smem + c * 16u + (XSPAD ? (c >> 6) * 128u : P512 ? (c * 16u / (P512 ? SS512 : 1u)) * 64u : 0u)) = creg[r];
+                }
                 }
                 SGX_STAMP(0);  // wait for the samples + staging writes
                 __syncthreads();  // barrier 1: xs complete
@@ -786,7 +864,8 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
         if (next >= hi) next -= half;  // no tile of its own next round: repeat the first half's
         // requested after pass 1 so the previous tile's store burst has had that long to drain: a vector load issued while
         // the CU's store FIFO is backed up stalls its wave for thousands of cycles
-        if (lead + slots * 2u < hi) load_tile(next);  // in flight during pass 2
+        if constexpr (!DMA)
+            if (lead + slots * 2u < hi) load_tile(next);  // in flight during pass 2
         SGX_STAMP(5);  // load issue
         __syncthreads();  // barrier 3: ex complete
         SGX_STAMP(6);
@@ -813,6 +892,12 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
         } else if constexpr (P512) {
             p2ex = p2f;             // slot
             p2ofs = f0 + 2u * p2f;  // its first frame
+        } else if constexpr (PACK) {
+            // slot -> (signal, frame): the offset is relative to the tile's first signal b, where the descriptor starts
+            const unsigned p2f_eff = ALLSTORE ? min(p2f, nf - 1u) : p2f;
+            const unsigned fl = f0 + p2f_eff, bq = fl / a.n_frames;  // signals past b
+            p2ex = p2f_eff;
+            p2ofs = bq * NB * a.n_frames + (fl - bq * a.n_frames);
         } else {
             const unsigned p2f_eff = ALLSTORE ? min(p2f, nf - 1u) : p2f;
             p2ex = p2f_eff;
@@ -823,6 +908,10 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
         SGX_STAMP(7);  // row reads
         __syncthreads();  // barrier 4: ex consumed: the next staging (or the pw overlay) may overwrite it
         SGX_STAMP(8);
+        // DMA: the staging area (below the |X|^2 tile) is free from here on; the next tile's samples land in it during the real split
+        // and the band stage (~5 k cycles: more than an HBM round trip)
+        if constexpr (DMA)
+            if (lead + slots * 2u < hi) load_tile(next);
         float *pwf = (float *)(smem + (PWT ? kOutOff : 0));  // PWT: above the staged samples, so the next staging does not wait for it
         if constexpr (MODE == OUT_MEL) {
             if constexpr (P512) {  // bins 257..267 are read with zero weights
@@ -846,7 +935,7 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
                                      pws + pwt512_index(r2, 0u), pws + pwt512_index(256u, 0u));
         } else if (ALLSTORE || p2f < nf) {
             const unsigned c1 = j == 0 ? 16u : j, c2 = j == 0 ? 0u : j + 256u;
-            const unsigned long long obytes = (unsigned long long)min(2u, a.batch - p2b) * 513ull * a.n_frames * ES;
+            const unsigned long long obytes = (unsigned long long)min(PACK ? 17u : 2u, a.batch - p2b) * 513ull * a.n_frames * ES;
             const __amdgpu_buffer_rsrc_t ro = make_rsrc((unsigned char *)a.out + (size_t)p2b * 513u * a.n_frames * ES, (unsigned)obytes);
             {
                 auto slot_of = [&](unsigned k) { return pwf + (PWT ? pwt_index(k, p2f) : p2f * kPS + k); };  // bins k + 32 i follow at i * PSTEP
@@ -862,7 +951,7 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
             if (a.n_mels == 12345u)
 #endif
             if constexpr (P512) mel_tile_sched512<AMP>(a, pwf, sched, b, f0, nf, eps, tid);
-            else if constexpr (PWT) mel_tile_sched<AMP>(a, pwf, sched, b, f0, nf, eps, tid SGX_STAMP_ARGS);
+            else if constexpr (PWT) mel_tile_sched<AMP, PACK>(a, pwf, sched, b, f0, nf, eps, tid SGX_STAMP_ARGS);
             else if (a.mm_frag) map_tile_mfma<AMP>(a, pwf, b, f0, nf, eps, tid, 2u * half);
             else mel_tile_csr<AMP>(a, pwf, b, f0, nf, eps, tid, 256u);
             if constexpr (!PWT) __syncthreads();  // pw consumed before the next staging overwrites it
@@ -886,9 +975,25 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
 #endif
 }
 
+// Packed tiles pay 5 more vector instructions per sample pair and give up the staged loads and the wide stores — measured 1.0-1.1 G
+// frames/s (linear power and Mel-80 dB, 4 ... 40 frames per signal) against 1.4-1.5 G x the filled share of one-signal tiles
+// (profiles/bench_r03_short_signals.txt): packed once a quarter or more of the one-signal tiles' slots would be empty (626 frames: 2
+// of 640 slots, 40 frames: 8 of 48 — not packed; 17 frames: 15 of 32 — packed)
+static bool want_pack(const StftArgs &a, bool mel, bool pwt) {
+    if (a.n_fft != 1024u || a.batch < 2u || (mel && !pwt)) return false;
+    const unsigned long long slots16 = (unsigned long long)a.tiles * 16ull, g = (unsigned long long)a.batch * a.n_frames;
+    if ((slots16 - a.n_frames) * 4ull < slots16) return false;
+    if (g >= 0x7fffffffull || (unsigned long long)a.batch * a.sample_stride * 4ull >= 0xfffffff0ull) return false;  // 32-bit offsets
+    return 17ull * 513ull * a.n_frames * 8ull < 0x7fffffffull;
+}
+
 template <int MODE, int AMP>
-hipError_t launch_variant(const StftArgs &a, hipStream_t s) {
-    const unsigned total = a.tiles * a.batch;
+hipError_t launch_variant(const StftArgs &a0, hipStream_t s) {
+    StftArgs a = a0;
+    const bool pack = want_pack(a, MODE == OUT_MEL, MODE == OUT_MEL && a.mel_sched != nullptr);
+    a.gframes = a.batch * a.n_frames;
+    a.x_bytes = pack ? (unsigned)((unsigned long long)a.batch * a.sample_stride * 4ull) : 0u;
+    const unsigned total = pack ? (a.gframes + 15u) / 16u : a.tiles * a.batch;
     const unsigned per_xcd = (total + 7) / 8;
     const unsigned chunks = (15u * a.hop + 1024u + 3u) >> 2;
     const unsigned pairs = (per_xcd + 1) / 2;
@@ -905,6 +1010,7 @@ hipError_t launch_variant(const StftArgs &a, hipStream_t s) {
         return hipGetLastError();
     };
     constexpr bool W = MODE != OUT_MEL;
+    if (pack) return go(k_r32x16<MODE, AMP, 0, false, false, MODE == OUT_MEL, 0, true>);
     if constexpr (MODE == OUT_MEL) {
         if (pwt) {
             if (a.n_fft == 512u) {  // two frames per transform

@@ -70,6 +70,8 @@ struct StftArgs {
     // filterbank schedule of the tuned kernel (r32x16_layout.h), nullptr: bank not schedulable (matrix cores / CSR path)
     const unsigned *mel_sched;
     unsigned mel_sched_words;
+    // tuned kernel, packed tiles (batches of short signals; set by its launcher): batch * n_frames, bytes of the whole sample buffer
+    unsigned gframes, x_bytes;
 };
 
 // launchers (kernels_generic.hip / kernels_r32x16.hip); return hipSuccess or the launch error

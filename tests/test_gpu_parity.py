@@ -573,3 +573,44 @@ def test_config4_shard_full_size_mel_power():
     # sharding is by utterance with no halo: two half batches give the same bits as the whole
     lo, hi = plan.compute_batch(x[:512]), plan.compute_batch(x[512:])
     assert torch.equal(torch.cat([lo, hi]), out)
+
+
+# ------------------------------------------------------------------ tiles that continue into the next signal (batches of short signals)
+@pytest.mark.parametrize("amp,n_mels,floor", [("power", 0, None), ("complex", 0, None), ("db", 80, -80.0), ("magnitude", 40, None)])
+@pytest.mark.parametrize("n,centre", [(1, True), (300, True), (700, True), (1000, True), (1279, True), (1024, False), (1800, False),
+                                       (4000, True), (5120, True)])
+def test_packed_tiles_short_signals(n, centre, amp, n_mels, floor):
+    """n_fft 1024 / hop 256 over many short signals: 1 ... 21 frames per signal, so a 16-frame tile of the tuned kernel holds frames
+    of up to 16 different signals (the reference's per-frame loop knows no tiles, src/spectrogram.rs:240-294, 1230-1250).  Every
+    signal of the batch must come out bit for bit as from its own B = 1 launch, and agree with the oracle; odd lengths put the row
+    end inside a sample pair, odd batch sizes leave the last tile partly empty."""
+    batch = 37
+    plan, got = run_case(n=n, batch=batch, seed=n, n_fft=1024, hop=256, centre=centre, amp=amp, n_mels=n_mels, floor=floor)
+    assert plan.kernel_name == "r32x16_f32"
+    x = signals(batch, n, np.float32, n)
+    for b in (0, 1, 17, 35, 36):
+        one = plan.compute_batch(x[b:b + 1])
+        assert np.array_equal(np.asarray(one[0]), np.asarray(got[b])), b
+
+
+def test_packed_tiles_large_batch_linear():
+    """65 536 signals of 4 frames (the shape of profiles/bench_r02_sweep_misc.txt's slowest rows) through one launch: spot-checked
+    against the oracle and against B = 1 launches, the whole output finite; a row stride larger than the row length."""
+    import torch
+
+    batch, n, stride = 65536, 1000, 1008
+    rng = np.random.default_rng(5)
+    buf = torch.zeros((batch, stride), dtype=torch.float32, device="cuda")
+    xh = (0.2 * rng.standard_normal((batch, n))).astype(np.float32)
+    buf[:, :n] = torch.from_numpy(xh).cuda()
+    buf[:, n:] = 1e30  # the stride padding must never be read as samples
+    plan, op = make(n_fft=1024, hop=256)
+    out = plan.compute_batch(buf[:, :n])
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == (batch, 513, 4) and bool(torch.isfinite(out).all())
+    idx = [0, 1, 2, 3, 4, 5, 4095, 4096, 32767, 65534, 65535]
+    ref = orc.spectrogram_batch(op, xh[idx].astype(np.float64))
+    check(out[idx].cpu().numpy(), ref, "power", "float32")
+    for b in (3, 65535):
+        one = plan.compute_batch(xh[b:b + 1])
+        assert np.array_equal(one[0], out[b].cpu().numpy())
