@@ -365,6 +365,8 @@ sgx_status upload_cast(sgx_plan *pl, void **dst, const std::vector<double> &src)
     return upload<T>(pl, dst, tmp);
 }
 
+sgx_status grow(sgx_plan *pl, void **buf, size_t *have, size_t need);
+
 // Band schedule of the tuned f32 kernel (n_fft 1024, and 512 in its two-frames-per-transform mode), built on the HOST at plan
 // creation — before the kernel kind is resolved, so that a bank without a schedule (rows that are not runs of bins, too many
 // words) resolves to the kernel that will really run it, and the split-filterbank decision is made for that kernel.
@@ -608,6 +610,60 @@ sgx_status build_device_tables(sgx_plan *pl) {
         if ((st = upload<float>(pl, &pl->d_window_half, wh)) != SGX_OK) return st;
         if ((st = upload<float>(pl, &pl->d_ones_half, oh)) != SGX_OK) return st;
     }
+    if (pl->kind == K_BLUESTEIN) {  // chirp-z tables (bluestein.hip), evaluated in f64
+        const unsigned M = pl->bs_M;
+        // c_j = e^(+i pi j^2 / n): the angle is reduced in integers, j^2 mod 2 n, so that a large j loses nothing
+        auto chirp = [&](unsigned j, double &re, double &im) {
+            const unsigned long long q = (unsigned long long)j * j % (2ull * n);
+            const double ang = kPi * double(q) / double(n);
+            re = std::cos(ang);
+            im = std::sin(ang);
+        };
+        std::vector<double> cc(2 * size_t(n)), bre(M, 0.0), bim(M, 0.0), twm(2 * size_t(M));
+        for (unsigned j = 0; j < n; ++j) {
+            double re, im;
+            chirp(j, re, im);
+            cc[2 * j] = re;
+            cc[2 * j + 1] = -im;  // conj(c_j): multiplies the samples going in and the bins coming out
+            bre[j] = re;
+            bim[j] = im;
+            if (j) { bre[M - j] = re; bim[M - j] = im; }  // b[-j] = c_j
+        }
+        // FFT_M(b) on the host: iterative radix-2, f64
+        for (unsigned i = 1, j = 0; i < M; ++i) {
+            unsigned bit = M >> 1;
+            for (; j & bit; bit >>= 1) j ^= bit;
+            j ^= bit;
+            if (i < j) { std::swap(bre[i], bre[j]); std::swap(bim[i], bim[j]); }
+        }
+        for (unsigned len = 2; len <= M; len <<= 1) {
+            const double ang = -2.0 * kPi / double(len);
+            for (unsigned i = 0; i < M; i += len)
+                for (unsigned k = 0; k < len / 2; ++k) {
+                    const double wr = std::cos(ang * k), wi = std::sin(ang * k);
+                    const double ur = bre[i + k], ui = bim[i + k];
+                    const double vr = bre[i + k + len / 2] * wr - bim[i + k + len / 2] * wi;
+                    const double vi = bre[i + k + len / 2] * wi + bim[i + k + len / 2] * wr;
+                    bre[i + k] = ur + vr; bim[i + k] = ui + vi;
+                    bre[i + k + len / 2] = ur - vr; bim[i + k + len / 2] = ui - vi;
+                }
+        }
+        std::vector<double> bh(2 * size_t(M));
+        for (unsigned k = 0; k < M; ++k) {
+            bh[2 * k] = bre[k] / double(M);  // the inverse transform's 1 / M folded in
+            bh[2 * k + 1] = bim[k] / double(M);
+            const double a = -2.0 * kPi * double(k) / double(M);
+            twm[2 * k] = std::cos(a);
+            twm[2 * k + 1] = std::sin(a);
+        }
+        if ((st = upload_cast<T>(pl, &pl->d_bs_chirp, cc)) != SGX_OK) return st;
+        if ((st = upload_cast<T>(pl, &pl->d_bs_bhat, bh)) != SGX_OK) return st;
+        if ((st = upload_cast<T>(pl, &pl->d_bs_tw, twm)) != SGX_OK) return st;
+        // one frame of scratch now, so that the per-frame entry point (sgx_r2c) never allocates
+        const size_t one = size_t(M) * 2 * pl->elem * 32;
+        if ((st = grow(pl, &pl->d_bs_a, &pl->d_bs_a_bytes, one)) != SGX_OK) return st;
+        if ((st = grow(pl, &pl->d_bs_b, &pl->d_bs_b_bytes, one)) != SGX_OK) return st;
+    }
     return SGX_OK;
 }
 
@@ -662,13 +718,40 @@ bool set_geometry(const sgx_plan *pl, StftArgs &a, KernelKind kind) {
     case K_DIRECT_DFT: ok = plan_geometry_direct_dft(a, pl->dtype); break;
     case K_TWO_FACTOR: ok = plan_geometry_two_factor(a, pl->dtype); break;
     case K_REG_RADIX: ok = plan_geometry_reg_radix(a, pl->dtype); break;
+    case K_BLUESTEIN: a.ft = 1; ok = pl->bs_M != 0 && a.out_mode != OUT_MEL; break;  // (filterbank outputs: the split path)
     }
     if (ok) a.tiles = (a.n_frames + a.ft - 1) / a.ft;
     return ok;
 }
 
-hipError_t launch(const sgx_plan *pl, const StftArgs &a, KernelKind kind, hipStream_t s) {
+sgx_status grow(sgx_plan *pl, void **buf, size_t *have, size_t need);
+
+// frames of the chirp-z path per pass over its two scratch buffers: <= 1 GiB each, <= 32768 (grid.y)
+unsigned long long bluestein_chunk(const sgx_plan *pl, unsigned long long frames) {
+    const unsigned long long per = (unsigned long long)pl->bs_M * 2ull * pl->elem;
+    unsigned long long c = (1ull << 30) / per;
+    c = std::max<unsigned long long>(32ull, std::min<unsigned long long>(c, 32768ull));
+    return std::min(c, std::max<unsigned long long>(frames, 1ull));
+}
+
+hipError_t launch_bluestein_plan(sgx_plan *pl, const StftArgs &a, hipStream_t s) {
+    BsArgs b{};
+    b.x = a.x; b.out = a.out;
+    b.sample_stride = a.sample_stride; b.n_samples = a.n_samples;
+    b.batch = a.batch; b.n_fft = a.n_fft; b.hop = a.hop; b.pad = a.pad; b.n_frames = a.n_frames; b.nb = a.nb_fft;
+    b.M = pl->bs_M; b.log2M = pl->bs_log2M; b.c2c_tile = pl->bs_tile;
+    b.window = a.window; b.chirp = pl->d_bs_chirp; b.bhat = pl->d_bs_bhat; b.tw_m = pl->d_bs_tw;
+    b.chunk_frames = bluestein_chunk(pl, (unsigned long long)a.batch * a.n_frames);
+    const size_t need = size_t(b.chunk_frames) * pl->bs_M * 2 * pl->elem;
+    if (grow(pl, &pl->d_bs_a, &pl->d_bs_a_bytes, need) != SGX_OK || grow(pl, &pl->d_bs_b, &pl->d_bs_b_bytes, need) != SGX_OK) return hipErrorOutOfMemory;
+    b.scratch_a = pl->d_bs_a; b.scratch_b = pl->d_bs_b;
+    b.complex_out = a.out_mode == OUT_COMPLEX; b.amp = a.amp; b.eps = a.eps;
+    return launch_bluestein(b, pl->dtype, s);
+}
+
+hipError_t launch(sgx_plan *pl, const StftArgs &a, KernelKind kind, hipStream_t s) {
     switch (kind) {
+    case K_BLUESTEIN: return launch_bluestein_plan(pl, a, s);
     case K_R32X16_F32: return launch_r32x16_f32(a, s);
     case K_LDS_RADIX2: return launch_lds_radix2(a, pl->dtype, s);
     case K_TWO_FACTOR: return launch_two_factor(a, pl->dtype, s);
@@ -724,7 +807,7 @@ bool resolve_geometry(const sgx_plan *pl, StftArgs &a, KernelKind &kind) {
     if (!ok) ok = set_geometry(pl, a, kind = K_DIRECT_DFT);
     return ok;
 }
-int chain_pos(KernelKind k) { return k == K_R32X16_F32 ? 0 : k == K_REG_RADIX ? 1 : k == K_DIRECT_DFT ? 3 : 2; }
+int chain_pos(KernelKind k) { return k == K_R32X16_F32 ? 0 : k == K_REG_RADIX ? 1 : k == K_DIRECT_DFT ? 3 : 2; }  // (K_BLUESTEIN is chosen after the chain, at creation)
 
 sgx_status run_device(sgx_plan *pl, const void *x, size_t batch, size_t n_samples, size_t stride, void *out,
                       size_t n_frames, hipStream_t s, int iters, float *ms) {
@@ -788,7 +871,7 @@ sgx_status grow(sgx_plan *pl, void **buf, size_t *have, size_t need) {
 
 void free_device(sgx_plan *pl) {
     void **bufs[] = {&pl->d_window, &pl->d_tw, &pl->d_tw1, &pl->d_tw2, &pl->d_mel_ptr, &pl->d_mel_col,
-                     &pl->d_mel_val, &pl->d_dct, &pl->d_lifter, &pl->d_melbuf, &pl->d_pwbuf, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_mm_frag, &pl->d_mm_blk, &pl->d_mel_sched, &pl->d_itw, &pl->d_itwr, &pl->d_itw1, &pl->d_frames, &pl->d_flag, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half};
+                     &pl->d_mel_val, &pl->d_dct, &pl->d_lifter, &pl->d_melbuf, &pl->d_pwbuf, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_mm_frag, &pl->d_mm_blk, &pl->d_mel_sched, &pl->d_itw, &pl->d_itwr, &pl->d_itw1, &pl->d_frames, &pl->d_flag, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half, &pl->d_bs_chirp, &pl->d_bs_bhat, &pl->d_bs_tw, &pl->d_bs_a, &pl->d_bs_b};
     for (void **b : bufs)
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
@@ -930,6 +1013,7 @@ const char *sgx_kernel_name(const sgx_plan *plan) {
     case K_LDS_RADIX2: return "lds_radix2";
     case K_TWO_FACTOR: return "two_factor_dft";
     case K_REG_RADIX: return "reg_radix";
+    case K_BLUESTEIN: return "bluestein";
     default: return "direct_dft";
     }
 }
@@ -994,6 +1078,30 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
             if (ok_lin && (long_frames || f64_mixed || further_up)) {
                 pl->split_bank = true;
                 kind = kind_lin;
+                ok = true;
+            }
+        }
+        // Lengths the chain above runs as a direct sum (primes: n / 2 multiply-adds per sample) or as a two-factor transform with a
+        // large factor (n = a b: a + b / 2 per sample) go through the chirp-z transform on the power-of-two kernels instead
+        // (bluestein.hip: two length-M transforms and five passes over a [frames][M] scratch, M >= 2 n - 1) once that is cheaper
+        // — the reference's RustFFT plans such lengths with Rader / Bluestein too (src/fft_backend.rs:376-385).
+        {
+            const unsigned n = params->n_fft;
+            unsigned M = 1, l2 = 0;
+            while (M < 2 * n - 1) { M <<= 1; ++l2; }
+            double per_sample = 0.0;
+            if (kind == K_DIRECT_DFT) per_sample = double(n) / 2.0;
+            if (kind == K_TWO_FACTOR) {
+                unsigned fa = 1;
+                for (unsigned d = 2; (unsigned long long)d * d <= n; ++d)
+                    if (n % d == 0) fa = d;
+                per_sample = double(fa) + double(n / fa) / 2.0;
+            }
+            const unsigned tile = n >= 8 && l2 >= 4 ? fft2d_tile_for(M, pl->dtype) : 0;
+            if ((!ok || per_sample > 6.0 * double(l2) * double(M) / double(n)) && tile != 0) {
+                pl->bs_M = M; pl->bs_log2M = l2; pl->bs_tile = tile;
+                kind = K_BLUESTEIN;
+                pl->split_bank = pl->out_mode == OUT_MEL;  // per-bin power, then the bank's rows
                 ok = true;
             }
         }
@@ -1244,6 +1352,11 @@ sgx_status sgx_reserve(sgx_plan *plan, size_t batch, size_t n_samples, int32_t h
     if (!inverse && plan->split_bank &&
         (st = grow(plan, &plan->d_pwbuf, &plan->d_pwbuf_bytes, batch * size_t(plan->nb_fft) * nf * plan->elem)) != SGX_OK)
         return st;
+    if (!inverse && plan->kind == K_BLUESTEIN) {
+        const size_t need = size_t(bluestein_chunk(plan, (unsigned long long)batch * nf)) * plan->bs_M * 2 * plan->elem;
+        if ((st = grow(plan, &plan->d_bs_a, &plan->d_bs_a_bytes, need)) != SGX_OK) return st;
+        if ((st = grow(plan, &plan->d_bs_b, &plan->d_bs_b_bytes, need)) != SGX_OK) return st;
+    }
     if (inverse) {  // sgx_istft of `batch` spectra whose frame count is that of n_samples-long signals
         // the same tests run_istft applies: tuned n_fft = 1024 kernel, else the fused register-tiled kernel; only the unfused
         // fallback (rows + overlap-add) touches the frame scratch

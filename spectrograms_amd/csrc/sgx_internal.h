@@ -19,7 +19,7 @@ namespace sgx {
 enum OutMode : int { OUT_LINEAR = 0, OUT_MEL = 1, OUT_COMPLEX = 2 };
 // AMP_MAG_IN: the mapping consumes sqrt(power) and its output is final (chromagram: bank applied to magnitudes)
 enum AmpMode : int { AMP_POWER = 0, AMP_MAGNITUDE = 1, AMP_DB = 2, AMP_MAG_IN = 3 };
-enum KernelKind : int { K_DIRECT_DFT = 0, K_LDS_RADIX2 = 1, K_R32X16_F32 = 2, K_TWO_FACTOR = 3, K_REG_RADIX = 4 };
+enum KernelKind : int { K_DIRECT_DFT = 0, K_LDS_RADIX2 = 1, K_R32X16_F32 = 2, K_TWO_FACTOR = 3, K_REG_RADIX = 4, K_BLUESTEIN = 5 };
 
 // Kernel arguments (POD, passed by value).  Layouts in HBM:
 //   x      : [batch][sample_stride] T, row b valid for n_samples elements
@@ -91,6 +91,25 @@ hipError_t launch_reg_radix(const StftArgs &a, int dtype, hipStream_t s);
 // filterbank rows over a [batch][nb_fft][n_frames] power / magnitude tensor (split filterbank path): CSR bank, amp and eps from `a`
 hipError_t launch_bank_rows(const void *pw, void *out, const StftArgs &a, int dtype, hipStream_t s);
 bool plan_geometry_r32x16_f32(StftArgs &a);
+
+// chirp-z (Bluestein) forward frames on the power-of-two complex kernels (bluestein.hip): lengths with a large prime factor
+struct BsArgs {
+    const void *x;
+    void *out;  // [batch][nb][n_frames] T, or complex pairs
+    unsigned long long sample_stride, n_samples;
+    unsigned batch, n_fft, hop, pad, n_frames, nb;
+    unsigned M, log2M;      // convolution length: the power of two >= 2 n_fft - 1
+    unsigned c2c_tile;      // sequences per workgroup of the LDS-tile C2C kernel at length M (fft2d_tile_for)
+    const void *window;     // [n_fft] T
+    const void *chirp;      // [n_fft] complex T: conj(c_n) = e^(-i pi n^2 / n_fft)
+    const void *bhat;       // [M] complex T: FFT_M of the wrapped chirp, divided by M
+    const void *tw_m;       // [M] complex T: e^(-2 pi i k / M)
+    void *scratch_a, *scratch_b;  // [chunk_frames][M] complex T each
+    unsigned long long chunk_frames;
+    int complex_out, amp;
+    double eps;
+};
+hipError_t launch_bluestein(const BsArgs &a, int dtype, hipStream_t s);
 
 // ---- 2-D FFT path (kernels_fft2d.hip)
 struct C2cArgs {
@@ -267,6 +286,10 @@ struct sgx_plan {
     // inverse path (sgx_istft / sgx_c2r), created on first use: full twiddle table e^{-2 pi i k/n}, frame scratch, flag
     void *d_itw = nullptr, *d_frames = nullptr, *d_flag = nullptr;
     void *d_itwr = nullptr, *d_itw1 = nullptr;  // tuned f32 n_fft = 1024 inverse: conj(W_1024^k) [32][16], W_512^(k1 n2) [32][16]
+    // K_BLUESTEIN: chirp, transformed chirp, length-M twiddles, two frame scratch buffers (grown on demand, sgx_reserve sizes them)
+    void *d_bs_chirp = nullptr, *d_bs_bhat = nullptr, *d_bs_tw = nullptr, *d_bs_a = nullptr, *d_bs_b = nullptr;
+    size_t d_bs_a_bytes = 0, d_bs_b_bytes = 0;
+    unsigned bs_M = 0, bs_log2M = 0, bs_tile = 0;
     size_t d_frames_bytes = 0;
 
     // plan-owned staging for host-pointer execution

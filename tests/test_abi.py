@@ -157,8 +157,14 @@ def test_kernel_selection():
     assert host_plan(400, 160).kernel_name == "reg_radix"       # m = 200 = 25 x 8
     assert host_plan(100, 40).kernel_name == "two_factor_dft"   # even, but not in the register-tiled list: 10 x 10
     assert host_plan(441, 160).kernel_name == "two_factor_dft"  # odd: 21 x 21
-    assert host_plan(401, 160).kernel_name == "direct_dft"      # prime length
+    assert host_plan(97, 40).kernel_name == "direct_dft"        # small prime: the direct sum is cheaper than two 256-point transforms
     assert host_plan(2, 1).kernel_name == "direct_dft"
+    # lengths with a large prime factor: chirp-z (Bluestein) on the power-of-two complex kernels
+    assert host_plan(401, 160).kernel_name == "bluestein"       # prime
+    assert host_plan(5003, 2000, dtype="float32").kernel_name == "bluestein"
+    assert host_plan(1006, 500).kernel_name == "bluestein"      # 2 x 503: the two-factor kernel would pay 2 + 251 multiply-adds per sample
+    assert host_plan(1023, 256).kernel_name == "two_factor_dft"  # 31 x 33 stays
+    assert host_plan(4099, 1000, dtype="float64").kernel_name == "direct_dft"  # f64: M = 16384 does not fit the complex kernels' tile
 
 
 def test_shard_range_partitions_batch():

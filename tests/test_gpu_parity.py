@@ -159,11 +159,11 @@ def test_long_frames_filterbank_in_a_second_launch(n_fft, hop, dtype, n_mels, no
 
 
 @pytest.mark.parametrize("n_fft,hop,dtype,kernel", [(6000, 1500, "float32", "two_factor_dft"), (6000, 2000, "float64", "two_factor_dft"),
-                                                    (3000, 700, "float64", "two_factor_dft"), (5003, 2000, "float32", "direct_dft")])
+                                                    (3000, 700, "float64", "two_factor_dft"), (5003, 2000, "float32", "bluestein")])
 @pytest.mark.parametrize("amp", ["complex", "power"])
 def test_long_composite_frames_stay_on_the_two_factor_kernel(n_fft, hop, dtype, kernel, amp):
     """Composite lengths outside the register-tiled lists with tiles above 64 KiB (the large LDS window; f64 6000 without the LDS
-    twiddle copy) run the two-factor kernel, not the O(n^2) direct sum; a prime length has nothing else."""
+    twiddle copy) run the two-factor kernel, not the O(n^2) direct sum; a prime length takes the chirp-z path."""
     plan, _ = run_case(n=3 * n_fft + 77, batch=2, n_fft=n_fft, hop=hop, amp=amp, dtype=dtype)
     assert plan.kernel_name == kernel
 
@@ -516,7 +516,7 @@ def test_fuzz_shapes():
     power-of-two / mixed radix, LDS radix-2, two-factor, direct) against the oracle, including hops that do not divide n_fft,
     odd hops (unaligned frames), signals shorter than a frame and lengths that leave partial tiles."""
     rng = np.random.default_rng(20260)
-    pool = [4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048] + MIXED + [6, 10, 30, 50, 100, 250, 330, 441, 97, 127]
+    pool = [4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048] + MIXED + [6, 10, 30, 50, 100, 250, 330, 441, 97, 127, 509, 1006, 1009]
     seen = set()
     for case in range(90):
         n_fft = int(pool[rng.integers(len(pool))])
@@ -542,7 +542,7 @@ def test_fuzz_shapes():
                 kw.update(n_mels=int(rng.integers(4, 41)), fmin=0.0, fmax=8000.0, amp="power")
         plan, _ = run_case(n=n, batch=int(rng.integers(1, 4)), seed=case, **kw)
         seen.add(plan.kernel_name)
-    assert {"reg_radix", "two_factor_dft", "direct_dft", "lds_radix2"} <= seen, seen
+    assert {"reg_radix", "two_factor_dft", "direct_dft", "lds_radix2", "bluestein"} <= seen, seen
 
 
 def test_config4_shard_full_size_mel_power():
@@ -614,3 +614,38 @@ def test_packed_tiles_large_batch_linear():
     for b in (3, 65535):
         one = plan.compute_batch(xh[b:b + 1])
         assert np.array_equal(one[0], out[b].cpu().numpy())
+
+
+# ------------------------------------------------------------------ lengths with a large prime factor: chirp-z (Bluestein)
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("n_fft,hop", [(251, 100), (401, 160), (509, 127), (1006, 251), (1009, 256), (2003, 500), (4093, 1024)])
+def test_bluestein_sizes(n_fft, hop, dtype):
+    """Primes and 2 x prime through the chirp-z path (the reference's RustFFT plans these with Rader / Bluestein,
+    src/fft_backend.rs:376-385): complex, power, dB and Mel outputs against the oracle at the usual tolerances, the batch bit for
+    bit equal to single-signal launches, centred and not."""
+    for amp, extra in (("complex", {}), ("power", {}), ("db", {"floor": -80.0}), ("power", {"n_mels": 40})):
+        plan, got = run_case(n=5 * n_fft + 321, batch=3, n_fft=n_fft, hop=hop, amp=amp, dtype=dtype, **extra)
+        assert plan.kernel_name == "bluestein"
+        x = signals(3, 5 * n_fft + 321, np.float32 if dtype == "float32" else np.float64, 0)
+        assert np.array_equal(np.asarray(plan.compute_batch(x[2:3]))[0], np.asarray(got)[2])
+    run_case(n=3 * n_fft, batch=2, n_fft=n_fft, hop=hop, amp="power", dtype=dtype, centre=False, window="kaiser")
+    # the conforming per-frame R2cPlan::process on the same plan kind
+    p1, _ = make(n_fft, hop, amp="complex", dtype=dtype)
+    fr = signals(1, n_fft, np.float32 if dtype == "float32" else np.float64, 3)[0]
+    ref = np.fft.rfft(fr.astype(np.float64))
+    err = np.max(np.abs(p1.r2c(fr) - ref)) / np.max(np.abs(ref))
+    assert err < (2e-5 if dtype == "float32" else 1e-10), err
+
+
+def test_bluestein_many_frames_in_chunks():
+    """More frames than one pass over the chirp-z scratch holds (32 768): 64 x 10 s at n_fft 1009 / hop 16 = 640 k frames in 20
+    chunks; first, a middle and the last signal against the oracle, and a signal straddling a chunk boundary against its own launch."""
+    n_fft, hop, batch = 1009, 16, 64
+    plan, op = make(n_fft, hop)
+    x = H.cfg2_batch(batch)
+    got = plan.compute_batch(x)
+    assert plan.kernel_name == "bluestein" and got.shape == (batch, 505, 10000)
+    idx = [0, 3, 31, 63]
+    ref = orc.spectrogram_batch(op, x[idx].astype(np.float64), nthreads=orc.max_threads())
+    check(got[idx], ref, "power", "float32")
+    assert np.array_equal(plan.compute_batch(x[3:4])[0], got[3])  # 32768 / 10000: the chunk boundary falls inside signal 3
