@@ -400,9 +400,12 @@ def fft2d_legs(torch, sg, dev, which, args, peak):
 
 
 def device_identity(torch, dev) -> int:
-    """A number that is the same for two ranks exactly when they sit on the same physical GPU (uuid, else the PCI address)."""
+    """A number that is the same for two ranks when they use the same device ordinal of the same physical GPU.  Both must repeat
+    for a collision: the ordinal alone repeats legitimately when every rank is confined to one visible device, and a runtime that
+    reports a placeholder uuid for every GPU must not make a correct launch look wrong."""
     p = torch.cuda.get_device_properties(dev)
-    ident = str(getattr(p, "uuid", "")) or "%s:%s:%s" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", dev.index), getattr(p, "pci_device_id", 0))
+    ident = "%d|%s|%s:%s:%s" % (dev.index, getattr(p, "uuid", ""), getattr(p, "pci_domain_id", ""), getattr(p, "pci_bus_id", ""),
+                                getattr(p, "pci_device_id", ""))
     return int.from_bytes(hashlib.sha256(ident.encode()).digest()[:7], "little")
 
 

@@ -87,6 +87,9 @@ __device__ unsigned long long g_stamps[32];
 #ifndef SGX_BANDPF
 #define SGX_BANDPF 0  // 1: the band reduction of the n_fft 1024 kernel reads one 8-step group ahead (plan.hip pads L to multiples of 8)
 #endif
+#ifndef SGX_ODDHOP
+#define SGX_ODDHOP 1  // odd hops at n_fft 1024 run here too: sample pairs of odd frames by ds_read2_b32 (staged) / with the row-start pair patched (direct); 0: register-tiled kernel
+#endif
 #ifndef SGX_DMA
 #define SGX_DMA 0  // 1: filterbank outputs at n_fft 1024: the next tile's samples go HBM -> LDS directly (buffer_load ... lds), issued behind barrier 4
 #endif
@@ -147,6 +150,14 @@ __device__ __forceinline__ void read_cols512(v2f (&x)[16], v2f (&w)[16], const u
           x[K], base[(2 * K + PAR) >> 2]),
       ds_read64<(2 * K + PAR) * 128>(w[K], waddr)),
      ...);
+}
+
+// Odd hops: odd frames start on an odd sample, i.e. their pairs sit at 4-byte-aligned LDS addresses, where a ds_read_b64 takes
+// several passes (measured: the whole kernel at half speed).  ds_read2_b32 reads the same pair as two dwords at half the
+// ds_read_b64 rate and has no alignment to respect; one base register per 8 columns keeps its 8-bit dword offsets in range.
+template <int PAR, int... K>
+__device__ __forceinline__ void read_cols_odd(v2f (&x)[16], v2f (&w)[16], const unsigned (&base)[4], unsigned waddr, std::integer_sequence<int, K...>) {
+    ((ds_read2x32<((2 * K + PAR) & 7) * 32, ((2 * K + PAR) & 7) * 32 + 1>(x[K], base[(2 * K + PAR) >> 3]), ds_read64<(2 * K + PAR) * 128>(w[K], waddr)), ...);
 }
 
 template <int PAR, int... K>
@@ -311,7 +322,9 @@ __device__ __forceinline__ void pass2_compute(v2f (&A)[16], v2f (&B)[16], bool j
 // Filterbank outputs: the pair's two powers go to the |X|^2 tile as one 8-byte LDS write (pw1 / pw2 / pwm: this lane's slots of the
 // rows the two loops and bin 256 start at; 32 bins further = kP512Step floats, see pwt512_index).
 constexpr unsigned kP512Step = 16u * 64u;
-template <int MODE, int AMP>
+// PACK (tiles that continue into the next signal): the slot's two frames need not be neighbours in memory — `vfull` is then the first
+// frame's own offset and `vhalf` the second's (either may be out of range: dropped), two element-sized stores per pair.
+template <int MODE, int AMP, bool PACK = false>
 __device__ __forceinline__ void pass2_pair512(v2f (&A)[16], v2f (&B)[16], bool j0, float eps, __amdgpu_buffer_rsrc_t ro, unsigned vfull1,
                                               unsigned vhalf1, unsigned vfull2, unsigned vhalf2, unsigned vfullm, unsigned vhalfm, unsigned step,
                                               float *pw1, float *pw2, float *pwm) {
@@ -338,12 +351,24 @@ __device__ __forceinline__ void pass2_pair512(v2f (&A)[16], v2f (&B)[16], bool j
         } else if constexpr (MODE == OUT_COMPLEX) {
             const float sg = conj ? -1.f : 1.f;
             const v4f V = (v4f){Xa.x, sg * Xa.y, Xb.x, sg * Xb.y};
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, V), ro, (int)vfull, soff, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, (v2f){V.x, V.y}), ro, (int)vhalf, soff, 0);
+            if constexpr (PACK) {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, (v2f){V.x, V.y}), ro, (int)vfull, soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, (v2f){V.z, V.w}), ro, (int)vhalf, soff, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, V), ro, (int)vfull, soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, (v2f){V.x, V.y}), ro, (int)vhalf, soff, 0);
+            }
         } else {
             const v2f V = (v2f){amp_f32<AMP>(power_of(Xa), eps), amp_f32<AMP>(power_of(Xb), eps)};
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, V), ro, (int)vfull, soff, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, V.x), ro, (int)vhalf, soff, 0);
+            if constexpr (PACK) {
+                // (scalars first: __builtin_bit_cast of a vector COMPONENT other than .x reads the vector's first element — hipcc 7.2)
+                const float va = V.x, vb = V.y;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, va), ro, (int)vfull, soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, vb), ro, (int)vhalf, soff, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, V), ro, (int)vfull, soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, V.x), ro, (int)vhalf, soff, 0);
+            }
         }
     };
     auto pair = [&](v2f P, v2f Q, v2f &Xa, v2f &Xb) {
@@ -625,12 +650,13 @@ __device__ __forceinline__ void mel_tile_sched512(const StftArgs &a, const float
 template <int MODE, int AMP, int ROUNDS, bool WIDE, bool XSPAD, bool PWT, int HOP512 = 0, bool PACK = false>
 __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd, unsigned total, unsigned slots) {
     constexpr bool P512 = HOP512 != 0;           // n_fft 512 at hop HOP512
-    static_assert(!PACK || (ROUNDS == 0 && !WIDE && !XSPAD && HOP512 == 0 && (MODE != OUT_MEL || PWT)), "PACK: direct loads, 16-frame tiles, scheduled band stage");
+    static_assert(!PACK || (ROUNDS == 0 && !WIDE && !XSPAD && (HOP512 == 0 ? (MODE != OUT_MEL || PWT) : MODE != OUT_MEL)),
+                  "PACK: direct loads, one-half tiles; n_fft 1024: scheduled band stage, n_fft 512: per-bin outputs");
     constexpr unsigned SS512 = 8u * HOP512;      // bytes from one slot's (frame pair's) first sample to the next slot's
-    static_assert(!P512 || (HOP512 % 4 == 0 && ROUNDS * 256 * 4 >= 31 * HOP512 + 512), "P512: 16-byte chunks, the whole tile staged");
+    static_assert(!P512 || PACK || (HOP512 % 4 == 0 && ROUNDS * 256 * 4 >= 31 * HOP512 + 512), "P512: 16-byte chunks, the whole tile staged");
     static_assert(!WIDE || MODE != OUT_MEL, "wide pass 2 needs a per-bin output");
     static_assert(!PWT || MODE == OUT_MEL, "PWT is a filterbank layout");
-    static_assert(!P512 || (!WIDE && !XSPAD && ROUNDS > 0 && (PWT == (MODE == OUT_MEL))), "P512: staged samples, scheduled band stage");
+    static_assert(!P512 || (!WIDE && !XSPAD && (ROUNDS > 0 || PACK) && (PWT == (MODE == OUT_MEL))), "P512: staged samples (PACK: per-lane loads), scheduled band stage");
     constexpr bool DMA = SGX_DMA != 0 && PWT && ROUNDS > 0 && !P512;  // samples HBM -> LDS without registers (see dma16_to_lds)
     constexpr unsigned FPT = P512 ? 32u : 16u;   // frames per tile
     constexpr unsigned NB = P512 ? 257u : 513u;  // bins
@@ -674,7 +700,7 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
     v4f creg[NCR];
     v2f xd[ROUNDS > 0 ? 1 : 32];
     const unsigned chunks = XSPAD ? 1216u : P512 ? (31u * HOP512 + 512u + 3u) >> 2 : (15u * a.hop + 1024u + 3u) >> 2;
-    const unsigned hop = XSPAD ? 256u : P512 ? (unsigned)HOP512 : a.hop;
+    const unsigned hop = XSPAD ? 256u : (P512 && !PACK) ? (unsigned)HOP512 : a.hop;  // (PACK at n_fft 512: HOP512 only marks the mode)
     const unsigned row_bytes = (unsigned)a.n_samples * 4u;  // host: n_samples < 2^29
     auto load_tile = [&](unsigned w) {
         const unsigned b = w / a.tiles, tile = w - b * a.tiles;
@@ -713,6 +739,25 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
                     creg[r] = __builtin_bit_cast(v4f, c);
                 }
             }
+        } else if constexpr (PACK && P512) {
+            // Slot p1f of packed tile w = slot q of the batch = frames (2 pr, 2 pr + 1) of signal bq (PP = ceil(n_frames / 2) slots per
+            // signal): the pairing of a one-signal tile, so a signal's bits do not depend on the batch around it — its last slot's
+            // second frame may be the virtual frame n_frames, loaded like any other and never stored.  One dword per sample and frame,
+            // range-checked against the row in the lane.
+            const __amdgpu_buffer_rsrc_t rall = make_rsrc(a.x, a.x_bytes);
+            const unsigned ns = (unsigned)a.n_samples, PP = (a.n_frames + 1u) >> 1;
+            const unsigned q = w * 16u + p1f;
+            const bool live = q < a.gframes;
+            const unsigned bq = live ? q / PP : 0u, pr = q - bq * PP;
+            const int sA = (int)(2u * pr * hop) - (int)a.pad + (int)n2, sB = sA + (int)hop;
+            const unsigned row = bq * (unsigned)a.sample_stride;
+#pragma unroll
+            for (int n1 = 0; n1 < 32; ++n1) {
+                const int ia = sA + 16 * n1, ib = sB + 16 * n1;
+                const int va = __builtin_amdgcn_raw_buffer_load_b32(rall, (live && (unsigned)ia < ns) ? (int)((row + (unsigned)ia) * 4u) : (int)0xfffffff0u, 0, 0);
+                const int vb = __builtin_amdgcn_raw_buffer_load_b32(rall, (live && (unsigned)ib < ns) ? (int)((row + (unsigned)ib) * 4u) : (int)0xfffffff0u, 0, 0);
+                xd[n1] = (v2f){__builtin_bit_cast(float, va), __builtin_bit_cast(float, vb)};
+            }
         } else if constexpr (PACK) {
             // slot p1f of packed tile w = global frame g = frame fq of signal bq.  One descriptor over the whole batch (host: its bytes
             // fit 32 bits): the row's own range is checked here — a pair is inside, outside (offset past the descriptor: reads 0, the
@@ -734,9 +779,19 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
             }
         } else {
             const int vo = ((int)(p1f * hop) + tile_lo + 2 * (int)n2) * 4;
-            if (SGX_ONEPATH || interior) {  // (one path here too: a pair never straddles the row start — hop and the padding are even)
+            if (SGX_ONEPATH || interior) {  // (one path here too: with an even hop a pair never straddles the row start)
 #pragma unroll
                 for (int n1 = 0; n1 < 32; ++n1) xd[n1] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rx, vo + n1 * 128, 0, 0));
+#if SGX_ODDHOP
+                if (a.hop & 1u) {  // uniform.  Odd frames sit on odd sample offsets: the pair (x[-1], x[0]) starts outside the row, and an
+                                   // 8-byte access whose first dword is out of range returns 0 for both: put x[0] back
+                    const float x0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, 0, 0, 0));
+                    const int s0 = (int)(p1f * hop) + tile_lo + 2 * (int)n2;
+#pragma unroll
+                    for (int n1 = 0; n1 < 32; ++n1)
+                        if (s0 + 32 * n1 == -1) xd[n1].y = x0;
+                }
+#endif
             } else {
 #pragma unroll
                 for (int n1 = 0; n1 < 32; ++n1) {
@@ -783,7 +838,9 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
 #endif
     while (lead < hi) {
         // (PACK: b = the tile's first signal, f0 = its first frame's index in that signal, nf = the tile's live slots)
-        const unsigned b = PACK ? wid * 16u / a.n_frames : wid / a.tiles, tile = wid - b * a.tiles;
+        // (PACK at n_fft 512 packs SLOTS — frame pairs of one signal, PP per signal —: b = the first slot's signal, nf = live slots)
+        const unsigned PP = (a.n_frames + 1u) >> 1;
+        const unsigned b = PACK ? (P512 ? wid * 16u / PP : wid * 16u / a.n_frames) : wid / a.tiles, tile = wid - b * a.tiles;
         const unsigned f0 = PACK ? wid * 16u - b * a.n_frames : tile * FPT;
         const unsigned nf = PACK ? min(16u, a.gframes - wid * 16u) : min(FPT, a.n_frames - f0);
         v2f xr[32];
@@ -830,8 +887,14 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
                     tie16<15>(e);
                     tie16<-1>(we);
                 } else {
+                if (SGX_ODDHOP && !XSPAD && (a.hop & 1u)) {  // uniform
+                    const unsigned base[4] = {xaddr, xaddr + 1024u, xaddr + 2048u, xaddr + 3072u};
+                    read_cols_odd<0>(e, we, base, waddr, std::make_integer_sequence<int, 16>{});
+                    read_cols_odd<1>(o, wo, base, waddr, std::make_integer_sequence<int, 16>{});
+                } else {
                 read_cols<XSPAD, 0>(e, we, xaddr, waddr, std::make_integer_sequence<int, 16>{});
                 read_cols<XSPAD, 1>(o, wo, xaddr, waddr, std::make_integer_sequence<int, 16>{});
+                }
                 tie16<15>(e);  // at most 15 of the 64 reads outstanding: the 32 of (e, we) have landed
                 tie16<-1>(we);
                 }
@@ -922,7 +985,18 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
                 if (tid < 48u) pwf[(tid / 3u) * kPS + 513u + tid % 3u] = 0.0f;
             }
         }
-        if constexpr (P512) {
+        if constexpr (P512 && PACK) {
+            constexpr unsigned kDrop = 0x80000000u;  // out of the descriptor's range: the store is dropped
+            const __amdgpu_buffer_rsrc_t ro = make_rsrc((unsigned char *)a.out + (size_t)b * NB * a.n_frames * ES, min(17u, a.batch - b) * NB * a.n_frames * ES);
+            const unsigned c1 = j == 0 ? 16u : j, r2 = j == 0 ? 0u : 32u - j;
+            // the slot's signal and pair; offsets count from the tile's first signal b
+            const unsigned q = wid * 16u + p2f, bq = q / PP, pr = q - bq * PP;
+            const unsigned oA = p2f < nf ? ((bq - b) * NB * a.n_frames + 2u * pr) * ES : kDrop;
+            const unsigned oB = (p2f < nf && 2u * pr + 1u < a.n_frames) ? oA + ES : kDrop;
+            auto at = [&](unsigned base, unsigned row) { return base == kDrop ? kDrop : base + row * a.n_frames * ES; };
+            pass2_pair512<MODE, AMP, true>(A, B, j == 0, eps, ro, at(oA, c1), at(oB, c1), at(oA, r2), at(oB, r2), at(oA, 256u), at(oB, 256u), step,
+                                           nullptr, nullptr, nullptr);
+        } else if constexpr (P512) {
             constexpr unsigned kDrop = 0x80000000u;  // out of the descriptor's range: the store is dropped
             const __amdgpu_buffer_rsrc_t ro = make_rsrc((unsigned char *)a.out + (size_t)b * NB * a.n_frames * ES, NB * a.n_frames * ES);
             // rows: first loop c1 + 32 i; second loop 32 t (job 0) or 256 - j - 32 t = (32 - j) + 32 (7 - t); bin 256
@@ -980,18 +1054,22 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
 // (profiles/bench_r03_short_signals.txt): packed once a quarter or more of the one-signal tiles' slots would be empty (626 frames: 2
 // of 640 slots, 40 frames: 8 of 48 — not packed; 17 frames: 15 of 32 — packed)
 static bool want_pack(const StftArgs &a, bool mel, bool pwt) {
-    if (a.n_fft != 1024u || a.batch < 2u || (mel && !pwt)) return false;
-    const unsigned long long slots16 = (unsigned long long)a.tiles * 16ull, g = (unsigned long long)a.batch * a.n_frames;
-    if ((slots16 - a.n_frames) * 4ull < slots16) return false;
+    const bool p512 = a.n_fft == 512u;  // two frames per transform, 32-frame tiles; per-bin outputs only
+    if ((a.n_fft != 1024u && !p512) || a.batch < 2u || (mel && (!pwt || p512)) || (a.hop & 1u)) return false;
+    // (n_fft 512 packs slots = frame pairs of one signal: an odd frame count leaves half a slot empty either way)
+    const unsigned long long slots = (unsigned long long)a.tiles * a.ft, g = (unsigned long long)a.batch * a.n_frames;
+    const unsigned long long used = p512 ? 2ull * ((a.n_frames + 1ull) / 2ull) : a.n_frames;
+    if ((slots - used) * 4ull < slots) return false;
     if (g >= 0x7fffffffull || (unsigned long long)a.batch * a.sample_stride * 4ull >= 0xfffffff0ull) return false;  // 32-bit offsets
-    return 17ull * 513ull * a.n_frames * 8ull < 0x7fffffffull;
+    return (a.ft + 1ull) * (a.n_fft / 2u + 1ull) * a.n_frames * 8ull < 0x7fffffffull;
 }
 
 template <int MODE, int AMP>
 hipError_t launch_variant(const StftArgs &a0, hipStream_t s) {
     StftArgs a = a0;
     const bool pack = want_pack(a, MODE == OUT_MEL, MODE == OUT_MEL && a.mel_sched != nullptr);
-    a.gframes = a.batch * a.n_frames;
+    const bool pack512 = pack && a.n_fft == 512u;
+    a.gframes = pack512 ? a.batch * ((a.n_frames + 1u) / 2u) : a.batch * a.n_frames;  // n_fft 512: slots (frame pairs) of the batch
     a.x_bytes = pack ? (unsigned)((unsigned long long)a.batch * a.sample_stride * 4ull) : 0u;
     const unsigned total = pack ? (a.gframes + 15u) / 16u : a.tiles * a.batch;
     const unsigned per_xcd = (total + 7) / 8;
@@ -1010,6 +1088,8 @@ hipError_t launch_variant(const StftArgs &a0, hipStream_t s) {
         return hipGetLastError();
     };
     constexpr bool W = MODE != OUT_MEL;
+    if constexpr (MODE != OUT_MEL)
+        if (pack && a.n_fft == 512u) return go(k_r32x16<MODE, AMP, 0, false, false, false, 128, true>);  // (128: any hop, the mode's marker)
     if (pack) return go(k_r32x16<MODE, AMP, 0, false, false, MODE == OUT_MEL, 0, true>);
     if constexpr (MODE == OUT_MEL) {
         if (pwt) {
@@ -1062,7 +1142,7 @@ bool plan_geometry_r32x16_f32(StftArgs &a) {
         a.ft = 32;
         return true;
     }
-    if (a.n_fft != 1024 || (a.hop & 1u)) return false;
+    if (a.n_fft != 1024 || (!SGX_ODDHOP && (a.hop & 1u))) return false;
     if (a.n_samples >= (1ull << 29)) return false;                                       // 32-bit byte offsets into a sample row
     if ((unsigned long long)a.n_frames * 513ull * 8ull >= 0x7fffffffull) return false;  // and into a pair of output signals
     a.ft = 16;

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, (rr_waves<T, A_, B_, C_>())) void k_c2c_reg(C2
         if (s >= ns) continue;
         V v = buf[(size_t)s * FS + L::of_output(k)] * (V){sc, cj * sc};
         if (a.mul) {  // fused spectrum product (uniform branch)
-            const size_t mi = (size_t)k * a.mul_ks + (s0 + s);
+            const size_t mi = (size_t)k * a.mul_ks + (a.mul_bcast ? 0 : s0 + s);  // mul_bcast: one table for every sequence
             if (a.mul_real) {
                 const T mk = ((const T *)a.mul)[mi];
                 v = v * (V){mk, mk};

@@ -19,6 +19,9 @@ using namespace sgx;
 #ifndef SGX_BANDPF
 #define SGX_BANDPF 0  // must match kernels_r32x16.hip
 #endif
+#ifndef SGX_ODDHOP
+#define SGX_ODDHOP 1  // must match kernels_r32x16.hip
+#endif
 namespace {
 
 thread_local std::string g_create_err;
@@ -726,7 +729,7 @@ bool set_geometry(const sgx_plan *pl, StftArgs &a, KernelKind kind) {
 
 sgx_status grow(sgx_plan *pl, void **buf, size_t *have, size_t need);
 
-// frames of the chirp-z path per pass over its two scratch buffers: <= 1 GiB each, <= 32768 (grid.y)
+// sequences (frame pairs) of the chirp-z path per pass over its two scratch buffers: <= 1 GiB each, <= 32768 (grid.y)
 unsigned long long bluestein_chunk(const sgx_plan *pl, unsigned long long frames) {
     const unsigned long long per = (unsigned long long)pl->bs_M * 2ull * pl->elem;
     unsigned long long c = (1ull << 30) / per;
@@ -1056,7 +1059,7 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
     // powers of two (32..8192) and the listed even composite sizes: register-tiled kernel; other powers of two: LDS radix-2;
     // other composite lengths: two-factor DFT; primes fall through to the direct sum
     pl->kind = (pow2 || params->n_fft % 2 == 0) ? K_REG_RADIX : K_TWO_FACTOR;  // (even sizes outside the register-tiled list fall through)
-    if (params->dtype == SGX_F32 && params->n_fft == 1024 && params->hop_size % 2 == 0) pl->kind = K_R32X16_F32;
+    if (params->dtype == SGX_F32 && params->n_fft == 1024 && (SGX_ODDHOP || params->hop_size % 2 == 0)) pl->kind = K_R32X16_F32;
     if (params->dtype == SGX_F32 && params->n_fft == 512 && (params->hop_size == 64 || params->hop_size == 128 || params->hop_size == 160 || params->hop_size == 256)) pl->kind = K_R32X16_F32;  // per-bin outputs (else falls back)
     if (pl->kind == K_R32X16_F32) build_band_schedule(pl);  // before the kind is resolved: plan_geometry_r32x16_f32 asks for it
     {

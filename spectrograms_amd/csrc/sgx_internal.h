@@ -130,6 +130,7 @@ struct C2cArgs {
     const void *mul;
     unsigned long long mul_ks;
     int mul_real;
+    int mul_bcast;  // 1: mul[k * mul_ks] for every sequence (the chirp-z path's transformed chirp)
 };
 struct C2rArgs {
     const void *in;  // half spectrum, element (row r, col k) at in[b*in_img + k*in_ks + r*in_rs]

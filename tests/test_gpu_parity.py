@@ -133,7 +133,7 @@ def test_pow2_sizes(n_fft, hop, amp, dtype):
     (unaligned frames), the LDS radix-2 kernel below 32 points."""
     plan, _ = run_case(n=max(6000, 3 * n_fft), n_fft=n_fft, hop=hop, amp=amp, dtype=dtype)
     fits = n_fft <= (4096 if dtype == "float64" else 8192)  # an 8192-point f64 tile (164 KB with its tables) exceeds the CU's LDS
-    tuned = dtype == "float32" and ((n_fft == 1024 and hop % 2 == 0) or (n_fft == 512 and hop in (64, 128, 160, 256)))
+    tuned = dtype == "float32" and (n_fft == 1024 or (n_fft == 512 and hop in (64, 128, 160, 256)))
     if 32 <= n_fft and fits and not tuned:
         assert plan.kernel_name == "reg_radix"
 
@@ -649,3 +649,32 @@ def test_bluestein_many_frames_in_chunks():
     ref = orc.spectrogram_batch(op, x[idx].astype(np.float64), nthreads=orc.max_threads())
     check(got[idx], ref, "power", "float32")
     assert np.array_equal(plan.compute_batch(x[3:4])[0], got[3])  # 32768 / 10000: the chunk boundary falls inside signal 3
+
+
+@pytest.mark.parametrize("amp", ["power", "complex", "db"])
+@pytest.mark.parametrize("n,hop", [(1, 128), (100, 128), (400, 128), (600, 128), (1000, 128), (1500, 64), (700, 160), (900, 256)])
+def test_packed_tiles_short_signals_n512(n, hop, amp):
+    """The n_fft 512 mode (two frames per transform) over many short signals: a tile packs SLOTS — the frame pairs (2p, 2p + 1) of one
+    signal — of consecutive signals, so the pairing of every frame is that of a single-signal launch and every signal must come
+    out bit for bit as from its own B = 1 launch; against the oracle at the usual tolerances."""
+    batch = 41
+    floor = -80.0 if amp == "db" else None
+    plan, got = run_case(n=n, batch=batch, seed=n + hop, n_fft=512, hop=hop, amp=amp, floor=floor)
+    assert plan.kernel_name == "r32x16_f32"
+    x = signals(batch, n, np.float32, n + hop)
+    for b in (0, 1, 20, 39, 40):
+        one = np.asarray(plan.compute_batch(x[b:b + 1])[0])
+        assert np.array_equal(one, np.asarray(got[b])), b
+
+
+@pytest.mark.parametrize("amp,n_mels,floor", [("power", 0, None), ("complex", 0, None), ("db", 80, -80.0)])
+@pytest.mark.parametrize("hop,centre", [(255, True), (257, False), (441, True), (1, True), (1023, False), (271, True), (273, True), (101, False)])
+def test_odd_hops_on_the_tuned_kernel(hop, centre, amp, n_mels, floor):
+    """Odd hops at n_fft 1024 (44.1 kHz / 10 ms = 441 samples is one): odd frames start on odd samples, so their sample pairs sit at
+    4-byte-aligned LDS addresses (read with ds_read2_b32 in the staged path) and, in the direct path, the pair (x[-1], x[0]) straddles
+    the row start.  Staged (hop <= 272) and direct (above) paths, centred and not, against the oracle; batch vs single-signal bits."""
+    n = 3000 if hop == 1 else 20011
+    plan, got = run_case(n=n, batch=3, n_fft=1024, hop=hop, centre=centre, amp=amp, n_mels=n_mels, floor=floor)
+    assert plan.kernel_name == "r32x16_f32"
+    x = signals(3, n, np.float32, 0)
+    assert np.array_equal(np.asarray(plan.compute_batch(x[1:2]))[0], np.asarray(got)[1])

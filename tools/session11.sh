@@ -1,0 +1,5 @@
+#!/bin/bash
+mkdir -p gpurun_out
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/s11_pytest.log 2>&1; echo "pytest rc=$? $(tail -1 gpurun_out/s11_pytest.log)"; grep -E "^FAILED|^E  " gpurun_out/s11_pytest.log | head -20
+timeout -k 10 300 python tools/time_odd_lengths.py > gpurun_out/s11_odd_lengths.txt 2>&1; echo "odd rc=$?"; grep bluestein gpurun_out/s11_odd_lengths.txt
+timeout -k 10 300 python tools/sweep_short.py > gpurun_out/s11_sweep_short.txt 2>&1; grep "n_fft=  512" gpurun_out/s11_sweep_short.txt

@@ -28,5 +28,5 @@ def run(n_fft, hop, frames, n_mels=None):
 for mel in (None, 80):
     for fr in (1, 2, 4, 5, 8, 12, 15, 16, 17, 20, 31, 40, 63):
         run(1024, 256, fr, mel)
-for fr in (4, 8):
+for fr in (1, 2, 4, 5, 8, 16, 24, 31, 32, 33, 40):
     run(512, 128, fr)
