@@ -84,6 +84,9 @@ __device__ unsigned long long g_stamps[32];
 #define SGX_STAMP_ARGS
 #endif
 
+#ifndef SGX_BANDFMA
+#define SGX_BANDFMA 0  // experiment: band sums as four interleaved fused partial sums (not the reference order)
+#endif
 #ifndef SGX_BANDPF
 #define SGX_BANDPF 0  // 1: the band reduction of the n_fft 1024 kernel reads one 8-step group ahead (plan.hip pads L to multiples of 8)
 #endif
@@ -560,6 +563,19 @@ __device__ __forceinline__ void mel_tile_sched(const StftArgs &a, const float *p
             ld8(wa, pa, t + 16u);
             __builtin_amdgcn_sched_barrier(0);
             sum8(wb, pb);
+        }
+#elif SGX_BANDFMA
+        // experiment: four interleaved partial sums with fused multiply-adds (NOT the reference's summation order)
+        {
+            v2f a0 = {0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+            for (unsigned t = 0; t < L; t += 4u) {
+                const v4f w4 = wr[t >> 2], q0 = pr[(t >> 1) * 8u], q1 = pr[(t >> 1) * 8u + 8u];
+                a0 = pfma((v2f){w4.x, w4.x}, (v2f){q0.x, q0.y}, a0);
+                a1 = pfma((v2f){w4.y, w4.y}, (v2f){q0.z, q0.w}, a1);
+                a2 = pfma((v2f){w4.z, w4.z}, (v2f){q1.x, q1.y}, a2);
+                a3 = pfma((v2f){w4.w, w4.w}, (v2f){q1.z, q1.w}, a3);
+            }
+            acc = (a0 + a1) + (a2 + a3);
         }
 #else
         for (unsigned t = 0; t < L; t += 4u) {  // q0 = (bin t: frames f, f+1; bin t+1: frames f, f+1)
