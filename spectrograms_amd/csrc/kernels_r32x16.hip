@@ -34,6 +34,7 @@
 //
 // Reference semantics implemented: spectrogram.rs:1301-1334 (framing, window, R2C, |.|^2), :1845-1865,
 // :2068-2080; replaces the per-frame `R2cPlan::process` call at :1323 (fft_backend.rs:423-431).
+#include <type_traits>
 #include <utility>
 
 #include "buffer_ops.h"
@@ -84,6 +85,9 @@ __device__ unsigned long long g_stamps[32];
 #define SGX_STAMP_ARGS
 #endif
 
+#ifndef SGX_BANDTRIP
+#define SGX_BANDTRIP 0  // band stage in trips of 16 steps with their reads requested together
+#endif
 #ifndef SGX_BANDFMA
 #define SGX_BANDFMA 0  // experiment: band sums as four interleaved fused partial sums (not the reference order)
 #endif
@@ -529,6 +533,10 @@ __device__ __forceinline__ void mel_tile_sched(const StftArgs &a, const float *p
         const unsigned L = __builtin_amdgcn_readfirstlane(cur.x);
         const v4f *wr = (const v4f *)((const float *)sched + cur.y);
         const v4f *pr = (const v4f *)(pwT + (cur.z >> 1) * 32u) + fp;  // kstart is even
+#ifdef SGX_STAMPS2  // finer diagnostic: 12 = record + setup of every segment, 13 = the step loops, 14 = epilogues + stores
+        asm volatile("" ::"s"(L), "v"(wr), "v"(pr));
+        SGX_STAMP(12);
+#endif
         v2f acc = {0.0f, 0.0f};
 #if SGX_BANDPF
         // Software pipeline, 8 steps (two weight quads, four bin pairs) per group, L a multiple of 8 (host): the operands of group
@@ -564,6 +572,48 @@ __device__ __forceinline__ void mel_tile_sched(const StftArgs &a, const float *p
             __builtin_amdgcn_sched_barrier(0);
             sum8(wb, pb);
         }
+#elif SGX_BANDTRIP
+        // Trips of 16 steps whose 12 reads are requested together and then summed, and a remainder of 4, 8 or 12 steps handled the same
+        // way: one LDS round trip per 16 steps.  (hipcc's own loop requests everything up front only from L = 32 on and otherwise
+        // waits for its three reads every 4 steps, so the wave holding the medium-length segments — 24 + 20 + 4 steps for Mel-80 —
+        // sets the stage's time.)  Same terms, same order.
+        {
+            v2f pa[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+            auto trip = [&](auto nq, unsigned t) {
+                constexpr int NQ = decltype(nq)::value;
+                v4f w[NQ], qa[NQ], qb[NQ];
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) {
+                    w[i] = wr[(t >> 2) + i];
+                    qa[i] = pr[((t >> 1) + 2 * i) * 8u];
+                    qb[i] = pr[((t >> 1) + 2 * i) * 8u + 8u];
+                }
+                __builtin_amdgcn_sched_barrier(0);  // (the scheduler sinks the requests next to their uses otherwise)
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) {
+#if SGX_BANDTRIP == 2  // four interleaved partial sums (bins = 0, 1, 2, 3 mod 4), un-fused: NOT the reference's order
+                    pa[0] = mul_add_unfused(w[i].x, (v2f){qa[i].x, qa[i].y}, pa[0]);
+                    pa[1] = mul_add_unfused(w[i].y, (v2f){qa[i].z, qa[i].w}, pa[1]);
+                    pa[2] = mul_add_unfused(w[i].z, (v2f){qb[i].x, qb[i].y}, pa[2]);
+                    pa[3] = mul_add_unfused(w[i].w, (v2f){qb[i].z, qb[i].w}, pa[3]);
+#else
+                    acc = mul_add_unfused(w[i].x, (v2f){qa[i].x, qa[i].y}, acc);
+                    acc = mul_add_unfused(w[i].y, (v2f){qa[i].z, qa[i].w}, acc);
+                    acc = mul_add_unfused(w[i].z, (v2f){qb[i].x, qb[i].y}, acc);
+                    acc = mul_add_unfused(w[i].w, (v2f){qb[i].z, qb[i].w}, acc);
+#endif
+                }
+            };
+            unsigned t = 0;
+            for (; t + 16u <= L; t += 16u) trip(std::integral_constant<int, 4>{}, t);
+            const unsigned rem = L - t;
+            if (rem == 12u) trip(std::integral_constant<int, 3>{}, t);
+            else if (rem == 8u) trip(std::integral_constant<int, 2>{}, t);
+            else if (rem == 4u) trip(std::integral_constant<int, 1>{}, t);
+#if SGX_BANDTRIP == 2
+            acc = (pa[0] + pa[1]) + (pa[2] + pa[3]);
+#endif
+        }
 #elif SGX_BANDFMA
         // experiment: four interleaved partial sums with fused multiply-adds (NOT the reference's summation order)
         {
@@ -579,7 +629,15 @@ __device__ __forceinline__ void mel_tile_sched(const StftArgs &a, const float *p
         }
 #else
         for (unsigned t = 0; t < L; t += 4u) {  // q0 = (bin t: frames f, f+1; bin t+1: frames f, f+1)
+#if defined(SGX_ABL_BANDW) && defined(SGX_ABL_BANDP)  // timing experiments only (wrong results): no reads at all
+            const v4f w4 = {1.f, 0.5f, 0.25f, 2.f}, q0 = {(float)t, 1.f, 2.f, 3.f}, q1 = {4.f, 5.f, (float)t, 7.f};
+#elif defined(SGX_ABL_BANDW)  // no weight reads / no |X|^2 reads
+            const v4f w4 = {1.f, 0.5f, 0.25f, 2.f}, q0 = pr[(t >> 1) * 8u], q1 = pr[(t >> 1) * 8u + 8u];
+#elif defined(SGX_ABL_BANDP)
+            const v4f w4 = wr[t >> 2], q0 = {(float)t, 1.f, 2.f, 3.f}, q1 = {4.f, 5.f, (float)t, 7.f};
+#else
             const v4f w4 = wr[t >> 2], q0 = pr[(t >> 1) * 8u], q1 = pr[(t >> 1) * 8u + 8u];
+#endif
             acc = mul_add_unfused(w4.x, (v2f){q0.x, q0.y}, acc);
             acc = mul_add_unfused(w4.y, (v2f){q0.z, q0.w}, acc);
             acc = mul_add_unfused(w4.z, (v2f){q1.x, q1.y}, acc);
@@ -592,6 +650,9 @@ __device__ __forceinline__ void mel_tile_sched(const StftArgs &a, const float *p
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, amp_f32<AMP>(acc.x, eps)), ro, (int)((have && fo0 != kDrop) ? bo + fo0 : kDrop), 0, 0);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, amp_f32<AMP>(acc.y, eps)), ro, (int)((have && fo1 != kDrop) ? bo + fo1 : kDrop), 0, 0);
         cur = nxt;
+#ifdef SGX_STAMPS2
+        SGX_STAMP(14);
+#endif
     }
 }
 
