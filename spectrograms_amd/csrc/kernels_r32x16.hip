@@ -85,6 +85,9 @@ __device__ unsigned long long g_stamps[32];
 #define SGX_STAMP_ARGS
 #endif
 
+#ifndef SGX_BANDSEG
+#define SGX_BANDSEG 0  // band stage: all segment records up front, empty segments skipped
+#endif
 #ifndef SGX_BANDTRIP
 #define SGX_BANDTRIP 0  // band stage in trips of 16 steps with their reads requested together
 #endif
@@ -525,11 +528,26 @@ __device__ __forceinline__ void mel_tile_sched(const StftArgs &a, const float *p
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(obase, obytes);
     // one 16-byte record per (segment, wave, slot): {L of the wave, word offset of the slot's weight row, first bin, band}
     const uint4 *info = (const uint4 *)(sched + kSchedHdr) + wave * 8u + slot;
+#if SGX_BANDSEG
+    // All records of the stage requested at once: one LDS round trip instead of one per segment (hipcc sinks a record's read next
+    // to its first use).  (Skipping the empty segments under a uniform branch is not an option: with a store behind a branch the
+    // compiler no longer counts the stage's stores and waits vmcnt(0) at the top of the next tile.)
+    uint4 rec[kSchedSegs];
+#pragma unroll
+    for (int q = 0; q < kSchedSegs; ++q) rec[q] = info[q * 32];
+    __builtin_amdgcn_sched_barrier(0);
+    uint4 cur = rec[0];
+#else
     uint4 cur = info[0];
+#endif
     SGX_STAMP(12);  // mel prologue
 #pragma unroll
     for (unsigned seg = 0; seg < (unsigned)kSchedSegs; ++seg) {
+#if SGX_BANDSEG
+        const uint4 nxt = rec[seg + 1u < (unsigned)kSchedSegs ? seg + 1u : seg];
+#else
         const uint4 nxt = info[(seg + 1u) * 32u];  // fetched ahead; the table always holds kSchedSegs + 1 segments
+#endif
         const unsigned L = __builtin_amdgcn_readfirstlane(cur.x);
         const v4f *wr = (const v4f *)((const float *)sched + cur.y);
         const v4f *pr = (const v4f *)(pwT + (cur.z >> 1) * 32u) + fp;  // kstart is even
