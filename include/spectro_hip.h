@@ -256,7 +256,7 @@ sgx_status sgx_membench(int32_t device, size_t bytes, int32_t mode, int32_t iter
 
 const char *sgx_last_error(const sgx_plan *plan);
 const char *sgx_last_create_error(void);
-/* Name of the kernel variant the plan dispatches to ("r32x16_f32", "reg_radix", "lds_radix2", "two_factor_dft", "direct_dft"). */
+/* Name of the kernel variant the plan dispatches to ("r32x16_f32", "reg_radix", "lds_radix2", "two_factor_dft", "bluestein", "direct_dft"). */
 const char *sgx_kernel_name(const sgx_plan *plan);
 int32_t sgx_abi_version(void);
 int32_t sgx_device_count(void);
