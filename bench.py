@@ -270,6 +270,8 @@ def stft_roofline(kernel_wl: str, batch: int, n_frames: int, kernel_ms: float, p
             r["peak_measured"] = peak_measured
         if peak_measured.get("copy"):
             r["frac_of_measured_copy"] = achieved / peak_measured["copy"]
+        if kernel_wl == "linear_power" and peak_measured.get("mix_1r2w"):
+            r["frac_of_measured_mix"] = achieved / peak_measured["mix_1r2w"]  # against a plain kernel moving the same read : write mix
     return r
 
 
@@ -311,12 +313,12 @@ def measured_peak(lib, device: int):
     import ctypes as C
 
     out = {}
-    for mode, name in ((0, "copy"), (1, "read"), (2, "write")):
+    for mode, name in ((0, "copy"), (1, "read"), (2, "write"), (3, "mix_1r2w")):
         g = C.c_double()
         st = lib.sgx_membench(device, 0, mode, 5, C.byref(g))
         out[name] = float(g.value) if st == 0 else None
     out["unit"] = "GB/s"
-    out["how"] = "sgx_membench in this process: 1 GiB per buffer (4x the Infinity Cache), 16 B per lane, mean of 5 passes; copy counts bytes read + written"
+    out["how"] = "sgx_membench in this process: 1 GiB per buffer (4x the Infinity Cache), 16 B per lane, mean of 5 passes, best of four grids; copy counts bytes read + written, mix_1r2w reads one buffer and writes two (the linear-power STFT's read : write ratio)"
     return out
 
 

@@ -250,7 +250,8 @@ const char *sgx_c2c_last_error(const sgx_c2c *plan);
 
 /* ---- measurement utility ("verify the HBM peak on the box with a device memcpy / triad and quote the measured
  * peak next to the nominal"): streams `bytes` (0 = 1 GiB, four times the Infinity Cache) `iters` times with 16-byte accesses
- * from every CU and returns the rate in GB/s.  mode 0: copy (bytes read + bytes written per pass), 1: read only, 2: write only.
+ * from every CU and returns the rate in GB/s.  mode 0: copy (bytes read + bytes written per pass), 1: read only, 2: write only,
+ * 3: one buffer read and two written per pass (the read : write mix of the linear-power STFT), counted as 3 x `bytes`.
  * Allocates and frees its own buffers on `device` (-1 = current); no plan involved, nothing on the transform path calls it. */
 sgx_status sgx_membench(int32_t device, size_t bytes, int32_t mode, int32_t iters, double *gb_per_s);
 

@@ -3,9 +3,9 @@
 // the measured peak next to the nominal").  Measurement utility of the C ABI: it allocates its own buffers, runs, frees them; no
 // plan is involved and nothing on the transform path calls it.
 //
-// Three kernels, all 16 bytes per lane, grid-stride, 4 / 8 / 16 workgroups of 256 threads per CU or one pass per workgroup (the best
+// Four kernels, all 16 bytes per lane, grid-stride, 4 / 8 / 16 workgroups of 256 threads per CU or one pass per workgroup (the best
 // of the four is reported): copy (read + write), read (sum kept
-// alive, nothing written), write (fill).  Buffers default to 1 GiB each — four times the 256 MiB Infinity Cache — so the rate is
+// alive, nothing written), write (fill), and the linear-power STFT's own mix (one buffer read, two written).  Buffers default to 1 GiB each — four times the 256 MiB Infinity Cache — so the rate is
 // the memory's, not the cache's (MI355X_MICROARCH.md §Infinity Cache).
 #include <algorithm>
 #include <new>
@@ -52,13 +52,29 @@ __global__ __launch_bounds__(256) void k_mb_write(v4f *__restrict__ dst, size_t 
     }
 }
 
+// the linear-power STFT's traffic mix: every 16 bytes read go with 32 bytes written (1022 B read, 2052 B written per frame)
+__global__ __launch_bounds__(256) void k_mb_mix(const v4f *__restrict__ src, v4f *__restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 256u * 4u;
+    for (size_t i = (size_t)blockIdx.x * 256u * 4u + threadIdx.x; i < n; i += stride) {
+        v4f r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = i + u * 256u < n ? src[i + u * 256u] : (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * 256u < n) {
+                dst[i + u * 256u] = r[u];
+                dst[n + i + u * 256u] = r[u] + r[u];
+            }
+    }
+}
+
 }  // namespace
 }  // namespace sgx
 
 using namespace sgx;
 
 extern "C" sgx_status sgx_membench(int32_t device, size_t bytes, int32_t mode, int32_t iters, double *gb_per_s) {
-    if (!gb_per_s || mode < 0 || mode > 2 || iters <= 0) return SGX_INVALID_INPUT;
+    if (!gb_per_s || mode < 0 || mode > 3 || iters <= 0) return SGX_INVALID_INPUT;
     *gb_per_s = 0.0;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SGX_BACKEND;
@@ -84,11 +100,12 @@ extern "C" sgx_status sgx_membench(int32_t device, size_t bytes, int32_t mode, i
     auto run = [&](unsigned grid) {
         if (mode == 0) hipLaunchKernelGGL(k_mb_copy, dim3(grid), dim3(256), 0, nullptr, (const v4f *)src, (v4f *)dst, n);
         else if (mode == 1) hipLaunchKernelGGL(k_mb_read, dim3(grid), dim3(256), 0, nullptr, (const v4f *)src, (float *)dst, n);
+        else if (mode == 3) hipLaunchKernelGGL(k_mb_mix, dim3(grid), dim3(256), 0, nullptr, (const v4f *)src, (v4f *)dst, n);
         else hipLaunchKernelGGL(k_mb_write, dim3(grid), dim3(256), 0, nullptr, (v4f *)dst, n, 1.0f);
     };
     do {
         if (mode != 2 && hipMalloc(&src, bytes) != hipSuccess) break;
-        if (hipMalloc(&dst, mode == 1 ? 4096 : bytes) != hipSuccess) break;
+        if (hipMalloc(&dst, mode == 1 ? 4096 : mode == 3 ? 2 * bytes : bytes) != hipSuccess) break;
         if (src && hipMemsetAsync(src, 0, bytes, nullptr) != hipSuccess) break;
         if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) break;
         bool ok = true;
@@ -99,7 +116,7 @@ extern "C" sgx_status sgx_membench(int32_t device, size_t bytes, int32_t mode, i
             if (hipEventRecord(e1, nullptr) != hipSuccess) { ok = false; break; }
             if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) { ok = false; break; }
             if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0.f) { ok = false; break; }
-            const double moved = double(bytes) * (mode == 0 ? 2.0 : 1.0) * double(iters);
+            const double moved = double(bytes) * (mode == 0 ? 2.0 : mode == 3 ? 3.0 : 1.0) * double(iters);
             *gb_per_s = std::max(*gb_per_s, moved / (double(ms) * 1e-3) / 1e9);
         }
         if (ok) st = SGX_OK;
