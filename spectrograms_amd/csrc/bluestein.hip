@@ -16,7 +16,8 @@
 // apart by their Hermitian symmetry, X_2p[k] = (Z[k] + conj Z[N - k]) / 2, X_2p+1[k] = -i (Z[k] - conj Z[N - k]) / 2.  Pairs
 // never cross a signal (an odd last frame rides alone), so a signal's output does not depend on the batch it is in.
 //
-// Four launches per chunk of frame pairs over two plan-owned scratch buffers of [pairs][M] complex T (five above M = 4096):
+// Up to M = 4096 the whole chain runs in ONE kernel with the sequence resident in LDS (k_bs_fused below).  Longer convolutions
+// take four launches per chunk of frame pairs over two plan-owned scratch buffers of [pairs][M] complex T (five with the product):
 //   k_bs_pre   framing with virtual zero padding (S1), window multiply in T (S4), chirp        x -> A
 //   C2C        forward, length M, its store multiplying by FFT_M(b) / M (k_c2c_reg up to M = 4096; above that k_c2c_tile and
 //              a k_pointwise launch)                                                            A -> B
@@ -24,7 +25,23 @@
 //   k_bs_post  Z[k] = conj(c_k) Y[k], the two-frame split, k <= N / 2, |.|^2 / sqrt / dB or complex, transposed through LDS
 //              into the reference's [signal][bin][frame] layout (S9)
 // Filterbank outputs take the plan's split path: per-bin power here, then k_bank_rows.
+#include "reg_radix.h"
+#include "rr_layout.h"
 #include "sgx_internal.h"
+#include "xcd_map.h"
+
+// LDS per workgroup of k_bs_fused.  The f32 instances fit 4 waves per SIMD in registers (<= 128 VGPRs up to M = 2048), so four
+// workgroups per CU; the f64 ones run at 1-2 waves per SIMD and want the larger tile (>= 256 pass-1 work items) instead.
+// Measured, 64 x 10 s: f32 n_fft 1009 218 -> 169 us, 251 204 -> 150 us with 36 KiB; f64 509 316 -> 455 us (kept at 72 KiB).
+#ifndef SGX_BS_LDS32
+#define SGX_BS_LDS32 (36 * 1024)
+#endif
+#ifndef SGX_BS_LDS64
+#define SGX_BS_LDS64 (72 * 1024)
+#endif
+#ifndef SGX_BS_OCC
+#define SGX_BS_OCC 0  // waves per SIMD the register allocation of k_bs_fused aims at; 0: as k_c2c_reg (rr_waves)
+#endif
 
 namespace sgx {
 namespace {
@@ -109,6 +126,352 @@ __global__ __launch_bounds__(256) void k_bs_post(const C2<T> *__restrict__ y, co
     }
 }
 
+// ---- the fused kernel ----------------------------------------------------------------------------------------------------
+// One workgroup carries `tile` sequences (frame pairs) through the whole chain in LDS; the only HBM traffic is the samples in
+// and the bins out (the unfused chain above moves six [pairs][M] complex passes: n_fft 1009, 64 x 10 s: 2 GB for 78 MB of
+// input and output, and was bound by exactly that).
+//
+// The length-M transform is k_c2c_reg's (kernels_reg2d.hip): M = A B C, passes P1 (A points, over n1 of n = n1 B C + r), T1
+// (twiddle W_M^(r k1)), P2 (B points), T2, P3 (C points), each in place on the elements its work item owns, bin
+// k = k1 + A (k2 + B k3) ending at row k1, position (k2, k3) of the swizzled tile (rr_layout.h).  The convolution needs no
+// reordering at all: the product with FFT_M(b) / M is taken where P3 leaves the bins, and the inverse transform runs the SAME
+// passes in the opposite order on the same elements,
+//     y = P1^-1 T1^-1 P2^-1 T2^-1 P3^-1 (D X),   Pi^-1 z = conj(Pi conj z),  Ti^-1 = conj Ti
+// so with c = conj(D X) it is the forward operators again, conj(y) = P1 T1 P2 T2 P3 c: twiddle BEFORE each transform instead of
+// after, nothing else changes.  P3, the product and P3^-1 are one step on a work item's registers (two-pass splits: P2, product,
+// P2^-1).  P1^-1 leaves y[n1 B C + r] in the registers of the work item that loaded x[n1 B C + r]; Z[m] = conj(c_m) y[m]
+// (m < n only) goes back to that element's own place, and the two-frame split reads Z[k] and Z[n - k] from there.
+// Only the first half of a sequence is non-zero going in (n <= M / 2) and only the first half is wanted coming out: the first
+// and the last A-point transform have half their inputs / outputs as compile-time zeros / dead values.
+//
+// Deviation from S4, f32 / f64 alike: the kernel multiplies a sample by wc[m] = w[m] conj(c_m), ONE table rounded from f64, rather
+// than by w[m] (rounded) and then by the chirp; the chirp-z result is not bit-comparable with a direct transform either way.
+#ifdef SGX_BS_STAMPS  // diagnostic build only (tools/stamps_bs.py): a wave's cycles per stage of k_bs_fused
+__device__ unsigned long long g_bs_stamps[16];
+#define BS_STAMP(i)                                                                \
+    do {                                                                           \
+        unsigned long long t_;                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+        st_acc[i] += t_ - st_prev;                                                 \
+        st_prev = t_;                                                              \
+    } while (0)
+#else
+#define BS_STAMP(i)
+#endif
+
+struct BsFused {
+    const void *x;
+    void *out;
+    unsigned long long sample_stride, n_samples, total;  // total = batch * pairs
+    unsigned n, hop, pad, n_frames, nb, pairs, tiles;
+    const void *wc, *chirp, *bhp, *tw;  // [n] w conj(c), [n] conj(c), [M] FFT_M(b) / M in the order the product step reads it, [M] W_M^k
+    int complex_out, amp;
+    double eps;
+};
+
+template <typename T, int A, int B, int C>
+constexpr unsigned bs_waves() { return SGX_BS_OCC && sizeof(T) == 4 ? SGX_BS_OCC : rr_waves<T, A, B, C>(); }
+
+template <typename T, int A_, int B_, int C_>
+__global__ __launch_bounds__(256, (bs_waves<T, A_, B_, C_>())) void k_bs_fused(BsFused a, unsigned ltile) {
+    typedef typename PairOf<T>::type V;
+    constexpr unsigned A = A_, B = B_, C = C_, BC = B * C, N = A * BC, HA = A / 2;
+    constexpr int LA = ct_log2_ceil(A), LB = ct_log2_ceil(B);
+    static_assert(ct_is_pow2(N) && A % 2 == 0, "k_bs_fused: power-of-two convolution lengths");
+    typedef RrLayout<sizeof(V), A_, B_, C_> L;
+    constexpr unsigned RS = L::RS, FS = L::FS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    V *buf = (V *)smem;  // [tile][FS]
+    __shared__ unsigned long long sig_of[32];
+    __shared__ unsigned frame_of[32], interior_of[32];
+    const unsigned tid = threadIdx.x, tile = 1u << ltile;
+    const unsigned lb = xcd_logical_block(a.tiles);  // a signal's pairs write neighbouring frames of the same output rows
+    if (lb >= a.tiles) return;
+#ifdef SGX_BS_STAMPS
+    unsigned long long st_acc[14] = {0}, st_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+#endif
+    const unsigned long long q0 = (unsigned long long)lb * tile;
+    const unsigned ns = (unsigned)min((unsigned long long)tile, a.total - q0);
+    if (tid < tile) {  // sequence q = pair p of signal b: frames 2 p and 2 p + 1
+        const unsigned long long q = q0 + tid, b = q / a.pairs;
+        const unsigned f = 2u * (unsigned)(q - b * a.pairs);
+        sig_of[tid] = b;
+        frame_of[tid] = f;
+        // both frames of the pair exist and lie inside the signal: their loads need no range checks
+        interior_of[tid] = f + 1u < a.n_frames && (unsigned long long)f * a.hop >= a.pad &&
+                           (unsigned long long)(f + 1u) * a.hop + a.n <= a.n_samples + a.pad;
+    }
+    __syncthreads();
+    BS_STAMP(0);
+    const T *x = (const T *)a.x;
+    const V *wc = (const V *)a.wc, *chirp = (const V *)a.chirp, *bhp = (const V *)a.bhp, *tw = (const V *)a.tw;
+    const unsigned n = a.n;
+    auto wrap = [](unsigned e) { return e & (N - 1); };
+    auto item = [&](unsigned idx, unsigned &s, unsigned &r) {
+        r = idx % BC;
+        s = idx / BC;
+        return idx < tile * BC && s < ns;
+    };
+
+    // P1 + T1: framing with virtual zero padding (S1), window and chirp, A-point transform.  The samples of work item idx + 256
+    // are in flight while item idx is transformed.
+    auto fetch = [&](unsigned idx, T (&xa)[HA], T (&xb)[HA], V (&w)[HA]) {
+        unsigned s, r;
+        if (!item(idx, s, r)) return;
+        const T *xs = x + sig_of[s] * a.sample_stride;
+        const unsigned f = frame_of[s];
+        const long long base = (long long)f * a.hop - (long long)a.pad + r;
+        if (interior_of[s]) {
+            const T *pa = xs + base, *pb = pa + a.hop;
+#pragma unroll
+            for (unsigned n1 = 0; n1 < HA; ++n1) {
+                const bool in = n1 * BC + r < n;
+                xa[n1] = in ? pa[n1 * BC] : T(0);
+                xb[n1] = in ? pb[n1 * BC] : T(0);
+                w[n1] = in ? wc[n1 * BC + r] : (V){T(0), T(0)};
+            }
+            return;
+        }
+        const bool two = f + 1u < a.n_frames;
+#pragma unroll
+        for (unsigned n1 = 0; n1 < HA; ++n1) {
+            const unsigned m = n1 * BC + r;
+            xa[n1] = T(0);
+            xb[n1] = T(0);
+            w[n1] = (V){T(0), T(0)};
+            if (m < n) {
+                const long long sa = base + (long long)(n1 * BC), sb = sa + a.hop;
+                if (sa >= 0 && (unsigned long long)sa < a.n_samples) xa[n1] = xs[sa];
+                if (two && sb >= 0 && (unsigned long long)sb < a.n_samples) xb[n1] = xs[sb];
+                w[n1] = wc[m];
+            }
+        }
+    };
+    {
+        T nxa[HA], nxb[HA];
+        V nw[HA];
+#pragma unroll
+        for (unsigned n1 = 0; n1 < HA; ++n1) {
+            nxa[n1] = nxb[n1] = T(0);
+            nw[n1] = (V){T(0), T(0)};
+        }
+        fetch(tid, nxa, nxb, nw);
+        for (unsigned idx = tid; idx < tile * BC; idx += 256) {
+            V v[A];
+#pragma unroll
+            for (unsigned n1 = 0; n1 < HA; ++n1) {  // (xa + i xb) wc
+                const V p = {nxa[n1], nxb[n1]};
+                v[n1] = inreg::cmulv(p, nw[n1]);
+                v[n1 + HA] = (V){T(0), T(0)};
+            }
+            fetch(idx + 256, nxa, nxb, nw);
+            unsigned s, r;
+            if (!item(idx, s, r)) continue;
+            inreg::MixFft<A, V>::run(v);
+            V pw2[LA];
+#pragma unroll
+            for (int j = 0; j < LA; ++j) pw2[j] = tw[wrap((1u << j) * r)];
+            V *dst = buf + (size_t)s * FS;
+            const unsigned pp = L::hi_part(r / C) ^ (r % C);
+            dst[pp ^ L::k1_mask(0)] = v[0];
+#pragma unroll
+            for (unsigned k1 = 1; k1 < A; ++k1) (dst + (pp ^ L::k1_mask(k1)))[k1 * RS] = inreg::cmulv(v[k1], rr_twiddle<LA>(pw2, k1));
+        }
+    }
+    BS_STAMP(1);
+    __syncthreads();
+    BS_STAMP(2);
+    // P2 (+ T2); two-pass splits: P2, product, P2^-1
+    for (unsigned idx = tid; idx < ns * A * C; idx += 256) {
+        const unsigned s = idx / (A * C), q = idx % (A * C), k1 = q / C, n3 = q % C;
+        V *row = buf + (size_t)s * FS + k1 * RS;
+        const unsigned lp = n3 ^ L::k1_mask(k1);
+        V v[B];
+#pragma unroll
+        for (unsigned n2 = 0; n2 < B; ++n2) v[n2] = row[lp ^ L::hi_part(n2)];
+        inreg::MixFft<B, V>::run(v);
+        if constexpr (C > 1) {
+            V q2[LB];
+#pragma unroll
+            for (int j = 0; j < LB; ++j) q2[j] = tw[wrap((A << j) * n3)];
+            row[lp ^ L::hi_part(0)] = v[0];
+#pragma unroll
+            for (unsigned k2 = 1; k2 < B; ++k2) row[lp ^ L::hi_part(k2)] = inreg::cmulv(v[k2], rr_twiddle<LB>(q2, k2));
+        } else {
+#pragma unroll
+            for (unsigned k2 = 0; k2 < B; ++k2) {  // bin k1 + A k2; the table is [k2][k1]
+                const V y = inreg::cmulv(v[k2], bhp[k2 * A + k1]);
+                v[k2] = (V){y.x, -y.y};
+            }
+            inreg::MixFft<B, V>::run(v);
+#pragma unroll
+            for (unsigned n2 = 0; n2 < B; ++n2) row[lp ^ L::hi_part(n2)] = v[n2];
+        }
+    }
+    BS_STAMP(3);
+    __syncthreads();
+    BS_STAMP(4);
+    if constexpr (C > 1) {
+        // P3, product, P3^-1 (from here on the data is the conjugate of the inverse transform's)
+        for (unsigned idx = tid; idx < ns * A * B; idx += 256) {
+            const unsigned s = idx / (A * B), q = idx % (A * B), k1 = q / B, k2 = q % B;
+            V *row = buf + (size_t)s * FS + k1 * RS;
+            const unsigned lp = L::hi_part(k2) ^ L::k1_mask(k1);
+            V v[C], h[C];
+#pragma unroll
+            for (unsigned k3 = 0; k3 < C; ++k3) h[k3] = bhp[k3 * (A * B) + q];  // bin k1 + A (k2 + B k3); the table is [k3][k1][k2]
+#pragma unroll
+            for (unsigned n3 = 0; n3 < C; ++n3) v[n3] = row[lp ^ n3];
+            inreg::MixFft<C, V>::run(v);
+#pragma unroll
+            for (unsigned k3 = 0; k3 < C; ++k3) {
+                const V y = inreg::cmulv(v[k3], h[k3]);
+                v[k3] = (V){y.x, -y.y};
+            }
+            inreg::MixFft<C, V>::run(v);
+#pragma unroll
+            for (unsigned n3 = 0; n3 < C; ++n3) row[lp ^ n3] = v[n3];
+        }
+        BS_STAMP(5);
+        __syncthreads();
+        BS_STAMP(6);
+        // T2, P2
+        for (unsigned idx = tid; idx < ns * A * C; idx += 256) {
+            const unsigned s = idx / (A * C), q = idx % (A * C), k1 = q / C, n3 = q % C;
+            V *row = buf + (size_t)s * FS + k1 * RS;
+            const unsigned lp = n3 ^ L::k1_mask(k1);
+            V q2[LB];
+#pragma unroll
+            for (int j = 0; j < LB; ++j) q2[j] = tw[wrap((A << j) * n3)];
+            V v[B];
+            v[0] = row[lp ^ L::hi_part(0)];
+#pragma unroll
+            for (unsigned k2 = 1; k2 < B; ++k2) v[k2] = inreg::cmulv(row[lp ^ L::hi_part(k2)], rr_twiddle<LB>(q2, k2));
+            inreg::MixFft<B, V>::run(v);
+#pragma unroll
+            for (unsigned n2 = 0; n2 < B; ++n2) row[lp ^ L::hi_part(n2)] = v[n2];
+        }
+        BS_STAMP(7);
+        __syncthreads();
+        BS_STAMP(8);
+    }
+    // T1, P1, then Z[m] = conj(c_m) y[m] for m < n back to element m's own place
+    for (unsigned idx = tid; idx < tile * BC; idx += 256) {
+        unsigned s, r;
+        if (!item(idx, s, r)) continue;
+        V ch[HA];
+#pragma unroll
+        for (unsigned n1 = 0; n1 < HA; ++n1) ch[n1] = n1 * BC + r < n ? chirp[n1 * BC + r] : (V){T(0), T(0)};
+        V pw2[LA];
+#pragma unroll
+        for (int j = 0; j < LA; ++j) pw2[j] = tw[wrap((1u << j) * r)];
+        V *dst = buf + (size_t)s * FS;
+        const unsigned pp = L::hi_part(r / C) ^ (r % C);
+        V v[A];
+        v[0] = dst[pp ^ L::k1_mask(0)];
+#pragma unroll
+        for (unsigned k1 = 1; k1 < A; ++k1) v[k1] = inreg::cmulv((dst + (pp ^ L::k1_mask(k1)))[k1 * RS], rr_twiddle<LA>(pw2, k1));
+        inreg::MixFft<A, V>::run(v);
+#pragma unroll
+        for (unsigned n1 = 0; n1 < HA; ++n1) {
+            const V y = {v[n1].x, -v[n1].y};
+            (dst + (pp ^ L::k1_mask(n1)))[n1 * RS] = inreg::cmulv(y, ch[n1]);
+        }
+    }
+    BS_STAMP(9);
+    __syncthreads();
+    BS_STAMP(10);
+    // the two frames of a pair come apart by their Hermitian symmetry; lanes walk the tile's pairs first (neighbouring frames of
+    // one output row), a work item writes both frames of its pair
+    const unsigned nb = a.nb;
+    const T eps = (T)a.eps;
+    for (unsigned idx = tid; idx < tile * nb; idx += 256) {
+        const unsigned s = idx & (tile - 1u), k = idx >> ltile;
+        if (s >= ns) continue;
+        const unsigned f = frame_of[s];
+        const V *seq = buf + (size_t)s * FS;
+        auto at = [&](unsigned m) {
+            const unsigned n1 = m / BC, r = m % BC;
+            return seq[n1 * RS + ((L::hi_part(r / C) ^ (r % C)) ^ L::k1_mask(n1))];
+        };
+        const V Z = at(k), Zc = at(k == 0 ? 0u : n - k);  // Zm = conj Z[n - k] = (Zc.x, -Zc.y)
+        const V Xa = {T(0.5) * (Z.x + Zc.x), T(0.5) * (Z.y - Zc.y)};   //    (Z + Zm) / 2
+        const V Xb = {T(0.5) * (Z.y + Zc.y), T(-0.5) * (Z.x - Zc.x)};  // -i (Z - Zm) / 2
+        const unsigned long long o = (sig_of[s] * nb + k) * a.n_frames + f;
+        const bool two = f + 1u < a.n_frames;
+        if (a.complex_out) {
+            ((V *)a.out)[o] = Xa;
+            if (two) ((V *)a.out)[o + 1] = Xb;
+        } else {
+            const T pa = Xa.x * Xa.x + Xa.y * Xa.y, pb = Xb.x * Xb.x + Xb.y * Xb.y;  // norm_sqr (spectrogram.rs:1332-1334)
+            T *dst = (T *)a.out + o;
+            dst[0] = a.amp == AMP_MAGNITUDE ? sqrt(pa) : a.amp == AMP_DB ? bs_db(pa > eps ? pa : eps) : pa;
+            if (two) dst[1] = a.amp == AMP_MAGNITUDE ? sqrt(pb) : a.amp == AMP_DB ? bs_db(pb > eps ? pb : eps) : pb;
+        }
+    }
+    BS_STAMP(11);
+#ifdef SGX_BS_STAMPS
+    if ((threadIdx.x & 63u) == 0 && (lb & 127u) == 0) {  // a sample of the tiles: the atomics of every wave would be the slowest part of the run
+        for (int q = 0; q < 12; ++q) atomicAdd(&g_bs_stamps[q], st_acc[q]);
+        atomicAdd(&g_bs_stamps[12], 1ull);
+    }
+#endif
+}
+
+size_t bs_lds_budget(int dtype) { return dtype == SGX_F64 ? (size_t)SGX_BS_LDS64 : (size_t)SGX_BS_LDS32; }
+
+bool fused_geometry(unsigned M, int dtype, unsigned &fa, unsigned &fb, unsigned &fc, unsigned &ltile, size_t &lds) {
+    if (M & (M - 1)) return false;
+    if (!reg_split_len(M, dtype, &fa, &fb, &fc)) return false;
+    const size_t es = dtype == SGX_F64 ? 8 : 4;
+    const size_t fs = rr_frame_stride(fa, rr_swizzle(2 * (unsigned)es, fa, fb, fc).rs);
+    const size_t budget = bs_lds_budget(dtype);
+    ltile = 4;  // up to 16 pairs = 32 frames per workgroup
+    while (ltile > 0 && (size_t)(1u << ltile) * fs * 2 * es > budget) --ltile;
+    lds = (size_t)(1u << ltile) * fs * 2 * es;
+    return lds <= budget;
+}
+
+template <typename T, int A, int B, int C>
+hipError_t launch_fused_t(const BsFused &f, unsigned ltile, size_t lds, hipStream_t s) {
+    if (lds > 64 * 1024) {
+        hipError_t e = set_max_dynamic_lds((const void *)k_bs_fused<T, A, B, C>, (int)bs_lds_budget(sizeof(T) == 8 ? SGX_F64 : SGX_F32));
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_bs_fused<T, A, B, C>), dim3(xcd_grid(f.tiles)), dim3(256), lds, s, f, ltile);
+    return hipGetLastError();
+}
+
+hipError_t run_fused(const BsArgs &a, int dtype, hipStream_t s) {
+    unsigned fa, fb, fc, ltile;
+    size_t lds;
+    if (!fused_geometry(a.M, dtype, fa, fb, fc, ltile, lds)) return hipErrorNotSupported;
+    BsFused f{};
+    f.x = a.x; f.out = a.out;
+    f.sample_stride = a.sample_stride; f.n_samples = a.n_samples;
+    f.n = a.n_fft; f.hop = a.hop; f.pad = a.pad; f.n_frames = a.n_frames; f.nb = a.nb;
+    f.pairs = (a.n_frames + 1u) / 2u;
+    f.total = (unsigned long long)a.batch * f.pairs;
+    const unsigned long long tiles = (f.total + (1ull << ltile) - 1) >> ltile;
+    if (tiles == 0 || tiles >= 0x7fffffffull) return hipErrorInvalidConfiguration;
+    f.tiles = (unsigned)tiles;
+    f.wc = a.wc; f.chirp = a.chirp; f.bhp = a.bhat_fused; f.tw = a.tw_m;
+    f.complex_out = a.complex_out; f.amp = a.amp; f.eps = a.eps;
+#define SGX_BSF_F32(A, B, C) if (fa == A && fb == B && fc == C) return launch_fused_t<float, A, B, C>(f, ltile, lds, s);
+#define SGX_BSF_F64(A, B, C) if (fa == A && fb == B && fc == C) return launch_fused_t<double, A, B, C>(f, ltile, lds, s);
+    if (dtype == SGX_F64) {
+        SGX_RR_SPLITS_F64(SGX_BSF_F64)
+    } else {
+        SGX_RR_SPLITS_F32(SGX_BSF_F32)
+    }
+#undef SGX_BSF_F32
+#undef SGX_BSF_F64
+    return hipErrorNotSupported;
+}
+
 template <typename T>
 hipError_t run_t(const BsArgs &a, int dtype, hipStream_t s) {
     const unsigned pairs = (a.n_frames + 1u) / 2u;
@@ -149,8 +512,27 @@ hipError_t run_t(const BsArgs &a, int dtype, hipStream_t s) {
 
 }  // namespace
 
+// the (A, B, C) split of the fused kernel at convolution length M, or false: the plan then keeps the scratch-buffer chain
+bool bluestein_fused_split(unsigned M, int dtype, unsigned *fa, unsigned *fb, unsigned *fc) {
+    unsigned ltile;
+    size_t lds;
+    return fused_geometry(M, dtype, *fa, *fb, *fc, ltile, lds);
+}
+
 hipError_t launch_bluestein(const BsArgs &a, int dtype, hipStream_t s) {
+    if (a.bhat_fused) return run_fused(a, dtype, s);
     return dtype == SGX_F64 ? run_t<double>(a, dtype, s) : run_t<float>(a, dtype, s);
 }
 
 }  // namespace sgx
+
+#ifdef SGX_BS_STAMPS
+extern "C" int sgx_debug_read_bs_stamps(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sgx::g_bs_stamps), sizeof(sgx::g_bs_stamps)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(sgx::g_bs_stamps), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif

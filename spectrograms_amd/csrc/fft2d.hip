@@ -32,6 +32,9 @@ struct sgx_fft2d {
     int mask_kind = -1;
     double mask_lo = 0.0, mask_hi = 0.0;
     hipStream_t mask_stream = nullptr;
+    // second stream of the chunked convolve / filter schedule (fused_product_dev), forked from and joined to the caller's
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     mutable std::string err;
 };
 
@@ -155,22 +158,29 @@ sgx_status inverse_dev(sgx_fft2d *p, const void *spec, size_t batch, void *img, 
 
 // convolve_fft / filters with the fused column stage (f32, 1024 rows): rows R2C -> k_colconv1024 -> rows C2R.  `mul` is the
 // kernel's half spectrum (complex) or a real mask, both [row][col].
-sgx_status fused_product_dev(sgx_fft2d *p, const void *img, size_t batch, const void *mul, bool real_mask, void *out, hipStream_t s) {
+//
+// The three passes of one image group are bound by different things (the row passes by HBM, the column pass by LDS and VALU), so a
+// large batch runs as chunks of kConvChunk images alternating between the caller's stream and a plan-owned second stream: the row
+// passes of one chunk overlap the column pass of the other (measured on 256 x 1024^2: 2.99 -> 2.76 ms,
+// profiles/experiments_r03/fft2d_two_stream_chunks.txt).  The second stream forks from and joins the caller's stream through
+// events, so the call keeps plain stream semantics (and stays capturable into a hipGraph); every image's arithmetic is the same
+// in either schedule, so the result does not depend on the batch it came in.
+constexpr size_t kConvChunk = 64;
+
+sgx_status fused_product_chunk(sgx_fft2d *p, const void *img, size_t batch, const void *mul, bool real_mask, void *out, void *inter,
+                               void *spec, hipStream_t s) {
     const size_t R = p->nrows, C = p->ncols, Cb = p->cb;
-    sgx_status st = grow2(p, &p->d_inter, &p->inter_bytes, batch * Cb * R * 2 * p->elem);
-    if (st != SGX_OK) return st;
-    if ((st = grow2(p, &p->d_spec, &p->spec_bytes, batch * R * Cb * 2 * p->elem)) != SGX_OK) return st;
-    st = sgx_execute(p->rows, img, batch, R * C, R * C, p->d_inter, batch * Cb * R * 2, SGX_MEM_DEVICE, s);
+    sgx_status st = sgx_execute(p->rows, img, batch, R * C, R * C, inter, batch * Cb * R * 2, SGX_MEM_DEVICE, s);
     if (st != SGX_OK) return fail(p, st, sgx_last_error(p->rows));
     C2cArgs a{};
-    a.in = p->d_inter; a.out = p->d_spec;
+    a.in = inter; a.out = spec;
     a.n = unsigned(R); a.log2n = p->log2r; a.nseq = unsigned(Cb); a.batch = unsigned(batch);
     a.in_img = Cb * R; a.out_img = R * Cb;
     a.in_ss = R; a.in_is = 1; a.out_ss = 1; a.out_is = Cb;
     a.tile = 16; a.tiles = unsigned((Cb + 15) / 16);
     F2_HIP(p, launch_colconv1024(a, p->d_tw1c, mul, Cb, real_mask, s));
     C2rArgs c{};
-    c.in = p->d_spec; c.out = out;
+    c.in = spec; c.out = out;
     c.nrows = unsigned(R); c.ncols = unsigned(C); c.log2c = p->log2c; c.batch = unsigned(batch);
     c.in_img = Cb * R; c.in_ks = 1; c.in_rs = Cb; c.k_fast = 1;
     c.tw = p->d_tw_c; c.scale = 1.0 / (double(R) * double(C));
@@ -181,6 +191,46 @@ sgx_status fused_product_dev(sgx_fft2d *p, const void *img, size_t batch, const 
         c.tile = p->tile_c; c.tiles = unsigned((R + c.tile - 1) / c.tile);
         F2_HIP(p, launch_c2r_any(c, p->dtype, s));
     }
+    return SGX_OK;
+}
+
+// chunked only where all three passes are the tuned kernels (1024 x 1024 f32): those use no plan-owned scratch besides the two
+// buffers split below, so two chunks can be in flight at once (a Bluestein row plan, say, owns scratch that cannot be shared)
+bool fused_chunked(const sgx_fft2d *p, size_t batch) { return p->d_twr != nullptr && batch >= 2 * kConvChunk; }
+size_t fused_scratch_images(const sgx_fft2d *p, size_t batch) { return fused_chunked(p, batch) ? 2 * kConvChunk : batch; }
+
+sgx_status fused_streams(sgx_fft2d *p) {
+    if (p->aux_stream) return SGX_OK;
+    F2_HIP(p, hipStreamCreateWithFlags(&p->aux_stream, hipStreamNonBlocking));
+    F2_HIP(p, hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+    F2_HIP(p, hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+    return SGX_OK;
+}
+
+sgx_status fused_product_dev(sgx_fft2d *p, const void *img, size_t batch, const void *mul, bool real_mask, void *out, hipStream_t s) {
+    const size_t R = p->nrows, C = p->ncols, Cb = p->cb;
+    const size_t slice = Cb * R * 2 * p->elem;  // one image's intermediate / spectrum
+    sgx_status st = grow2(p, &p->d_inter, &p->inter_bytes, fused_scratch_images(p, batch) * slice);
+    if (st != SGX_OK) return st;
+    if ((st = grow2(p, &p->d_spec, &p->spec_bytes, fused_scratch_images(p, batch) * slice)) != SGX_OK) return st;
+    if (!fused_chunked(p, batch)) return fused_product_chunk(p, img, batch, mul, real_mask, out, p->d_inter, p->d_spec, s);
+    if ((st = fused_streams(p)) != SGX_OK) return st;
+    F2_HIP(p, hipEventRecord(p->ev_fork, s));
+    F2_HIP(p, hipStreamWaitEvent(p->aux_stream, p->ev_fork, 0));
+    const size_t img_bytes = R * C * p->elem;
+    size_t idx = 0;
+    for (size_t b0 = 0; b0 < batch; b0 += kConvChunk, ++idx) {
+        const size_t nb = std::min(kConvChunk, batch - b0), half = idx & 1;  // each stream owns one half of the scratch
+        st = fused_product_chunk(p, static_cast<const char *>(img) + b0 * img_bytes, nb, mul, real_mask,
+                                 static_cast<char *>(out) + b0 * img_bytes, static_cast<char *>(p->d_inter) + half * kConvChunk * slice,
+                                 static_cast<char *>(p->d_spec) + half * kConvChunk * slice, half ? p->aux_stream : s);
+        if (st != SGX_OK) break;
+    }
+    // join even after a failed launch: the caller's stream must not run ahead of work already queued on the second one
+    const hipError_t e1 = hipEventRecord(p->ev_join, p->aux_stream);
+    const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(s, p->ev_join, 0) : e1;
+    if (st != SGX_OK) return st;
+    F2_HIP(p, e2);
     return SGX_OK;
 }
 
@@ -239,6 +289,7 @@ sgx_status sgx_fft2d_reserve(sgx_fft2d *p, size_t batch, int32_t host_staging) {
     sgx_status st;
     if ((st = grow2(p, &p->d_inter, &p->inter_bytes, batch * Cb * R * 2 * p->elem)) != SGX_OK) return st;
     if ((st = grow2(p, &p->d_spec, &p->spec_bytes, batch * R * Cb * 2 * p->elem)) != SGX_OK) return st;
+    if (fused_chunked(p, batch) && (st = fused_streams(p)) != SGX_OK) return st;  // nothing left to create inside a graph capture
     if (host_staging) {
         const size_t big = batch * R * Cb * 2 * p->elem;  // a half spectrum is the larger of (image, spectrum)
         if ((st = grow2(p, &p->d_in, &p->in_bytes, big)) != SGX_OK) return st;
@@ -332,6 +383,9 @@ void sgx_fft2d_destroy(sgx_fft2d *p) {
         void *bufs[] = {p->d_tw_r, p->d_tw_c, p->d_tw1c, p->d_twr, p->d_tw1r, p->d_inter, p->d_spec, p->d_kspec, p->d_mask, p->d_in, p->d_out, p->d_kimg};
         for (void *b : bufs)
             if (b) (void)hipFree(b);
+        if (p->aux_stream) (void)hipStreamDestroy(p->aux_stream);
+        if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+        if (p->ev_join) (void)hipEventDestroy(p->ev_join);
         sgx_plan_destroy(p->rows);
     }
     delete p;

@@ -149,6 +149,22 @@ class Fft2dPlan:
                                                  out.data_ptr(), _ffi.MEM_DEVICE, C.c_void_p(s)))
         return out
 
+    def filter_torch(self, x, kind: int, lo: float, hi: float = 0.0, out=None):
+        """lowpass (0) / highpass (1) / bandpass (2) of [B, nrows, ncols] device images, device resident (src/image_ops.rs:301-430)."""
+        import torch
+        tdt = torch.float32 if self._dt == _ffi.F32 else torch.float64
+        self._device_images(x, "images", (self.nrows, self.ncols), tdt)
+        if out is None:
+            out = torch.empty_like(x)
+        else:
+            self._device_images(out, "out", (self.nrows, self.ncols), tdt)
+            if out.shape[0] != x.shape[0]:
+                raise _ffi.DimensionMismatchError(f"Dimension mismatch: expected {x.shape[0]}, got {out.shape[0]}", x.shape[0], out.shape[0])
+        s = torch.cuda.current_stream(x.device).cuda_stream
+        self._check(self._lib.sgx_fft2d_filter(self._h, x.data_ptr(), x.shape[0], kind, float(lo), float(hi), out.data_ptr(),
+                                               _ffi.MEM_DEVICE, C.c_void_p(s)))
+        return out
+
 
 class C2cPlan:
     """1-D complex-to-complex plan: C2cPlan<T> of the reference (src/fft_backend.rs:113-137).  `forward` / `inverse` return a

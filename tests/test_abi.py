@@ -155,15 +155,21 @@ def test_kernel_selection():
     assert host_plan(4096, 1024, dtype="float64").kernel_name == "reg_radix"
     assert host_plan(16, 4, dtype="float32").kernel_name == "lds_radix2"
     assert host_plan(400, 160).kernel_name == "reg_radix"       # m = 200 = 25 x 8
-    assert host_plan(100, 40).kernel_name == "two_factor_dft"   # even, but not in the register-tiled list: 10 x 10
-    assert host_plan(441, 160).kernel_name == "two_factor_dft"  # odd: 21 x 21
-    assert host_plan(97, 40).kernel_name == "direct_dft"        # small prime: the direct sum is cheaper than two 256-point transforms
-    assert host_plan(2, 1).kernel_name == "direct_dft"
-    # lengths with a large prime factor: chirp-z (Bluestein) on the power-of-two complex kernels
+    # lengths outside the register-tiled lists: chirp-z (Bluestein), one kernel with the sequence resident in LDS up to
+    # n_fft 2048 (M <= 4096) — faster than the two-factor / direct sums from n_fft ~17 on
+    assert host_plan(100, 40).kernel_name == "bluestein"        # 10 x 10
+    assert host_plan(441, 160).kernel_name == "bluestein"       # 21 x 21
+    assert host_plan(97, 40).kernel_name == "bluestein"         # small prime
+    assert host_plan(1023, 256).kernel_name == "bluestein"      # 31 x 33
     assert host_plan(401, 160).kernel_name == "bluestein"       # prime
+    assert host_plan(1006, 500).kernel_name == "bluestein"      # 2 x 503
+    assert host_plan(2, 1).kernel_name == "direct_dft"
+    assert host_plan(11, 4).kernel_name == "direct_dft"         # below 16 points the direct sum stays
+    assert host_plan(34, 8, mel=sg.MelParams(8, 0.0, 8000.0), dtype="float32").kernel_name == "two_factor_dft"  # short frames into a filterbank (f32): the two-factor kernel's fused bank wins
+    assert host_plan(34, 8).kernel_name == "bluestein"
+    # above M = 4096 the chirp-z path is a chain of launches over HBM scratch: only where the sums are far more expensive
     assert host_plan(5003, 2000, dtype="float32").kernel_name == "bluestein"
-    assert host_plan(1006, 500).kernel_name == "bluestein"      # 2 x 503: the two-factor kernel would pay 2 + 251 multiply-adds per sample
-    assert host_plan(1023, 256).kernel_name == "two_factor_dft"  # 31 x 33 stays
+    assert host_plan(3000, 700).kernel_name == "two_factor_dft"  # 50 x 60 stays
     assert host_plan(4099, 1000, dtype="float64").kernel_name == "direct_dft"  # f64: M = 16384 does not fit the complex kernels' tile
 
 

@@ -223,6 +223,48 @@ def test_gpu_fused_column_stage_1024_rows(shape):
 
 
 @pytest.mark.gpu
+def test_gpu_convolve_large_batch_runs_in_chunks_on_two_streams():
+    """From 128 images of 1024 x 1024 f32 on, convolve_fft runs as chunks of 64 alternating between the caller's stream and a
+    plan-owned second one (fft2d.hip: fused_product_dev).  The result must be, bit for bit, what the same images give in small
+    batches (which take the single-stream schedule); the call must behave as ONE operation of the caller's stream — work queued
+    behind it sees all of its output, work queued before it is seen by all of its chunks — and must replay from a hipGraph."""
+    torch = pytest.importorskip("torch")
+    B, R, Cn = 168, 1024, 1024  # 64 + 64 + 40: both streams, a ragged last chunk
+    g = torch.Generator(device="cuda").manual_seed(21)
+    x = torch.randn((B, R, Cn), generator=g, device="cuda", dtype=torch.float32)
+    k = sg.gaussian_kernel_2d(9, 2.0, dtype="float32")
+    small = sg.Fft2dPlan(R, Cn, "float32")
+    ref = torch.cat([small.convolve_torch(x[i:i + 24], k) for i in range(0, B, 24)])
+    plan = sg.Fft2dPlan(R, Cn, "float32")
+    plan.reserve(B, host_staging=False)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        xin = torch.zeros_like(x)
+        xin.copy_(x)                       # queued before the call, on the caller's stream
+        y = plan.convolve_torch(xin, k)
+        tot = y.sum(dim=(1, 2))            # queued behind the call
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref)
+    assert torch.equal(tot, ref.sum(dim=(1, 2)))
+    # same kernel on the same stream again -> no host copy in the call -> capturable; the replay works on new input in the same buffers
+    out = torch.empty_like(x)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr, stream=side):
+        plan.convolve_torch(xin, k, out=out)
+    xin.copy_(x.flip(0))
+    out.zero_()
+    gr.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref.flip(0))
+    # the radial filters share the schedule
+    f = plan.filter_torch(x, 1, 0.2, 0.0)
+    fr = torch.cat([small.filter_torch(x[i:i + 24], 1, 0.2, 0.0) for i in range(0, B, 24)])
+    assert torch.equal(f, fr)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape,dtype", [((1024, 64), "float32"), ((64, 48), "float32"), ((40, 64), "float64")])
 def test_gpu_kernel_spectrum_and_mask_are_reused_only_when_unchanged(shape, dtype):
     """A plan keeps the last kernel's spectrum / the last filter mask on the device and prepares them again only when the kernel

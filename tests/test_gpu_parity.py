@@ -516,7 +516,7 @@ def test_fuzz_shapes():
     power-of-two / mixed radix, LDS radix-2, two-factor, direct) against the oracle, including hops that do not divide n_fft,
     odd hops (unaligned frames), signals shorter than a frame and lengths that leave partial tiles."""
     rng = np.random.default_rng(20260)
-    pool = [4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048] + MIXED + [6, 10, 30, 50, 100, 250, 330, 441, 97, 127, 509, 1006, 1009]
+    pool = [4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048] + MIXED + [6, 10, 30, 50, 100, 250, 330, 441, 97, 127, 509, 1006, 1009, 7, 11, 13, 3000]
     seen = set()
     for case in range(90):
         n_fft = int(pool[rng.integers(len(pool))])
@@ -637,9 +637,10 @@ def test_bluestein_sizes(n_fft, hop, dtype):
     assert err < (2e-5 if dtype == "float32" else 1e-10), err
 
 
-def test_bluestein_many_frames_in_chunks():
-    """More frames than one pass over the chirp-z scratch holds (32 768): 64 x 10 s at n_fft 1009 / hop 16 = 640 k frames in 20
-    chunks; first, a middle and the last signal against the oracle, and a signal straddling a chunk boundary against its own launch."""
+def test_bluestein_many_frames_one_launch():
+    """64 x 10 s at n_fft 1009 / hop 16 = 640 k frames (320 k frame pairs) through the one-kernel chirp-z path (M = 2048: the
+    sequence stays in LDS, one launch whatever the frame count); first, a middle and the last signal against the oracle, a signal
+    against its own launch."""
     n_fft, hop, batch = 1009, 16, 64
     plan, op = make(n_fft, hop)
     x = H.cfg2_batch(batch)
@@ -648,7 +649,28 @@ def test_bluestein_many_frames_in_chunks():
     idx = [0, 3, 31, 63]
     ref = orc.spectrogram_batch(op, x[idx].astype(np.float64), nthreads=orc.max_threads())
     check(got[idx], ref, "power", "float32")
-    assert np.array_equal(plan.compute_batch(x[3:4])[0], got[3])  # 32768 / 10000: the chunk boundary falls inside signal 3
+    assert np.array_equal(plan.compute_batch(x[3:4])[0], got[3])
+
+
+def test_bluestein_long_frames_in_chunks():
+    """Above M = 4096 (n_fft > 2048) the chirp-z path is a chain of launches over plan-owned scratch, in chunks of at most 1 GiB
+    per buffer: n_fft 4093 (M = 8192, 64 KiB per frame pair -> 16 384 pairs per chunk), 3 x 10 s at hop 12 = 20 001 pairs, the
+    chunk boundary inside the last signal.  That signal against its own single-chunk launch bit for bit; frames from both
+    sides of the boundary against a float64 rfft of the same windowed samples."""
+    n_fft, hop, batch, n = 4093, 12, 3, 160000
+    plan, op = make(n_fft, hop)
+    x = signals(batch, n, np.float32, 5)
+    got = plan.compute_batch(x)
+    nf = n // hop + 1
+    assert plan.kernel_name == "bluestein" and got.shape == (batch, n_fft // 2 + 1, nf)
+    assert np.array_equal(plan.compute_batch(x[2:3])[0], got[2])
+    w = orc.make_window("hanning", n_fft)
+    pad = n_fft // 2
+    xp = np.pad(x.astype(np.float64), ((0, 0), (pad, pad)))
+    for b, f in ((0, 0), (1, nf - 1), (2, 6098), (2, 6099), (2, 6100), (2, 6101), (2, nf - 1)):  # pair 16384 = frames 6100, 6101 of signal 2
+        fr = (xp[b, f * hop:f * hop + n_fft].astype(np.float32) * w.astype(np.float32)).astype(np.float64)
+        ref = np.abs(np.fft.rfft(fr)) ** 2
+        assert np.max(np.abs(got[b, :, f] - ref)) <= GUARD32 * max(1.0, float(ref.max())), (b, f)
 
 
 @pytest.mark.parametrize("amp", ["power", "complex", "db"])

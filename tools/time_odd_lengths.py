@@ -10,10 +10,12 @@ import torch
 import spectrograms_amd as sg
 
 B, N = 64, 160000
-for dtype in ("float32", "float64"):
+LENGTHS = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [256, 251, 512, 509, 1006, 1009, 1023, 1024, 2003, 2048, 4093, 4096, 5003, 8192]
+DTYPES = sys.argv[2].split(",") if len(sys.argv) > 2 else ["float32", "float64"]
+for dtype in DTYPES:
     tdt = torch.float32 if dtype == "float32" else torch.float64
     x = torch.randn((B, N), dtype=tdt, device="cuda")
-    for n_fft in (256, 251, 512, 509, 1006, 1009, 1023, 1024, 2003, 2048, 4093, 4096, 5003, 8192):
+    for n_fft in LENGTHS:
         if dtype == "float64" and n_fft > 4096:
             continue
         hop = max(1, n_fft // 4)
