@@ -161,11 +161,14 @@ sgx_status inverse_dev(sgx_fft2d *p, const void *spec, size_t batch, void *img, 
 //
 // The three passes of one image group are bound by different things (the row passes by HBM, the column pass by LDS and VALU), so a
 // large batch runs as chunks of kConvChunk images alternating between the caller's stream and a plan-owned second stream: the row
-// passes of one chunk overlap the column pass of the other (measured on 256 x 1024^2: 2.99 -> 2.76 ms,
-// profiles/experiments_r03/fft2d_two_stream_chunks.txt).  The second stream forks from and joins the caller's stream through
+// passes of one chunk overlap the column pass of the other (measured on 512 x 1024^2: 2.83 -> 2.70 ms; chunks of 32: 2.72, of 128:
+// 2.75; profiles/experiments_r03/convolve_two_stream_in_library_abv.txt).  The second stream forks from and joins the caller's stream through
 // events, so the call keeps plain stream semantics (and stays capturable into a hipGraph); every image's arithmetic is the same
 // in either schedule, so the result does not depend on the batch it came in.
-constexpr size_t kConvChunk = 64;
+#ifndef SGX_CONV_CHUNK
+#define SGX_CONV_CHUNK 64
+#endif
+constexpr size_t kConvChunk = SGX_CONV_CHUNK;
 
 sgx_status fused_product_chunk(sgx_fft2d *p, const void *img, size_t batch, const void *mul, bool real_mask, void *out, void *inter,
                                void *spec, hipStream_t s) {
