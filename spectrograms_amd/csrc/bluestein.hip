@@ -16,14 +16,12 @@
 // apart by their Hermitian symmetry, X_2p[k] = (Z[k] + conj Z[N - k]) / 2, X_2p+1[k] = -i (Z[k] - conj Z[N - k]) / 2.  Pairs
 // never cross a signal (an odd last frame rides alone), so a signal's output does not depend on the batch it is in.
 //
-// Up to M = 4096 the whole chain runs in ONE kernel with the sequence resident in LDS (k_bs_fused below).  Longer convolutions
-// take four launches per chunk of frame pairs over two plan-owned scratch buffers of [pairs][M] complex T (five with the product):
-//   k_bs_pre   framing with virtual zero padding (S1), window multiply in T (S4), chirp        x -> A
-//   C2C        forward, length M, its store multiplying by FFT_M(b) / M (k_c2c_reg up to M = 4096; above that k_c2c_tile and
-//              a k_pointwise launch)                                                            A -> B
-//   C2C        inverse (unnormalised)                                                           B -> A
-//   k_bs_post  Z[k] = conj(c_k) Y[k], the two-frame split, k <= N / 2, |.|^2 / sqrt / dB or complex, transposed through LDS
-//              into the reference's [signal][bin][frame] layout (S9)
+// The whole chain runs in ONE kernel with the sequence resident in LDS (k_bs_fused below): framing with virtual zero padding (S1),
+// window x chirp, forward transform, product with FFT_M(b) / M, inverse transform, Z[k] = conj(c_k) Y[k], the two-frame split,
+// |.|^2 / sqrt / dB or complex, stores into the reference's [signal][bin][frame] layout (S9).  M up to 16384 in f32 and 8192 in f64,
+// i.e. n_fft <= 8192 / 4096; beyond that a plan keeps the two-factor kernel or the direct sum.  (Round 3 first built this as four
+// launches per chunk of frame pairs over two [pairs][M] scratch buffers: bound by its six HBM passes — n_fft 1009 616 us against
+// 180 us now, 5003 4.3 ms against 0.48 ms.)
 // Filterbank outputs take the plan's split path: per-bin power here, then k_bank_rows.
 #include "reg_radix.h"
 #include "rr_layout.h"
@@ -46,90 +44,12 @@
 namespace sgx {
 namespace {
 
-template <typename T>
-struct C2 {
-    T re, im;
-};
-
-// sequence q = pair p of signal b (pairs per signal P = ceil(n_frames / 2)): real part frame 2 p, imaginary part frame 2 p + 1
-template <typename T>
-__global__ __launch_bounds__(256) void k_bs_pre(const T *__restrict__ x, const T *__restrict__ win, const C2<T> *__restrict__ chirp,
-                                                C2<T> *__restrict__ a, unsigned long long q0, unsigned M, unsigned n, unsigned hop,
-                                                unsigned pad, unsigned long long n_samples, unsigned long long stride, unsigned n_frames,
-                                                unsigned pairs) {
-    const unsigned m = blockIdx.x * 256u + threadIdx.x;
-    if (m >= M) return;
-    const unsigned long long q = q0 + blockIdx.y;
-    const unsigned long long b = q / pairs;
-    const unsigned f = 2u * (unsigned)(q - b * pairs);
-    C2<T> v = {T(0), T(0)};
-    if (m < n) {
-        const T wm = win[m];
-        const C2<T> c = chirp[m];
-        // virtual index into the zero-padded signal (spectrogram.rs:1301-1320); sample x window in T, then the transform in T (S4)
-        const long long s0 = (long long)f * hop + m - pad, s1 = s0 + hop;
-        const T xa = (s0 >= 0 && (unsigned long long)s0 < n_samples) ? x[b * stride + (unsigned long long)s0] * wm : T(0);
-        const T xb = (f + 1u < n_frames && s1 >= 0 && (unsigned long long)s1 < n_samples) ? x[b * stride + (unsigned long long)s1] * wm : T(0);
-        v.re = xa * c.re - xb * c.im;
-        v.im = xa * c.im + xb * c.re;
-    }
-    a[(unsigned long long)blockIdx.y * M + m] = v;
-}
-
 __device__ __forceinline__ float bs_db(float p) { return __builtin_log2f(p) * 3.01029995663981195f; }  // as the other f32 kernels
 __device__ __forceinline__ double bs_db(double p) { return 10.0 * log10(p); }
 
-// 16 pairs (32 frames) x 32 bins per workgroup: read along bins (contiguous in Y) — bin k and its mirror n - k —, write along
-// frames (contiguous in the output)
-template <typename T>
-__global__ __launch_bounds__(256) void k_bs_post(const C2<T> *__restrict__ y, const C2<T> *__restrict__ chirp, T *__restrict__ out,
-                                                 unsigned long long q0, unsigned count, unsigned M, unsigned n, unsigned nb, unsigned n_frames,
-                                                 unsigned pairs, int complex_out, int amp, T eps) {
-    __shared__ C2<T> tile[32][33];  // [frame within the workgroup][bin]
-    const unsigned tx = threadIdx.x & 31u, ty = threadIdx.x >> 5;
-    const unsigned k0 = blockIdx.x * 32u, p0 = blockIdx.y * 16u;
-#pragma unroll
-    for (unsigned r = 0; r < 2; ++r) {
-        const unsigned pl = ty + 8u * r, k = k0 + tx;  // pair within the workgroup
-        C2<T> Xa = {T(0), T(0)}, Xb = {T(0), T(0)};
-        if (p0 + pl < count && k < nb) {
-            const C2<T> *row = y + (unsigned long long)(p0 + pl) * M;
-            const unsigned km = k == 0 ? 0u : n - k;
-            const C2<T> v = row[k], c = chirp[k], vm = row[km], cm = chirp[km];
-            const C2<T> Z = {v.re * c.re - v.im * c.im, v.re * c.im + v.im * c.re};
-            const C2<T> Zm = {vm.re * cm.re - vm.im * cm.im, -(vm.re * cm.im + vm.im * cm.re)};  // conj Z[n - k]
-            Xa.re = T(0.5) * (Z.re + Zm.re);
-            Xa.im = T(0.5) * (Z.im + Zm.im);
-            Xb.re = T(0.5) * (Z.im - Zm.im);   // -i (Z - conj Z[n - k]) / 2
-            Xb.im = T(-0.5) * (Z.re - Zm.re);
-        }
-        tile[2u * pl][tx] = Xa;
-        tile[2u * pl + 1u][tx] = Xb;
-    }
-    __syncthreads();
-#pragma unroll
-    for (unsigned r = 0; r < 4; ++r) {
-        const unsigned k = k0 + ty + 8u * r, fl = tx;  // frame within the workgroup: pair fl / 2, member fl & 1
-        const unsigned long long q = q0 + p0 + (fl >> 1);
-        if (p0 + (fl >> 1) >= count || k >= nb) continue;
-        const unsigned long long b = q / pairs;
-        const unsigned f = 2u * (unsigned)(q - b * pairs) + (fl & 1u);
-        if (f >= n_frames) continue;
-        const C2<T> X = tile[fl][ty + 8u * r];
-        const unsigned long long o = (b * nb + k) * n_frames + f;
-        if (complex_out) {
-            ((C2<T> *)out)[o] = X;
-        } else {
-            const T p = X.re * X.re + X.im * X.im;  // norm_sqr (spectrogram.rs:1332-1334)
-            out[o] = amp == AMP_MAGNITUDE ? sqrt(p) : amp == AMP_DB ? bs_db(p > eps ? p : eps) : p;
-        }
-    }
-}
-
 // ---- the fused kernel ----------------------------------------------------------------------------------------------------
 // One workgroup carries `tile` sequences (frame pairs) through the whole chain in LDS; the only HBM traffic is the samples in
-// and the bins out (the unfused chain above moves six [pairs][M] complex passes: n_fft 1009, 64 x 10 s: 2 GB for 78 MB of
-// input and output, and was bound by exactly that).
+// and the bins out.
 //
 // The length-M transform is k_c2c_reg's (kernels_reg2d.hip): M = A B C, passes P1 (A points, over n1 of n = n1 B C + r), T1
 // (twiddle W_M^(r k1)), P2 (B points), T2, P3 (C points), each in place on the elements its work item owns, bin
@@ -172,7 +92,7 @@ struct BsFused {
 };
 
 template <typename T, int A, int B, int C>
-constexpr unsigned bs_waves() { return SGX_BS_OCC && sizeof(T) == 4 ? SGX_BS_OCC : rr_waves<T, A, B, C>(); }
+constexpr unsigned bs_waves() { return A > 16 ? 1 : SGX_BS_OCC && sizeof(T) == 4 ? SGX_BS_OCC : rr_waves<T, A, B, C>(); }  // 32-point passes: the 512-register budget
 
 template <typename T, int A_, int B_, int C_>
 __global__ __launch_bounds__(256, (bs_waves<T, A_, B_, C_>())) void k_bs_fused(BsFused a, unsigned ltile) {
@@ -421,14 +341,25 @@ __global__ __launch_bounds__(256, (bs_waves<T, A_, B_, C_>())) void k_bs_fused(B
 #endif
 }
 
-size_t bs_lds_budget(int dtype) { return dtype == SGX_F64 ? (size_t)SGX_BS_LDS64 : (size_t)SGX_BS_LDS32; }
+// M = 8192 / 16384 (n_fft 2049 ... 8192): one sequence per workgroup, 32-point first and last pass; 64 / 128 KiB of LDS (f64: 8192 only)
+#define SGX_BS_SPLITS_BIG_F32(X) X(32, 16, 16) X(32, 32, 16)
+#define SGX_BS_SPLITS_BIG_F64(X) X(32, 16, 16)
+constexpr size_t kBsBigLds = 136 * 1024;
+
+size_t bs_lds_budget(int dtype, unsigned M) { return M > 4096 ? kBsBigLds : dtype == SGX_F64 ? (size_t)SGX_BS_LDS64 : (size_t)SGX_BS_LDS32; }
+
+bool bs_split(unsigned M, int dtype, unsigned &fa, unsigned &fb, unsigned &fc) {
+    if (M == 8192) { fa = 32; fb = 16; fc = 16; return true; }
+    if (M == 16384 && dtype == SGX_F32) { fa = 32; fb = 32; fc = 16; return true; }
+    return M <= 4096 && reg_split_len(M, dtype, &fa, &fb, &fc);
+}
 
 bool fused_geometry(unsigned M, int dtype, unsigned &fa, unsigned &fb, unsigned &fc, unsigned &ltile, size_t &lds) {
     if (M & (M - 1)) return false;
-    if (!reg_split_len(M, dtype, &fa, &fb, &fc)) return false;
+    if (!bs_split(M, dtype, fa, fb, fc)) return false;
     const size_t es = dtype == SGX_F64 ? 8 : 4;
     const size_t fs = rr_frame_stride(fa, rr_swizzle(2 * (unsigned)es, fa, fb, fc).rs);
-    const size_t budget = bs_lds_budget(dtype);
+    const size_t budget = bs_lds_budget(dtype, M);
     ltile = 4;  // up to 16 pairs = 32 frames per workgroup
     while (ltile > 0 && (size_t)(1u << ltile) * fs * 2 * es > budget) --ltile;
     lds = (size_t)(1u << ltile) * fs * 2 * es;
@@ -438,7 +369,7 @@ bool fused_geometry(unsigned M, int dtype, unsigned &fa, unsigned &fb, unsigned 
 template <typename T, int A, int B, int C>
 hipError_t launch_fused_t(const BsFused &f, unsigned ltile, size_t lds, hipStream_t s) {
     if (lds > 64 * 1024) {
-        hipError_t e = set_max_dynamic_lds((const void *)k_bs_fused<T, A, B, C>, (int)bs_lds_budget(sizeof(T) == 8 ? SGX_F64 : SGX_F32));
+        hipError_t e = set_max_dynamic_lds((const void *)k_bs_fused<T, A, B, C>, (int)bs_lds_budget(sizeof(T) == 8 ? SGX_F64 : SGX_F32, A * B * C));
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL((k_bs_fused<T, A, B, C>), dim3(xcd_grid(f.tiles)), dim3(256), lds, s, f, ltile);
@@ -464,65 +395,26 @@ hipError_t run_fused(const BsArgs &a, int dtype, hipStream_t s) {
 #define SGX_BSF_F64(A, B, C) if (fa == A && fb == B && fc == C) return launch_fused_t<double, A, B, C>(f, ltile, lds, s);
     if (dtype == SGX_F64) {
         SGX_RR_SPLITS_F64(SGX_BSF_F64)
+        SGX_BS_SPLITS_BIG_F64(SGX_BSF_F64)
     } else {
         SGX_RR_SPLITS_F32(SGX_BSF_F32)
+        SGX_BS_SPLITS_BIG_F32(SGX_BSF_F32)
     }
 #undef SGX_BSF_F32
 #undef SGX_BSF_F64
     return hipErrorNotSupported;
 }
 
-template <typename T>
-hipError_t run_t(const BsArgs &a, int dtype, hipStream_t s) {
-    const unsigned pairs = (a.n_frames + 1u) / 2u;
-    const unsigned long long total = (unsigned long long)a.batch * pairs;
-    const unsigned long long chunk = a.chunk_frames < 32768ull ? a.chunk_frames : 32768ull;  // sequences per pass (grid.y)
-    if (chunk == 0) return hipErrorInvalidConfiguration;
-    for (unsigned long long q0 = 0; q0 < total; q0 += chunk) {
-        const unsigned count = (unsigned)(total - q0 < chunk ? total - q0 : chunk);
-        hipLaunchKernelGGL(k_bs_pre<T>, dim3((a.M + 255u) / 256u, count), dim3(256), 0, s, (const T *)a.x, (const T *)a.window,
-                           (const C2<T> *)a.chirp, (C2<T> *)a.scratch_a, q0, a.M, a.n_fft, a.hop, a.pad, a.n_samples, a.sample_stride, a.n_frames,
-                           pairs);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        C2cArgs c{};
-        c.in = a.scratch_a; c.out = a.scratch_b;
-        c.n = a.M; c.log2n = a.log2M; c.nseq = count; c.batch = 1;
-        c.in_img = c.out_img = 0;
-        c.in_ss = c.out_ss = a.M; c.in_is = c.out_is = 1;
-        c.tile = a.c2c_tile; c.tiles = c.tile ? (count + c.tile - 1) / c.tile : 0;
-        c.tw = a.tw_m; c.inverse = 0; c.in_seq_fast = 0; c.out_seq_fast = 0; c.scale = 1.0;
-        c.mul = a.bhat; c.mul_ks = 1; c.mul_real = 0; c.mul_bcast = 1;  // the product with the transformed chirp rides the store
-        e = launch_c2c_reg(c, dtype, s);
-        if (e == hipErrorNotSupported) {  // above the register-tiled range: LDS-tile transform, then the product as its own pass
-            c.mul = nullptr;
-            if ((e = launch_c2c_tile(c, dtype, s)) != hipSuccess) return e;
-            e = launch_pointwise(a.scratch_b, a.bhat, a.scratch_b, (unsigned long long)count * a.M, a.M, 0, dtype, s);
-        }
-        if (e != hipSuccess) return e;
-        c.mul = nullptr; c.mul_bcast = 0;
-        c.in = a.scratch_b; c.out = a.scratch_a; c.inverse = 1;
-        if ((e = launch_c2c_any(c, dtype, s)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_bs_post<T>, dim3((a.nb + 31u) / 32u, (count + 15u) / 16u), dim3(256), 0, s, (const C2<T> *)a.scratch_a,
-                           (const C2<T> *)a.chirp, (T *)a.out, q0, count, a.M, a.n_fft, a.nb, a.n_frames, pairs, a.complex_out, a.amp, (T)a.eps);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-    }
-    return hipSuccess;
-}
-
 }  // namespace
 
-// the (A, B, C) split of the fused kernel at convolution length M, or false: the plan then keeps the scratch-buffer chain
+// the (A, B, C) split of the kernel at convolution length M, or false: no chirp-z at this length and type
 bool bluestein_fused_split(unsigned M, int dtype, unsigned *fa, unsigned *fb, unsigned *fc) {
     unsigned ltile;
     size_t lds;
     return fused_geometry(M, dtype, *fa, *fb, *fc, ltile, lds);
 }
 
-hipError_t launch_bluestein(const BsArgs &a, int dtype, hipStream_t s) {
-    if (a.bhat_fused) return run_fused(a, dtype, s);
-    return dtype == SGX_F64 ? run_t<double>(a, dtype, s) : run_t<float>(a, dtype, s);
-}
+hipError_t launch_bluestein(const BsArgs &a, int dtype, hipStream_t s) { return run_fused(a, dtype, s); }
 
 }  // namespace sgx
 

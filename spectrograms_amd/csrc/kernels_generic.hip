@@ -28,6 +28,9 @@
 
 namespace sgx {
 
+#ifndef SGX_RR_STAGGER
+#define SGX_RR_STAGGER 0
+#endif
 #ifdef SGX_RR_STAMPS  // diagnostic build only (tools/stamps_generic.py): a wave's cycles per phase of k_reg_radix
 __device__ unsigned long long g_rr_stamps[32];
 #define RR_STAMP(i)                                                                         \
@@ -428,6 +431,13 @@ __global__ __launch_bounds__(256, (rr_stft_waves<T, A_, B_, C_, STAGED_>())) voi
             for (unsigned n1 = 0; n1 < A; ++n1) asm volatile("" : "+v"(raw[j][n1]));
     }
     __syncthreads();
+#if SGX_RR_STAGGER  // experiment (as k_r32x16's SGX_STAGGER): the workgroups of an XCD start a few hundred cycles apart, so that the
+                    // CUs' store bursts and arithmetic phases do not coincide
+    if (a.out_mode != OUT_MEL) {
+        for (unsigned q = 0; q < (blockIdx.x >> 3) * SGX_RR_STAGGER; ++q) __builtin_amdgcn_s_sleep(1);
+        __syncthreads();
+    }
+#endif
     const unsigned lft = __ffs(a.ft) - 1u;
 #ifdef SGX_RR_STAMPS
     unsigned long long st_acc[16] = {0}, st_prev;

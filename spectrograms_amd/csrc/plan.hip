@@ -14,19 +14,15 @@
 #include "r32x16_layout.h"
 #include "sgx_internal.h"
 
-// chirp-z vs the direct / two-factor sums: multiply-adds per sample the latter may cost, per log2(M) M / n.  The scratch-buffer
-// chain (M > 4096) pays six HBM passes per transform pair; the one-kernel form does not.
+// chirp-z vs the direct / two-factor sums: multiply-adds per sample the latter may cost, per log2(M) M / n.  Measured crossovers
+// (64 x 10 s, hop n / 4, profiles/bench_r03_chirpz_crossover.txt): per-bin outputs win from n_fft 17-18 on (0.25); filterbank outputs
+// pay the split path's second launch and win from n_fft ~46 in f32 (0.65), from 18 in f64 (0.25), where the direct kernels' own
+// filterbank stage is the slow part.
 #ifndef SGX_BS_COST
-#define SGX_BS_COST 6.0
+#define SGX_BS_COST 0.25
 #endif
-// Measured crossovers of the one-kernel form (64 x 10 s, hop n / 4, profiles/bench_r03_chirpz_crossover.txt): per-bin outputs win
-// from n_fft 17-18 on (0.25); filterbank outputs pay the split path's second launch and win from n_fft ~46 in f32 (0.65), from
-// 18 in f64 (0.25), where the direct kernels' own filterbank stage is the slow part.
-#ifndef SGX_BS_COST_FUSED
-#define SGX_BS_COST_FUSED 0.25
-#endif
-#ifndef SGX_BS_COST_FUSED_BANK32
-#define SGX_BS_COST_FUSED_BANK32 0.65
+#ifndef SGX_BS_COST_BANK32
+#define SGX_BS_COST_BANK32 0.65
 #endif
 
 using namespace sgx;
@@ -674,32 +670,25 @@ sgx_status build_device_tables(sgx_plan *pl) {
             twm[2 * k] = std::cos(a);
             twm[2 * k + 1] = std::sin(a);
         }
-        if ((st = upload_cast<T>(pl, &pl->d_bs_chirp, cc)) != SGX_OK) return st;
-        if ((st = upload_cast<T>(pl, &pl->d_bs_bhat, bh)) != SGX_OK) return st;
-        if ((st = upload_cast<T>(pl, &pl->d_bs_tw, twm)) != SGX_OK) return st;
         unsigned fa = 0, fb = 0, fc = 0;
-        if (bluestein_fused_split(M, pl->dtype, &fa, &fb, &fc)) {
-            // the one-kernel form (k_bs_fused): window and chirp as one table, FFT_M(b) / M in the order its product step reads it
-            // — [k3][k1][k2] for bin k1 + A (k2 + B k3), [k2][k1] for the two-pass splits
-            std::vector<double> wc(2 * size_t(n)), bp(2 * size_t(M));
-            for (unsigned j = 0; j < n; ++j) {
-                wc[2 * j] = pl->window[j] * cc[2 * j];
-                wc[2 * j + 1] = pl->window[j] * cc[2 * j + 1];
-            }
-            for (unsigned k = 0; k < M; ++k) {
-                const unsigned k1 = k % fa, k2 = (k / fa) % fb, k3 = k / (fa * fb);
-                const size_t at = fc > 1 ? (size_t(k3) * fa + k1) * fb + k2 : size_t(k2) * fa + k1;
-                bp[2 * at] = bh[2 * k];
-                bp[2 * at + 1] = bh[2 * k + 1];
-            }
-            if ((st = upload_cast<T>(pl, &pl->d_bs_wc, wc)) != SGX_OK) return st;
-            if ((st = upload_cast<T>(pl, &pl->d_bs_bhp, bp)) != SGX_OK) return st;
-        } else {
-            // one frame of scratch now, so that the per-frame entry point (sgx_r2c) never allocates
-            const size_t one = size_t(M) * 2 * pl->elem * 32;
-            if ((st = grow(pl, &pl->d_bs_a, &pl->d_bs_a_bytes, one)) != SGX_OK) return st;
-            if ((st = grow(pl, &pl->d_bs_b, &pl->d_bs_b_bytes, one)) != SGX_OK) return st;
+        if (!bluestein_fused_split(M, pl->dtype, &fa, &fb, &fc)) return set_err(pl, SGX_INTERNAL, "Internal error: chirp-z plan without a pass split");
+        // window and chirp as one table; FFT_M(b) / M in the order the kernel's product step reads it — [k3][k1][k2] for bin
+        // k1 + A (k2 + B k3), [k2][k1] for the two-pass splits
+        std::vector<double> wc(2 * size_t(n)), bp(2 * size_t(M));
+        for (unsigned j = 0; j < n; ++j) {
+            wc[2 * j] = pl->window[j] * cc[2 * j];
+            wc[2 * j + 1] = pl->window[j] * cc[2 * j + 1];
         }
+        for (unsigned k = 0; k < M; ++k) {
+            const unsigned k1 = k % fa, k2 = (k / fa) % fb, k3 = k / (fa * fb);
+            const size_t at = fc > 1 ? (size_t(k3) * fa + k1) * fb + k2 : size_t(k2) * fa + k1;
+            bp[2 * at] = bh[2 * k];
+            bp[2 * at + 1] = bh[2 * k + 1];
+        }
+        if ((st = upload_cast<T>(pl, &pl->d_bs_chirp, cc)) != SGX_OK) return st;
+        if ((st = upload_cast<T>(pl, &pl->d_bs_tw, twm)) != SGX_OK) return st;
+        if ((st = upload_cast<T>(pl, &pl->d_bs_wc, wc)) != SGX_OK) return st;
+        if ((st = upload_cast<T>(pl, &pl->d_bs_bhp, bp)) != SGX_OK) return st;
     }
     return SGX_OK;
 }
@@ -763,29 +752,15 @@ bool set_geometry(const sgx_plan *pl, StftArgs &a, KernelKind kind) {
 
 sgx_status grow(sgx_plan *pl, void **buf, size_t *have, size_t need);
 
-// sequences (frame pairs) of the chirp-z path per pass over its two scratch buffers: <= 1 GiB each, <= 32768 (grid.y)
-unsigned long long bluestein_chunk(const sgx_plan *pl, unsigned long long frames) {
-    const unsigned long long per = (unsigned long long)pl->bs_M * 2ull * pl->elem;
-    unsigned long long c = (1ull << 30) / per;
-    c = std::max<unsigned long long>(32ull, std::min<unsigned long long>(c, 32768ull));
-    return std::min(c, std::max<unsigned long long>(frames, 1ull));
-}
-
 hipError_t launch_bluestein_plan(sgx_plan *pl, const StftArgs &a, hipStream_t s) {
     BsArgs b{};
     b.x = a.x; b.out = a.out;
     b.sample_stride = a.sample_stride; b.n_samples = a.n_samples;
     b.batch = a.batch; b.n_fft = a.n_fft; b.hop = a.hop; b.pad = a.pad; b.n_frames = a.n_frames; b.nb = a.nb_fft;
-    b.M = pl->bs_M; b.log2M = pl->bs_log2M; b.c2c_tile = pl->bs_tile;
-    b.window = a.window; b.chirp = pl->d_bs_chirp; b.bhat = pl->d_bs_bhat; b.tw_m = pl->d_bs_tw;
+    b.M = pl->bs_M;
     // (the per-frame entry point sgx_r2c transforms unwindowed frames: ones x conj(c) is the chirp table itself)
-    b.wc = a.window == pl->d_ones ? pl->d_bs_chirp : pl->d_bs_wc; b.bhat_fused = pl->d_bs_bhp;
-    if (!b.bhat_fused) {  // the scratch-buffer chain (M > 4096)
-        b.chunk_frames = bluestein_chunk(pl, (unsigned long long)a.batch * a.n_frames);
-        const size_t need = size_t(b.chunk_frames) * pl->bs_M * 2 * pl->elem;
-        if (grow(pl, &pl->d_bs_a, &pl->d_bs_a_bytes, need) != SGX_OK || grow(pl, &pl->d_bs_b, &pl->d_bs_b_bytes, need) != SGX_OK) return hipErrorOutOfMemory;
-        b.scratch_a = pl->d_bs_a; b.scratch_b = pl->d_bs_b;
-    }
+    b.wc = a.window == pl->d_ones ? pl->d_bs_chirp : pl->d_bs_wc;
+    b.chirp = pl->d_bs_chirp; b.bhat_fused = pl->d_bs_bhp; b.tw_m = pl->d_bs_tw;
     b.complex_out = a.out_mode == OUT_COMPLEX; b.amp = a.amp; b.eps = a.eps;
     return launch_bluestein(b, pl->dtype, s);
 }
@@ -912,7 +887,7 @@ sgx_status grow(sgx_plan *pl, void **buf, size_t *have, size_t need) {
 
 void free_device(sgx_plan *pl) {
     void **bufs[] = {&pl->d_window, &pl->d_tw, &pl->d_tw1, &pl->d_tw2, &pl->d_mel_ptr, &pl->d_mel_col,
-                     &pl->d_mel_val, &pl->d_dct, &pl->d_lifter, &pl->d_melbuf, &pl->d_pwbuf, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_mm_frag, &pl->d_mm_blk, &pl->d_mel_sched, &pl->d_itw, &pl->d_itwr, &pl->d_itw1, &pl->d_frames, &pl->d_flag, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half, &pl->d_bs_chirp, &pl->d_bs_bhat, &pl->d_bs_tw, &pl->d_bs_a, &pl->d_bs_b, &pl->d_bs_wc, &pl->d_bs_bhp};
+                     &pl->d_mel_val, &pl->d_dct, &pl->d_lifter, &pl->d_melbuf, &pl->d_pwbuf, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_mm_frag, &pl->d_mm_blk, &pl->d_mel_sched, &pl->d_itw, &pl->d_itwr, &pl->d_itw1, &pl->d_frames, &pl->d_flag, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half, &pl->d_bs_chirp, &pl->d_bs_tw, &pl->d_bs_wc, &pl->d_bs_bhp};
     for (void **b : bufs)
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
@@ -1122,10 +1097,10 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
                 ok = true;
             }
         }
-        // Lengths the chain above runs as a direct sum (primes: n / 2 multiply-adds per sample) or as a two-factor transform with a
-        // large factor (n = a b: a + b / 2 per sample) go through the chirp-z transform on the power-of-two kernels instead
-        // (bluestein.hip: two length-M transforms and five passes over a [frames][M] scratch, M >= 2 n - 1) once that is cheaper
-        // — the reference's RustFFT plans such lengths with Rader / Bluestein too (src/fft_backend.rs:376-385).
+        // Lengths the chain above runs as a direct sum (primes: n / 2 multiply-adds per sample) or as a two-factor transform
+        // (n = a b: a + b / 2 per sample) go through the chirp-z transform instead (bluestein.hip: one kernel, the length-M
+        // convolution resident in LDS, M >= 2 n - 1) wherever that is cheaper — the reference's RustFFT plans such lengths with
+        // Rader / Bluestein too (src/fft_backend.rs:376-385).
         {
             const unsigned n = params->n_fft;
             unsigned M = 1, l2 = 0;
@@ -1138,13 +1113,11 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
                     if (n % d == 0) fa = d;
                 per_sample = double(fa) + double(n / fa) / 2.0;
             }
-            const unsigned tile = n >= 16 ? fft2d_tile_for(M, pl->dtype) : 0;
             unsigned fa3 = 0, fb3 = 0, fc3 = 0;
-            const double cost = !bluestein_fused_split(M, pl->dtype, &fa3, &fb3, &fc3)        ? SGX_BS_COST
-                                : pl->out_mode == OUT_MEL && pl->dtype == SGX_F32            ? SGX_BS_COST_FUSED_BANK32
-                                                                                             : SGX_BS_COST_FUSED;
-            if ((!ok || per_sample > cost * double(l2) * double(M) / double(n)) && tile != 0) {
-                pl->bs_M = M; pl->bs_log2M = l2; pl->bs_tile = tile;
+            const bool can = n >= 16 && bluestein_fused_split(M, pl->dtype, &fa3, &fb3, &fc3);
+            const double cost = pl->out_mode == OUT_MEL && pl->dtype == SGX_F32 ? SGX_BS_COST_BANK32 : SGX_BS_COST;
+            if (can && (!ok || per_sample > cost * double(l2) * double(M) / double(n))) {
+                pl->bs_M = M;
                 kind = K_BLUESTEIN;
                 pl->split_bank = pl->out_mode == OUT_MEL;  // per-bin power, then the bank's rows
                 ok = true;
@@ -1397,11 +1370,6 @@ sgx_status sgx_reserve(sgx_plan *plan, size_t batch, size_t n_samples, int32_t h
     if (!inverse && plan->split_bank &&
         (st = grow(plan, &plan->d_pwbuf, &plan->d_pwbuf_bytes, batch * size_t(plan->nb_fft) * nf * plan->elem)) != SGX_OK)
         return st;
-    if (!inverse && plan->kind == K_BLUESTEIN && !plan->d_bs_bhp) {
-        const size_t need = size_t(bluestein_chunk(plan, (unsigned long long)batch * nf)) * plan->bs_M * 2 * plan->elem;
-        if ((st = grow(plan, &plan->d_bs_a, &plan->d_bs_a_bytes, need)) != SGX_OK) return st;
-        if ((st = grow(plan, &plan->d_bs_b, &plan->d_bs_b_bytes, need)) != SGX_OK) return st;
-    }
     if (inverse) {  // sgx_istft of `batch` spectra whose frame count is that of n_samples-long signals
         // the same tests run_istft applies: tuned n_fft = 1024 kernel, else the fused register-tiled kernel; only the unfused
         // fallback (rows + overlap-add) touches the frame scratch

@@ -98,16 +98,11 @@ struct BsArgs {
     void *out;  // [batch][nb][n_frames] T, or complex pairs
     unsigned long long sample_stride, n_samples;
     unsigned batch, n_fft, hop, pad, n_frames, nb;
-    unsigned M, log2M;      // convolution length: the power of two >= 2 n_fft - 1
-    unsigned c2c_tile;      // sequences per workgroup of the LDS-tile C2C kernel at length M (fft2d_tile_for)
-    const void *window;     // [n_fft] T
-    const void *chirp;      // [n_fft] complex T: conj(c_n) = e^(-i pi n^2 / n_fft)
-    const void *bhat;       // [M] complex T: FFT_M of the wrapped chirp, divided by M
+    unsigned M;             // convolution length: the power of two >= 2 n_fft - 1
+    const void *wc;         // [n_fft] complex T: window[m] conj(c_m), c_n = e^(+i pi n^2 / n_fft)
+    const void *chirp;      // [n_fft] complex T: conj(c_n)
+    const void *bhat_fused; // [M] complex T: FFT_M of the wrapped chirp, divided by M, in the order the kernel's product step reads it
     const void *tw_m;       // [M] complex T: e^(-2 pi i k / M)
-    const void *wc;         // fused kernel (M <= 4096): [n_fft] complex T, window[m] conj(c_m); and FFT_M(b) / M in the order its
-    const void *bhat_fused; // product step reads it (bluestein_fused_split); null: the scratch-buffer chain
-    void *scratch_a, *scratch_b;  // [chunk_frames][M] complex T each
-    unsigned long long chunk_frames;
     int complex_out, amp;
     double eps;
 };
@@ -291,9 +286,8 @@ struct sgx_plan {
     void *d_itw = nullptr, *d_frames = nullptr, *d_flag = nullptr;
     void *d_itwr = nullptr, *d_itw1 = nullptr;  // tuned f32 n_fft = 1024 inverse: conj(W_1024^k) [32][16], W_512^(k1 n2) [32][16]
     // K_BLUESTEIN: chirp, transformed chirp, length-M twiddles, two frame scratch buffers (grown on demand, sgx_reserve sizes them)
-    void *d_bs_chirp = nullptr, *d_bs_bhat = nullptr, *d_bs_tw = nullptr, *d_bs_a = nullptr, *d_bs_b = nullptr, *d_bs_wc = nullptr, *d_bs_bhp = nullptr;
-    size_t d_bs_a_bytes = 0, d_bs_b_bytes = 0;
-    unsigned bs_M = 0, bs_log2M = 0, bs_tile = 0;
+    void *d_bs_chirp = nullptr, *d_bs_tw = nullptr, *d_bs_wc = nullptr, *d_bs_bhp = nullptr;
+    unsigned bs_M = 0;
     size_t d_frames_bytes = 0;
 
     // plan-owned staging for host-pointer execution

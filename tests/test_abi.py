@@ -167,10 +167,13 @@ def test_kernel_selection():
     assert host_plan(11, 4).kernel_name == "direct_dft"         # below 16 points the direct sum stays
     assert host_plan(34, 8, mel=sg.MelParams(8, 0.0, 8000.0), dtype="float32").kernel_name == "two_factor_dft"  # short frames into a filterbank (f32): the two-factor kernel's fused bank wins
     assert host_plan(34, 8).kernel_name == "bluestein"
-    # above M = 4096 the chirp-z path is a chain of launches over HBM scratch: only where the sums are far more expensive
+    # n_fft 2049 ... 8192: one 8192- / 16384-point sequence per workgroup (f32), 8192 only in f64
     assert host_plan(5003, 2000, dtype="float32").kernel_name == "bluestein"
-    assert host_plan(3000, 700).kernel_name == "two_factor_dft"  # 50 x 60 stays
-    assert host_plan(4099, 1000, dtype="float64").kernel_name == "direct_dft"  # f64: M = 16384 does not fit the complex kernels' tile
+    assert host_plan(3000, 700).kernel_name == "bluestein"       # 50 x 60: M = 8192
+    assert host_plan(6000, 1500, dtype="float32").kernel_name == "bluestein"
+    assert host_plan(6000, 1500, dtype="float64").kernel_name == "two_factor_dft"  # f64: M = 16384 does not fit LDS
+    assert host_plan(4099, 1000, dtype="float64").kernel_name == "direct_dft"
+    assert host_plan(9001, 1000, dtype="float32").kernel_name == "direct_dft"       # M = 32768: nothing but the sum
 
 
 def test_shard_range_partitions_batch():

@@ -151,21 +151,25 @@ def test_long_frames_filterbank_in_a_second_launch(n_fft, hop, dtype, n_mels, no
     plan-owned tensor, then one wave per (band, 64 frames)): the same terms in the reference's order; frame counts that are not
     multiples of 64, one signal vs the batch, and a second call on the same plan (the tensor is reused)."""
     plan, got = run_case(n=5 * n_fft + 123, batch=3, n_fft=n_fft, hop=hop, n_mels=n_mels, norm=norm, amp=amp, floor=floor, dtype=dtype)
-    assert plan.kernel_name == {(16384, "float32"): "lds_radix2", (8192, "float64"): "lds_radix2", (3000, "float32"): "two_factor_dft",
-                                (6000, "float32"): "two_factor_dft"}.get((n_fft, dtype), "reg_radix")
+    assert plan.kernel_name == {(16384, "float32"): "lds_radix2", (8192, "float64"): "lds_radix2", (3000, "float32"): "bluestein",
+                                (6000, "float32"): "bluestein"}.get((n_fft, dtype), "reg_radix")
     x = signals(3, 5 * n_fft + 123, np.float32 if dtype == "float32" else np.float64, 0)
     assert np.array_equal(np.asarray(plan.compute_batch(x[1:2]))[0], np.asarray(got)[1])
     assert np.array_equal(np.asarray(plan.compute_batch(x)), np.asarray(got))
 
 
-@pytest.mark.parametrize("n_fft,hop,dtype,kernel", [(6000, 1500, "float32", "two_factor_dft"), (6000, 2000, "float64", "two_factor_dft"),
-                                                    (3000, 700, "float64", "two_factor_dft"), (5003, 2000, "float32", "bluestein")])
+@pytest.mark.parametrize("n_fft,hop,dtype,kernel", [(6000, 1500, "float32", "bluestein"), (6000, 2000, "float64", "two_factor_dft"),
+                                                    (3000, 700, "float64", "bluestein"), (5003, 2000, "float32", "bluestein"),
+                                                    (8191, 2048, "float32", "bluestein"), (4099, 1000, "float64", "direct_dft")])
 @pytest.mark.parametrize("amp", ["complex", "power"])
-def test_long_composite_frames_stay_on_the_two_factor_kernel(n_fft, hop, dtype, kernel, amp):
-    """Composite lengths outside the register-tiled lists with tiles above 64 KiB (the large LDS window; f64 6000 without the LDS
-    twiddle copy) run the two-factor kernel, not the O(n^2) direct sum; a prime length takes the chirp-z path."""
-    plan, _ = run_case(n=3 * n_fft + 77, batch=2, n_fft=n_fft, hop=hop, amp=amp, dtype=dtype)
+def test_long_frames_outside_the_register_tiled_lists(n_fft, hop, dtype, kernel, amp):
+    """Frames of 2049 ... 8192 samples that are not a listed size: chirp-z with one 8192- / 16384-point sequence per workgroup in
+    LDS (f32 up to n_fft 8192, f64 up to 4096 — 128 KiB of LDS either way); f64 above 4096 keeps the two-factor kernel (composites)
+    or the direct sum (primes), one frame per tile, twiddle table in global memory."""
+    plan, got = run_case(n=3 * n_fft + 77, batch=2, n_fft=n_fft, hop=hop, amp=amp, dtype=dtype)
     assert plan.kernel_name == kernel
+    x = signals(2, 3 * n_fft + 77, np.float32 if dtype == "float32" else np.float64, 0)
+    assert np.array_equal(np.asarray(plan.compute_batch(x[1:2]))[0], np.asarray(got)[1])
 
 
 MIXED = [80, 120, 160, 200, 240, 320, 400, 480, 600, 640, 800, 960, 1000, 1200, 1440, 1600, 1280, 1920, 2000, 2160, 2400, 2560]
@@ -542,7 +546,7 @@ def test_fuzz_shapes():
                 kw.update(n_mels=int(rng.integers(4, 41)), fmin=0.0, fmax=8000.0, amp="power")
         plan, _ = run_case(n=n, batch=int(rng.integers(1, 4)), seed=case, **kw)
         seen.add(plan.kernel_name)
-    assert {"reg_radix", "two_factor_dft", "direct_dft", "lds_radix2", "bluestein"} <= seen, seen
+    assert {"reg_radix", "direct_dft", "lds_radix2", "bluestein"} <= seen, seen  # (two-factor: its own tests above)
 
 
 def test_config4_shard_full_size_mel_power():
@@ -652,11 +656,10 @@ def test_bluestein_many_frames_one_launch():
     assert np.array_equal(plan.compute_batch(x[3:4])[0], got[3])
 
 
-def test_bluestein_long_frames_in_chunks():
-    """Above M = 4096 (n_fft > 2048) the chirp-z path is a chain of launches over plan-owned scratch, in chunks of at most 1 GiB
-    per buffer: n_fft 4093 (M = 8192, 64 KiB per frame pair -> 16 384 pairs per chunk), 3 x 10 s at hop 12 = 20 001 pairs, the
-    chunk boundary inside the last signal.  That signal against its own single-chunk launch bit for bit; frames from both
-    sides of the boundary against a float64 rfft of the same windowed samples."""
+def test_bluestein_long_frames_many_pairs():
+    """n_fft 4093 (M = 8192: one frame pair per workgroup, 64 KiB of LDS, 32-point first and last pass), 3 x 10 s at hop 12 = 20 001
+    pairs.  The last signal against its own launch bit for bit; frames of every signal against a float64 rfft of the same
+    windowed samples."""
     n_fft, hop, batch, n = 4093, 12, 3, 160000
     plan, op = make(n_fft, hop)
     x = signals(batch, n, np.float32, 5)
@@ -667,7 +670,7 @@ def test_bluestein_long_frames_in_chunks():
     w = orc.make_window("hanning", n_fft)
     pad = n_fft // 2
     xp = np.pad(x.astype(np.float64), ((0, 0), (pad, pad)))
-    for b, f in ((0, 0), (1, nf - 1), (2, 6098), (2, 6099), (2, 6100), (2, 6101), (2, nf - 1)):  # pair 16384 = frames 6100, 6101 of signal 2
+    for b, f in ((0, 0), (0, 1), (1, nf - 1), (2, 6099), (2, 6100), (2, nf - 2), (2, nf - 1)):
         fr = (xp[b, f * hop:f * hop + n_fft].astype(np.float32) * w.astype(np.float32)).astype(np.float64)
         ref = np.abs(np.fft.rfft(fr)) ** 2
         assert np.max(np.abs(got[b, :, f] - ref)) <= GUARD32 * max(1.0, float(ref.max())), (b, f)
