@@ -23,6 +23,10 @@
 // launches per chunk of frame pairs over two [pairs][M] scratch buffers: bound by its six HBM passes — n_fft 1009 616 us against
 // 180 us now, 5003 4.3 ms against 0.48 ms.)
 // Filterbank outputs take the plan's split path: per-bin power here, then k_bank_rows.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
 #include "reg_radix.h"
 #include "rr_layout.h"
 #include "sgx_internal.h"
@@ -77,8 +81,12 @@ __device__ unsigned long long g_bs_stamps[16];
         st_acc[i] += t_ - st_prev;                                                 \
         st_prev = t_;                                                              \
     } while (0)
+#define BS_STAMP_PARAMS , unsigned long long *st_acc, unsigned long long &st_prev
+#define BS_STAMP_ARGS , st_acc, st_prev
 #else
 #define BS_STAMP(i)
+#define BS_STAMP_PARAMS
+#define BS_STAMP_ARGS
 #endif
 
 struct BsFused {
@@ -90,6 +98,95 @@ struct BsFused {
     int complex_out, amp;
     double eps;
 };
+
+// The middle of the convolution, shared by the frame kernel and the complex-sequence kernel: on entry every work item has written
+// its P1 + T1 results to the tile; on return the tile holds conj(T1^-1-input of P1^-1), i.e. what P1^-1's work items read.
+template <typename T, int A_, int B_, int C_>
+__device__ __forceinline__ void bs_middle(typename PairOf<T>::type *buf, unsigned ns, unsigned tid, const typename PairOf<T>::type *tw,
+                                          const typename PairOf<T>::type *bhp BS_STAMP_PARAMS) {
+    typedef typename PairOf<T>::type V;
+    constexpr unsigned A = A_, B = B_, C = C_, N = A * B * C;
+    constexpr int LB = ct_log2_ceil(B);
+    typedef RrLayout<sizeof(V), A_, B_, C_> L;
+    constexpr unsigned RS = L::RS, FS = L::FS;
+    auto wrap = [](unsigned e) { return e & (N - 1); };
+    __syncthreads();
+    BS_STAMP(2);
+    // P2 (+ T2); two-pass splits: P2, product, P2^-1
+    for (unsigned idx = tid; idx < ns * A * C; idx += 256) {
+        const unsigned s = idx / (A * C), q = idx % (A * C), k1 = q / C, n3 = q % C;
+        V *row = buf + (size_t)s * FS + k1 * RS;
+        const unsigned lp = n3 ^ L::k1_mask(k1);
+        V v[B];
+#pragma unroll
+        for (unsigned n2 = 0; n2 < B; ++n2) v[n2] = row[lp ^ L::hi_part(n2)];
+        inreg::MixFft<B, V>::run(v);
+        if constexpr (C > 1) {
+            V q2[LB];
+#pragma unroll
+            for (int j = 0; j < LB; ++j) q2[j] = tw[wrap((A << j) * n3)];
+            row[lp ^ L::hi_part(0)] = v[0];
+#pragma unroll
+            for (unsigned k2 = 1; k2 < B; ++k2) row[lp ^ L::hi_part(k2)] = inreg::cmulv(v[k2], rr_twiddle<LB>(q2, k2));
+        } else {
+#pragma unroll
+            for (unsigned k2 = 0; k2 < B; ++k2) {  // bin k1 + A k2; the table is [k2][k1]
+                const V y = inreg::cmulv(v[k2], bhp[k2 * A + k1]);
+                v[k2] = (V){y.x, -y.y};
+            }
+            inreg::MixFft<B, V>::run(v);
+#pragma unroll
+            for (unsigned n2 = 0; n2 < B; ++n2) row[lp ^ L::hi_part(n2)] = v[n2];
+        }
+    }
+    BS_STAMP(3);
+    __syncthreads();
+    BS_STAMP(4);
+    if constexpr (C > 1) {
+        // P3, product, P3^-1 (from here on the data is the conjugate of the inverse transform's)
+        for (unsigned idx = tid; idx < ns * A * B; idx += 256) {
+            const unsigned s = idx / (A * B), q = idx % (A * B), k1 = q / B, k2 = q % B;
+            V *row = buf + (size_t)s * FS + k1 * RS;
+            const unsigned lp = L::hi_part(k2) ^ L::k1_mask(k1);
+            V v[C], h[C];
+#pragma unroll
+            for (unsigned k3 = 0; k3 < C; ++k3) h[k3] = bhp[k3 * (A * B) + q];  // bin k1 + A (k2 + B k3); the table is [k3][k1][k2]
+#pragma unroll
+            for (unsigned n3 = 0; n3 < C; ++n3) v[n3] = row[lp ^ n3];
+            inreg::MixFft<C, V>::run(v);
+#pragma unroll
+            for (unsigned k3 = 0; k3 < C; ++k3) {
+                const V y = inreg::cmulv(v[k3], h[k3]);
+                v[k3] = (V){y.x, -y.y};
+            }
+            inreg::MixFft<C, V>::run(v);
+#pragma unroll
+            for (unsigned n3 = 0; n3 < C; ++n3) row[lp ^ n3] = v[n3];
+        }
+        BS_STAMP(5);
+        __syncthreads();
+        BS_STAMP(6);
+        // T2, P2
+        for (unsigned idx = tid; idx < ns * A * C; idx += 256) {
+            const unsigned s = idx / (A * C), q = idx % (A * C), k1 = q / C, n3 = q % C;
+            V *row = buf + (size_t)s * FS + k1 * RS;
+            const unsigned lp = n3 ^ L::k1_mask(k1);
+            V q2[LB];
+#pragma unroll
+            for (int j = 0; j < LB; ++j) q2[j] = tw[wrap((A << j) * n3)];
+            V v[B];
+            v[0] = row[lp ^ L::hi_part(0)];
+#pragma unroll
+            for (unsigned k2 = 1; k2 < B; ++k2) v[k2] = inreg::cmulv(row[lp ^ L::hi_part(k2)], rr_twiddle<LB>(q2, k2));
+            inreg::MixFft<B, V>::run(v);
+#pragma unroll
+            for (unsigned n2 = 0; n2 < B; ++n2) row[lp ^ L::hi_part(n2)] = v[n2];
+        }
+        BS_STAMP(7);
+        __syncthreads();
+        BS_STAMP(8);
+    }
+}
 
 template <typename T, int A, int B, int C>
 constexpr unsigned bs_waves() { return A > 16 ? 1 : SGX_BS_OCC && sizeof(T) == 4 ? SGX_BS_OCC : rr_waves<T, A, B, C>(); }  // 32-point passes: the 512-register budget
@@ -202,82 +299,7 @@ __global__ __launch_bounds__(256, (bs_waves<T, A_, B_, C_>())) void k_bs_fused(B
         }
     }
     BS_STAMP(1);
-    __syncthreads();
-    BS_STAMP(2);
-    // P2 (+ T2); two-pass splits: P2, product, P2^-1
-    for (unsigned idx = tid; idx < ns * A * C; idx += 256) {
-        const unsigned s = idx / (A * C), q = idx % (A * C), k1 = q / C, n3 = q % C;
-        V *row = buf + (size_t)s * FS + k1 * RS;
-        const unsigned lp = n3 ^ L::k1_mask(k1);
-        V v[B];
-#pragma unroll
-        for (unsigned n2 = 0; n2 < B; ++n2) v[n2] = row[lp ^ L::hi_part(n2)];
-        inreg::MixFft<B, V>::run(v);
-        if constexpr (C > 1) {
-            V q2[LB];
-#pragma unroll
-            for (int j = 0; j < LB; ++j) q2[j] = tw[wrap((A << j) * n3)];
-            row[lp ^ L::hi_part(0)] = v[0];
-#pragma unroll
-            for (unsigned k2 = 1; k2 < B; ++k2) row[lp ^ L::hi_part(k2)] = inreg::cmulv(v[k2], rr_twiddle<LB>(q2, k2));
-        } else {
-#pragma unroll
-            for (unsigned k2 = 0; k2 < B; ++k2) {  // bin k1 + A k2; the table is [k2][k1]
-                const V y = inreg::cmulv(v[k2], bhp[k2 * A + k1]);
-                v[k2] = (V){y.x, -y.y};
-            }
-            inreg::MixFft<B, V>::run(v);
-#pragma unroll
-            for (unsigned n2 = 0; n2 < B; ++n2) row[lp ^ L::hi_part(n2)] = v[n2];
-        }
-    }
-    BS_STAMP(3);
-    __syncthreads();
-    BS_STAMP(4);
-    if constexpr (C > 1) {
-        // P3, product, P3^-1 (from here on the data is the conjugate of the inverse transform's)
-        for (unsigned idx = tid; idx < ns * A * B; idx += 256) {
-            const unsigned s = idx / (A * B), q = idx % (A * B), k1 = q / B, k2 = q % B;
-            V *row = buf + (size_t)s * FS + k1 * RS;
-            const unsigned lp = L::hi_part(k2) ^ L::k1_mask(k1);
-            V v[C], h[C];
-#pragma unroll
-            for (unsigned k3 = 0; k3 < C; ++k3) h[k3] = bhp[k3 * (A * B) + q];  // bin k1 + A (k2 + B k3); the table is [k3][k1][k2]
-#pragma unroll
-            for (unsigned n3 = 0; n3 < C; ++n3) v[n3] = row[lp ^ n3];
-            inreg::MixFft<C, V>::run(v);
-#pragma unroll
-            for (unsigned k3 = 0; k3 < C; ++k3) {
-                const V y = inreg::cmulv(v[k3], h[k3]);
-                v[k3] = (V){y.x, -y.y};
-            }
-            inreg::MixFft<C, V>::run(v);
-#pragma unroll
-            for (unsigned n3 = 0; n3 < C; ++n3) row[lp ^ n3] = v[n3];
-        }
-        BS_STAMP(5);
-        __syncthreads();
-        BS_STAMP(6);
-        // T2, P2
-        for (unsigned idx = tid; idx < ns * A * C; idx += 256) {
-            const unsigned s = idx / (A * C), q = idx % (A * C), k1 = q / C, n3 = q % C;
-            V *row = buf + (size_t)s * FS + k1 * RS;
-            const unsigned lp = n3 ^ L::k1_mask(k1);
-            V q2[LB];
-#pragma unroll
-            for (int j = 0; j < LB; ++j) q2[j] = tw[wrap((A << j) * n3)];
-            V v[B];
-            v[0] = row[lp ^ L::hi_part(0)];
-#pragma unroll
-            for (unsigned k2 = 1; k2 < B; ++k2) v[k2] = inreg::cmulv(row[lp ^ L::hi_part(k2)], rr_twiddle<LB>(q2, k2));
-            inreg::MixFft<B, V>::run(v);
-#pragma unroll
-            for (unsigned n2 = 0; n2 < B; ++n2) row[lp ^ L::hi_part(n2)] = v[n2];
-        }
-        BS_STAMP(7);
-        __syncthreads();
-        BS_STAMP(8);
-    }
+    bs_middle<T, A_, B_, C_>(buf, ns, tid, tw, bhp BS_STAMP_ARGS);
     // T1, P1, then Z[m] = conj(c_m) y[m] for m < n back to element m's own place
     for (unsigned idx = tid; idx < tile * BC; idx += 256) {
         unsigned s, r;
@@ -339,6 +361,129 @@ __global__ __launch_bounds__(256, (bs_waves<T, A_, B_, C_>())) void k_bs_fused(B
         atomicAdd(&g_bs_stamps[12], 1ull);
     }
 #endif
+}
+
+// ---- complex sequences (columns of the 2-D path, the 1-D C2C plan, Hermitian rows -> real) ------------------------------------
+// The same chain for `tile` complex sequences of length n with k_c2c_reg's addressing (arbitrary element strides on both sides, the
+// thread mapping of the loads / stores follows the unit stride): x[m] conj(c_m) in, conj(c_k) Y[k] out, forward or inverse (conjugate
+// on the way in and out).  HERM: the input is the half spectrum of a real row (n / 2 + 1 bins, the rest by Hermitian symmetry; the
+// imaginary parts of the DC and, for even n, Nyquist bins are dropped and reported as realfft's C2R does, src/fft_backend.rs:782-793)
+// and the output is the row's n real samples, scaled and optionally windowed — the inverse row pass of ifft2d / the per-frame C2R of
+// the generic inverse STFT at lengths without a pass split.
+struct BsC2c {
+    const void *in;
+    void *out;
+    unsigned n, nseq, tiles, total_tiles;  // tiles per image, tiles * batch
+    unsigned long long in_img, out_img, in_ss, in_is, out_ss, out_is;
+    int inverse, in_seq_fast, out_seq_fast;
+    double scale;
+    const void *chirp, *bhp, *tw;
+    const void *win;     // HERM: optional [n] window applied after the scale
+    unsigned *bad_flag;  // HERM: set when a DC / Nyquist bin carries an imaginary part
+};
+
+template <typename T, int A_, int B_, int C_, bool HERM>
+__global__ __launch_bounds__(256, (bs_waves<T, A_, B_, C_>())) void k_bs_c2c(BsC2c a, unsigned ltile) {
+    typedef typename PairOf<T>::type V;
+    constexpr unsigned A = A_, B = B_, C = C_, BC = B * C, N = A * BC, HA = A / 2;
+    constexpr int LA = ct_log2_ceil(A);
+    typedef RrLayout<sizeof(V), A_, B_, C_> L;
+    constexpr unsigned RS = L::RS, FS = L::FS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    V *buf = (V *)smem;  // [tile][FS]
+    const unsigned tid = threadIdx.x, tile = 1u << ltile;
+    const unsigned lb = xcd_logical_block(a.total_tiles);
+    if (lb >= a.total_tiles) return;
+#ifdef SGX_BS_STAMPS
+    unsigned long long st_acc[14] = {0}, st_prev = 0;
+#endif
+    const unsigned t = lb % a.tiles, b = lb / a.tiles;
+    const unsigned s0 = t * tile, ns = min(tile, a.nseq - s0);
+    const V *in = (const V *)a.in + (size_t)b * a.in_img;
+    const V *chirp = (const V *)a.chirp, *bhp = (const V *)a.bhp, *tw = (const V *)a.tw;
+    const unsigned n = a.n, half = n / 2;
+    const T cj = (!HERM && a.inverse) ? T(-1) : T(1);  // inverse = conj(forward(conj x)); HERM is an inverse by construction (below)
+    auto wrap = [](unsigned e) { return e & (N - 1); };
+    auto item = [&](unsigned idx, unsigned &s, unsigned &r) {
+        if (a.in_seq_fast) { s = idx & (tile - 1); r = idx >> ltile; } else { r = idx % BC; s = idx / BC; }
+        return idx < tile * BC && s < ns;
+    };
+    // element m of sequence s, conjugated for an inverse transform.  HERM: X[m] = in[m] (m <= n / 2), conj(in[n - m]) above; the
+    // real row is x = IDFT(X) = conj(DFT(conj X)), and conj X is again Hermitian, so Re(DFT(conj X)) is the answer: no conj out.
+    auto element = [&](const V *seq, unsigned m) {
+        if constexpr (HERM) {
+            const bool up = m > half;
+            V v = seq[(size_t)(up ? n - m : m) * a.in_is];
+            if (m == 0 || (2 * m == n)) {
+                if (v.y != T(0) && a.bad_flag) *a.bad_flag = 1u;
+                v.y = T(0);
+            }
+            return (V){v.x, up ? v.y : -v.y};  // conj X[m]
+        } else {
+            const V v = seq[(size_t)m * a.in_is];
+            return (V){v.x, cj * v.y};
+        }
+    };
+    for (unsigned idx = tid; idx < tile * BC; idx += 256) {
+        unsigned s, r;
+        if (!item(idx, s, r)) continue;
+        const V *seq = in + (size_t)(s0 + s) * a.in_ss;
+        V v[A];
+#pragma unroll
+        for (unsigned n1 = 0; n1 < HA; ++n1) {
+            const unsigned m = n1 * BC + r;
+            v[n1] = m < n ? inreg::cmulv(element(seq, m), chirp[m]) : (V){T(0), T(0)};
+            v[n1 + HA] = (V){T(0), T(0)};
+        }
+        inreg::MixFft<A, V>::run(v);
+        V pw2[LA];
+#pragma unroll
+        for (int j = 0; j < LA; ++j) pw2[j] = tw[wrap((1u << j) * r)];
+        V *dst = buf + (size_t)s * FS;
+        const unsigned pp = L::hi_part(r / C) ^ (r % C);
+        dst[pp ^ L::k1_mask(0)] = v[0];
+#pragma unroll
+        for (unsigned k1 = 1; k1 < A; ++k1) (dst + (pp ^ L::k1_mask(k1)))[k1 * RS] = inreg::cmulv(v[k1], rr_twiddle<LA>(pw2, k1));
+    }
+    bs_middle<T, A_, B_, C_>(buf, ns, tid, tw, bhp BS_STAMP_ARGS);
+    for (unsigned idx = tid; idx < tile * BC; idx += 256) {
+        unsigned s, r;
+        if (!item(idx, s, r)) continue;
+        V ch[HA];
+#pragma unroll
+        for (unsigned n1 = 0; n1 < HA; ++n1) ch[n1] = n1 * BC + r < n ? chirp[n1 * BC + r] : (V){T(0), T(0)};
+        V pw2[LA];
+#pragma unroll
+        for (int j = 0; j < LA; ++j) pw2[j] = tw[wrap((1u << j) * r)];
+        V *dst = buf + (size_t)s * FS;
+        const unsigned pp = L::hi_part(r / C) ^ (r % C);
+        V v[A];
+        v[0] = dst[pp ^ L::k1_mask(0)];
+#pragma unroll
+        for (unsigned k1 = 1; k1 < A; ++k1) v[k1] = inreg::cmulv((dst + (pp ^ L::k1_mask(k1)))[k1 * RS], rr_twiddle<LA>(pw2, k1));
+        inreg::MixFft<A, V>::run(v);
+#pragma unroll
+        for (unsigned n1 = 0; n1 < HA; ++n1) {
+            const V y = {v[n1].x, -v[n1].y};
+            (dst + (pp ^ L::k1_mask(n1)))[n1 * RS] = inreg::cmulv(y, ch[n1]);
+        }
+    }
+    __syncthreads();
+    const T sc = (T)a.scale;
+    for (unsigned idx = tid; idx < tile * n; idx += 256) {
+        unsigned s, k;
+        if (a.out_seq_fast) { s = idx & (tile - 1); k = idx >> ltile; } else { k = idx % n; s = idx / n; }
+        if (s >= ns) continue;
+        const unsigned n1 = k / BC, r = k % BC;
+        const V Z = buf[(size_t)s * FS + n1 * RS + ((L::hi_part(r / C) ^ (r % C)) ^ L::k1_mask(n1))];
+        if constexpr (HERM) {
+            T x = Z.x * sc;
+            if (a.win) x *= ((const T *)a.win)[k];
+            ((T *)a.out + (size_t)b * a.out_img)[(size_t)(s0 + s) * a.out_ss + (size_t)k * a.out_is] = x;
+        } else {
+            ((V *)a.out + (size_t)b * a.out_img)[(size_t)(s0 + s) * a.out_ss + (size_t)k * a.out_is] = Z * (V){sc, cj * sc};
+        }
+    }
 }
 
 // M = 8192 / 16384 (n_fft 2049 ... 8192): one sequence per workgroup, 32-point first and last pass; 64 / 128 KiB of LDS (f64: 8192 only)
@@ -405,6 +550,45 @@ hipError_t run_fused(const BsArgs &a, int dtype, hipStream_t s) {
     return hipErrorNotSupported;
 }
 
+template <typename T, int A, int B, int C>
+hipError_t launch_bsc_t(const BsC2c &f, bool herm, unsigned ltile, size_t lds, hipStream_t s) {
+    if (lds > 64 * 1024) {
+        const int cap = (int)bs_lds_budget(sizeof(T) == 8 ? SGX_F64 : SGX_F32, A * B * C);
+        hipError_t e = herm ? set_max_dynamic_lds((const void *)k_bs_c2c<T, A, B, C, true>, cap) : set_max_dynamic_lds((const void *)k_bs_c2c<T, A, B, C, false>, cap);
+        if (e != hipSuccess) return e;
+    }
+    if (herm) hipLaunchKernelGGL((k_bs_c2c<T, A, B, C, true>), dim3(xcd_grid(f.total_tiles)), dim3(256), lds, s, f, ltile);
+    else hipLaunchKernelGGL((k_bs_c2c<T, A, B, C, false>), dim3(xcd_grid(f.total_tiles)), dim3(256), lds, s, f, ltile);
+    return hipGetLastError();
+}
+
+hipError_t run_bsc(BsC2c f, bool herm, unsigned M, unsigned batch, int dtype, hipStream_t s) {
+    unsigned fa, fb, fc, ltile;
+    size_t lds;
+    if (!fused_geometry(M, dtype, fa, fb, fc, ltile, lds)) return hipErrorNotSupported;
+    ltile = std::min(ltile + 1u, 5u);  // (fused_geometry caps at 16 frame pairs; sequences: up to 32, no more than the job has)
+    const size_t es = dtype == SGX_F64 ? 8 : 4;
+    const size_t fs = rr_frame_stride(fa, rr_swizzle(2 * (unsigned)es, fa, fb, fc).rs);
+    while (ltile > 0 && ((size_t)(1u << ltile) * fs * 2 * es > bs_lds_budget(dtype, M) || (1u << (ltile - 1)) >= f.nseq)) --ltile;
+    lds = (size_t)(1u << ltile) * fs * 2 * es;
+    f.tiles = (f.nseq + (1u << ltile) - 1) >> ltile;
+    const unsigned long long total = (unsigned long long)f.tiles * batch;
+    if (total == 0 || total >= 0x7fffffffull) return hipErrorInvalidConfiguration;
+    f.total_tiles = (unsigned)total;
+#define SGX_BSC_F32(A, B, C) if (fa == A && fb == B && fc == C) return launch_bsc_t<float, A, B, C>(f, herm, ltile, lds, s);
+#define SGX_BSC_F64(A, B, C) if (fa == A && fb == B && fc == C) return launch_bsc_t<double, A, B, C>(f, herm, ltile, lds, s);
+    if (dtype == SGX_F64) {
+        SGX_RR_SPLITS_F64(SGX_BSC_F64)
+        SGX_BS_SPLITS_BIG_F64(SGX_BSC_F64)
+    } else {
+        SGX_RR_SPLITS_F32(SGX_BSC_F32)
+        SGX_BS_SPLITS_BIG_F32(SGX_BSC_F32)
+    }
+#undef SGX_BSC_F32
+#undef SGX_BSC_F64
+    return hipErrorNotSupported;
+}
+
 }  // namespace
 
 // the (A, B, C) split of the kernel at convolution length M, or false: no chirp-z at this length and type
@@ -415,6 +599,85 @@ bool bluestein_fused_split(unsigned M, int dtype, unsigned *fa, unsigned *fb, un
 }
 
 hipError_t launch_bluestein(const BsArgs &a, int dtype, hipStream_t s) { return run_fused(a, dtype, s); }
+
+// Host side of the tables for transform length n: M, conj(c) [n], FFT_M(b) / M in the kernel's product order [M], W_M [M] — all as
+// interleaved (re, im) doubles for the caller to cast and upload.  false: no chirp-z at this length and type.
+bool bluestein_host_tables(unsigned n, int dtype, BsHostTables &t) {
+    if (n < 2) return false;
+    unsigned M = 1, l2 = 0;
+    while (M < 2 * n - 1) { M <<= 1; ++l2; }
+    unsigned fa, fb, fc;
+    if (!bluestein_fused_split(M, dtype, &fa, &fb, &fc)) return false;
+    constexpr double kPi = 3.14159265358979323846264338327950288;
+    t.M = M;
+    t.chirp.assign(2 * size_t(n), 0.0);
+    t.bhp.assign(2 * size_t(M), 0.0);
+    t.tw.assign(2 * size_t(M), 0.0);
+    std::vector<double> bre(M, 0.0), bim(M, 0.0);
+    for (unsigned j = 0; j < n; ++j) {
+        // c_j = e^(+i pi j^2 / n): the angle is reduced in integers, j^2 mod 2 n, so that a large j loses nothing
+        const unsigned long long q = (unsigned long long)j * j % (2ull * n);
+        const double ang = kPi * double(q) / double(n), re = std::cos(ang), im = std::sin(ang);
+        t.chirp[2 * j] = re;
+        t.chirp[2 * j + 1] = -im;  // conj(c_j): multiplies the samples going in and the bins coming out
+        bre[j] = re;
+        bim[j] = im;
+        if (j) { bre[M - j] = re; bim[M - j] = im; }  // b[-j] = c_j
+    }
+    // FFT_M(b) on the host: iterative radix-2, f64
+    for (unsigned i = 1, j = 0; i < M; ++i) {
+        unsigned bit = M >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { std::swap(bre[i], bre[j]); std::swap(bim[i], bim[j]); }
+    }
+    for (unsigned len = 2; len <= M; len <<= 1) {
+        const double ang = -2.0 * kPi / double(len);
+        for (unsigned i = 0; i < M; i += len)
+            for (unsigned k = 0; k < len / 2; ++k) {
+                const double wr = std::cos(ang * k), wi = std::sin(ang * k);
+                const double ur = bre[i + k], ui = bim[i + k];
+                const double vr = bre[i + k + len / 2] * wr - bim[i + k + len / 2] * wi;
+                const double vi = bre[i + k + len / 2] * wi + bim[i + k + len / 2] * wr;
+                bre[i + k] = ur + vr; bim[i + k] = ui + vi;
+                bre[i + k + len / 2] = ur - vr; bim[i + k + len / 2] = ui - vi;
+            }
+    }
+    for (unsigned k = 0; k < M; ++k) {
+        // the inverse transform's 1 / M folded in; [k3][k1][k2] for bin k1 + A (k2 + B k3), [k2][k1] for the two-pass splits
+        const unsigned k1 = k % fa, k2 = (k / fa) % fb, k3 = k / (fa * fb);
+        const size_t at = fc > 1 ? (size_t(k3) * fa + k1) * fb + k2 : size_t(k2) * fa + k1;
+        t.bhp[2 * at] = bre[k] / double(M);
+        t.bhp[2 * at + 1] = bim[k] / double(M);
+        const double a = -2.0 * kPi * double(k) / double(M);
+        t.tw[2 * k] = std::cos(a);
+        t.tw[2 * k + 1] = std::sin(a);
+    }
+    return true;
+}
+
+// complex sequences with C2cArgs' addressing (a.tw / a.tile / a.tiles / a.log2n / a.mul are not used)
+hipError_t launch_c2c_bluestein(const C2cArgs &a, const BsDevTables &t, int dtype, hipStream_t s) {
+    if (a.mul) return hipErrorNotSupported;
+    BsC2c f{};
+    f.in = a.in; f.out = a.out; f.n = a.n; f.nseq = a.nseq;
+    f.in_img = a.in_img; f.out_img = a.out_img; f.in_ss = a.in_ss; f.in_is = a.in_is; f.out_ss = a.out_ss; f.out_is = a.out_is;
+    f.inverse = a.inverse; f.in_seq_fast = a.in_seq_fast; f.out_seq_fast = a.out_seq_fast; f.scale = a.scale;
+    f.chirp = t.chirp; f.bhp = t.bhp; f.tw = t.tw;
+    return run_bsc(f, false, t.M, a.batch, dtype, s);
+}
+
+// half spectrum -> real rows with C2rArgs' addressing (rows = sequences)
+hipError_t launch_c2r_bluestein(const C2rArgs &a, const BsDevTables &t, int dtype, hipStream_t s) {
+    if (a.nbk) return hipErrorNotSupported;  // (the fused overlap-add belongs to k_c2r_reg)
+    BsC2c f{};
+    f.in = a.in; f.out = a.out; f.n = a.ncols; f.nseq = a.nrows;
+    f.in_img = a.in_img; f.out_img = (unsigned long long)a.nrows * a.ncols; f.in_ss = a.in_rs; f.in_is = a.in_ks; f.out_ss = a.ncols; f.out_is = 1;
+    f.inverse = 1; f.in_seq_fast = a.k_fast ? 0 : 1; f.out_seq_fast = 0; f.scale = a.scale;
+    f.chirp = t.chirp; f.bhp = t.bhp; f.tw = t.tw; f.win = a.win; f.bad_flag = a.bad_flag;
+    return run_bsc(f, true, t.M, a.batch, dtype, s);
+}
+
 
 }  // namespace sgx
 

@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 
+#include "reg_radix.h"
 #include "sgx_internal.h"
 
 using namespace sgx;
@@ -23,6 +24,8 @@ struct sgx_fft2d {
     void *d_inter = nullptr, *d_spec = nullptr, *d_kspec = nullptr, *d_mask = nullptr, *d_in = nullptr, *d_out = nullptr, *d_kimg = nullptr;
     size_t inter_bytes = 0, spec_bytes = 0, kspec_bytes = 0, mask_bytes = 0, in_bytes = 0, out_bytes = 0, kimg_bytes = 0;
     unsigned log2r = 0, log2c = 0, tile_r = 0, tile_c = 0;
+    // chirp-z tables for a dimension that is neither a power of two nor a listed size (bluestein.hip): columns (length nrows), inverse rows (ncols)
+    BsDevTables bs_r, bs_c;
     // what d_kspec / d_mask currently hold, and the stream they were produced on: a plan that convolves or filters batch after
     // batch with the same kernel / cut-offs (on the same stream, so the order is the stream's) prepares them once, not per call
     std::vector<unsigned char> kspec_of;
@@ -84,6 +87,41 @@ sgx_status upload_tw(sgx_fft2d *p, void **dst, size_t n) {
     return SGX_OK;
 }
 
+template <typename T>
+sgx_status upload_bs(sgx_fft2d *p, BsDevTables &d, const BsHostTables &h) {
+    auto up = [&](void **dst, const std::vector<double> &v) -> sgx_status {
+        std::vector<T> c(v.begin(), v.end());
+        F2_HIP(p, hipMalloc(dst, c.size() * sizeof(T)));
+        F2_HIP(p, hipMemcpy(*dst, c.data(), c.size() * sizeof(T), hipMemcpyHostToDevice));
+        return SGX_OK;
+    };
+    sgx_status st;
+    if ((st = up(&d.chirp, h.chirp)) != SGX_OK || (st = up(&d.bhp, h.bhp)) != SGX_OK || (st = up(&d.tw, h.tw)) != SGX_OK) return st;
+    d.M = h.M;
+    return SGX_OK;
+}
+
+// would a length take the chirp-z kernels: not a power of two (those have their own radix-2 tile kernel at any size that fits), no
+// register-tiled pass split, and a convolution length that fits LDS
+bool wants_bluestein(size_t n, bool has_split, int dtype, BsHostTables &h) {
+#ifdef SGX_NO_BS_C2C  // A/B builds only: the LDS-tile kernels (two-factor / direct sums) as before
+    return false;
+#endif
+    return n >= 16 && (n & (n - 1)) != 0 && !has_split && bluestein_host_tables(unsigned(n), dtype, h);
+}
+
+// complex sequences: register-tiled passes, else chirp-z, else the LDS-tile kernel (radix-2 / two-factor / direct sum)
+hipError_t c2c_dispatch(const sgx_fft2d *p, const C2cArgs &a, const BsDevTables &bs, hipStream_t s) {
+    hipError_t e = launch_c2c_reg(a, p->dtype, s);
+    if (e == hipErrorNotSupported && bs.M && !a.mul) e = launch_c2c_bluestein(a, bs, p->dtype, s);
+    return e == hipErrorNotSupported ? launch_c2c_tile(a, p->dtype, s) : e;
+}
+hipError_t c2r_dispatch(const sgx_fft2d *p, const C2rArgs &c, hipStream_t s) {
+    hipError_t e = launch_c2r_reg(c, p->dtype, s);
+    if (e == hipErrorNotSupported && p->bs_c.M) e = launch_c2r_bluestein(c, p->bs_c, p->dtype, s);
+    return e == hipErrorNotSupported ? launch_c2r_rows(c, p->dtype, s) : e;
+}
+
 // device pointers in, device pointers out
 // `mul` (optional): kernel spectrum / real mask [R][Cb] multiplied into the result (convolve_fft, filters) — fused into the
 // column kernel's store where the register-tiled kernel runs, a k_pointwise launch otherwise
@@ -111,7 +149,7 @@ sgx_status forward_dev(sgx_fft2d *p, const void *img, size_t batch, void *spec, 
         const hipError_t e = launch_c2c_reg(a, p->dtype, s);
         if (e == hipErrorNotSupported) {
             a.mul = nullptr;
-            F2_HIP(p, launch_c2c_tile(a, p->dtype, s));
+            F2_HIP(p, c2c_dispatch(p, a, p->bs_r, s));
         } else {
             F2_HIP(p, e);
             fused_mul = true;
@@ -142,7 +180,7 @@ sgx_status inverse_dev(sgx_fft2d *p, const void *spec, size_t batch, void *img, 
         F2_HIP(p, launch_c2c1024(a, p->d_tw1c, s));
         c.in_ks = 1; c.in_rs = Cb; c.k_fast = 1;
     } else {
-        F2_HIP(p, launch_c2c_any(a, p->dtype, s));
+        F2_HIP(p, c2c_dispatch(p, a, p->bs_r, s));
         c.in_ks = R; c.in_rs = 1; c.k_fast = 0;
     }
     c.tile = p->tile_c; c.tiles = unsigned((R + c.tile - 1) / c.tile);
@@ -151,7 +189,7 @@ sgx_status inverse_dev(sgx_fft2d *p, const void *spec, size_t batch, void *img, 
         c.tile = 16; c.tiles = unsigned((R + 15) / 16);
         F2_HIP(p, launch_c2r1024(c, p->d_twr, p->d_tw1r, s));
     } else {
-        F2_HIP(p, launch_c2r_any(c, p->dtype, s));
+        F2_HIP(p, c2r_dispatch(p, c, s));
     }
     return SGX_OK;
 }
@@ -192,7 +230,7 @@ sgx_status fused_product_chunk(sgx_fft2d *p, const void *img, size_t batch, cons
         F2_HIP(p, launch_c2r1024(c, p->d_twr, p->d_tw1r, s));
     } else {
         c.tile = p->tile_c; c.tiles = unsigned((R + c.tile - 1) / c.tile);
-        F2_HIP(p, launch_c2r_any(c, p->dtype, s));
+        F2_HIP(p, c2r_dispatch(p, c, s));
     }
     return SGX_OK;
 }
@@ -339,6 +377,17 @@ sgx_status sgx_fft2d_create(size_t nrows, size_t ncols, int32_t dtype, int32_t d
         if (s1 != SGX_OK) return s1;
         s1 = dtype == SGX_F64 ? upload_tw<double>(p, &p->d_tw_c, ncols) : upload_tw<float>(p, &p->d_tw_c, ncols);
         if (s1 != SGX_OK) return s1;
+        {
+            unsigned fa, fb, fc;
+            BsHostTables h;
+            if (wants_bluestein(nrows, reg_split_len(unsigned(nrows), dtype, &fa, &fb, &fc), dtype, h) &&
+                (s1 = dtype == SGX_F64 ? upload_bs<double>(p, p->bs_r, h) : upload_bs<float>(p, p->bs_r, h)) != SGX_OK)
+                return s1;
+            // (the inverse row pass is register-tiled for even ncols whose half has a split)
+            if (wants_bluestein(ncols, ncols % 2 == 0 && reg_split_len(unsigned(ncols / 2), dtype, &fa, &fb, &fc), dtype, h) &&
+                (s1 = dtype == SGX_F64 ? upload_bs<double>(p, p->bs_c, h) : upload_bs<float>(p, p->bs_c, h)) != SGX_OK)
+                return s1;
+        }
         if (dtype == SGX_F32 && nrows == 1024) {
             std::vector<float> t(2 * 32 * 32);
             for (unsigned k1 = 0; k1 < 32; ++k1)
@@ -383,7 +432,8 @@ void sgx_fft2d_destroy(sgx_fft2d *p) {
     if (p->rows) {
         DeviceGuard dg;
         (void)dg.enter(p->device);
-        void *bufs[] = {p->d_tw_r, p->d_tw_c, p->d_tw1c, p->d_twr, p->d_tw1r, p->d_inter, p->d_spec, p->d_kspec, p->d_mask, p->d_in, p->d_out, p->d_kimg};
+        void *bufs[] = {p->d_tw_r, p->d_tw_c, p->d_tw1c, p->d_twr, p->d_tw1r, p->d_inter, p->d_spec, p->d_kspec, p->d_mask, p->d_in, p->d_out, p->d_kimg,
+                        p->bs_r.chirp, p->bs_r.bhp, p->bs_r.tw, p->bs_c.chirp, p->bs_c.bhp, p->bs_c.tw};
         for (void *b : bufs)
             if (b) (void)hipFree(b);
         if (p->aux_stream) (void)hipStreamDestroy(p->aux_stream);
@@ -518,6 +568,7 @@ struct sgx_c2c {
     size_t elem = 4;
     unsigned log2n = 0, tile = 0;
     void *d_tw = nullptr, *d_buf = nullptr, *d_out = nullptr;
+    BsDevTables bs;  // chirp-z tables (lengths without a pass split that are not powers of two)
     mutable std::string err;
 };
 
@@ -544,6 +595,7 @@ sgx_status c2c_run(sgx_c2c *p, void *buf, size_t len, int inverse) {
     a.tile = p->tile; a.tiles = 1;
     a.tw = p->d_tw; a.inverse = inverse; a.in_seq_fast = 0; a.out_seq_fast = 0; a.scale = 1.0;
     hipError_t e = launch_c2c_reg(a, p->dtype, nullptr);  // picks its own tile
+    if (e == hipErrorNotSupported && p->bs.M) e = launch_c2c_bluestein(a, p->bs, p->dtype, nullptr);
     if (e == hipErrorNotSupported) {
         if (p->tile == 0) return fail1(p, SGX_BACKEND, "hip -- FFT backend error: length too large for the on-chip tile");
         e = launch_c2c_tile(a, p->dtype, nullptr);
@@ -588,8 +640,22 @@ sgx_status sgx_c2c_create(size_t n, int32_t dtype, int32_t device, sgx_c2c **out
             ok = hipMemcpy(p->d_tw, t32.data(), 2 * n * 4, hipMemcpyHostToDevice) == hipSuccess;
         }
     }
+    if (ok) {
+        unsigned fa, fb, fc;
+        BsHostTables h;
+        if (wants_bluestein(n, reg_split_len(unsigned(n), dtype, &fa, &fb, &fc), dtype, h)) {
+            auto up = [&](void **dst, const std::vector<double> &v) {
+                if (hipMalloc(dst, v.size() * p->elem) != hipSuccess) return false;
+                if (dtype == SGX_F64) return hipMemcpy(*dst, v.data(), v.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+                std::vector<float> c(v.begin(), v.end());
+                return hipMemcpy(*dst, c.data(), c.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+            };
+            ok = up(&p->bs.chirp, h.chirp) && up(&p->bs.bhp, h.bhp) && up(&p->bs.tw, h.tw);
+            p->bs.M = h.M;
+        }
+    }
     if (!ok) {
-        for (void *b : {p->d_tw, p->d_buf, p->d_out}) if (b) (void)hipFree(b);
+        for (void *b : {p->d_tw, p->d_buf, p->d_out, p->bs.chirp, p->bs.bhp, p->bs.tw}) if (b) (void)hipFree(b);
         delete p;
         return fail1(nullptr, SGX_BACKEND, "hip -- FFT backend error: could not set up the C2C plan (allocation failed)");
     }
@@ -601,7 +667,7 @@ void sgx_c2c_destroy(sgx_c2c *p) {
     if (p->device >= 0) {
         DeviceGuard dg;
         (void)dg.enter(p->device);
-        for (void *b : {p->d_tw, p->d_buf, p->d_out}) if (b) (void)hipFree(b);
+        for (void *b : {p->d_tw, p->d_buf, p->d_out, p->bs.chirp, p->bs.bhp, p->bs.tw}) if (b) (void)hipFree(b);
     }
     delete p;
 }

@@ -962,7 +962,18 @@ sgx_status launch_c2r_frames(sgx_plan *pl, const void *spec, void *frames, size_
     c.scale = pl->dtype == SGX_F64 ? 1.0 / double(n) : double(1.0f / float(n));  // T::one() / T::from_usize(n_fft)
     c.win = win;
     c.bad_flag = (unsigned *)pl->d_flag;
-    SGX_HIP(pl, launch_c2r_any(c, pl->dtype, s));
+    // register-tiled passes; at lengths without a split the chirp-z rows (a plan of such a length carries the tables); else the
+    // LDS-tile rows (radix-2 / two-factor / direct sum)
+    hipError_t e = launch_c2r_reg(c, pl->dtype, s);
+#ifndef SGX_NO_BS_C2C
+    if (e == hipErrorNotSupported && pl->d_bs_bhp && (n & (n - 1)) != 0) {
+        BsDevTables t;
+        t.M = pl->bs_M; t.chirp = pl->d_bs_chirp; t.bhp = pl->d_bs_bhp; t.tw = pl->d_bs_tw;
+        e = launch_c2r_bluestein(c, t, pl->dtype, s);
+    }
+#endif
+    if (e == hipErrorNotSupported) e = launch_c2r_rows(c, pl->dtype, s);
+    SGX_HIP(pl, e);
     return SGX_OK;
 }
 

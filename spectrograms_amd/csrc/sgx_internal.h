@@ -108,6 +108,20 @@ struct BsArgs {
 };
 hipError_t launch_bluestein(const BsArgs &a, int dtype, hipStream_t s);
 bool bluestein_fused_split(unsigned M, int dtype, unsigned *fa, unsigned *fb, unsigned *fc);
+// chirp-z for complex sequences / Hermitian rows at lengths without a pass split (bluestein.hip)
+struct BsHostTables {
+    unsigned M = 0;
+    std::vector<double> chirp, bhp, tw;  // interleaved (re, im): conj(c) [n], FFT_M(b) / M in the kernel's product order [M], W_M [M]
+};
+struct BsDevTables {
+    unsigned M = 0;
+    void *chirp = nullptr, *bhp = nullptr, *tw = nullptr;
+};
+bool bluestein_host_tables(unsigned n, int dtype, BsHostTables &t);
+struct C2cArgs;
+struct C2rArgs;
+hipError_t launch_c2c_bluestein(const C2cArgs &a, const BsDevTables &t, int dtype, hipStream_t s);
+hipError_t launch_c2r_bluestein(const C2rArgs &a, const BsDevTables &t, int dtype, hipStream_t s);
 
 // ---- 2-D FFT path (kernels_fft2d.hip)
 struct C2cArgs {

@@ -116,6 +116,10 @@ def test_host_validation():
                                             # lengths without a register-tiled split: two-factor transform in LDS (1000 = 25 x 40, 1023 = 31 x 33,
                                             # 1001 = 13 x 77), the direct sum where its two buffers do not fit (6000 in f64) or the length is prime
                                             (1000, 6), (6, 1023), (63, 35), (1001, 4), (6000, 2), (509, 3),
+                                            # neither a power of two nor a listed size, 16 ... 8192 (f64: 4096): chirp-z columns (length =
+                                            # rows) and chirp-z inverse rows (length = columns), odd and even, primes and composites
+                                            (251, 509), (509, 251), (1009, 12), (12, 1009), (1023, 1023), (127, 90), (90, 127), (2003, 5),
+                                            (5, 2003), (4093, 3), (3, 4093), (17, 19), (6000, 3), (3, 6000), (98, 94),
                                             # 1000 / 1200 / 1280 as column lengths and as (halved) row lengths: register-tiled, 40-point second pass
                                             (1200, 5), (1280, 3), (5, 2000), (3, 2400), (1080, 6), (6, 1280), (640, 4)])
 def test_gpu_fft2d_matches_oracle(shape, dtype):
@@ -344,6 +348,8 @@ def test_c2c_plan_host_validation():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,dtype,tol", [(8, "float64", 1e-12), (1024, "float32", 2e-6), (1000, "float64", 1e-11), (100, "float32", 2e-6),
+                                         (1009, "float32", 2e-6), (1009, "float64", 1e-11), (251, "float32", 2e-6), (97, "float64", 1e-11), (4093, "float32", 2e-6),
+                                         (5003, "float32", 2e-6), (3000, "float64", 1e-11), (17, "float32", 2e-6),
                                          (7, "float64", 1e-12), (4096, "float64", 1e-11)])
 def test_gpu_c2c_plan_matches_numpy(n, dtype, tol):
     """C2cPlan<T>::forward / inverse (src/fft_backend.rs:113-137): unnormalised both ways; inverse(forward(x)) = n x

@@ -28,7 +28,9 @@ def np_istft(S, n_fft, hop, w, centre):
 
 
 CASES = [(512, 128, True, "hanning"), (512, 256, True, "hanning"), (400, 100, False, "hamming"), (1024, 256, True, "hanning"),
-         (400, 160, True, "blackman"), (256, 256, False, "rectangular"), (8, 3, True, "hanning"), (15, 4, True, "hamming")]
+         (400, 160, True, "blackman"), (256, 256, False, "rectangular"), (8, 3, True, "hanning"), (15, 4, True, "hamming"),
+         # lengths without a pass split: chirp-z rows (odd: the half spectrum has no Nyquist bin)
+         (251, 62, True, "hanning"), (1009, 252, True, "hamming"), (1023, 256, False, "hamming"), (1006, 300, True, "blackman")]
 
 
 @pytest.mark.parametrize("n_fft,hop,centre,window", CASES)

@@ -25,8 +25,11 @@ def timed(fn, iters=3):
 for dtype in os.environ.get("DTYPES", "float32,float64").split(","):
     tdt = torch.float32 if dtype == "float32" else torch.float64
     es = 4 if dtype == "float32" else 8
-    for R, C in ((64, 64), (100, 50), (256, 256), (512, 512), (1000, 1000), (1024, 1000), (1000, 1024), (1023, 1023), (1024, 1024), (2048, 2048), (4096, 4096), (37, 1024),
-                 (1024, 37), (4096, 64)):
+    shapes = ((64, 64), (100, 50), (256, 256), (512, 512), (1000, 1000), (1024, 1000), (1000, 1024), (1023, 1023), (1024, 1024), (2048, 2048), (4096, 4096), (37, 1024),
+              (1024, 37), (4096, 64))
+    if os.environ.get("SHAPES"):  # e.g. SHAPES=1023x1023,509x509
+        shapes = tuple(tuple(int(v) for v in t.split("x")) for t in os.environ["SHAPES"].split(","))
+    for R, C in shapes:
         batch = max(1, (1 << 27) // (R * C) // (es // 4))
         x = torch.randn((batch, R, C), dtype=tdt, device="cuda")
         plan = sg.Fft2dPlan(R, C, dtype)
