@@ -11,8 +11,8 @@ signals that is already resident in HBM.  Workloads (BASELINE.json configs):
 
 The default run (what the driver records) carries, next to the headline line of `--workload` (default linear_power), a
 `workloads` object with short legs of the other BASELINE configurations — mel_power (north_star's target sentence), mel_db
-(configs[2]), config4's per-GPU shard (configs[3]) and configs[4]: fft2d / convolve_fft over 512 x 1024 x 1024 images — each
-with its own ms_per_step, value and roofline; `cold_ms_per_step` (the W + K steps from idle clocks, measured before anything
+(configs[2]), config4's per-GPU shard (configs[3]), configs[4]: fft2d / convolve_fft over 512 x 1024 x 1024 images, and chirpz_1009
+(a prime frame length, 64 utterances: the reference plans every length) — each with its own ms_per_step, value and roofline; `cold_ms_per_step` (the W + K steps from idle clocks, measured before anything
 else has run); `roofline.peak_measured` (sgx_membench: copy / read / write rates of this very device, in-process); and a
 NumPy / pocketfft datapoint inside `cpu_baseline`.  `--no-legs` switches the extra legs off.
 
@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak is ~6290 GB/s
 VALU_PEAK_TFLOPS = 157.3   # FP32 vector peak (same guide)
 FLOPS_PER_FRAME = {"linear_power": 28.1e3, "stft": 26.6e3, "mel_power": 30.1e3, "mel_db": 30.1e3}  # FFT 25.6 k + window 1 k (+ |.|^2 1.5 k, Mel 2 k)
-LEGS = ("mel_power", "mel_db", "config4", "fft2d", "convolve_fft")  # the default run's extra legs (besides the headline workload)
+LEGS = ("mel_power", "mel_db", "config4", "fft2d", "convolve_fft", "chirpz_1009")  # the default run's extra legs (besides the headline workload)
 IMG_SIDE, IMG_BATCH = 1024, 512  # BASELINE configs[4]
 SR, N_FFT, HOP, N_SAMPLES = 16000.0, 1024, 256, 160000
 WORKLOADS = {  # name -> (kernel workload, utterances per GPU, BASELINE config index)
@@ -350,6 +350,42 @@ def stft_leg(torch, sg, dev, name: str, xs256, args, peak):
             "roofline": stft_roofline(kernel_wl, batch, n_frames, kernel_ms, peak)}
 
 
+def chirpz_leg(torch, sg, dev, xs256, args):
+    """A frame length outside the power-of-two / listed sizes (the reference plans every length through RustFFT, src/fft_backend.rs:376-385):
+    n_fft 1009 (prime) / hop 252, linear power, the first 64 utterances of the batch — the chirp-z kernel."""
+    n_fft, hop, batch = 1009, 252, 64
+    params = sg.SpectrogramParams(sg.StftParams(n_fft, hop, sg.WindowType.hanning, True), SR)
+    plan = sg.SpectrogramPlanner().linear_power_plan(params, dtype="float32")
+    n_bins, n_frames = plan.output_shape(N_SAMPLES)
+    xs = [x[:batch].contiguous() for x in xs256]
+    outs = [torch.empty((batch, n_bins, n_frames), dtype=torch.float32, device=dev) for _ in xs]
+    stream = torch.cuda.current_stream(dev)
+
+    def step(i):
+        plan.compute_batch(xs[i % len(xs)], out=outs[i % len(xs)])
+
+    def fence():
+        torch.cuda.synchronize(dev)
+
+    ph = preheat(step, fence, min(args.preheat_s, 0.1))
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    dt, kernel_ms = timed_steps(torch, stream, step, args.steps, fence)
+    frames = batch * n_frames
+    fps = frames / (kernel_ms * 1e-3)
+    bpf = 4.0 * (N_SAMPLES / n_frames) + 4.0 * n_bins  # every sample once + the bins
+    # two length-2048 complex transforms per frame PAIR (5 N log2 N each) + chirps, product and split
+    flops = (2 * 5 * 2048 * 11 + 8 * 2048 + 6 * 2 * n_fft + 10 * n_bins) / 2.0
+    return {"config": f"{batch} x 10 s 16 kHz f32, linear_power n_fft={n_fft} (prime) hop={hop} Hanning centre",
+            "kernel": plan.kernel_name, "steps": args.steps, "warmup": args.warmup, "preheat_steps": ph,
+            "ms_per_step": dt / args.steps * 1e3, "value": frames * args.steps / dt, "unit": "frames/s",
+            "roofline": {"bound": "valu", "achieved": flops * fps / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flops * fps / (VALU_PEAK_TFLOPS * 1e12), "kernel_ms": kernel_ms, "hbm_frac": bpf * fps / 1e9 / HBM_PEAK_GBS,
+                         "flops_per_frame": flops, "algorithmic_bytes_per_frame": bpf, "traffic": None,
+                         "note": "bound by its instruction count (VALU issue 71 % of the kernel's cycles, profiles/r03_chirpz_1009_rocprof_summary.txt); peak = FP32 vector"}}
+
+
 def fft2d_legs(torch, sg, dev, which, args, peak):
     """BASELINE configs[4]: 512 x 1024 x 1024 f32 images, img[r, c] = sin(0.01 r) + cos(0.02 c) + N(0, 0.05^2) (32 distinct noise
     fields, tiled): `fft2d` alone and `convolve_fft` with gaussian_kernel_2d(9, 2.0).  Algorithmic bytes per image: fft2d 4 MiB
@@ -575,7 +611,7 @@ def main() -> int:
         for name in legs:
             if name in ("fft2d", "convolve_fft") or name == args.workload:
                 continue
-            wl[name] = stft_leg(torch, sg, dev, name, xs256, args, peak)
+            wl[name] = chirpz_leg(torch, sg, dev, xs256, args) if name == "chirpz_1009" else stft_leg(torch, sg, dev, name, xs256, args, peak)
             torch.cuda.empty_cache()
         two_d = [l for l in legs if l in ("fft2d", "convolve_fft")]
         if two_d:
