@@ -1015,7 +1015,7 @@ static unsigned reg_radix_waves(size_t es, unsigned fa, unsigned fc, bool staged
 
 // the staged variant is the one to use (see rr_can_stage): per-bin outputs, f32 or the long f64 transforms
 static bool reg_radix_want_staged(const StftArgs &a, unsigned fa, unsigned fc, size_t es) {
-    return SGX_RR_STAGED && a.out_mode != OUT_MEL && (es == 4 || (fa >= 16 && fc > 1));
+    return SGX_RR_STAGED && a.out_mode != OUT_MEL && (es == 4 || SGX_RR_STAGE_F64 || (fa >= 16 && fc > 1));
 }
 
 static bool reg_radix_stage_ok(const StftArgs &a, unsigned ft, unsigned fa, unsigned fb, unsigned fc, size_t es) {

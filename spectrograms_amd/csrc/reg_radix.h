@@ -52,8 +52,11 @@ constexpr unsigned rr_stage_rounds(unsigned m, unsigned elem) { return 2u * m * 
 // Instances that have a staged variant (the host picks it for per-bin outputs: measured faster there — f32 n_fft 512 201 -> 180,
 // 2048 276 -> 244 us — and slower for filterbank outputs, whose kernels wait for no stores, and for f64 below n_fft 2048,
 // where two pass-1 items per thread held across a barrier spill)
+#ifndef SGX_RR_STAGE_F64
+#define SGX_RR_STAGE_F64 0  // experiment: staged samples for every f64 transform
+#endif
 template <typename T, int A, int C>
-constexpr bool rr_can_stage() { return SGX_RR_STAGED && (sizeof(T) == 4 || (A >= 16 && C > 1)); }
+constexpr bool rr_can_stage() { return SGX_RR_STAGED && (sizeof(T) == 4 || SGX_RR_STAGE_F64 || (A >= 16 && C > 1)); }
 
 // k_reg_radix: waves per SIMD (= resident workgroups per CU) the register allocation aims at.  With the twiddle products rebuilt
 // per tile the two-pass f32 instances up to 16-point passes stay under 128 registers.
