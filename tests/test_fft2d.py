@@ -335,6 +335,41 @@ def test_gpu_fft2d_fuzz_shapes():
         assert np.max(np.abs(got - reff)) <= (1e-9 if dtype == "float64" else 3e-5) * max(1.0, np.max(np.abs(reff))), (shape, dtype)
 
 
+@pytest.mark.gpu
+def test_gpu_fft2d_chirpz_fuzz_batched():
+    """Seeded sweep over shapes whose column and / or row length has neither a power of two nor a listed split — chirp-z columns
+    (`k_bs_c2c`) and chirp-z inverse rows (`HERM`) — in BATCHES (several images per call, more images than one tile holds sequences,
+    sequence counts that leave partial tiles): fft2d, ifft2d, convolve_fft and a filter per image against the oracle, both dtypes."""
+    rng = np.random.default_rng(777)
+    odd = [17, 19, 23, 31, 37, 53, 61, 97, 101, 127, 131, 211, 251, 257, 331, 509, 521, 1009, 1021, 2003, 98, 94, 202, 1006, 1023]
+    easy = [16, 20, 64, 100, 128, 256]
+    for case in range(20):
+        pick = rng.integers(3)
+        r = int(odd[rng.integers(len(odd))]) if pick != 1 else int(easy[rng.integers(len(easy))])
+        c = int(odd[rng.integers(len(odd))]) if pick != 0 else int(easy[rng.integers(len(easy))])
+        if r * c > 600000:
+            c = int(easy[rng.integers(len(easy))])
+        dtype = ["float32", "float64"][rng.integers(2)]
+        npdt = np.float32 if dtype == "float32" else np.float64
+        batch = int(rng.integers(1, 6))
+        x = np.stack([img((r, c), 900 + 7 * case + b, npdt) for b in range(batch)])
+        plan = sg.Fft2dPlan(r, c, dtype)
+        S = plan.forward(x)
+        y = plan.inverse(S)
+        k = sg.gaussian_kernel_2d(3, 1.0, dtype=dtype)
+        Y = plan.convolve(x, k)
+        F = plan.filter(x, 1, 0.3, 0.0)
+        tol = 1e-10 if dtype == "float64" else 3e-5
+        for b in range(batch):
+            ref = orc.fft2d(x[b].astype(np.float64))
+            assert np.max(np.abs(S[b] - ref)) <= tol * max(1.0, np.max(np.abs(ref))), (r, c, dtype, b)
+            assert np.max(np.abs(y[b] - x[b])) <= tol * max(1.0, np.max(np.abs(x[b]))), (r, c, dtype, b)
+            refc = orc.convolve_fft(x[b].astype(np.float64), k.astype(np.float64))
+            assert np.max(np.abs(Y[b] - refc)) <= 10 * tol * max(1.0, np.max(np.abs(refc))), (r, c, dtype, b)
+            reff = orc.filter2d(x[b].astype(np.float64), 1, 0.3, 0.0)
+            assert np.max(np.abs(F[b] - reff)) <= 10 * tol * max(1.0, np.max(np.abs(reff))), (r, c, dtype, b)
+
+
 def test_c2c_plan_host_validation():
     p = sg.C2cPlan(16, "float32", device=_ffi.DEVICE_HOST_ONLY)
     with pytest.raises(sg.DimensionMismatchError) as ei:

@@ -549,6 +549,48 @@ def test_fuzz_shapes():
     assert {"reg_radix", "direct_dft", "lds_radix2", "bluestein"} <= seen, seen  # (two-factor: its own tests above)
 
 
+def test_fuzz_chirpz_lengths():
+    """Seeded sweep over frame lengths that take the chirp-z kernel (primes, 2 x prime, odd composites, unlisted even sizes; every
+    convolution length from 64 to 16384): random hop, centre, window, signal length (shorter than a frame included), batch, output
+    mode, both dtypes — against the oracle; a batch's last signal against its own launch."""
+    rng = np.random.default_rng(31337)
+    pool = [17, 23, 37, 61, 97, 127, 129, 251, 257, 509, 521, 1009, 1021, 1023, 1025, 2003, 2039, 2049, 3000, 4093, 100, 441, 98, 1006, 2900]
+    seen_m = set()
+    for case in range(60):
+        n_fft = int(pool[rng.integers(len(pool))])
+        dtype = ["float32", "float64"][rng.integers(2)]
+        if case % 15 == 14:
+            n_fft, dtype = [5003, 6000, 8191][(case // 15) % 3], "float32"
+        hop = int(rng.integers(1, n_fft + 1)) if rng.integers(3) else max(1, n_fft // 4)
+        centre = bool(rng.integers(2))
+        window = sorted(WINDOWS)[rng.integers(len(WINDOWS))]
+        n = int(rng.integers(1, 5 * n_fft + 50))
+        if not centre and n < n_fft:
+            n = n_fft + int(rng.integers(0, 3 * n_fft))
+        n = min(n, 40000 + 2 * n_fft)  # (the oracle's prime lengths are O(n^2))
+        hop = max(hop, (n + n_fft) // 400 + 1)  # at most ~400 frames per signal
+        batch = int(rng.integers(1, 5))
+        kind = rng.integers(4)
+        kw = dict(n_fft=n_fft, hop=hop, centre=centre, window=window, dtype=dtype)
+        if kind == 0:
+            kw["amp"] = "complex"
+        elif kind == 1:
+            kw["amp"] = "power"
+        elif kind == 2:
+            kw.update(amp="db", floor=-80.0)
+        else:
+            kw.update(n_mels=int(rng.integers(4, 41)), fmin=0.0, fmax=8000.0, amp="power")
+        plan, got = run_case(n=n, batch=batch, seed=1000 + case, **kw)
+        assert plan.kernel_name == "bluestein", (n_fft, dtype, kw)
+        x = signals(batch, n, np.float32 if dtype == "float32" else np.float64, 1000 + case)
+        assert np.array_equal(np.asarray(plan.compute_batch(x[batch - 1:]))[0], np.asarray(got)[batch - 1]), (n_fft, dtype, kw)
+        m = 1
+        while m < 2 * n_fft - 1:
+            m *= 2
+        seen_m.add(m)
+    assert {64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384} <= seen_m, sorted(seen_m)
+
+
 def test_config4_shard_full_size_mel_power():
     """BASELINE configs[3], one GPU's shard: 1024 x 10 s utterances, Mel-80 power, ONE launch (40 960 tiles: a different
     persistent-grid regime from configs 2/3).  Oracle on eight rows including the last; over the whole output: finite,
