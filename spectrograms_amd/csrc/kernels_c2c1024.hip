@@ -470,119 +470,185 @@ constexpr int kBWin = kBTw + 4096;       // 71 936: the window (4096 B): 32 ds_r
                                          // in-order vector-memory pipe
 constexpr int kBLds = kBWin + 4096;      // 76 032 B -> two workgroups per CU
 
-__global__ __launch_bounds__(256, 2) void k_istft1024b(IstftArgs a, const v2f *twr, const v2f *tw1) {
+#ifndef SGX_ISTFT_NT
+#define SGX_ISTFT_NT 0
+#endif
+#ifdef SGX_IS_STAMPS  // diagnostic build only (tools/stamps_istft.py): a wave's cycles per phase of k_istft1024b
+__device__ unsigned long long g_is_stamps[16];
+#define IS_STAMP(i)                                                                \
+    do {                                                                           \
+        unsigned long long t_;                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+        st_acc[i] += t_ - st_prev;                                                 \
+        st_prev = t_;                                                              \
+    } while (0)
+#else
+#define IS_STAMP(i)
+#endif
+// Persistent form (round 3): a workgroup walks its XCD's run of tiles (neighbouring tiles share their 3 halo frames in L2) and
+// requests the NEXT tile's 33 spectrum pairs per lane as soon as the current tile's have been folded, so that they are in flight during
+// the 32-point transforms, the windowing and the overlap-add.  Measured: 310-322 us per 256 x [513, 626] against 312 us for one tile
+// per workgroup — no gain: the phase stamps (profiles/r03_istft_stamps_pmc.txt) show a third of a wave's time going into ISSUING those 33
+// loads (~290 cycles each: the read path is back-pressured, TCP pending stalls 45 % of the CU cycles on 128-byte row segments at a
+// 5008-byte pitch) and another third into the overlap-add's stores queued behind them; VALU issue is 33 %.  Non-temporal loads:
+// 355 us.
+__global__ __launch_bounds__(256, 2) void k_istft1024b(IstftArgs a, const v2f *twr, const v2f *tw1, unsigned per_xcd, unsigned total,
+                                                       unsigned slots) {
     constexpr unsigned NF = 16, NT = 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned tid = threadIdx.x;
-    const unsigned lb = xcd_logical_block(a.tiles * a.batch);
-    if (lb >= a.tiles * a.batch) return;
-    const unsigned t = lb % a.tiles, b = lb / a.tiles;
-    const long long h0 = (long long)t * a.nbk;      // first hop block of this tile
-    const long long fbase = h0 - (long long)a.ov;   // frame held in row 0
     v2f *twl = (v2f *)(smem + kBTw);
     twl[tid] = twr[tid];
     twl[tid + 256u] = twr[tid + 256u];
     ((v4f *)(smem + kBWin))[tid] = ((const v4f *)a.win)[tid];
     __syncthreads();
-    {
-        const unsigned lane = tid & 63u, jq = lane >> 4, fl = lane & 15u;
-        const unsigned j = (tid >> 6) + 4u * jq;
-        const bool j0 = j == 0u;
-        const long long f = fbase + fl;
-        const bool valid = f >= 0 && f < (long long)a.n_frames;
-        const float vm = valid ? 1.f : 0.f;  // a frame outside the signal reads frame 0 and is zeroed in the fold
-        const unsigned fcl = valid ? (unsigned)f : 0u;
+    const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const unsigned lo = xcd * per_xcd, hi = min(lo + per_xcd, total);
+    const unsigned lane = tid & 63u, jq = lane >> 4, fl = lane & 15u;
+    const unsigned j = (tid >> 6) + 4u * jq;
+    const bool j0 = j == 0u;
+    const unsigned nf8 = a.n_frames * 8u;
+    // pair p: bin kp and its mirror 512 - kp.  General job: kp = j + 32 p.  Job 0: kp = 16 + 32 p (row 16) for p < 8 and
+    // kp = 32 (p - 8) (row 0) for p >= 8; bin 256 pairs with itself and is handled apart.
+    const unsigned ka = j0 ? 16u : j, kb = j0 ? 0u : j + 256u;
+    const unsigned st = 32u * nf8;  // byte offsets are stepped by 32 bins (no per-load multiply)
+    v2f P[16], Q[16], X256;
+    auto request = [&](unsigned w) {
+        const unsigned t = w % a.tiles, b = w / a.tiles;
+        const long long f = (long long)t * a.nbk - (long long)a.ov + fl;
+        const unsigned fcl = (f >= 0 && f < (long long)a.n_frames) ? (unsigned)f : 0u;  // a frame outside the signal reads frame 0 and is zeroed in the fold
         const unsigned char *inb = (const unsigned char *)a.spec + (size_t)b * 513u * a.n_frames * 8u;
-        const unsigned nf8 = a.n_frames * 8u;
-        // pair p: bin kp and its mirror 512 - kp.  General job: kp = j + 32 p.  Job 0: kp = 16 + 32 p (row 16) for p < 8 and
-        // kp = 32 (p - 8) (row 0) for p >= 8; bin 256 pairs with itself and is handled apart.
-        const unsigned ka = j0 ? 16u : j, kb = j0 ? 0u : j + 256u;
-        v2f PA[16], QB[16];
-        // byte offsets of bin kp and of its mirror, stepped by 32 bins (no per-load multiply); the twiddles sit 32 entries apart
-        const unsigned st = 32u * nf8;
         unsigned oa = ka * nf8 + fcl * 8u, oy = (512u - ka) * nf8 + fcl * 8u;
-        const v2f *tp = twl + ka;
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
             if (p == 8) {
                 oa = kb * nf8 + fcl * 8u;
                 oy = (512u - kb) * nf8 + fcl * 8u;
-                tp = twl + kb;
             }
-            v2f P = *(const v2f *)(inb + oa);
-            v2f Q = *(const v2f *)(inb + oy);
+#if SGX_ISTFT_NT  // experiment: streaming (non-temporal) loads — every pair is read once
+            P[p] = __builtin_nontemporal_load((const v2f *)(inb + oa));
+            Q[p] = __builtin_nontemporal_load((const v2f *)(inb + oy));
+#else
+            P[p] = *(const v2f *)(inb + oa);
+            Q[p] = *(const v2f *)(inb + oy);
+#endif
             oa += st;
             oy -= st;
-            if (p == 8) {  // job 0: kp = 0 — DC and Nyquist bins: realfft ignores (and reports) their imaginary parts
-                if (j0) {
-                    if (a.bad_flag && valid && (P.y != 0.f || Q.y != 0.f)) atomicOr(a.bad_flag, 1u);
-                    P.y = 0.f;
-                    Q.y = 0.f;
-                }
-            }
-            const v2f cw = tp[32 * (p & 7)];  // conj(W_1024^kp)
-            const v2f S = pfma(Q, (v2f){1.f, -1.f}, P), D = pfma(Q, (v2f){-1.f, 1.f}, P);
-            const v2f T = cmulv(D, cw);
-            PA[p] = pfma(swp(T), (v2f){-vm, -vm}, S * (v2f){vm, -vm});  // conj(S + i T)
-            QB[p] = pfma(swp(T), (v2f){vm, -vm}, S * (v2f){vm, vm});    // S - i T
         }
-        v2f A[16], B[16];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            A[i] = j0 ? PA[8 + i] : PA[i];        // job 0: v[32 i]
-            B[8 + i] = QB[7 - i];                 // both: element 15 - p of the mirror row, p = 7 - i
-            B[i] = j0 ? PA[i] : QB[15 - i];       // job 0: v[16 + 32 i]
-        }
+        X256 = *(const v2f *)(inb + 256u * nf8 + fcl * 8u);
+    };
+    unsigned w = lo + slot;
+    if (w < hi) request(w);
+#ifdef SGX_IS_STAMPS
+    unsigned long long st_acc[12] = {0}, st_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+#endif
+    for (; w < hi; w += slots) {
+        const unsigned t = w % a.tiles, b = w / a.tiles;
+        const long long h0 = (long long)t * a.nbk;      // first hop block of this tile
+        const long long fbase = h0 - (long long)a.ov;   // frame held in row 0
         {
+            const long long f = fbase + fl;
+            const bool valid = f >= 0 && f < (long long)a.n_frames;
+            const float vm = valid ? 1.f : 0.f;
+            v2f PA[16], QB[16];
+            const v2f *tp = twl + ka;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                if (p == 8) tp = twl + kb;
+                v2f Pp = P[p], Qp = Q[p];
+                if (p == 8) {  // job 0: kp = 0 — DC and Nyquist bins: realfft ignores (and reports) their imaginary parts
+                    if (j0) {
+                        if (a.bad_flag && valid && (Pp.y != 0.f || Qp.y != 0.f)) atomicOr(a.bad_flag, 1u);
+                        Pp.y = 0.f;
+                        Qp.y = 0.f;
+                    }
+                }
+                const v2f cw = tp[32 * (p & 7)];  // conj(W_1024^kp)
+                const v2f S = pfma(Qp, (v2f){1.f, -1.f}, Pp), D = pfma(Qp, (v2f){-1.f, 1.f}, Pp);
+                const v2f T = cmulv(D, cw);
+                PA[p] = pfma(swp(T), (v2f){-vm, -vm}, S * (v2f){vm, -vm});  // conj(S + i T)
+                QB[p] = pfma(swp(T), (v2f){vm, -vm}, S * (v2f){vm, vm});    // S - i T
+            }
+            v2f A[16], B[16];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                A[i] = j0 ? PA[8 + i] : PA[i];        // job 0: v[32 i]
+                B[8 + i] = QB[7 - i];                 // both: element 15 - p of the mirror row, p = 7 - i
+                B[i] = j0 ? PA[i] : QB[15 - i];       // job 0: v[16 + 32 i]
+            }
             // job 0, bin 256: v[256] = conj(Z'[256]) = 2 X[256]
-            const v2f X256 = *(const v2f *)(inb + 256u * nf8 + fcl * 8u);
             A[8] = j0 ? X256 * (v2f){2.f * vm, 2.f * vm} : PA[8];
 #pragma unroll
             for (int i = 1; i < 8; ++i) A[8 + i] = j0 ? QB[16 - i] : PA[8 + i];  // job 0: v[512 - 32 (8 - i)] = v[32 (8 + i)]
-        }
-        Fft<16, false>::run(A, A);
-        Fft<16, false>::run(B, B);
-        const unsigned ra = j, rb = j0 ? 16u : 32u - j;
-        v4f *da = (v4f *)(smem + fl * kBFS + ra * 128u), *db = (v4f *)(smem + fl * kBFS + rb * 128u);
+            IS_STAMP(0);  // wait for the pairs + fold
+            // the pairs are consumed: the next tile's go out now and land during the rest of this tile
+            if (w + slots < hi) request(w + slots);
+            IS_STAMP(1);  // request issue
+            Fft<16, false>::run(A, A);
+            Fft<16, false>::run(B, B);
+            const unsigned ra = j, rb = j0 ? 16u : 32u - j;
+            v4f *da = (v4f *)(smem + fl * kBFS + ra * 128u), *db = (v4f *)(smem + fl * kBFS + rb * 128u);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            da[c] = (v4f){A[2 * c].x, A[2 * c].y, A[2 * c + 1].x, A[2 * c + 1].y};
-            db[c] = (v4f){B[2 * c].x, B[2 * c].y, B[2 * c + 1].x, B[2 * c + 1].y};
+            for (int c = 0; c < 8; ++c) {
+                da[c] = (v4f){A[2 * c].x, A[2 * c].y, A[2 * c + 1].x, A[2 * c + 1].y};
+                db[c] = (v4f){B[2 * c].x, B[2 * c].y, B[2 * c + 1].x, B[2 * c + 1].y};
+            }
         }
+        IS_STAMP(2);  // 16-point transforms + exchange writes
+        __syncthreads();
+        IS_STAMP(3);
+        const unsigned f2 = tid >> 4, n2 = tid & 15u;
+        v2f v[32];
+        {
+            const unsigned char *src = smem + f2 * kBFS + n2 * 8u;
+#pragma unroll
+            for (int k1 = 0; k1 < 32; ++k1) v[k1] = *(const v2f *)(src + k1 * 128);
+            v2f twa[4], twb[8];  // W_512^(k1 n2) = twa[k1 >> 3] * twb[k1 & 7]
+#pragma unroll
+            for (int q = 0; q < 4; ++q) twa[q] = tw1[16 * 8 * q + n2];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) twb[q] = tw1[16 * q + n2];
+#pragma unroll
+            for (int k1 = 1; k1 < 32; ++k1) {
+                const int qa = k1 >> 3, qb = k1 & 7;
+                if (qb) v[k1] = cmulv(v[k1], twb[qb]);
+                if (qa) v[k1] = cmulv(v[k1], twa[qa]);
+            }
+            Fft<32, false>::run(v, v);
+        }
+        IS_STAMP(4);  // column reads, twiddles, 32-point transform
+        __syncthreads();  // exchange buffer consumed: overlay the real frames
+        IS_STAMP(5);
+        {
+            const v2f *w2 = (const v2f *)(smem + kBWin) + n2;
+            v2f *fr2 = (v2f *)smem + f2 * 512u + n2;
+#pragma unroll
+            for (int n1 = 0; n1 < 32; ++n1) {
+                const v2f ww = w2[16 * n1];
+                const v2f sc = v[n1] * (v2f){a.scale, -a.scale};  // conj + 1/n: (x[2n], x[2n+1]), n = n2 + 16 n1
+                fr2[16 * n1] = (v2f){__fmul_rn(sc.x, ww.x), __fmul_rn(sc.y, ww.y)};
+            }
+        }
+        IS_STAMP(6);  // scale, window, frame writes
+        __syncthreads();
+        IS_STAMP(7);
+        istft_ola<NF, NT>(a, smem, tid, b, h0, fbase);
+        IS_STAMP(8);  // overlap-add, normalise, stores
+        __syncthreads();  // the frames are consumed: the next tile's exchange rows may overwrite them
+        IS_STAMP(9);
+#ifdef SGX_IS_STAMPS
+        st_acc[10] += 1;
+#endif
     }
-    __syncthreads();
-    const unsigned f2 = tid >> 4, n2 = tid & 15u;
-    v2f v[32];
-    {
-        const unsigned char *src = smem + f2 * kBFS + n2 * 8u;
-#pragma unroll
-        for (int k1 = 0; k1 < 32; ++k1) v[k1] = *(const v2f *)(src + k1 * 128);
-        v2f twa[4], twb[8];  // W_512^(k1 n2) = twa[k1 >> 3] * twb[k1 & 7]
-#pragma unroll
-        for (int q = 0; q < 4; ++q) twa[q] = tw1[16 * 8 * q + n2];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) twb[q] = tw1[16 * q + n2];
-#pragma unroll
-        for (int k1 = 1; k1 < 32; ++k1) {
-            const int qa = k1 >> 3, qb = k1 & 7;
-            if (qb) v[k1] = cmulv(v[k1], twb[qb]);
-            if (qa) v[k1] = cmulv(v[k1], twa[qa]);
-        }
-        Fft<32, false>::run(v, v);
+#ifdef SGX_IS_STAMPS
+    if ((threadIdx.x & 63u) == 0) {
+        for (int q = 0; q < 11; ++q) atomicAdd(&g_is_stamps[q], st_acc[q]);
+        atomicAdd(&g_is_stamps[11], 1ull);
     }
-    __syncthreads();  // exchange buffer consumed: overlay the real frames
-    {
-        const v2f *w2 = (const v2f *)(smem + kBWin) + n2;
-        v2f *fr2 = (v2f *)smem + f2 * 512u + n2;
-#pragma unroll
-        for (int n1 = 0; n1 < 32; ++n1) {
-            const v2f w = w2[16 * n1];
-            const v2f sc = v[n1] * (v2f){a.scale, -a.scale};  // conj + 1/n: (x[2n], x[2n+1]), n = n2 + 16 n1
-            fr2[16 * n1] = (v2f){__fmul_rn(sc.x, w.x), __fmul_rn(sc.y, w.y)};
-        }
-    }
-    __syncthreads();
-    istft_ola<NF, NT>(a, smem, tid, b, h0, fbase);
+#endif
 }
 
 }  // namespace
@@ -607,7 +673,10 @@ hipError_t launch_istft1024(const void *spec, void *out, const void *win, unsign
     if (g == 0 || g >= 0x7fffffffull) return hipErrorInvalidConfiguration;
     hipError_t e = set_max_dynamic_lds((const void *)k_istft1024b, kBLds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_istft1024b, dim3(xcd_grid(g)), dim3(256), kBLds, s, a, (const v2f *)twr, (const v2f *)tw1);
+    // persistent workgroups: two per CU (LDS), each XCD's share of them walking that XCD's contiguous run of tiles
+    const unsigned total = (unsigned)g, per_xcd = (total + 7u) / 8u;
+    const unsigned slots = std::max(1u, std::min(per_xcd, 2u * device_cu_count() / 8u));
+    hipLaunchKernelGGL(k_istft1024b, dim3(8u * slots), dim3(256), kBLds, s, a, (const v2f *)twr, (const v2f *)tw1, per_xcd, total, slots);
     return hipGetLastError();
 }
 
@@ -671,3 +740,14 @@ hipError_t launch_c2c1024(const C2cArgs &a0, const void *tw1c, hipStream_t s) {
 }
 
 }  // namespace sgx
+
+#ifdef SGX_IS_STAMPS
+extern "C" int sgx_debug_read_is_stamps(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sgx::g_is_stamps), sizeof(sgx::g_is_stamps)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(sgx::g_is_stamps), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
