@@ -473,6 +473,9 @@ constexpr int kBLds = kBWin + 4096;      // 76 032 B -> two workgroups per CU
 #ifndef SGX_ISTFT_NT
 #define SGX_ISTFT_NT 0
 #endif
+#ifndef SGX_ISTFT_REQPOS
+#define SGX_ISTFT_REQPOS 0  // where the next tile's pairs are requested: 0 after the fold, 1 after the 32-point transforms, 2 after the frame writes, 3 after the overlap-add
+#endif
 #ifdef SGX_IS_STAMPS  // diagnostic build only (tools/stamps_istft.py): a wave's cycles per phase of k_istft1024b
 __device__ unsigned long long g_is_stamps[16];
 #define IS_STAMP(i)                                                                \
@@ -585,7 +588,9 @@ __global__ __launch_bounds__(256, 2) void k_istft1024b(IstftArgs a, const v2f *t
             for (int i = 1; i < 8; ++i) A[8 + i] = j0 ? QB[16 - i] : PA[8 + i];  // job 0: v[512 - 32 (8 - i)] = v[32 (8 + i)]
             IS_STAMP(0);  // wait for the pairs + fold
             // the pairs are consumed: the next tile's go out now and land during the rest of this tile
+#if SGX_ISTFT_REQPOS == 0
             if (w + slots < hi) request(w + slots);
+#endif
             IS_STAMP(1);  // request issue
             Fft<16, false>::run(A, A);
             Fft<16, false>::run(B, B);
@@ -619,6 +624,9 @@ __global__ __launch_bounds__(256, 2) void k_istft1024b(IstftArgs a, const v2f *t
             }
             Fft<32, false>::run(v, v);
         }
+#if SGX_ISTFT_REQPOS == 1
+        if (w + slots < hi) request(w + slots);
+#endif
         IS_STAMP(4);  // column reads, twiddles, 32-point transform
         __syncthreads();  // exchange buffer consumed: overlay the real frames
         IS_STAMP(5);
@@ -632,10 +640,16 @@ __global__ __launch_bounds__(256, 2) void k_istft1024b(IstftArgs a, const v2f *t
                 fr2[16 * n1] = (v2f){__fmul_rn(sc.x, ww.x), __fmul_rn(sc.y, ww.y)};
             }
         }
+#if SGX_ISTFT_REQPOS == 2
+        if (w + slots < hi) request(w + slots);
+#endif
         IS_STAMP(6);  // scale, window, frame writes
         __syncthreads();
         IS_STAMP(7);
         istft_ola<NF, NT>(a, smem, tid, b, h0, fbase);
+#if SGX_ISTFT_REQPOS == 3
+        if (w + slots < hi) request(w + slots);
+#endif
         IS_STAMP(8);  // overlap-add, normalise, stores
         __syncthreads();  // the frames are consumed: the next tile's exchange rows may overwrite them
         IS_STAMP(9);
