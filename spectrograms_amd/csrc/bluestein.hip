@@ -189,7 +189,11 @@ __device__ __forceinline__ void bs_middle(typename PairOf<T>::type *buf, unsigne
 }
 
 template <typename T, int A, int B, int C>
-constexpr unsigned bs_waves() { return A > 16 ? 1 : SGX_BS_OCC && sizeof(T) == 4 ? SGX_BS_OCC : rr_waves<T, A, B, C>(); }  // 32-point passes: the 512-register budget
+constexpr unsigned bs_waves() {
+    if (A > 16) return 1;  // 32-point passes: the 512-register budget
+    if (sizeof(T) == 8 && A == 16 && B * C <= 128) return 2;  // f64 16 x 16 x 8 and shorter: two 72 KiB workgroups per CU only if they fit 256 registers
+    return SGX_BS_OCC && sizeof(T) == 4 ? SGX_BS_OCC : rr_waves<T, A, B, C>();
+}
 
 template <typename T, int A_, int B_, int C_>
 __global__ __launch_bounds__(256, (bs_waves<T, A_, B_, C_>())) void k_bs_fused(BsFused a, unsigned ltile) {
@@ -233,60 +237,53 @@ __global__ __launch_bounds__(256, (bs_waves<T, A_, B_, C_>())) void k_bs_fused(B
         return idx < tile * BC && s < ns;
     };
 
-    // P1 + T1: framing with virtual zero padding (S1), window and chirp, A-point transform.  The samples of work item idx + 256
-    // are in flight while item idx is transformed.
-    auto fetch = [&](unsigned idx, T (&xa)[HA], T (&xb)[HA], V (&w)[HA]) {
-        unsigned s, r;
-        if (!item(idx, s, r)) return;
-        const T *xs = x + sig_of[s] * a.sample_stride;
-        const unsigned f = frame_of[s];
-        const long long base = (long long)f * a.hop - (long long)a.pad + r;
-        if (interior_of[s]) {
-            const T *pa = xs + base, *pb = pa + a.hop;
+    // P1 + T1: framing with virtual zero padding (S1), window x chirp, A-point transform.  Work items are taken NI at a time, all
+    // their loads first.  (A software prefetch of the NEXT item's samples in loop-carried registers cost more moves than this stage
+    // has butterflies — 435 of its 1000 vector instructions at M = 2048; no overlap at all lost 10 % where a thread has two items.)
+    constexpr unsigned NI = A <= 8 ? 2 : 1;  // (the 16- and 32-point instances hold one item's samples at a time: registers = workgroups per CU)
+    for (unsigned idx0 = tid; idx0 < tile * BC; idx0 += 256 * NI) {
+        V p[NI][HA], w[NI][HA];
 #pragma unroll
-            for (unsigned n1 = 0; n1 < HA; ++n1) {
-                const bool in = n1 * BC + r < n;
-                xa[n1] = in ? pa[n1 * BC] : T(0);
-                xb[n1] = in ? pb[n1 * BC] : T(0);
-                w[n1] = in ? wc[n1 * BC + r] : (V){T(0), T(0)};
+        for (unsigned q = 0; q < NI; ++q) {
+            unsigned s, r;
+            if (!item(idx0 + 256 * q, s, r)) continue;
+            const T *xs = x + sig_of[s] * a.sample_stride;
+            const unsigned f = frame_of[s];
+            const long long base = (long long)f * a.hop - (long long)a.pad + r;
+            if (interior_of[s]) {
+                const T *pa = xs + base, *pb = pa + a.hop;
+#pragma unroll
+                for (unsigned n1 = 0; n1 < HA; ++n1) {
+                    const bool in = n1 * BC + r < n;
+                    p[q][n1] = (V){in ? pa[n1 * BC] : T(0), in ? pb[n1 * BC] : T(0)};
+                    w[q][n1] = in ? wc[n1 * BC + r] : (V){T(0), T(0)};
+                }
+            } else {
+                const bool two = f + 1u < a.n_frames;
+#pragma unroll
+                for (unsigned n1 = 0; n1 < HA; ++n1) {
+                    const unsigned m = n1 * BC + r;
+                    p[q][n1] = (V){T(0), T(0)};
+                    w[q][n1] = (V){T(0), T(0)};
+                    if (m < n) {
+                        const long long sa = base + (long long)(n1 * BC), sb = sa + a.hop;
+                        if (sa >= 0 && (unsigned long long)sa < a.n_samples) p[q][n1].x = xs[sa];
+                        if (two && sb >= 0 && (unsigned long long)sb < a.n_samples) p[q][n1].y = xs[sb];
+                        w[q][n1] = wc[m];
+                    }
+                }
             }
-            return;
         }
-        const bool two = f + 1u < a.n_frames;
 #pragma unroll
-        for (unsigned n1 = 0; n1 < HA; ++n1) {
-            const unsigned m = n1 * BC + r;
-            xa[n1] = T(0);
-            xb[n1] = T(0);
-            w[n1] = (V){T(0), T(0)};
-            if (m < n) {
-                const long long sa = base + (long long)(n1 * BC), sb = sa + a.hop;
-                if (sa >= 0 && (unsigned long long)sa < a.n_samples) xa[n1] = xs[sa];
-                if (two && sb >= 0 && (unsigned long long)sb < a.n_samples) xb[n1] = xs[sb];
-                w[n1] = wc[m];
-            }
-        }
-    };
-    {
-        T nxa[HA], nxb[HA];
-        V nw[HA];
-#pragma unroll
-        for (unsigned n1 = 0; n1 < HA; ++n1) {
-            nxa[n1] = nxb[n1] = T(0);
-            nw[n1] = (V){T(0), T(0)};
-        }
-        fetch(tid, nxa, nxb, nw);
-        for (unsigned idx = tid; idx < tile * BC; idx += 256) {
+        for (unsigned q = 0; q < NI; ++q) {
+            unsigned s, r;
+            if (!item(idx0 + 256 * q, s, r)) continue;
             V v[A];
 #pragma unroll
-            for (unsigned n1 = 0; n1 < HA; ++n1) {  // (xa + i xb) wc
-                const V p = {nxa[n1], nxb[n1]};
-                v[n1] = inreg::cmulv(p, nw[n1]);
+            for (unsigned n1 = 0; n1 < HA; ++n1) {
+                v[n1] = inreg::cmulv(p[q][n1], w[q][n1]);  // (xa + i xb) wc
                 v[n1 + HA] = (V){T(0), T(0)};
             }
-            fetch(idx + 256, nxa, nxb, nw);
-            unsigned s, r;
-            if (!item(idx, s, r)) continue;
             inreg::MixFft<A, V>::run(v);
             V pw2[LA];
 #pragma unroll
@@ -327,31 +324,52 @@ __global__ __launch_bounds__(256, (bs_waves<T, A_, B_, C_>())) void k_bs_fused(B
     __syncthreads();
     BS_STAMP(10);
     // the two frames of a pair come apart by their Hermitian symmetry; lanes walk the tile's pairs first (neighbouring frames of
-    // one output row), a work item writes both frames of its pair
-    const unsigned nb = a.nb;
-    const T eps = (T)a.eps;
-    for (unsigned idx = tid; idx < tile * nb; idx += 256) {
-        const unsigned s = idx & (tile - 1u), k = idx >> ltile;
-        if (s >= ns) continue;
-        const unsigned f = frame_of[s];
-        const V *seq = buf + (size_t)s * FS;
-        auto at = [&](unsigned m) {
-            const unsigned n1 = m / BC, r = m % BC;
-            return seq[n1 * RS + ((L::hi_part(r / C) ^ (r % C)) ^ L::k1_mask(n1))];
-        };
-        const V Z = at(k), Zc = at(k == 0 ? 0u : n - k);  // Zm = conj Z[n - k] = (Zc.x, -Zc.y)
-        const V Xa = {T(0.5) * (Z.x + Zc.x), T(0.5) * (Z.y - Zc.y)};   //    (Z + Zm) / 2
-        const V Xb = {T(0.5) * (Z.y + Zc.y), T(-0.5) * (Z.x - Zc.x)};  // -i (Z - Zm) / 2
-        const unsigned long long o = (sig_of[s] * nb + k) * a.n_frames + f;
-        const bool two = f + 1u < a.n_frames;
-        if (a.complex_out) {
-            ((V *)a.out)[o] = Xa;
-            if (two) ((V *)a.out)[o + 1] = Xb;
-        } else {
-            const T pa = Xa.x * Xa.x + Xa.y * Xa.y, pb = Xb.x * Xb.x + Xb.y * Xb.y;  // norm_sqr (spectrogram.rs:1332-1334)
-            T *dst = (T *)a.out + o;
-            dst[0] = a.amp == AMP_MAGNITUDE ? sqrt(pa) : a.amp == AMP_DB ? bs_db(pa > eps ? pa : eps) : pa;
-            if (two) dst[1] = a.amp == AMP_MAGNITUDE ? sqrt(pb) : a.amp == AMP_DB ? bs_db(pb > eps ? pb : eps) : pb;
+    // one output row), a work item writes both frames of its pair.  A thread keeps its pair over all its bins (256 is a multiple of
+    // the tile), and the output mode picks one of four specialised loops (uniform branch) — the selects of a single loop made
+    // every item pay a sqrt and a log2.
+    {
+        const unsigned s = tid & (tile - 1u);
+        if (s < ns) {
+            const unsigned nb = a.nb, f = frame_of[s], kstep = 256u >> ltile;
+            const bool two = f + 1u < a.n_frames;
+            const V *seq = buf + (size_t)s * FS;
+            const unsigned long long o0 = sig_of[s] * nb * a.n_frames + f;
+            const T eps = (T)a.eps;
+            auto at = [&](unsigned m) {
+                const unsigned n1 = m / BC, r = m % BC;
+                return seq[n1 * RS + ((L::hi_part(r / C) ^ (r % C)) ^ L::k1_mask(n1))];
+            };
+            auto walk = [&](auto &&emit) {
+                for (unsigned k = tid >> ltile; k < nb; k += kstep) {
+                    const V Z = at(k), Zc = at(k == 0 ? 0u : n - k);  // Zm = conj Z[n - k] = (Zc.x, -Zc.y)
+                    const V Xa = {T(0.5) * (Z.x + Zc.x), T(0.5) * (Z.y - Zc.y)};   //    (Z + Zm) / 2
+                    const V Xb = {T(0.5) * (Z.y + Zc.y), T(-0.5) * (Z.x - Zc.x)};  // -i (Z - Zm) / 2
+                    emit(o0 + (unsigned long long)k * a.n_frames, Xa, Xb);
+                }
+            };
+            auto power = [](V X) { return X.x * X.x + X.y * X.y; };  // norm_sqr (spectrogram.rs:1332-1334)
+            if (a.complex_out) {
+                walk([&](unsigned long long o, V Xa, V Xb) {
+                    ((V *)a.out)[o] = Xa;
+                    if (two) ((V *)a.out)[o + 1] = Xb;
+                });
+            } else if (a.amp == AMP_MAGNITUDE) {
+                walk([&](unsigned long long o, V Xa, V Xb) {
+                    ((T *)a.out)[o] = sqrt(power(Xa));
+                    if (two) ((T *)a.out)[o + 1] = sqrt(power(Xb));
+                });
+            } else if (a.amp == AMP_DB) {
+                walk([&](unsigned long long o, V Xa, V Xb) {
+                    const T pa = power(Xa), pb = power(Xb);
+                    ((T *)a.out)[o] = bs_db(pa > eps ? pa : eps);
+                    if (two) ((T *)a.out)[o + 1] = bs_db(pb > eps ? pb : eps);
+                });
+            } else {
+                walk([&](unsigned long long o, V Xa, V Xb) {
+                    ((T *)a.out)[o] = power(Xa);
+                    if (two) ((T *)a.out)[o + 1] = power(Xb);
+                });
+            }
         }
     }
     BS_STAMP(11);
