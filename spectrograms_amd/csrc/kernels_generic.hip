@@ -31,6 +31,9 @@ namespace sgx {
 #ifndef SGX_RR_STAGGER
 #define SGX_RR_STAGGER 0
 #endif
+#ifndef SGX_RR_STAGE_MEL
+#define SGX_RR_STAGE_MEL 0
+#endif
 #ifdef SGX_RR_STAMPS  // diagnostic build only (tools/stamps_generic.py): a wave's cycles per phase of k_reg_radix
 __device__ unsigned long long g_rr_stamps[32];
 #define RR_STAMP(i)                                                                         \
@@ -1015,7 +1018,7 @@ static unsigned reg_radix_waves(size_t es, unsigned fa, unsigned fc, bool staged
 
 // the staged variant is the one to use (see rr_can_stage): per-bin outputs, f32 or the long f64 transforms
 static bool reg_radix_want_staged(const StftArgs &a, unsigned fa, unsigned fc, size_t es) {
-    return SGX_RR_STAGED && a.out_mode != OUT_MEL && (es == 4 || SGX_RR_STAGE_F64 || (fa >= 16 && fc > 1));
+    return SGX_RR_STAGED && (SGX_RR_STAGE_MEL || a.out_mode != OUT_MEL) && (es == 4 || SGX_RR_STAGE_F64 || (fa >= 16 && fc > 1));
 }
 
 static bool reg_radix_stage_ok(const StftArgs &a, unsigned ft, unsigned fa, unsigned fb, unsigned fc, size_t es) {
@@ -1060,6 +1063,9 @@ bool plan_geometry_reg_radix(StftArgs &a, int dtype) {
                     a.mel_sub = ft / parts;
                 }
             }
+#if SGX_RR_STAGE_MEL  // experiment: staged samples for filterbank outputs too
+        if (best) a.staged = reg_radix_want_staged(a, fa, fc, es) && 2 * a.hop <= a.n_fft && reg_radix_stage_ok(a, a.ft, fa, fb, fc, es);
+#endif
         if (best) return true;
     } else {
         // staged samples where frames overlap by at least half and the samples of the tile the budget allows fit the chunk
