@@ -48,6 +48,9 @@
 namespace sgx {
 namespace {
 
+// one term of the reference's filterbank sum: the product rounded, then the sum (no fused multiply-add)
+__device__ __forceinline__ float bs_mul_add_unfused(float w, float p, float acc) { return __fadd_rn(__fmul_rn(w, p), acc); }
+__device__ __forceinline__ double bs_mul_add_unfused(double w, double p, double acc) { return __dadd_rn(__dmul_rn(w, p), acc); }
 __device__ __forceinline__ float bs_db(float p) { return __builtin_log2f(p) * 3.01029995663981195f; }  // as the other f32 kernels
 __device__ __forceinline__ double bs_db(double p) { return 10.0 * log10(p); }
 
@@ -97,6 +100,11 @@ struct BsFused {
     const void *wc, *chirp, *bhp, *tw;  // [n] w conj(c), [n] conj(c), [M] FFT_M(b) / M in the order the product step reads it, [M] W_M^k
     int complex_out, amp;
     double eps;
+    // filterbank outputs: the bank's CSR rows over the bins (null: per-bin output); amp is then applied to the bank's sums
+    // (AMP_MAG_IN: the bank weighs magnitudes and its sums are final)
+    const unsigned *mel_ptr, *mel_col;
+    const void *mel_val;
+    unsigned n_mels, n_out;
 };
 
 // The middle of the convolution, shared by the frame kernel and the complex-sequence kernel: on entry every work item has written
@@ -348,7 +356,19 @@ __global__ __launch_bounds__(256, (bs_waves<T, A_, B_, C_>())) void k_bs_fused(B
                 }
             };
             auto power = [](V X) { return X.x * X.x + X.y * X.y; };  // norm_sqr (spectrogram.rs:1332-1334)
-            if (a.complex_out) {
+            if (a.mel_ptr) {
+                // filterbank outputs: the pair's two powers (magnitudes) take the place of Z[k] — read by this work item only (the
+                // mirror Z[n - k] of another bin k' would need k + k' = n, i.e. both n / 2) —, the bank's rows follow below
+                V *wseq = buf + (size_t)s * FS;
+                for (unsigned k = tid >> ltile; k < nb; k += kstep) {
+                    const unsigned n1 = k / BC, r = k % BC, pos = n1 * RS + ((L::hi_part(r / C) ^ (r % C)) ^ L::k1_mask(n1));
+                    const V Z = wseq[pos], Zc = at(k == 0 ? 0u : n - k);
+                    const V Xa = {T(0.5) * (Z.x + Zc.x), T(0.5) * (Z.y - Zc.y)};
+                    const V Xb = {T(0.5) * (Z.y + Zc.y), T(-0.5) * (Z.x - Zc.x)};
+                    const T pa = power(Xa), pb = power(Xb);
+                    wseq[pos] = a.amp == AMP_MAG_IN ? (V){sqrt(pa), sqrt(pb)} : (V){pa, pb};
+                }
+            } else if (a.complex_out) {
                 walk([&](unsigned long long o, V Xa, V Xb) {
                     ((V *)a.out)[o] = Xa;
                     if (two) ((V *)a.out)[o + 1] = Xb;
@@ -370,6 +390,30 @@ __global__ __launch_bounds__(256, (bs_waves<T, A_, B_, C_>())) void k_bs_fused(B
                     if (two) ((T *)a.out)[o + 1] = power(Xb);
                 });
             }
+        }
+    }
+    if (a.mel_ptr) {  // uniform
+        // SparseMatrix::multiply_vec (spectrogram.rs:102-117) per frame: sequential, un-fused, in ascending column order — two
+        // frames (one pair) per work item, lanes over the tile's pairs first
+        __syncthreads();
+        const T *val = (const T *)a.mel_val;
+        const T eps = (T)a.eps;
+        for (unsigned idx = tid; idx < (a.n_mels << ltile); idx += 256) {
+            const unsigned s = idx & (tile - 1u), m = idx >> ltile;
+            if (s >= ns) continue;
+            const V *seq = buf + (size_t)s * FS;
+            V acc = {T(0), T(0)};
+            for (unsigned i = a.mel_ptr[m], i1 = a.mel_ptr[m + 1]; i < i1; ++i) {
+                const unsigned k = a.mel_col[i], n1 = k / BC, r = k % BC;
+                const V P = seq[n1 * RS + ((L::hi_part(r / C) ^ (r % C)) ^ L::k1_mask(n1))];
+                const T w = val[i];
+                acc = (V){bs_mul_add_unfused(w, P.x, acc.x), bs_mul_add_unfused(w, P.y, acc.y)};
+            }
+            const unsigned f = frame_of[s];
+            T *o = (T *)a.out + (sig_of[s] * a.n_out + m) * a.n_frames + f;
+            auto fin = [&](T v) { return a.amp == AMP_MAGNITUDE ? sqrt(v) : a.amp == AMP_DB ? bs_db(v > eps ? v : eps) : v; };
+            o[0] = fin(acc.x);
+            if (f + 1u < a.n_frames) o[1] = fin(acc.y);
         }
     }
     BS_STAMP(11);
@@ -554,6 +598,7 @@ hipError_t run_fused(const BsArgs &a, int dtype, hipStream_t s) {
     f.tiles = (unsigned)tiles;
     f.wc = a.wc; f.chirp = a.chirp; f.bhp = a.bhat_fused; f.tw = a.tw_m;
     f.complex_out = a.complex_out; f.amp = a.amp; f.eps = a.eps;
+    f.mel_ptr = a.mel_ptr; f.mel_col = a.mel_col; f.mel_val = a.mel_val; f.n_mels = a.n_mels; f.n_out = a.n_out;
 #define SGX_BSF_F32(A, B, C) if (fa == A && fb == B && fc == C) return launch_fused_t<float, A, B, C>(f, ltile, lds, s);
 #define SGX_BSF_F64(A, B, C) if (fa == A && fb == B && fc == C) return launch_fused_t<double, A, B, C>(f, ltile, lds, s);
     if (dtype == SGX_F64) {

@@ -744,7 +744,7 @@ bool set_geometry(const sgx_plan *pl, StftArgs &a, KernelKind kind) {
     case K_DIRECT_DFT: ok = plan_geometry_direct_dft(a, pl->dtype); break;
     case K_TWO_FACTOR: ok = plan_geometry_two_factor(a, pl->dtype); break;
     case K_REG_RADIX: ok = plan_geometry_reg_radix(a, pl->dtype); break;
-    case K_BLUESTEIN: a.ft = 1; ok = pl->bs_M != 0 && a.out_mode != OUT_MEL; break;  // (filterbank outputs: the split path)
+    case K_BLUESTEIN: a.ft = 1; ok = pl->bs_M != 0 && (a.out_mode != OUT_MEL || a.mel_ptr != nullptr); break;
     }
     if (ok) a.tiles = (a.n_frames + a.ft - 1) / a.ft;
     return ok;
@@ -762,6 +762,9 @@ hipError_t launch_bluestein_plan(sgx_plan *pl, const StftArgs &a, hipStream_t s)
     b.wc = a.window == pl->d_ones ? pl->d_bs_chirp : pl->d_bs_wc;
     b.chirp = pl->d_bs_chirp; b.bhat_fused = pl->d_bs_bhp; b.tw_m = pl->d_bs_tw;
     b.complex_out = a.out_mode == OUT_COMPLEX; b.amp = a.amp; b.eps = a.eps;
+    if (a.out_mode == OUT_MEL) {  // (f32, M <= 1024) the bank's rows in the same launch: the |X|^2 of a tile never leave LDS
+        b.mel_ptr = a.mel_ptr; b.mel_col = a.mel_col; b.mel_val = a.mel_val; b.n_mels = a.n_mels; b.n_out = a.n_out;
+    }
     return launch_bluestein(b, pl->dtype, s);
 }
 
@@ -1130,7 +1133,11 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
             if (can && (!ok || per_sample > cost * double(l2) * double(M) / double(n))) {
                 pl->bs_M = M;
                 kind = K_BLUESTEIN;
-                pl->split_bank = pl->out_mode == OUT_MEL;  // per-bin power, then the bank's rows
+                // filterbank outputs: up to M = 1024 the bank's rows run inside the kernel (a tile holds >= 4 frame pairs: 320+ (band,
+                // pair) work items; n_fft 251 Mel-80 dB 195 -> 181 us); longer sequences leave too few items with too long rows
+                // (n_fft 2003: 323 us against 247) and take the split path: per-bin power, then one wave per (band, 64 frames)
+                // (f64: the split path is faster at every length — n_fft 509 305 us against 322)
+                pl->split_bank = pl->out_mode == OUT_MEL && (M > 1024 || pl->dtype == SGX_F64);
                 ok = true;
             }
         }

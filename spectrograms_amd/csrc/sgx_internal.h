@@ -105,6 +105,9 @@ struct BsArgs {
     const void *tw_m;       // [M] complex T: e^(-2 pi i k / M)
     int complex_out, amp;
     double eps;
+    const unsigned *mel_ptr, *mel_col;  // filterbank outputs: CSR rows of the bank (null: per-bin output), amp applies to its sums
+    const void *mel_val;
+    unsigned n_mels, n_out;
 };
 hipError_t launch_bluestein(const BsArgs &a, int dtype, hipStream_t s);
 bool bluestein_fused_split(unsigned M, int dtype, unsigned *fa, unsigned *fb, unsigned *fc);
