@@ -431,11 +431,13 @@ __global__ __launch_bounds__(256, (bs_waves<T, A_, B_, C_>())) void k_bs_fused(B
 // on the way in and out).  HERM: the input is the half spectrum of a real row (n / 2 + 1 bins, the rest by Hermitian symmetry; the
 // imaginary parts of the DC and, for even n, Nyquist bins are dropped and reported as realfft's C2R does, src/fft_backend.rs:782-793)
 // and the output is the row's n real samples, scaled and optionally windowed — the inverse row pass of ifft2d / the per-frame C2R of
-// the generic inverse STFT at lengths without a pass split.
+// the generic inverse STFT at lengths without a pass split.  TWO rows ride one sequence there too: with Z = X_a + i X_b the inverse
+// transform is x_a + i x_b, so sequence s carries rows 2 s and 2 s + 1 of its image (an odd last row rides alone).
 struct BsC2c {
     const void *in;
     void *out;
-    unsigned n, nseq, tiles, total_tiles;  // tiles per image, tiles * batch
+    unsigned n, nseq, tiles, total_tiles;  // tiles per image, tiles * batch (HERM: nseq = row PAIRS per image, nrows = rows)
+    unsigned nrows;
     unsigned long long in_img, out_img, in_ss, in_is, out_ss, out_is;
     int inverse, in_seq_fast, out_seq_fast;
     double scale;
@@ -470,17 +472,23 @@ __global__ __launch_bounds__(256, (bs_waves<T, A_, B_, C_>())) void k_bs_c2c(BsC
         if (a.in_seq_fast) { s = idx & (tile - 1); r = idx >> ltile; } else { r = idx % BC; s = idx / BC; }
         return idx < tile * BC && s < ns;
     };
-    // element m of sequence s, conjugated for an inverse transform.  HERM: X[m] = in[m] (m <= n / 2), conj(in[n - m]) above; the
-    // real row is x = IDFT(X) = conj(DFT(conj X)), and conj X is again Hermitian, so Re(DFT(conj X)) is the answer: no conj out.
-    auto element = [&](const V *seq, unsigned m) {
+    // element m of sequence s, conjugated for an inverse transform.  HERM: a row's X[m] = in[m] (m <= n / 2), conj(in[n - m]) above;
+    // rows a and b of the pair enter as conj(Z) = conj(X_a) - i conj(X_b), W = DFT(conj Z) = conj(x_a + i x_b): x_a = Re W, x_b = -Im W.
+    auto herm = [&](const V *row, unsigned m) {  // conj X[m] of one row
+        const bool up = m > half;
+        V v = row[(size_t)(up ? n - m : m) * a.in_is];
+        if (m == 0 || (2 * m == n)) {
+            if (v.y != T(0) && a.bad_flag) *a.bad_flag = 1u;
+            v.y = T(0);
+        }
+        return (V){v.x, up ? v.y : -v.y};
+    };
+    auto element = [&](const V *seq, unsigned m, bool second) {
         if constexpr (HERM) {
-            const bool up = m > half;
-            V v = seq[(size_t)(up ? n - m : m) * a.in_is];
-            if (m == 0 || (2 * m == n)) {
-                if (v.y != T(0) && a.bad_flag) *a.bad_flag = 1u;
-                v.y = T(0);
-            }
-            return (V){v.x, up ? v.y : -v.y};  // conj X[m]
+            const V ca = herm(seq, m);
+            if (!second) return ca;
+            const V cb = herm(seq + a.in_ss, m);
+            return (V){ca.x + cb.y, ca.y - cb.x};  // conj(X_a) - i conj(X_b)
         } else {
             const V v = seq[(size_t)m * a.in_is];
             return (V){v.x, cj * v.y};
@@ -489,12 +497,13 @@ __global__ __launch_bounds__(256, (bs_waves<T, A_, B_, C_>())) void k_bs_c2c(BsC
     for (unsigned idx = tid; idx < tile * BC; idx += 256) {
         unsigned s, r;
         if (!item(idx, s, r)) continue;
-        const V *seq = in + (size_t)(s0 + s) * a.in_ss;
+        const V *seq = in + (size_t)(s0 + s) * (HERM ? 2u : 1u) * a.in_ss;
+        const bool second = HERM && 2u * (s0 + s) + 1u < a.nrows;
         V v[A];
 #pragma unroll
         for (unsigned n1 = 0; n1 < HA; ++n1) {
             const unsigned m = n1 * BC + r;
-            v[n1] = m < n ? inreg::cmulv(element(seq, m), chirp[m]) : (V){T(0), T(0)};
+            v[n1] = m < n ? inreg::cmulv(element(seq, m, second), chirp[m]) : (V){T(0), T(0)};
             v[n1 + HA] = (V){T(0), T(0)};
         }
         inreg::MixFft<A, V>::run(v);
@@ -539,9 +548,15 @@ __global__ __launch_bounds__(256, (bs_waves<T, A_, B_, C_>())) void k_bs_c2c(BsC
         const unsigned n1 = k / BC, r = k % BC;
         const V Z = buf[(size_t)s * FS + n1 * RS + ((L::hi_part(r / C) ^ (r % C)) ^ L::k1_mask(n1))];
         if constexpr (HERM) {
-            T x = Z.x * sc;
-            if (a.win) x *= ((const T *)a.win)[k];
-            ((T *)a.out + (size_t)b * a.out_img)[(size_t)(s0 + s) * a.out_ss + (size_t)k * a.out_is] = x;
+            T xa = Z.x * sc, xb = -Z.y * sc;
+            if (a.win) {
+                const T w = ((const T *)a.win)[k];
+                xa *= w;
+                xb *= w;
+            }
+            T *o = (T *)a.out + (size_t)b * a.out_img + (size_t)(2u * (s0 + s)) * a.out_ss + (size_t)k * a.out_is;
+            o[0] = xa;
+            if (2u * (s0 + s) + 1u < a.nrows) o[a.out_ss] = xb;
         } else {
             ((V *)a.out + (size_t)b * a.out_img)[(size_t)(s0 + s) * a.out_ss + (size_t)k * a.out_is] = Z * (V){sc, cj * sc};
         }
@@ -734,7 +749,7 @@ hipError_t launch_c2c_bluestein(const C2cArgs &a, const BsDevTables &t, int dtyp
 hipError_t launch_c2r_bluestein(const C2rArgs &a, const BsDevTables &t, int dtype, hipStream_t s) {
     if (a.nbk) return hipErrorNotSupported;  // (the fused overlap-add belongs to k_c2r_reg)
     BsC2c f{};
-    f.in = a.in; f.out = a.out; f.n = a.ncols; f.nseq = a.nrows;
+    f.in = a.in; f.out = a.out; f.n = a.ncols; f.nseq = (a.nrows + 1u) / 2u; f.nrows = a.nrows;
     f.in_img = a.in_img; f.out_img = (unsigned long long)a.nrows * a.ncols; f.in_ss = a.in_rs; f.in_is = a.in_ks; f.out_ss = a.ncols; f.out_is = 1;
     f.inverse = 1; f.in_seq_fast = a.k_fast ? 0 : 1; f.out_seq_fast = 0; f.scale = a.scale;
     f.chirp = t.chirp; f.bhp = t.bhp; f.tw = t.tw; f.win = a.win; f.bad_flag = a.bad_flag;
