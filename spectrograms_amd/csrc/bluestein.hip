@@ -1,8 +1,10 @@
-// bluestein.hip — forward STFT frames of lengths the register-tiled / two-factor kernels do not take at speed (primes, 2 x prime,
-// other lengths with a large prime factor) as a chirp-z transform on top of the power-of-two complex kernels.
+// bluestein.hip — transforms of every length from 16 to 8192 (f64: 4096) that is neither a power of two nor one of the register-tiled
+// mixed-radix sizes (primes, 2 x prime, 1023, 3000, ...) as a chirp-z convolution resident in LDS: STFT frames (k_bs_fused), complex
+// sequences and Hermitian rows -> real (k_bs_c2c: the 2-D path's columns and inverse rows, the 1-D C2C plan, the generic inverse STFT).
 //
 // The reference plans EVERY length through realfft / RustFFT (src/fft_backend.rs:376-385), which pick mixed radix, Rader or
-// Bluestein per length; round 2 ran such frames as an O(n^2) direct sum (n_fft 5003: 12.5 M multiply-adds per frame).
+// Bluestein per length; round 2 ran such lengths as two-factor transforms or O(n^2) direct sums (n_fft 5003: 12.5 M multiply-adds
+// per frame).
 //
 //   X[k] = sum_n x[n] W^(n k),  W = e^(-2 pi i / N),  n k = (n^2 + k^2 - (k - n)^2) / 2
 //        = conj(c_k) * sum_n (x[n] conj(c_n)) c_(k - n),        c_n = e^(+i pi n^2 / N)
@@ -21,8 +23,9 @@
 // |.|^2 / sqrt / dB or complex, stores into the reference's [signal][bin][frame] layout (S9).  M up to 16384 in f32 and 8192 in f64,
 // i.e. n_fft <= 8192 / 4096; beyond that a plan keeps the two-factor kernel or the direct sum.  (Round 3 first built this as four
 // launches per chunk of frame pairs over two [pairs][M] scratch buffers: bound by its six HBM passes — n_fft 1009 616 us against
-// 180 us now, 5003 4.3 ms against 0.48 ms.)
-// Filterbank outputs take the plan's split path: per-bin power here, then k_bank_rows.
+// 160 us now, 5003 4.3 ms against 0.43 ms.)
+// Filterbank outputs: f32 up to M = 1024 apply the bank's rows inside the kernel (the |X|^2 of a tile stay in LDS); longer sequences and
+// f64 take the plan's split path — per-bin power here, then k_bank_rows.
 #include <algorithm>
 #include <cmath>
 #include <vector>
