@@ -34,6 +34,9 @@ namespace sgx {
 #ifndef SGX_RR_STAGE_MEL
 #define SGX_RR_STAGE_MEL 0
 #endif
+#ifndef SGX_RR_TWKEEP
+#define SGX_RR_TWKEEP 0
+#endif
 #ifdef SGX_RR_STAMPS  // diagnostic build only (tools/stamps_generic.py): a wave's cycles per phase of k_reg_radix
 __device__ unsigned long long g_rr_stamps[32];
 #define RR_STAMP(i)                                                                         \
@@ -322,7 +325,11 @@ __global__ __launch_bounds__(256, (rr_stft_waves<T, A_, B_, C_, STAGED_>())) voi
     // loop they would sit behind the previous tile's stores (one in-order counter) and wait for all of them.
     constexpr bool Q2_FIXED = C > 1 && 256u % (A * C) == 0;
     // instances short of registers (f64; f32 with 16-point passes in three-pass splits) rebuild the twiddle products per tile
+#if SGX_RR_TWKEEP  // experiment: let the f64 8-point instances carry their twiddle products through the tile loop
+    constexpr bool TW_OPAQUE = !(sizeof(T) == 8 && A <= 8);
+#else
     constexpr bool TW_OPAQUE = true;
+#endif
     V q2f[LB];
     if constexpr (Q2_FIXED) {
         const unsigned n3 = (tid % (A * C)) % C;
