@@ -358,7 +358,7 @@ def test_tuned_kernel_even_hops(hop):
     run_case(n=5000, batch=2, n_fft=1024, hop=hop, n_mels=40, amp="power")
 
 
-@pytest.mark.parametrize("n_fft,hop", [(1024, 256), (512, 128), (512, 160), (1024, 160), (400, 160)])
+@pytest.mark.parametrize("n_fft,hop", [(1024, 256), (512, 128), (512, 160), (1024, 160), (400, 160), (251, 63), (1009, 250), (1023, 255)])  # (the last three: chirp-z)
 def test_strided_rows_and_device_path_match_host_path(n_fft, hop):
     torch = pytest.importorskip("torch")
     plan, op = make(n_fft, hop, n_mels=80, amp="db", floor=-80.0)
