@@ -126,8 +126,64 @@ int main(void) {
     printf("stft -> istft round trip: max abs err %.3e\n", rt);
     CHECK(rt < 5e-6);
     sgx_plan_destroy(plan);
-    (void)hipFree(dx); (void)hipFree(dout); (void)hipFree(dspec); (void)hipFree(dy);
-    free(x); free(out); free(y);
+    (void)hipFree(dout); (void)hipFree(dspec); (void)hipFree(dy);
+    free(out); free(y);
+    /* a prime frame length (the reference plans every length, src/fft_backend.rs:376-385): the chirp-z kernel through the same
+     * entry points — complex STFT against a direct DFT, then stft -> istft back to the samples */
+    {
+        const size_t pn = 251, phop = 63, ppad = pn / 2;
+        sgx_params q = p;
+        q.n_fft = (uint32_t)pn; q.hop_size = (uint32_t)phop; q.amp_scale = SGX_AMP_COMPLEX;
+        sgx_plan *pp = NULL;
+        CHECK(sgx_plan_create(&q, &pp) == SGX_OK);
+        CHECK(strcmp(sgx_kernel_name(pp), "bluestein") == 0);
+        size_t pb = 0, pf = 0;
+        CHECK(sgx_output_shape(pp, N, &pb, &pf) == SGX_OK && pb == pn / 2 + 1);
+        float *dsp = NULL, *dyy = NULL;
+        CHECK(hipMalloc((void **)&dsp, B * pb * pf * 2 * sizeof(float)) == hipSuccess);
+        CHECK(sgx_execute(pp, dx, B, N, N, dsp, B * pb * pf * 2, SGX_MEM_DEVICE, NULL) == SGX_OK);
+        float *sp = (float *)malloc(B * pb * pf * 2 * sizeof(float));
+        CHECK(hipMemcpy(sp, dsp, B * pb * pf * 2 * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess);
+        double werr = 0.0, wpeak = 0.0;
+        const size_t fr[3] = {0, 11, pf - 1};
+        for (int c = 0; c < 3; ++c)
+            for (size_t k = 0; k < pb; k += 13) {
+                double re = 0.0, im = 0.0;
+                for (size_t i = 0; i < pn; ++i) {
+                    const long long sidx = (long long)(fr[c] * phop + i) - (long long)ppad;
+                    const double v = (sidx >= 0 && sidx < (long long)N) ? (double)x[2 * N + (size_t)sidx] : 0.0;
+                    const double w = (double)(float)(0.5 - 0.5 * cos(2.0 * kPi * (double)i / (double)(pn - 1)));
+                    const double a = -2.0 * kPi * (double)((i * k) % pn) / (double)pn;
+                    re += v * w * cos(a);
+                    im += v * w * sin(a);
+                }
+                const float *g = sp + ((2 * pb + k) * pf + fr[c]) * 2;
+                const double d = hypot((double)g[0] - re, (double)g[1] - im), m = hypot(re, im);
+                if (d > werr) werr = d;
+                if (m > wpeak) wpeak = m;
+            }
+        printf("n_fft 251 (chirp-z) complex STFT: max abs err %.3e (peak %.3e)\n", werr, wpeak);
+        CHECK(werr <= 1e-4 * wpeak);
+        size_t pny = 0;
+        CHECK(sgx_istft_length(pp, pf, &pny) == SGX_OK);
+        CHECK(hipMalloc((void **)&dyy, B * pny * sizeof(float)) == hipSuccess);
+        CHECK(sgx_istft(pp, dsp, B, pb, pf, dyy, B * pny, SGX_MEM_DEVICE, NULL) == SGX_OK);
+        float *yy = (float *)malloc(B * pny * sizeof(float));
+        CHECK(hipMemcpy(yy, dyy, B * pny * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess);
+        double prt = 0.0;
+        for (size_t b = 0; b < B; ++b)
+            for (size_t i = pn; i + pn < pny && i + pn < N; ++i) {
+                const double d = fabs((double)yy[b * pny + i] - (double)x[b * N + i]);
+                if (d > prt) prt = d;
+            }
+        printf("n_fft 251 stft -> istft round trip: max abs err %.3e\n", prt);
+        CHECK(prt < 5e-6);
+        sgx_plan_destroy(pp);
+        (void)hipFree(dsp); (void)hipFree(dyy);
+        free(sp); free(yy);
+    }
+    (void)hipFree(dx);
+    free(x);
     printf("c_abi device smoke passed\n");
     return 0;
 }
