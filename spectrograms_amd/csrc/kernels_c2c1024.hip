@@ -338,14 +338,15 @@ constexpr int kISeq = kRSeq + 16;
 // at hop 256) and doubles the load segments to 256 bytes, but measures slower (see launch_istft1024): 16 is the default.
 
 // Overlap-add of a tile's NF windowed real frames fr[NF][1024] (LDS) into the output signal.
+// `w`: the window as the caller holds it in LDS (a global pointer here put a vector-memory round trip — and, with the next tile's
+// spectrum pairs in flight, a wait for all of those — in front of every tile's normalisation sums: 312 -> 299 us)
 template <unsigned NF, unsigned NT>
-__device__ __forceinline__ void istft_ola(const IstftArgs &a, const unsigned char *smem, unsigned tid, unsigned b, long long h0,
+__device__ __forceinline__ void istft_ola(const IstftArgs &a, const unsigned char *smem, const float *w, unsigned tid, unsigned b, long long h0,
                                           long long fbase) {
         // overlap-add, one thread per offset `off` inside a hop block, walking the tile's hop blocks: no division per sample.
         // Position pos = (h0 + hb) hop + off receives frames f in [fh - q + 1, fh] (fh = h0 + hb, q = ceil((1024 - off) / hop)),
         // clipped to [0, n_frames): ascending f as the reference adds them (:4906-4925), frame sample j = (fh - f) hop + off.
         const float *fr = (const float *)smem;
-        const float *w = (const float *)a.win;
         float *o = (float *)a.out + (size_t)b * a.out_len;
         const unsigned long long p0 = (unsigned long long)h0 * a.hop;
         const long long last = (long long)a.n_frames - 1;
@@ -494,9 +495,11 @@ __device__ unsigned long long g_is_stamps[16];
 // requests the NEXT tile's 33 spectrum pairs per lane as soon as the current tile's have been folded, so that they are in flight during
 // the 32-point transforms, the windowing and the overlap-add.  Measured: 310-322 us per 256 x [513, 626] against 312 us for one tile
 // per workgroup — no gain: the phase stamps (profiles/r03_istft_stamps_pmc.txt) show a third of a wave's time going into ISSUING those 33
-// loads (~290 cycles each: the read path is back-pressured, TCP pending stalls 45 % of the CU cycles on 128-byte row segments at a
-// 5008-byte pitch) and another third into the overlap-add's stores queued behind them; VALU issue is 33 %.  Non-temporal loads:
-// 355 us.
+// loads (~300 cycles each) and another quarter into the overlap-add behind them; VALU issue is 33 %.  The access pattern itself reads
+// at 5 TB/s with 32 waves per CU (tools/ubench/istft_read_pattern.hip: 130 us for the whole spectrum): a CU drains one 512-byte
+// wave-load per ~44 cycles, and here all 8 waves of a CU (2 workgroups at 76 KB of LDS) request their 33 loads together and then
+// compute together.  Spreading the requests over the tile's phases (sched_barrier-pinned groups of 4 loads) spills and loses
+// (309-319 us); non-temporal loads lose (355 us).
 __global__ __launch_bounds__(256, 2) void k_istft1024b(IstftArgs a, const v2f *twr, const v2f *tw1, unsigned per_xcd, unsigned total,
                                                        unsigned slots) {
     constexpr unsigned NF = 16, NT = 256;
@@ -646,7 +649,7 @@ __global__ __launch_bounds__(256, 2) void k_istft1024b(IstftArgs a, const v2f *t
         IS_STAMP(6);  // scale, window, frame writes
         __syncthreads();
         IS_STAMP(7);
-        istft_ola<NF, NT>(a, smem, tid, b, h0, fbase);
+        istft_ola<NF, NT>(a, smem, (const float *)(smem + kBWin), tid, b, h0, fbase);
 #if SGX_ISTFT_REQPOS == 3
         if (w + slots < hi) request(w + slots);
 #endif
