@@ -436,6 +436,9 @@ __global__ __launch_bounds__(256, (bs_waves<T, A_, B_, C_>())) void k_bs_fused(B
 // and the output is the row's n real samples, scaled and optionally windowed — the inverse row pass of ifft2d / the per-frame C2R of
 // the generic inverse STFT at lengths without a pass split.  TWO rows ride one sequence there too: with Z = X_a + i X_b the inverse
 // transform is x_a + i x_b, so sequence s carries rows 2 s and 2 s + 1 of its image (an odd last row rides alone).
+// HALF: the same rows for an EVEN length 2 n whose full-length convolution does not fit LDS (f64 above 4096, f32 above 8192): the
+// half-length complex form Z'[k] = (X[k] + conj X[n - k]) + i conj(W_2n^k)(X[k] - conj X[n - k]), k < n, inverts to x[2 j] + i x[2 j + 1]
+// (k_c2r_reg's fold), one row per sequence, M >= 2 n - 1 = the row length - 1.
 struct BsC2c {
     const void *in;
     void *out;
@@ -445,12 +448,14 @@ struct BsC2c {
     int inverse, in_seq_fast, out_seq_fast;
     double scale;
     const void *chirp, *bhp, *tw;
-    const void *win;     // HERM: optional [n] window applied after the scale
+    const void *win;     // HERM / HALF: optional window (of the real row's length) applied after the scale
+    const void *twn;     // HALF: e^(-2 pi i k / (2 n)), k < n: the real row has 2 n samples, the sequence is its half-length complex form
     unsigned *bad_flag;  // HERM: set when a DC / Nyquist bin carries an imaginary part
 };
 
-template <typename T, int A_, int B_, int C_, bool HERM>
+template <typename T, int A_, int B_, int C_, int RMODE>
 __global__ __launch_bounds__(256, (bs_waves<T, A_, B_, C_>())) void k_bs_c2c(BsC2c a, unsigned ltile) {
+    constexpr bool HERM = RMODE == 1, HALF = RMODE == 2;  // 0: complex sequences
     typedef typename PairOf<T>::type V;
     constexpr unsigned A = A_, B = B_, C = C_, BC = B * C, N = A * BC, HA = A / 2;
     constexpr int LA = ct_log2_ceil(A);
@@ -469,7 +474,7 @@ __global__ __launch_bounds__(256, (bs_waves<T, A_, B_, C_>())) void k_bs_c2c(BsC
     const V *in = (const V *)a.in + (size_t)b * a.in_img;
     const V *chirp = (const V *)a.chirp, *bhp = (const V *)a.bhp, *tw = (const V *)a.tw;
     const unsigned n = a.n, half = n / 2;
-    const T cj = (!HERM && a.inverse) ? T(-1) : T(1);  // inverse = conj(forward(conj x)); HERM is an inverse by construction (below)
+    const T cj = (RMODE == 0 && a.inverse) ? T(-1) : T(1);  // inverse = conj(forward(conj x)); HERM is an inverse by construction (below)
     auto wrap = [](unsigned e) { return e & (N - 1); };
     auto item = [&](unsigned idx, unsigned &s, unsigned &r) {
         if (a.in_seq_fast) { s = idx & (tile - 1); r = idx >> ltile; } else { r = idx % BC; s = idx / BC; }
@@ -487,7 +492,18 @@ __global__ __launch_bounds__(256, (bs_waves<T, A_, B_, C_>())) void k_bs_c2c(BsC
         return (V){v.x, up ? v.y : -v.y};
     };
     auto element = [&](const V *seq, unsigned m, bool second) {
-        if constexpr (HERM) {
+        if constexpr (HALF) {
+            V Xk = seq[(size_t)m * a.in_is], Xm = seq[(size_t)(n - m) * a.in_is];
+            if (m == 0) {  // DC and Nyquist bins
+                if ((Xk.y != T(0) || Xm.y != T(0)) && a.bad_flag) *a.bad_flag = 1u;
+                Xk.y = T(0);
+                Xm.y = T(0);
+            }
+            const V Aa = {Xk.x + Xm.x, Xk.y - Xm.y}, D = {Xk.x - Xm.x, Xk.y + Xm.y};
+            const V wn = ((const V *)a.twn)[m];
+            const V Tt = inreg::cmulv(D, (V){wn.x, -wn.y});
+            return (V){Aa.x - Tt.y, -(Aa.y + Tt.x)};  // conj(A + i T)
+        } else if constexpr (HERM) {
             const V ca = herm(seq, m);
             if (!second) return ca;
             const V cb = herm(seq + a.in_ss, m);
@@ -500,7 +516,7 @@ __global__ __launch_bounds__(256, (bs_waves<T, A_, B_, C_>())) void k_bs_c2c(BsC
     for (unsigned idx = tid; idx < tile * BC; idx += 256) {
         unsigned s, r;
         if (!item(idx, s, r)) continue;
-        const V *seq = in + (size_t)(s0 + s) * (HERM ? 2u : 1u) * a.in_ss;
+        const V *seq = in + (size_t)(s0 + s) * (HERM ? 2u : 1u) * a.in_ss;  // (HALF: one row per sequence)
         const bool second = HERM && 2u * (s0 + s) + 1u < a.nrows;
         V v[A];
 #pragma unroll
@@ -550,7 +566,16 @@ __global__ __launch_bounds__(256, (bs_waves<T, A_, B_, C_>())) void k_bs_c2c(BsC
         if (s >= ns) continue;
         const unsigned n1 = k / BC, r = k % BC;
         const V Z = buf[(size_t)s * FS + n1 * RS + ((L::hi_part(r / C) ^ (r % C)) ^ L::k1_mask(n1))];
-        if constexpr (HERM) {
+        if constexpr (HALF) {  // W = DFT(conj Z'): x[2 k] = Re W, x[2 k + 1] = -Im W
+            T xa = Z.x * sc, xb = -Z.y * sc;
+            if (a.win) {
+                xa *= ((const T *)a.win)[2u * k];
+                xb *= ((const T *)a.win)[2u * k + 1u];
+            }
+            T *o = (T *)a.out + (size_t)b * a.out_img + (size_t)(s0 + s) * a.out_ss + 2u * (size_t)k;
+            o[0] = xa;
+            o[1] = xb;
+        } else if constexpr (HERM) {
             T xa = Z.x * sc, xb = -Z.y * sc;
             if (a.win) {
                 const T w = ((const T *)a.win)[k];
@@ -632,18 +657,20 @@ hipError_t run_fused(const BsArgs &a, int dtype, hipStream_t s) {
 }
 
 template <typename T, int A, int B, int C>
-hipError_t launch_bsc_t(const BsC2c &f, bool herm, unsigned ltile, size_t lds, hipStream_t s) {
+hipError_t launch_bsc_t(const BsC2c &f, int rmode, unsigned ltile, size_t lds, hipStream_t s) {
+    const void *fn = rmode == 2 ? (const void *)k_bs_c2c<T, A, B, C, 2> : rmode == 1 ? (const void *)k_bs_c2c<T, A, B, C, 1> : (const void *)k_bs_c2c<T, A, B, C, 0>;
     if (lds > 64 * 1024) {
-        const int cap = (int)bs_lds_budget(sizeof(T) == 8 ? SGX_F64 : SGX_F32, A * B * C);
-        hipError_t e = herm ? set_max_dynamic_lds((const void *)k_bs_c2c<T, A, B, C, true>, cap) : set_max_dynamic_lds((const void *)k_bs_c2c<T, A, B, C, false>, cap);
+        hipError_t e = set_max_dynamic_lds(fn, (int)bs_lds_budget(sizeof(T) == 8 ? SGX_F64 : SGX_F32, A * B * C));
         if (e != hipSuccess) return e;
     }
-    if (herm) hipLaunchKernelGGL((k_bs_c2c<T, A, B, C, true>), dim3(xcd_grid(f.total_tiles)), dim3(256), lds, s, f, ltile);
-    else hipLaunchKernelGGL((k_bs_c2c<T, A, B, C, false>), dim3(xcd_grid(f.total_tiles)), dim3(256), lds, s, f, ltile);
+    const dim3 grid(xcd_grid(f.total_tiles));
+    if (rmode == 2) hipLaunchKernelGGL((k_bs_c2c<T, A, B, C, 2>), grid, dim3(256), lds, s, f, ltile);
+    else if (rmode == 1) hipLaunchKernelGGL((k_bs_c2c<T, A, B, C, 1>), grid, dim3(256), lds, s, f, ltile);
+    else hipLaunchKernelGGL((k_bs_c2c<T, A, B, C, 0>), grid, dim3(256), lds, s, f, ltile);
     return hipGetLastError();
 }
 
-hipError_t run_bsc(BsC2c f, bool herm, unsigned M, unsigned batch, int dtype, hipStream_t s) {
+hipError_t run_bsc(BsC2c f, int herm, unsigned M, unsigned batch, int dtype, hipStream_t s) {
     unsigned fa, fb, fc, ltile;
     size_t lds;
     if (!fused_geometry(M, dtype, fa, fb, fc, ltile, lds)) return hipErrorNotSupported;
@@ -745,18 +772,28 @@ hipError_t launch_c2c_bluestein(const C2cArgs &a, const BsDevTables &t, int dtyp
     f.in_img = a.in_img; f.out_img = a.out_img; f.in_ss = a.in_ss; f.in_is = a.in_is; f.out_ss = a.out_ss; f.out_is = a.out_is;
     f.inverse = a.inverse; f.in_seq_fast = a.in_seq_fast; f.out_seq_fast = a.out_seq_fast; f.scale = a.scale;
     f.chirp = t.chirp; f.bhp = t.bhp; f.tw = t.tw;
-    return run_bsc(f, false, t.M, a.batch, dtype, s);
+    return run_bsc(f, 0, t.M, a.batch, dtype, s);
 }
 
 // half spectrum -> real rows with C2rArgs' addressing (rows = sequences)
-hipError_t launch_c2r_bluestein(const C2rArgs &a, const BsDevTables &t, int dtype, hipStream_t s) {
+// `half`: the tables are those of length ncols / 2 (even ncols): the half-length complex form, one row per sequence
+hipError_t launch_c2r_bluestein(const C2rArgs &a, const BsDevTables &t, int dtype, hipStream_t s, bool half) {
     if (a.nbk) return hipErrorNotSupported;  // (the fused overlap-add belongs to k_c2r_reg)
+    if (half) {
+        if (a.ncols & 1u) return hipErrorInvalidValue;
+        BsC2c h{};
+        h.in = a.in; h.out = a.out; h.n = a.ncols / 2u; h.nseq = a.nrows; h.nrows = a.nrows;
+        h.in_img = a.in_img; h.out_img = (unsigned long long)a.nrows * a.ncols; h.in_ss = a.in_rs; h.in_is = a.in_ks; h.out_ss = a.ncols; h.out_is = 1;
+        h.inverse = 1; h.in_seq_fast = a.k_fast ? 0 : 1; h.out_seq_fast = 0; h.scale = a.scale;
+        h.chirp = t.chirp; h.bhp = t.bhp; h.tw = t.tw; h.win = a.win; h.bad_flag = a.bad_flag; h.twn = a.tw;
+        return run_bsc(h, 2, t.M, a.batch, dtype, s);
+    }
     BsC2c f{};
     f.in = a.in; f.out = a.out; f.n = a.ncols; f.nseq = (a.nrows + 1u) / 2u; f.nrows = a.nrows;
     f.in_img = a.in_img; f.out_img = (unsigned long long)a.nrows * a.ncols; f.in_ss = a.in_rs; f.in_is = a.in_ks; f.out_ss = a.ncols; f.out_is = 1;
     f.inverse = 1; f.in_seq_fast = a.k_fast ? 0 : 1; f.out_seq_fast = 0; f.scale = a.scale;
     f.chirp = t.chirp; f.bhp = t.bhp; f.tw = t.tw; f.win = a.win; f.bad_flag = a.bad_flag;
-    return run_bsc(f, true, t.M, a.batch, dtype, s);
+    return run_bsc(f, 1, t.M, a.batch, dtype, s);
 }
 
 

@@ -12,6 +12,7 @@
 #include <type_traits>
 
 #include "r32x16_layout.h"
+#include "reg_radix.h"
 #include "sgx_internal.h"
 
 // chirp-z vs the direct / two-factor sums: multiply-adds per sample the latter may cost, per log2(M) M / n.  Measured crossovers
@@ -890,7 +891,7 @@ sgx_status grow(sgx_plan *pl, void **buf, size_t *have, size_t need) {
 
 void free_device(sgx_plan *pl) {
     void **bufs[] = {&pl->d_window, &pl->d_tw, &pl->d_tw1, &pl->d_tw2, &pl->d_mel_ptr, &pl->d_mel_col,
-                     &pl->d_mel_val, &pl->d_dct, &pl->d_lifter, &pl->d_melbuf, &pl->d_pwbuf, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_mm_frag, &pl->d_mm_blk, &pl->d_mel_sched, &pl->d_itw, &pl->d_itwr, &pl->d_itw1, &pl->d_frames, &pl->d_flag, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half, &pl->d_bs_chirp, &pl->d_bs_tw, &pl->d_bs_wc, &pl->d_bs_bhp};
+                     &pl->d_mel_val, &pl->d_dct, &pl->d_lifter, &pl->d_melbuf, &pl->d_pwbuf, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_mm_frag, &pl->d_mm_blk, &pl->d_mel_sched, &pl->d_itw, &pl->d_itwr, &pl->d_itw1, &pl->d_frames, &pl->d_flag, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half, &pl->d_bs_chirp, &pl->d_bs_tw, &pl->d_bs_wc, &pl->d_bs_bhp, &pl->bs_half.chirp, &pl->bs_half.bhp, &pl->bs_half.tw};
     for (void **b : bufs)
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
@@ -922,6 +923,20 @@ sgx_status inverse_tables(sgx_plan *pl) {
     }
     sgx_status st = upload<T>(pl, &pl->d_itw, tw);
     if (st != SGX_OK) return st;
+    // Even lengths whose rows have neither a register-tiled split (n / 2) nor a chirp-z convolution of their own in LDS (f64 above
+    // 4096, f32 above 8192) invert through the chirp-z kernel in half-length complex form: tables of length n / 2.  (Before: the
+    // direct sum — f64 n_fft 6000, 64 x 10 s: 1.27 s.)
+    {
+        unsigned fa, fb, fc;
+        BsHostTables h;
+        if (n >= 32 && n % 2 == 0 && (n & (n - 1)) != 0 && !pl->d_bs_bhp && !reg_split_len(unsigned(n / 2), pl->dtype, &fa, &fb, &fc) &&
+            bluestein_host_tables(unsigned(n / 2), pl->dtype, h)) {
+            if ((st = upload_cast<T>(pl, &pl->bs_half.chirp, h.chirp)) != SGX_OK) return st;
+            if ((st = upload_cast<T>(pl, &pl->bs_half.bhp, h.bhp)) != SGX_OK) return st;
+            if ((st = upload_cast<T>(pl, &pl->bs_half.tw, h.tw)) != SGX_OK) return st;
+            pl->bs_half.M = h.M;
+        }
+    }
     // The fused tuned kernel recomputes ov = floor(1023 / hop) halo frames per 16-frame tile.  Up to ov = 10 (hop >= 94) that beats
     // the register-tiled rows + overlap-add through a frame scratch; below, the halo wins (256 x 10 s: hop 100 1.62 vs 1.68 ms,
     // hop 80 2.93 vs 2.04 ms, hop 64 — one new hop block per tile — 11.3 vs 2.5 ms).
@@ -975,6 +990,7 @@ sgx_status launch_c2r_frames(sgx_plan *pl, const void *spec, void *frames, size_
         e = launch_c2r_bluestein(c, t, pl->dtype, s);
     }
 #endif
+    if (e == hipErrorNotSupported && pl->bs_half.M) e = launch_c2r_bluestein(c, pl->bs_half, pl->dtype, s, true);
     if (e == hipErrorNotSupported) e = launch_c2r_rows(c, pl->dtype, s);
     SGX_HIP(pl, e);
     return SGX_OK;

@@ -82,11 +82,16 @@ def test_host_istft_validation():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
-@pytest.mark.parametrize("n_fft,hop,centre,window", CASES + [(4096, 1024, True, "hanning"), (8192, 2048, True, "hanning")])
+@pytest.mark.parametrize("n_fft,hop,centre,window", CASES + [(4096, 1024, True, "hanning"), (8192, 2048, True, "hanning"),
+                                                         # even lengths whose own chirp-z does not fit LDS in f64 (6000) / in either type (8200):
+                                                         # half-length complex form on the chirp-z kernel where ITS convolution fits
+                                                         (6000, 1500, True, "hanning"), (8200, 2050, True, "hamming")])
 def test_gpu_istft_matches_oracle(n_fft, hop, centre, window, dtype):
+    if n_fft == 8200 and dtype == "float64":
+        pytest.skip("an 8200-sample f64 frame does not fit any forward kernel's tile (plan creation reports it)")
     rdt, cdt = (np.float32, np.complex64) if dtype == "float32" else (np.float64, np.complex128)
-    n = max(3000, 3 * n_fft)
-    x = np.random.default_rng(5).standard_normal((3, n)).astype(rdt)
+    n = max(3000, 3 * n_fft) if n_fft < 6000 else n_fft + 2 * hop  # (the oracle's non-power-of-two transforms are O(n^2))
+    x = np.random.default_rng(5).standard_normal((3 if n_fft < 6000 else 2, n)).astype(rdt)
     wt = getattr(sg.WindowType, window)
     params = sg.SpectrogramParams(sg.StftParams(n_fft, hop, wt, centre), 16000.0)
     plan = sg.Plan(params, _ffi.AMP_COMPLEX, None, None, dtype)
