@@ -26,6 +26,7 @@ struct sgx_fft2d {
     unsigned log2r = 0, log2c = 0, tile_r = 0, tile_c = 0;
     // chirp-z tables for a dimension that is neither a power of two nor a listed size (bluestein.hip): columns (length nrows), inverse rows (ncols)
     BsDevTables bs_r, bs_c;
+    BsDevTables bs_ch;  // inverse rows of an even ncols whose own chirp-z does not fit LDS: tables of length ncols / 2 (half-length complex form)
     // what d_kspec / d_mask currently hold, and the stream they were produced on: a plan that convolves or filters batch after
     // batch with the same kernel / cut-offs (on the same stream, so the order is the stream's) prepares them once, not per call
     std::vector<unsigned char> kspec_of;
@@ -119,6 +120,7 @@ hipError_t c2c_dispatch(const sgx_fft2d *p, const C2cArgs &a, const BsDevTables 
 hipError_t c2r_dispatch(const sgx_fft2d *p, const C2rArgs &c, hipStream_t s) {
     hipError_t e = launch_c2r_reg(c, p->dtype, s);
     if (e == hipErrorNotSupported && p->bs_c.M) e = launch_c2r_bluestein(c, p->bs_c, p->dtype, s);
+    if (e == hipErrorNotSupported && p->bs_ch.M) e = launch_c2r_bluestein(c, p->bs_ch, p->dtype, s, true);
     return e == hipErrorNotSupported ? launch_c2r_rows(c, p->dtype, s) : e;
 }
 
@@ -387,6 +389,11 @@ sgx_status sgx_fft2d_create(size_t nrows, size_t ncols, int32_t dtype, int32_t d
             if (wants_bluestein(ncols, ncols % 2 == 0 && reg_split_len(unsigned(ncols / 2), dtype, &fa, &fb, &fc), dtype, h) &&
                 (s1 = dtype == SGX_F64 ? upload_bs<double>(p, p->bs_c, h) : upload_bs<float>(p, p->bs_c, h)) != SGX_OK)
                 return s1;
+            // even ncols without either: the half-length complex form, if THAT convolution fits (f64 4098 ... 8192, f32 8194 ... 16384)
+            if (!p->bs_c.M && ncols % 2 == 0 && ncols >= 32 && (ncols & (ncols - 1)) != 0 && !reg_split_len(unsigned(ncols / 2), dtype, &fa, &fb, &fc) &&
+                bluestein_host_tables(unsigned(ncols / 2), dtype, h) &&
+                (s1 = dtype == SGX_F64 ? upload_bs<double>(p, p->bs_ch, h) : upload_bs<float>(p, p->bs_ch, h)) != SGX_OK)
+                return s1;
         }
         if (dtype == SGX_F32 && nrows == 1024) {
             std::vector<float> t(2 * 32 * 32);
@@ -433,7 +440,7 @@ void sgx_fft2d_destroy(sgx_fft2d *p) {
         DeviceGuard dg;
         (void)dg.enter(p->device);
         void *bufs[] = {p->d_tw_r, p->d_tw_c, p->d_tw1c, p->d_twr, p->d_tw1r, p->d_inter, p->d_spec, p->d_kspec, p->d_mask, p->d_in, p->d_out, p->d_kimg,
-                        p->bs_r.chirp, p->bs_r.bhp, p->bs_r.tw, p->bs_c.chirp, p->bs_c.bhp, p->bs_c.tw};
+                        p->bs_r.chirp, p->bs_r.bhp, p->bs_r.tw, p->bs_c.chirp, p->bs_c.bhp, p->bs_c.tw, p->bs_ch.chirp, p->bs_ch.bhp, p->bs_ch.tw};
         for (void *b : bufs)
             if (b) (void)hipFree(b);
         if (p->aux_stream) (void)hipStreamDestroy(p->aux_stream);

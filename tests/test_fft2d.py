@@ -120,6 +120,8 @@ def test_host_validation():
                                             # rows) and chirp-z inverse rows (length = columns), odd and even, primes and composites
                                             (251, 509), (509, 251), (1009, 12), (12, 1009), (1023, 1023), (127, 90), (90, 127), (2003, 5),
                                             (5, 2003), (4093, 3), (3, 4093), (17, 19), (6000, 3), (3, 6000), (98, 94),
+                                            # (3, 6000) in f64: inverse rows in half-length complex form (their own chirp-z does not fit LDS); (2, 8200) in f32 likewise
+                                            (2, 8200),
                                             # 1000 / 1200 / 1280 as column lengths and as (halved) row lengths: register-tiled, 40-point second pass
                                             (1200, 5), (1280, 3), (5, 2000), (3, 2400), (1080, 6), (6, 1280), (640, 4)])
 def test_gpu_fft2d_matches_oracle(shape, dtype):
