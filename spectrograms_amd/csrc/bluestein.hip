@@ -439,6 +439,8 @@ __global__ __launch_bounds__(256, (bs_waves<T, A_, B_, C_>())) void k_bs_fused(B
 // HALF: the same rows for an EVEN length 2 n whose full-length convolution does not fit LDS (f64 above 4096, f32 above 8192): the
 // half-length complex form Z'[k] = (X[k] + conj X[n - k]) + i conj(W_2n^k)(X[k] - conj X[n - k]), k < n, inverts to x[2 j] + i x[2 j + 1]
 // (k_c2r_reg's fold), one row per sequence, M >= 2 n - 1 = the row length - 1.
+// FWDH: the forward direction of the same: STFT frames of an even length 2 n (f64 4098 ... 8192, f32 8194 ... 16384, not powers of two or
+// listed sizes) as z[j] = w[2 j] x[2 j] + i w[2 j + 1] x[2 j + 1], Z = DFT_n(z), X[k] = (Z[k] + conj Z[n - k]) / 2 - (i / 2) W_2n^k (Z[k] - conj Z[n - k]).
 struct BsC2c {
     const void *in;
     void *out;
@@ -451,11 +453,18 @@ struct BsC2c {
     const void *win;     // HERM / HALF: optional window (of the real row's length) applied after the scale
     const void *twn;     // HALF: e^(-2 pi i k / (2 n)), k < n: the real row has 2 n samples, the sequence is its half-length complex form
     unsigned *bad_flag;  // HERM: set when a DC / Nyquist bin carries an imaginary part
+    // FWDH (forward STFT frames of an even length 2 n in half-length complex form): sequence s of image b = frame s of signal b, read
+    // from in[b * in_img + s * hop - pad + j] with virtual zero padding (S1) and the window `win` (S4), bins k <= n written to
+    // out[b * out_img + k * out_is + s]; twn as for HALF
+    unsigned hop, pad;
+    unsigned long long n_samples;
+    int complex_out, amp;
+    double eps;
 };
 
 template <typename T, int A_, int B_, int C_, int RMODE>
 __global__ __launch_bounds__(256, (bs_waves<T, A_, B_, C_>())) void k_bs_c2c(BsC2c a, unsigned ltile) {
-    constexpr bool HERM = RMODE == 1, HALF = RMODE == 2;  // 0: complex sequences
+    constexpr bool HERM = RMODE == 1, HALF = RMODE == 2, FWDH = RMODE == 3;  // 0: complex sequences
     typedef typename PairOf<T>::type V;
     constexpr unsigned A = A_, B = B_, C = C_, BC = B * C, N = A * BC, HA = A / 2;
     constexpr int LA = ct_log2_ceil(A);
@@ -492,7 +501,9 @@ __global__ __launch_bounds__(256, (bs_waves<T, A_, B_, C_>())) void k_bs_c2c(BsC
         return (V){v.x, up ? v.y : -v.y};
     };
     auto element = [&](const V *seq, unsigned m, bool second) {
-        if constexpr (HALF) {
+        if constexpr (FWDH) {  // seq: the signal's samples (as T), frame start in `fstart`
+            return (V){T(0), T(0)};  // (loaded in the stage itself: it needs the frame's start)
+        } else if constexpr (HALF) {
             V Xk = seq[(size_t)m * a.in_is], Xm = seq[(size_t)(n - m) * a.in_is];
             if (m == 0) {  // DC and Nyquist bins
                 if ((Xk.y != T(0) || Xm.y != T(0)) && a.bad_flag) *a.bad_flag = 1u;
@@ -519,11 +530,30 @@ __global__ __launch_bounds__(256, (bs_waves<T, A_, B_, C_>())) void k_bs_c2c(BsC
         const V *seq = in + (size_t)(s0 + s) * (HERM ? 2u : 1u) * a.in_ss;  // (HALF: one row per sequence)
         const bool second = HERM && 2u * (s0 + s) + 1u < a.nrows;
         V v[A];
+        if constexpr (FWDH) {
+            const T *xs = (const T *)a.in + (size_t)b * a.in_img;
+            const long long fstart = (long long)(s0 + s) * a.hop - (long long)a.pad;
+            const T *w = (const T *)a.win;
 #pragma unroll
-        for (unsigned n1 = 0; n1 < HA; ++n1) {
-            const unsigned m = n1 * BC + r;
-            v[n1] = m < n ? inreg::cmulv(element(seq, m, second), chirp[m]) : (V){T(0), T(0)};
-            v[n1 + HA] = (V){T(0), T(0)};
+            for (unsigned n1 = 0; n1 < HA; ++n1) {
+                const unsigned m = n1 * BC + r;
+                V z = {T(0), T(0)};
+                if (m < n) {
+                    const long long p0 = fstart + 2 * (long long)m;
+                    if (p0 >= 0 && (unsigned long long)p0 < a.n_samples) z.x = xs[p0] * w[2u * m];
+                    if (p0 + 1 >= 0 && (unsigned long long)(p0 + 1) < a.n_samples) z.y = xs[p0 + 1] * w[2u * m + 1u];
+                    z = inreg::cmulv(z, chirp[m]);
+                }
+                v[n1] = z;
+                v[n1 + HA] = (V){T(0), T(0)};
+            }
+        } else {
+#pragma unroll
+            for (unsigned n1 = 0; n1 < HA; ++n1) {
+                const unsigned m = n1 * BC + r;
+                v[n1] = m < n ? inreg::cmulv(element(seq, m, second), chirp[m]) : (V){T(0), T(0)};
+                v[n1 + HA] = (V){T(0), T(0)};
+            }
         }
         inreg::MixFft<A, V>::run(v);
         V pw2[LA];
@@ -559,6 +589,33 @@ __global__ __launch_bounds__(256, (bs_waves<T, A_, B_, C_>())) void k_bs_c2c(BsC
         }
     }
     __syncthreads();
+    if constexpr (FWDH) {
+        // bins 0 ... n of every frame of the tile; lanes walk the frames first (contiguous in the output)
+        const T eps = (T)a.eps;
+        const V *twn = (const V *)a.twn;
+        for (unsigned idx = tid; idx < (n + 1u) << ltile; idx += 256) {
+            const unsigned s = idx & (tile - 1u), k = idx >> ltile;
+            if (s >= ns) continue;
+            const V *seq = buf + (size_t)s * FS;
+            auto at = [&](unsigned m) {
+                const unsigned n1 = m / BC, r = m % BC;
+                return seq[n1 * RS + ((L::hi_part(r / C) ^ (r % C)) ^ L::k1_mask(n1))];
+            };
+            const V Zk = at(k == n ? 0u : k), Zc = at(k == 0u || k == n ? 0u : n - k);  // Zm = conj Z[n - k]
+            const V E = {T(0.5) * (Zk.x + Zc.x), T(0.5) * (Zk.y - Zc.y)};
+            const V O = {T(0.5) * (Zk.y + Zc.y), T(-0.5) * (Zk.x - Zc.x)};  // -i (Zk - Zm) / 2
+            const V wk = k == n ? (V){T(-1), T(0)} : twn[k];                    // W_2n^k
+            const V X = E + inreg::cmulv(O, wk);
+            const unsigned long long o = (size_t)b * a.out_img + (size_t)k * a.out_is + (s0 + s);
+            if (a.complex_out) {
+                ((V *)a.out)[o] = X;
+            } else {
+                const T pw = X.x * X.x + X.y * X.y;
+                ((T *)a.out)[o] = a.amp == AMP_MAGNITUDE ? sqrt(pw) : a.amp == AMP_DB ? bs_db(pw > eps ? pw : eps) : pw;
+            }
+        }
+        return;
+    }
     const T sc = (T)a.scale;
     for (unsigned idx = tid; idx < tile * n; idx += 256) {
         unsigned s, k;
@@ -658,13 +715,14 @@ hipError_t run_fused(const BsArgs &a, int dtype, hipStream_t s) {
 
 template <typename T, int A, int B, int C>
 hipError_t launch_bsc_t(const BsC2c &f, int rmode, unsigned ltile, size_t lds, hipStream_t s) {
-    const void *fn = rmode == 2 ? (const void *)k_bs_c2c<T, A, B, C, 2> : rmode == 1 ? (const void *)k_bs_c2c<T, A, B, C, 1> : (const void *)k_bs_c2c<T, A, B, C, 0>;
+    const void *fn = rmode == 3 ? (const void *)k_bs_c2c<T, A, B, C, 3> : rmode == 2 ? (const void *)k_bs_c2c<T, A, B, C, 2> : rmode == 1 ? (const void *)k_bs_c2c<T, A, B, C, 1> : (const void *)k_bs_c2c<T, A, B, C, 0>;
     if (lds > 64 * 1024) {
         hipError_t e = set_max_dynamic_lds(fn, (int)bs_lds_budget(sizeof(T) == 8 ? SGX_F64 : SGX_F32, A * B * C));
         if (e != hipSuccess) return e;
     }
     const dim3 grid(xcd_grid(f.total_tiles));
-    if (rmode == 2) hipLaunchKernelGGL((k_bs_c2c<T, A, B, C, 2>), grid, dim3(256), lds, s, f, ltile);
+    if (rmode == 3) hipLaunchKernelGGL((k_bs_c2c<T, A, B, C, 3>), grid, dim3(256), lds, s, f, ltile);
+    else if (rmode == 2) hipLaunchKernelGGL((k_bs_c2c<T, A, B, C, 2>), grid, dim3(256), lds, s, f, ltile);
     else if (rmode == 1) hipLaunchKernelGGL((k_bs_c2c<T, A, B, C, 1>), grid, dim3(256), lds, s, f, ltile);
     else hipLaunchKernelGGL((k_bs_c2c<T, A, B, C, 0>), grid, dim3(256), lds, s, f, ltile);
     return hipGetLastError();
@@ -762,6 +820,18 @@ bool bluestein_host_tables(unsigned n, int dtype, BsHostTables &t) {
         t.tw[2 * k + 1] = std::sin(a);
     }
     return true;
+}
+
+// forward STFT frames of an even n_fft in half-length complex form (t: tables of length n_fft / 2; twn: e^(-2 pi i k / n_fft))
+hipError_t launch_bluestein_half(const BsArgs &a, const BsDevTables &t, const void *window, const void *twn, int dtype, hipStream_t s) {
+    if ((a.n_fft & 1u) || a.mel_ptr) return hipErrorNotSupported;
+    BsC2c f{};
+    f.in = a.x; f.out = a.out; f.n = a.n_fft / 2u; f.nseq = a.n_frames; f.nrows = a.n_frames;
+    f.in_img = a.sample_stride; f.out_img = (unsigned long long)a.nb * a.n_frames; f.out_is = a.n_frames; f.out_ss = 1;
+    f.in_seq_fast = 0; f.out_seq_fast = 1; f.scale = 1.0;
+    f.chirp = t.chirp; f.bhp = t.bhp; f.tw = t.tw; f.win = window; f.twn = twn;
+    f.hop = a.hop; f.pad = a.pad; f.n_samples = a.n_samples; f.complex_out = a.complex_out; f.amp = a.amp; f.eps = a.eps;
+    return run_bsc(f, 3, t.M, a.batch, dtype, s);
 }
 
 // complex sequences with C2cArgs' addressing (a.tw / a.tile / a.tiles / a.log2n / a.mul are not used)

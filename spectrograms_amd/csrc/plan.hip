@@ -625,7 +625,14 @@ sgx_status build_device_tables(sgx_plan *pl) {
         if ((st = upload<float>(pl, &pl->d_window_half, wh)) != SGX_OK) return st;
         if ((st = upload<float>(pl, &pl->d_ones_half, oh)) != SGX_OK) return st;
     }
-    if (pl->kind == K_BLUESTEIN) {  // chirp-z tables (bluestein.hip), evaluated in f64
+    if (pl->kind == K_BLUESTEIN && pl->bs_fwd_half) {  // half-length complex form: tables of length n / 2 (shared with the inverse rows)
+        BsHostTables h;
+        if (!bluestein_host_tables(n / 2, pl->dtype, h)) return set_err(pl, SGX_INTERNAL, "Internal error: chirp-z plan without a pass split");
+        if ((st = upload_cast<T>(pl, &pl->bs_half.chirp, h.chirp)) != SGX_OK) return st;
+        if ((st = upload_cast<T>(pl, &pl->bs_half.bhp, h.bhp)) != SGX_OK) return st;
+        if ((st = upload_cast<T>(pl, &pl->bs_half.tw, h.tw)) != SGX_OK) return st;
+        pl->bs_half.M = h.M;
+    } else if (pl->kind == K_BLUESTEIN) {  // chirp-z tables (bluestein.hip), evaluated in f64
         const unsigned M = pl->bs_M;
         // c_j = e^(+i pi j^2 / n): the angle is reduced in integers, j^2 mod 2 n, so that a large j loses nothing
         auto chirp = [&](unsigned j, double &re, double &im) {
@@ -755,6 +762,7 @@ sgx_status grow(sgx_plan *pl, void **buf, size_t *have, size_t need);
 
 hipError_t launch_bluestein_plan(sgx_plan *pl, const StftArgs &a, hipStream_t s) {
     BsArgs b{};
+    const bool half = pl->bs_fwd_half;
     b.x = a.x; b.out = a.out;
     b.sample_stride = a.sample_stride; b.n_samples = a.n_samples;
     b.batch = a.batch; b.n_fft = a.n_fft; b.hop = a.hop; b.pad = a.pad; b.n_frames = a.n_frames; b.nb = a.nb_fft;
@@ -766,6 +774,7 @@ hipError_t launch_bluestein_plan(sgx_plan *pl, const StftArgs &a, hipStream_t s)
     if (a.out_mode == OUT_MEL) {  // (f32, M <= 1024) the bank's rows in the same launch: the |X|^2 of a tile never leave LDS
         b.mel_ptr = a.mel_ptr; b.mel_col = a.mel_col; b.mel_val = a.mel_val; b.n_mels = a.n_mels; b.n_out = a.n_out;
     }
+    if (half) return launch_bluestein_half(b, pl->bs_half, a.window, pl->d_tw, pl->dtype, s);
     return launch_bluestein(b, pl->dtype, s);
 }
 
@@ -929,7 +938,7 @@ sgx_status inverse_tables(sgx_plan *pl) {
     {
         unsigned fa, fb, fc;
         BsHostTables h;
-        if (n >= 32 && n % 2 == 0 && (n & (n - 1)) != 0 && !pl->d_bs_bhp && !reg_split_len(unsigned(n / 2), pl->dtype, &fa, &fb, &fc) &&
+        if (!pl->bs_half.M && n >= 32 && n % 2 == 0 && (n & (n - 1)) != 0 && !pl->d_bs_bhp && !reg_split_len(unsigned(n / 2), pl->dtype, &fa, &fb, &fc) &&
             bluestein_host_tables(unsigned(n / 2), pl->dtype, h)) {
             if ((st = upload_cast<T>(pl, &pl->bs_half.chirp, h.chirp)) != SGX_OK) return st;
             if ((st = upload_cast<T>(pl, &pl->bs_half.bhp, h.bhp)) != SGX_OK) return st;
@@ -1146,7 +1155,18 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
             unsigned fa3 = 0, fb3 = 0, fc3 = 0;
             const bool can = n >= 16 && bluestein_fused_split(M, pl->dtype, &fa3, &fb3, &fc3);
             const double cost = pl->out_mode == OUT_MEL && pl->dtype == SGX_F32 ? SGX_BS_COST_BANK32 : SGX_BS_COST;
-            if (can && (!ok || per_sample > cost * double(l2) * double(M) / double(n))) {
+            // even lengths whose own convolution does not fit LDS (f64 4098 ... 8192, f32 8194 ... 16384): half-length complex form,
+            // one frame per sequence of n / 2 points (k_bs_c2c, RMODE 3), M >= n - 1
+            unsigned Mh = 1, l2h = 0;
+            while (Mh < n - 1) { Mh <<= 1; ++l2h; }
+            if (!can && n >= 32 && n % 2 == 0 && (n & (n - 1)) != 0 && bluestein_fused_split(Mh, pl->dtype, &fa3, &fb3, &fc3) &&
+                (!ok || per_sample > cost * double(l2h) * double(Mh) / double(n / 2))) {
+                pl->bs_M = Mh;
+                pl->bs_fwd_half = true;
+                kind = K_BLUESTEIN;
+                pl->split_bank = pl->out_mode == OUT_MEL;
+                ok = true;
+            } else if (can && (!ok || per_sample > cost * double(l2) * double(M) / double(n))) {
                 pl->bs_M = M;
                 kind = K_BLUESTEIN;
                 // filterbank outputs: up to M = 1024 the bank's rows run inside the kernel (a tile holds >= 4 frame pairs: 320+ (band,

@@ -124,6 +124,7 @@ bool bluestein_host_tables(unsigned n, int dtype, BsHostTables &t);
 struct C2cArgs;
 struct C2rArgs;
 hipError_t launch_c2c_bluestein(const C2cArgs &a, const BsDevTables &t, int dtype, hipStream_t s);
+hipError_t launch_bluestein_half(const BsArgs &a, const BsDevTables &t, const void *window, const void *twn, int dtype, hipStream_t s);
 hipError_t launch_c2r_bluestein(const C2rArgs &a, const BsDevTables &t, int dtype, hipStream_t s, bool half = false);
 
 // ---- 2-D FFT path (kernels_fft2d.hip)
@@ -305,6 +306,7 @@ struct sgx_plan {
     // K_BLUESTEIN: chirp, transformed chirp, length-M twiddles, two frame scratch buffers (grown on demand, sgx_reserve sizes them)
     void *d_bs_chirp = nullptr, *d_bs_tw = nullptr, *d_bs_wc = nullptr, *d_bs_bhp = nullptr;
     unsigned bs_M = 0;
+    bool bs_fwd_half = false;  // K_BLUESTEIN in half-length complex form (even n_fft whose own convolution does not fit LDS)
     sgx::BsDevTables bs_half;  // inverse rows of an even n_fft whose own chirp-z does not fit: tables of length n_fft / 2 (inverse_tables)
     size_t d_frames_bytes = 0;
 

@@ -171,7 +171,9 @@ def test_kernel_selection():
     assert host_plan(5003, 2000, dtype="float32").kernel_name == "bluestein"
     assert host_plan(3000, 700).kernel_name == "bluestein"       # 50 x 60: M = 8192
     assert host_plan(6000, 1500, dtype="float32").kernel_name == "bluestein"
-    assert host_plan(6000, 1500, dtype="float64").kernel_name == "two_factor_dft"  # f64: M = 16384 does not fit LDS
+    assert host_plan(6000, 1500, dtype="float64").kernel_name == "bluestein"  # f64: M = 16384 does not fit LDS; even: half-length complex form (M = 8192)
+    assert host_plan(12000, 3000, dtype="float32").kernel_name == "bluestein"  # likewise in f32 above 8192
+    assert host_plan(6001, 1500, dtype="float64").kernel_name in ("two_factor_dft", "direct_dft")  # odd: no half-length form
     assert host_plan(4099, 1000, dtype="float64").kernel_name == "direct_dft"
     assert host_plan(9001, 1000, dtype="float32").kernel_name == "direct_dft"       # M = 32768: nothing but the sum
 

@@ -158,14 +158,16 @@ def test_long_frames_filterbank_in_a_second_launch(n_fft, hop, dtype, n_mels, no
     assert np.array_equal(np.asarray(plan.compute_batch(x)), np.asarray(got))
 
 
-@pytest.mark.parametrize("n_fft,hop,dtype,kernel", [(6000, 1500, "float32", "bluestein"), (6000, 2000, "float64", "two_factor_dft"),
+@pytest.mark.parametrize("n_fft,hop,dtype,kernel", [(6000, 1500, "float32", "bluestein"), (6000, 2000, "float64", "bluestein"), (8200, 2050, "float32", "bluestein"),
+                                                    (6003, 2000, "float64", "two_factor_dft"),
                                                     (3000, 700, "float64", "bluestein"), (5003, 2000, "float32", "bluestein"),
                                                     (8191, 2048, "float32", "bluestein"), (4099, 1000, "float64", "direct_dft")])
 @pytest.mark.parametrize("amp", ["complex", "power"])
 def test_long_frames_outside_the_register_tiled_lists(n_fft, hop, dtype, kernel, amp):
     """Frames of 2049 ... 8192 samples that are not a listed size: chirp-z with one 8192- / 16384-point sequence per workgroup in
-    LDS (f32 up to n_fft 8192, f64 up to 4096 — 128 KiB of LDS either way); f64 above 4096 keeps the two-factor kernel (composites)
-    or the direct sum (primes), one frame per tile, twiddle table in global memory."""
+    LDS (f32 up to n_fft 8192, f64 up to 4096 — 128 KiB of LDS either way); even lengths up to twice that take the half-length complex
+    form on the same kernels (one frame per sequence of n_fft / 2 points); odd ones keep the two-factor kernel (composites) or the
+    direct sum (primes), one frame per tile, twiddle table in global memory."""
     plan, got = run_case(n=3 * n_fft + 77, batch=2, n_fft=n_fft, hop=hop, amp=amp, dtype=dtype)
     assert plan.kernel_name == kernel
     x = signals(2, 3 * n_fft + 77, np.float32 if dtype == "float32" else np.float64, 0)
