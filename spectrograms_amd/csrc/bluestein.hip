@@ -845,6 +845,50 @@ hipError_t launch_c2c_bluestein(const C2cArgs &a, const BsDevTables &t, int dtyp
     return run_bsc(f, 0, t.M, a.batch, dtype, s);
 }
 
+// Complex sequences of an EVEN length n = 2 m whose own convolution does not fit LDS (f64 4098 ... 8192, f32 8194 ... 16384): one
+// radix-2 step outside — the even and the odd elements as two chirp-z transforms of length m (t: tables of length m) into
+// `scratch` ([batch][2][nseq][m] complex), then X[k] = E[k] + W_n^k O[k], X[k + m] = E[k] - W_n^k O[k] (inverse: conj W) with the
+// caller's output strides and scale.
+template <typename T>
+__global__ __launch_bounds__(256) void k_bs_combine(const typename PairOf<T>::type *eo, typename PairOf<T>::type *out, const typename PairOf<T>::type *twn,
+                                                    unsigned m, unsigned nseq, unsigned long long total, unsigned long long out_img,
+                                                    unsigned long long out_ss, unsigned long long out_is, int seq_fast, int inverse, T scale) {
+    typedef typename PairOf<T>::type V;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x; i < total; i += (unsigned long long)gridDim.x * 256u) {
+        const unsigned long long per = (unsigned long long)nseq * m, b = i / per, r = i - b * per;
+        const unsigned q = seq_fast ? (unsigned)(r % nseq) : (unsigned)(r / m), k = seq_fast ? (unsigned)(r / nseq) : (unsigned)(r % m);
+        const V E = eo[(b * 2u * nseq + q) * m + k], O = eo[((b * 2u + 1u) * nseq + q) * m + k];
+        const V w = twn[k];
+        const V t = inreg::cmulv(O, (V){w.x, inverse ? -w.y : w.y});
+        V *o = out + b * out_img + q * out_ss + k * out_is;
+        o[0] = (E + t) * (V){scale, scale};
+        o[(unsigned long long)m * out_is] = (E - t) * (V){scale, scale};
+    }
+}
+
+hipError_t launch_c2c_bluestein_split(const C2cArgs &a, const BsDevTables &t, void *scratch, int dtype, hipStream_t s) {
+    if (a.mul || (a.n & 1u) || !scratch) return hipErrorNotSupported;
+    const unsigned m = a.n / 2u;
+    const size_t es = dtype == SGX_F64 ? 8 : 4;
+    C2cArgs h = a;
+    h.n = m; h.in_is = 2ull * a.in_is; h.out_img = 2ull * a.nseq * m; h.out_ss = m; h.out_is = 1; h.out_seq_fast = 0; h.scale = 1.0;
+    for (unsigned par = 0; par < 2u; ++par) {
+        h.in = (const char *)a.in + (size_t)par * a.in_is * 2 * es;
+        h.out = (char *)scratch + (size_t)par * a.nseq * m * 2 * es;
+        const hipError_t e = launch_c2c_bluestein(h, t, dtype, s);
+        if (e != hipSuccess) return e;
+    }
+    const unsigned long long total = (unsigned long long)a.batch * a.nseq * m;
+    const unsigned blocks = (unsigned)std::min<unsigned long long>((total + 255) / 256, 65536ull);
+    if (dtype == SGX_F64)
+        hipLaunchKernelGGL(k_bs_combine<double>, dim3(blocks), dim3(256), 0, s, (const inreg::v2d *)scratch, (inreg::v2d *)a.out, (const inreg::v2d *)a.tw, m, a.nseq,
+                           total, a.out_img, a.out_ss, a.out_is, a.out_seq_fast, a.inverse, a.scale);
+    else
+        hipLaunchKernelGGL(k_bs_combine<float>, dim3(blocks), dim3(256), 0, s, (const inreg::v2f *)scratch, (inreg::v2f *)a.out, (const inreg::v2f *)a.tw, m, a.nseq,
+                           total, a.out_img, a.out_ss, a.out_is, a.out_seq_fast, a.inverse, (float)a.scale);
+    return hipGetLastError();
+}
+
 // half spectrum -> real rows with C2rArgs' addressing (rows = sequences)
 // `half`: the tables are those of length ncols / 2 (even ncols): the half-length complex form, one row per sequence
 hipError_t launch_c2r_bluestein(const C2rArgs &a, const BsDevTables &t, int dtype, hipStream_t s, bool half) {

@@ -26,6 +26,9 @@ struct sgx_fft2d {
     unsigned log2r = 0, log2c = 0, tile_r = 0, tile_c = 0;
     // chirp-z tables for a dimension that is neither a power of two nor a listed size (bluestein.hip): columns (length nrows), inverse rows (ncols)
     BsDevTables bs_r, bs_c;
+    BsDevTables bs_rh;  // columns of an even length whose own chirp-z does not fit LDS: tables of length nrows / 2 (radix-2 step outside)
+    void *d_half = nullptr;  // its [batch][2][cb][nrows / 2] scratch
+    size_t half_bytes = 0;
     BsDevTables bs_ch;  // inverse rows of an even ncols whose own chirp-z does not fit LDS: tables of length ncols / 2 (half-length complex form)
     // what d_kspec / d_mask currently hold, and the stream they were produced on: a plan that convolves or filters batch after
     // batch with the same kernel / cut-offs (on the same stream, so the order is the stream's) prepares them once, not per call
@@ -115,6 +118,8 @@ bool wants_bluestein(size_t n, bool has_split, int dtype, BsHostTables &h) {
 hipError_t c2c_dispatch(const sgx_fft2d *p, const C2cArgs &a, const BsDevTables &bs, hipStream_t s) {
     hipError_t e = launch_c2c_reg(a, p->dtype, s);
     if (e == hipErrorNotSupported && bs.M && !a.mul) e = launch_c2c_bluestein(a, bs, p->dtype, s);
+    if (e == hipErrorNotSupported && p->bs_rh.M && !a.mul && p->half_bytes >= (size_t)a.batch * a.nseq * a.n * 2 * p->elem)
+        e = launch_c2c_bluestein_split(a, p->bs_rh, p->d_half, p->dtype, s);
     return e == hipErrorNotSupported ? launch_c2c_tile(a, p->dtype, s) : e;
 }
 hipError_t c2r_dispatch(const sgx_fft2d *p, const C2rArgs &c, hipStream_t s) {
@@ -122,6 +127,12 @@ hipError_t c2r_dispatch(const sgx_fft2d *p, const C2rArgs &c, hipStream_t s) {
     if (e == hipErrorNotSupported && p->bs_c.M) e = launch_c2r_bluestein(c, p->bs_c, p->dtype, s);
     if (e == hipErrorNotSupported && p->bs_ch.M) e = launch_c2r_bluestein(c, p->bs_ch, p->dtype, s, true);
     return e == hipErrorNotSupported ? launch_c2r_rows(c, p->dtype, s) : e;
+}
+
+// the radix-2-outside column pass (bs_rh) works through a scratch of the spectrum's size
+sgx_status grow_half(sgx_fft2d *p, size_t batch) {
+    if (!p->bs_rh.M) return SGX_OK;
+    return grow2(p, &p->d_half, &p->half_bytes, batch * p->cb * p->nrows * 2 * p->elem);
 }
 
 // device pointers in, device pointers out
@@ -132,6 +143,7 @@ sgx_status forward_dev(sgx_fft2d *p, const void *img, size_t batch, void *spec, 
     const size_t R = p->nrows, C = p->ncols, Cb = p->cb;
     sgx_status st = grow2(p, &p->d_inter, &p->inter_bytes, batch * Cb * R * 2 * p->elem);
     if (st != SGX_OK) return st;
+    if ((st = grow_half(p, batch)) != SGX_OK) return st;
     // rows: every image is one "signal" of R*C samples, frames = rows -> inter[b][k][r]
     st = sgx_execute(p->rows, img, batch, R * C, R * C, p->d_inter, batch * Cb * R * 2, SGX_MEM_DEVICE, s);
     if (st != SGX_OK) return fail(p, st, sgx_last_error(p->rows));
@@ -165,6 +177,7 @@ sgx_status inverse_dev(sgx_fft2d *p, const void *spec, size_t batch, void *img, 
     const size_t R = p->nrows, C = p->ncols, Cb = p->cb;
     sgx_status st = grow2(p, &p->d_inter, &p->inter_bytes, batch * Cb * R * 2 * p->elem);
     if (st != SGX_OK) return st;
+    if ((st = grow_half(p, batch)) != SGX_OK) return st;
     C2cArgs a{};
     a.in = spec; a.out = p->d_inter;
     a.n = unsigned(R); a.log2n = p->log2r; a.nseq = unsigned(Cb); a.batch = unsigned(batch);
@@ -332,7 +345,8 @@ sgx_status sgx_fft2d_reserve(sgx_fft2d *p, size_t batch, int32_t host_staging) {
     sgx_status st;
     if ((st = grow2(p, &p->d_inter, &p->inter_bytes, batch * Cb * R * 2 * p->elem)) != SGX_OK) return st;
     if ((st = grow2(p, &p->d_spec, &p->spec_bytes, batch * R * Cb * 2 * p->elem)) != SGX_OK) return st;
-    if (fused_chunked(p, batch) && (st = fused_streams(p)) != SGX_OK) return st;  // nothing left to create inside a graph capture
+    if (fused_chunked(p, batch) && (st = fused_streams(p)) != SGX_OK) return st;
+    if ((st = grow_half(p, batch)) != SGX_OK) return st;  // nothing left to create inside a graph capture
     if (host_staging) {
         const size_t big = batch * R * Cb * 2 * p->elem;  // a half spectrum is the larger of (image, spectrum)
         if ((st = grow2(p, &p->d_in, &p->in_bytes, big)) != SGX_OK) return st;
@@ -384,6 +398,11 @@ sgx_status sgx_fft2d_create(size_t nrows, size_t ncols, int32_t dtype, int32_t d
             BsHostTables h;
             if (wants_bluestein(nrows, reg_split_len(unsigned(nrows), dtype, &fa, &fb, &fc), dtype, h) &&
                 (s1 = dtype == SGX_F64 ? upload_bs<double>(p, p->bs_r, h) : upload_bs<float>(p, p->bs_r, h)) != SGX_OK)
+                return s1;
+            // even column lengths with neither: one radix-2 step outside two half-length chirp-z transforms
+            if (!p->bs_r.M && nrows % 2 == 0 && nrows >= 32 && (nrows & (nrows - 1)) != 0 && !reg_split_len(unsigned(nrows), dtype, &fa, &fb, &fc) &&
+                wants_bluestein(nrows / 2, false, dtype, h) &&
+                (s1 = dtype == SGX_F64 ? upload_bs<double>(p, p->bs_rh, h) : upload_bs<float>(p, p->bs_rh, h)) != SGX_OK)
                 return s1;
             // (the inverse row pass is register-tiled for even ncols whose half has a split)
             if (wants_bluestein(ncols, ncols % 2 == 0 && reg_split_len(unsigned(ncols / 2), dtype, &fa, &fb, &fc), dtype, h) &&
@@ -440,7 +459,7 @@ void sgx_fft2d_destroy(sgx_fft2d *p) {
         DeviceGuard dg;
         (void)dg.enter(p->device);
         void *bufs[] = {p->d_tw_r, p->d_tw_c, p->d_tw1c, p->d_twr, p->d_tw1r, p->d_inter, p->d_spec, p->d_kspec, p->d_mask, p->d_in, p->d_out, p->d_kimg,
-                        p->bs_r.chirp, p->bs_r.bhp, p->bs_r.tw, p->bs_c.chirp, p->bs_c.bhp, p->bs_c.tw, p->bs_ch.chirp, p->bs_ch.bhp, p->bs_ch.tw};
+                        p->bs_r.chirp, p->bs_r.bhp, p->bs_r.tw, p->bs_c.chirp, p->bs_c.bhp, p->bs_c.tw, p->bs_ch.chirp, p->bs_ch.bhp, p->bs_ch.tw, p->bs_rh.chirp, p->bs_rh.bhp, p->bs_rh.tw, p->d_half};
         for (void *b : bufs)
             if (b) (void)hipFree(b);
         if (p->aux_stream) (void)hipStreamDestroy(p->aux_stream);

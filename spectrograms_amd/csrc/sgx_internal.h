@@ -124,6 +124,7 @@ bool bluestein_host_tables(unsigned n, int dtype, BsHostTables &t);
 struct C2cArgs;
 struct C2rArgs;
 hipError_t launch_c2c_bluestein(const C2cArgs &a, const BsDevTables &t, int dtype, hipStream_t s);
+hipError_t launch_c2c_bluestein_split(const C2cArgs &a, const BsDevTables &t, void *scratch, int dtype, hipStream_t s);
 hipError_t launch_bluestein_half(const BsArgs &a, const BsDevTables &t, const void *window, const void *twn, int dtype, hipStream_t s);
 hipError_t launch_c2r_bluestein(const C2rArgs &a, const BsDevTables &t, int dtype, hipStream_t s, bool half = false);
 
