@@ -8,7 +8,9 @@ It imports /root/reference/python/examples/numpy_impls.py — whose `stft`
 (:6-31), `hann_window` (:34-36), `power_spectrogram` / `magnitude_spectrogram`
 (:39-44) have the same semantics as the Rust hot path (zero padding of n_fft//2,
 frame count, symmetric Hann, unnormalised rfft, (bins, frames) layout; SURVEY.md
-§8c) — evaluates it on the BASELINE workloads and stores INPUT DESCRIPTIONS +
+§8c), and whose `log_frequency_matrix` / `logfreq_spectrogram` (:94-123) and `erb_centers` /
+`gammatone_response` / `erb_spectrogram` (:126-159) have those of build_loghz_matrix (src/spectrogram.rs:2438-2508) and of the
+linear-spaced ErbFilterbank (src/erb.rs:266-403) — evaluates it on the BASELINE workloads and stores INPUT DESCRIPTIONS +
 EXPECTED OUTPUTS as small .npz fixtures next to this script.  No reference source
 text is stored.  The fixtures are what travels to the GPU box; the reference
 does not.
@@ -94,7 +96,44 @@ def main():
             out[f"short_{n}_x"] = x
             out[f"short_{n}_stft"] = S.astype(np.complex128)
     np.savez_compressed(os.path.join(HERE, "short_ref.npz"), **out)
-    for f in ("config1_ref.npz", "config2_ref.npz", "short_ref.npz"):
+
+    # --- frequency mappings from the reference's own NumPy restatement --------------------------------
+    # log_frequency_matrix / logfreq_spectrogram (:94-123) have the semantics of build_loghz_matrix (src/spectrogram.rs:2438-2508;
+    # f_max below Nyquist, so the `.min(out_len - 1)` clamp at :2488 is not reached); erb / erb_to_hz / erb_centers /
+    # gammatone_response / erb_spectrogram (:126-159) those of ErbFilterbank::generate with ErbSpacing::Linear and
+    # apply_to_power_spectrum (src/erb.rs:206-210, 266-335, 374-403): sum_k |G(f_k) X_k|^2 = sum_k |H(f_k)|^2 |X_k|^2.
+    # NOT taken: numpy_impls.chroma (:198-215) — hard nearest-pitch-class assignment and per-frame sum normalisation, where
+    # build_chroma_filterbank (src/chroma.rs:262-345) spreads every bin over the 12 classes with a Gaussian of one semitone and
+    # normalises the filterbank rows: different semantics, like its mel_filterbank / db_spectrogram / mfcc.
+    w = ref.hann_window(1024)
+    lh = dict(n_bins=96, f_min=30.0, f_max=7900.0)
+    eb = dict(n_filters=64, f_min=50.0, f_max=7800.0)
+    out_l, out_e = {}, {}
+    M = ref.log_frequency_matrix(sr, 1024, lh["n_bins"], lh["f_min"], lh["f_max"])
+    out_l["matrix"] = M
+    out_l["params"] = np.asarray([lh["n_bins"], lh["f_min"], lh["f_max"]], dtype=np.float64)
+    cf = ref.erb_centers(eb["f_min"], eb["f_max"], eb["n_filters"])
+    out_e["centres"] = cf
+    out_e["params"] = np.asarray([eb["n_filters"], eb["f_min"], eb["f_max"]], dtype=np.float64)
+    for b in (0, 1):
+        x = cfg2_signal(b)
+        S, freqs, _ = ref.stft(x, sr, 1024, 256, w, centre=True)
+        sub = frame_subset(S.shape[1])
+        P = ref.power_spectrogram(S)
+        L = ref.logfreq_spectrogram(P, M)
+        out_l[f"c2_b{b}_frames"] = sub
+        out_l[f"c2_b{b}_loghz_power"] = L[:, sub]
+        out_l[f"c2_b{b}_loghz_rowsum"] = L.sum(axis=1)
+        E = ref.erb_spectrogram(S, freqs, cf)
+        out_e[f"c2_b{b}_frames"] = sub
+        out_e[f"c2_b{b}_erb_power"] = E[:, sub]
+        out_e[f"c2_b{b}_erb_rowsum"] = E.sum(axis=1)
+    # the |H(f)|^2 matrix itself, as the reference's gammatone_response gives it
+    out_e["matrix_cols"] = np.arange(0, 513, 4)
+    out_e["matrix"] = np.stack([np.abs(ref.gammatone_response(freqs, fc)) ** 2 for fc in cf])[:, ::4]  # every 4th bin: < 200 KB
+    np.savez_compressed(os.path.join(HERE, "loghz_ref.npz"), **out_l)
+    np.savez_compressed(os.path.join(HERE, "erb_ref.npz"), **out_e)
+    for f in ("config1_ref.npz", "config2_ref.npz", "short_ref.npz", "loghz_ref.npz", "erb_ref.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

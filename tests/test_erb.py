@@ -1,5 +1,7 @@
 """ERB / gammatone frequency-domain mapping (src/erb.rs:266-401): a dense n_filters x n_bins matrix
 of |H(f)|^2 applied to the power spectrum, sequential accumulation in T."""
+import os
+
 import numpy as np
 import pytest
 
@@ -92,3 +94,29 @@ def test_gpu_erb_full_batch_tuned_kernel():
     got = plan.compute_batch(x)
     ref = orc.spectrogram_batch(orc.Params(n_fft=1024, hop=256, n_mels=64, erb=True, f_min=0.0, f_max=8000.0), x.astype(np.float64))
     assert H.rel_err(got, ref) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("b", [0, 1])
+def test_gpu_erb_matches_reference_fixture(golden_dir, b, dtype):
+    """HIP against tests/golden/erb_ref.npz — outputs of the reference's own numpy_impls.erb_centers / gammatone_response /
+    erb_spectrogram (python/examples/numpy_impls.py:126-159) on config-2 rows; f64 <= 1e-10, f32 <= 1e-4 relative within 40 dB of
+    the peak (the dense bank runs on v_mfma_f32_16x16x4_f32 in f32)."""
+    g = np.load(os.path.join(golden_dir, "erb_ref.npz"))
+    nf, f_min, f_max = int(g["params"][0]), float(g["params"][1]), float(g["params"][2])
+    x = H.cfg2_signal(b).astype(np.float32 if dtype == "float32" else np.float64)
+    params = sg.SpectrogramParams(sg.StftParams(1024, 256, sg.WindowType.hanning, True), 16000.0)
+    plan = sg.Plan(params, _ffi.AMP_POWER, sg.ErbParams(nf, f_min, f_max, "linear"), None, dtype)
+    got = plan.compute_batch(x[None])[0].astype(np.float64)
+    ref = g[f"c2_b{b}_erb_power"]
+    sel = got[:, g[f"c2_b{b}_frames"]]
+    if dtype == "float64":
+        assert np.max(np.abs(sel - ref)) <= 1e-10 * ref.max()
+    else:
+        assert np.max(np.abs(sel - ref)) <= 1e-4 * ref.max()
+        near = ref > 1e-4 * ref.max()
+        assert np.max(np.abs(sel - ref)[near] / ref[near]) <= 1e-4
+    rs = g[f"c2_b{b}_erb_rowsum"]
+    assert np.max(np.abs(got.sum(axis=1) - rs)) <= (1e-10 if dtype == "float64" else 2e-5) * rs.max()
+    assert np.allclose(plan.axes(4)[0], g["centres"], rtol=1e-12)

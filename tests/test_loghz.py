@@ -1,5 +1,7 @@
 """LogHz frequency mapping (src/spectrogram.rs:2438-2508, 3935-3990): sparse <=2-nnz interpolation rows
 through the same mapping slot as Mel."""
+import os
+
 import numpy as np
 import pytest
 
@@ -76,3 +78,27 @@ def test_gpu_loghz_matches_oracle(n_fft, hop, amp, floor, dtype):
         assert H.rel_err(got, ref) < (1e-10 if dtype == "float64" else 2e-5)
     s = sg.compute_loghz_power_spectrogram(x[0], params, lp, dtype=dtype)
     assert s.shape == (96, got.shape[2]) and np.allclose(s.frequencies, orc.axes(op, 1)[0], rtol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("b", [0, 1])
+def test_gpu_loghz_matches_reference_fixture(golden_dir, b, dtype):
+    """HIP against tests/golden/loghz_ref.npz — outputs of the reference's own numpy_impls.log_frequency_matrix / logfreq_spectrogram
+    (python/examples/numpy_impls.py:94-123) on config-2 rows; f64 <= 1e-10, f32 <= 1e-4 relative within 40 dB of the peak."""
+    g = np.load(os.path.join(golden_dir, "loghz_ref.npz"))
+    n_bins, f_min, f_max = int(g["params"][0]), float(g["params"][1]), float(g["params"][2])
+    x = H.cfg2_signal(b).astype(np.float32 if dtype == "float32" else np.float64)
+    params = sg.SpectrogramParams(sg.StftParams(1024, 256, sg.WindowType.hanning, True), 16000.0)
+    plan = sg.Plan(params, _ffi.AMP_POWER, sg.LogHzParams(n_bins, f_min, f_max), None, dtype)
+    got = plan.compute_batch(x[None])[0].astype(np.float64)
+    ref = g[f"c2_b{b}_loghz_power"]
+    sel = got[:, g[f"c2_b{b}_frames"]]
+    if dtype == "float64":
+        assert np.max(np.abs(sel - ref)) <= 1e-10 * ref.max()
+    else:
+        assert np.max(np.abs(sel - ref)) <= 1e-4 * ref.max()
+        near = ref > 1e-4 * ref.max()
+        assert np.max(np.abs(sel - ref)[near] / ref[near]) <= 1e-4
+    rs = g[f"c2_b{b}_loghz_rowsum"]
+    assert np.max(np.abs(got.sum(axis=1) - rs)) <= (1e-10 if dtype == "float64" else 2e-5) * rs.max()

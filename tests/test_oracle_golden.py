@@ -272,3 +272,52 @@ def test_batch_matches_single_and_threads():
     assert np.array_equal(orc.spectrogram_batch(p, x, 4), one)
     s1 = np.stack([orc.stft(p, r) for r in x])
     assert np.array_equal(orc.stft_batch(p, x, 2), s1)
+
+
+# ---------------------------------------------------------------- frequency mappings pinned by the reference's numpy_impls
+# (tests/golden/make_golden.py: log_frequency_matrix / logfreq_spectrogram and erb_centers / gammatone_response / erb_spectrogram,
+# python/examples/numpy_impls.py:94-159 — the semantics of src/spectrogram.rs:2438-2508 and src/erb.rs:266-403, linear spacing)
+@pytest.mark.parametrize("b", [0, 1])
+def test_loghz_matches_reference(golden_dir, b):
+    g = np.load(os.path.join(golden_dir, "loghz_ref.npz"))
+    n_bins, f_min, f_max = int(g["params"][0]), float(g["params"][1]), float(g["params"][2])
+    x = H.cfg2_signal(b).astype(np.float64)
+    p = orc.Params(n_fft=1024, hop=256, n_mels=n_bins, loghz=True, f_min=f_min, f_max=f_max)
+    got = orc.spectrogram(p, x)
+    ref = g[f"c2_b{b}_loghz_power"]
+    assert got.shape == (n_bins, 626)
+    assert np.max(np.abs(got[:, g[f"c2_b{b}_frames"]] - ref)) <= 1e-10 * ref.max()
+    rs = g[f"c2_b{b}_loghz_rowsum"]
+    assert np.max(np.abs(got.sum(axis=1) - rs)) <= 1e-10 * rs.max()
+    # the interpolation matrix itself, through the host plan's CSR export
+    import spectrograms_amd as sg
+    from spectrograms_amd import _ffi
+    params = sg.SpectrogramParams(sg.StftParams(1024, 256, sg.WindowType.hanning, True), 16000.0)
+    pl = sg.Plan(params, _ffi.AMP_POWER, sg.LogHzParams(n_bins, f_min, f_max), None, "float64", device=_ffi.DEVICE_HOST_ONLY)
+    ptr, col, val = pl.mel_weights()
+    dense = np.zeros((n_bins, 513))
+    for r in range(n_bins):
+        dense[r, col[ptr[r]:ptr[r + 1]]] = val[ptr[r]:ptr[r + 1]]
+    assert np.max(np.abs(dense - g["matrix"])) <= 1e-9  # exp(log f) rounding moves the interpolation fraction by ~1e-13
+
+
+@pytest.mark.parametrize("b", [0, 1])
+def test_erb_matches_reference(golden_dir, b):
+    g = np.load(os.path.join(golden_dir, "erb_ref.npz"))
+    nf, f_min, f_max = int(g["params"][0]), float(g["params"][1]), float(g["params"][2])
+    x = H.cfg2_signal(b).astype(np.float64)
+    p = orc.Params(n_fft=1024, hop=256, n_mels=nf, erb=True, erb_spacing=0, f_min=f_min, f_max=f_max)
+    got = orc.spectrogram(p, x)
+    ref = g[f"c2_b{b}_erb_power"]
+    assert got.shape == (nf, 626)
+    assert np.max(np.abs(got[:, g[f"c2_b{b}_frames"]] - ref)) <= 1e-10 * ref.max()
+    rs = g[f"c2_b{b}_erb_rowsum"]
+    assert np.max(np.abs(got.sum(axis=1) - rs)) <= 1e-10 * rs.max()
+    assert np.allclose(orc.axes(p, 3)[0], g["centres"], rtol=1e-12)
+    import spectrograms_amd as sg
+    from spectrograms_amd import _ffi
+    params = sg.SpectrogramParams(sg.StftParams(1024, 256, sg.WindowType.hanning, True), 16000.0)
+    pl = sg.Plan(params, _ffi.AMP_POWER, sg.ErbParams(nf, f_min, f_max, "linear"), None, "float64", device=_ffi.DEVICE_HOST_ONLY)
+    _, _, val = pl.mel_weights()
+    assert np.allclose(val.reshape(nf, 513)[:, g["matrix_cols"]], g["matrix"], rtol=1e-11)
+    assert np.allclose(pl.axes(4)[0], g["centres"], rtol=1e-12)
