@@ -437,14 +437,19 @@ def fft2d_legs(torch, sg, dev, which, args, peak):
     return res
 
 
-def device_identity(torch, dev) -> int:
-    """A number that is the same for two ranks when they use the same device ordinal of the same physical GPU.  Both must repeat
-    for a collision: the ordinal alone repeats legitimately when every rank is confined to one visible device, and a runtime that
-    reports a placeholder uuid for every GPU must not make a correct launch look wrong."""
+def device_identity(torch, dev):
+    """(number, strong): the number is the same for two ranks when they use the same device ordinal of the same physical GPU.  The
+    ordinal alone repeats legitimately when every rank is confined to one visible device (HIP_VISIBLE_DEVICES per rank, ordinal 0), so
+    the rank's visible-device lists are part of the identity; `strong` says the runtime reported a real uuid or PCI address — only then
+    does a repeat prove that two ranks share a GPU (a build that reports placeholders for every GPU must not make a correct launch
+    look wrong: such a repeat is recorded in the JSON line, not fatal)."""
     p = torch.cuda.get_device_properties(dev)
-    ident = "%d|%s|%s:%s:%s" % (dev.index, getattr(p, "uuid", ""), getattr(p, "pci_domain_id", ""), getattr(p, "pci_bus_id", ""),
-                                getattr(p, "pci_device_id", ""))
-    return int.from_bytes(hashlib.sha256(ident.encode()).digest()[:7], "little")
+    uuid = str(getattr(p, "uuid", "") or "")
+    pci = "%s:%s:%s" % (getattr(p, "pci_domain_id", ""), getattr(p, "pci_bus_id", ""), getattr(p, "pci_device_id", ""))
+    strong = bool(uuid.strip("0-")) or pci not in ("::", "0:0:0")
+    vis = "|".join(os.environ.get(k, "") for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+    ident = "%d|%s|%s|%s" % (dev.index, uuid, pci, vis)
+    return int.from_bytes(hashlib.sha256(ident.encode()).digest()[:7], "little"), strong
 
 
 def main() -> int:
@@ -482,17 +487,23 @@ def main() -> int:
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     rccl_ranks = 1
+    device_note = None
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         rccl_ranks = dist.get_world_size()
         # one rank per GPU: two ranks on one device would report a scaling curve of a time-shared GPU
-        ids = torch.empty(world, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(ids, torch.tensor([device_identity(torch, dev)], dtype=torch.int64, device=dev))
-        if len(set(ids.tolist())) != world:
-            if rank == 0:
-                print(f"bench.py: {world} ranks but only {len(set(ids.tolist()))} distinct GPUs — a device ordinal repeats", file=sys.stderr)
-            dist.destroy_process_group()
-            return 3
+        ident, strong = device_identity(torch, dev)
+        ids = torch.empty(2 * world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(ids, torch.tensor([ident, int(strong)], dtype=torch.int64, device=dev))
+        ids = ids.view(world, 2).tolist()
+        distinct = len({i for i, _ in ids})
+        if distinct != world:
+            if any(st for _, st in ids):
+                if rank == 0:
+                    print(f"bench.py: {world} ranks but only {distinct} distinct GPUs — a device ordinal repeats", file=sys.stderr)
+                dist.destroy_process_group()
+                return 3
+            device_note = f"{world} ranks, {distinct} distinct device identities, but the runtime reports no uuid / PCI address: not checked"
 
     # ---- plan + synthetic device-resident batch (weak scaling: every rank owns `batch` utterances)
     plan = make_plan(sg, kernel_wl)
@@ -595,6 +606,7 @@ def main() -> int:
                        "gather": (args.gather if (gathered is not None or overlap is not None) else False),
                        "parallelism": f"utterance-shard x{world}"},
             "rccl_ranks": rccl_ranks, "kernel_ms_min": float(kmin.item()), "kernel_ms_max": float(kmax.item()),
+            **({"device_check": device_note} if device_note else {}),
             # the dominant kernel, measured live (hipEvents around back-to-back launches on the launch stream, no gather)
             "roofline": stft_roofline(kernel_wl, batch, n_frames, kernel_ms, peak, scope, full_peak=True),
         }

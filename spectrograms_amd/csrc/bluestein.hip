@@ -769,7 +769,7 @@ hipError_t launch_bluestein(const BsArgs &a, int dtype, hipStream_t s) { return 
 // Host side of the tables for transform length n: M, conj(c) [n], FFT_M(b) / M in the kernel's product order [M], W_M [M] — all as
 // interleaved (re, im) doubles for the caller to cast and upload.  false: no chirp-z at this length and type.
 bool bluestein_host_tables(unsigned n, int dtype, BsHostTables &t) {
-    if (n < 2) return false;
+    if (n < 2 || n > 16384u) return false;  // (M <= 32768 below: the 32-bit loop cannot overflow; no fused geometry exists past M = 16384)
     unsigned M = 1, l2 = 0;
     while (M < 2 * n - 1) { M <<= 1; ++l2; }
     unsigned fa, fb, fc;

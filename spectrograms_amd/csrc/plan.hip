@@ -938,8 +938,14 @@ sgx_status inverse_tables(sgx_plan *pl) {
     {
         unsigned fa, fb, fc;
         BsHostTables h;
-        if (!pl->bs_half.M && n >= 32 && n % 2 == 0 && (n & (n - 1)) != 0 && !pl->d_bs_bhp && !reg_split_len(unsigned(n / 2), pl->dtype, &fa, &fb, &fc) &&
-            bluestein_host_tables(unsigned(n / 2), pl->dtype, h)) {
+        // (the stated condition, checked: the length's own convolution M >= 2 n - 1 has no geometry in LDS.  Without it, short even
+        // lengths the forward cost model leaves on the direct / two-factor kernels — n_fft 34 — paid for these tables at every plan
+        // creation and inverted through k_bs_c2c<HALF> instead of launch_c2r_rows)
+        unsigned long long Mfull = 1;
+        while (Mfull < 2ull * n - 1ull) Mfull <<= 1;
+        const bool own_fits = Mfull <= 16384ull && bluestein_fused_split(unsigned(Mfull), pl->dtype, &fa, &fb, &fc);
+        if (!pl->bs_half.M && !own_fits && n >= 32 && n <= 32768 && n % 2 == 0 && (n & (n - 1)) != 0 && !pl->d_bs_bhp &&
+            !reg_split_len(unsigned(n / 2), pl->dtype, &fa, &fb, &fc) && bluestein_host_tables(unsigned(n / 2), pl->dtype, h)) {
             if ((st = upload_cast<T>(pl, &pl->bs_half.chirp, h.chirp)) != SGX_OK) return st;
             if ((st = upload_cast<T>(pl, &pl->bs_half.bhp, h.bhp)) != SGX_OK) return st;
             if ((st = upload_cast<T>(pl, &pl->bs_half.tw, h.tw)) != SGX_OK) return st;
@@ -1079,6 +1085,9 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
     std::string msg;
     sgx_status st = validate(*params, msg);
     if (st != SGX_OK) return create_fail(st, msg);
+    // No kernel holds a frame of more than 160 KiB of LDS (40 960 f32 samples): such a length fails here, before gigabytes of host
+    // tables are built for it (n_fft = 2^30 + 2: 49 s and 8.7 GB to reach the same answer further down)
+    if (params->n_fft > (1u << 17)) return create_fail(SGX_BACKEND, "hip -- FFT backend error: n_fft too large for the on-chip frame tile");
     sgx_plan *pl = new (std::nothrow) sgx_plan();
     if (!pl) return create_fail(SGX_INTERNAL, "Internal error: out of memory");
     pl->p = *params;
@@ -1142,8 +1151,13 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
         // Rader / Bluestein too (src/fft_backend.rs:376-385).
         {
             const unsigned n = params->n_fft;
-            unsigned M = 1, l2 = 0;
-            while (M < 2 * n - 1) { M <<= 1; ++l2; }
+            // (64-bit, and only for lengths a convolution can exist for — M <= 16384 fused, half-length form up to n = 16384: for n_fft
+            // above 2^30 a 32-bit M shifts to 0 and never reaches 2 n - 1, above 2^31 `2 * n` wraps and a tiny M would pass)
+            const bool bs_range = n <= 16384u;
+            unsigned long long M64 = 1;
+            unsigned l2 = 0;
+            while (bs_range && M64 < 2ull * n - 1ull) { M64 <<= 1; ++l2; }
+            const unsigned M = (unsigned)M64;
             double per_sample = 0.0;
             if (kind == K_DIRECT_DFT) per_sample = double(n) / 2.0;
             if (kind == K_TWO_FACTOR) {
@@ -1153,13 +1167,13 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
                 per_sample = double(fa) + double(n / fa) / 2.0;
             }
             unsigned fa3 = 0, fb3 = 0, fc3 = 0;
-            const bool can = n >= 16 && bluestein_fused_split(M, pl->dtype, &fa3, &fb3, &fc3);
+            const bool can = bs_range && n >= 16 && bluestein_fused_split(M, pl->dtype, &fa3, &fb3, &fc3);
             const double cost = pl->out_mode == OUT_MEL && pl->dtype == SGX_F32 ? SGX_BS_COST_BANK32 : SGX_BS_COST;
             // even lengths whose own convolution does not fit LDS (f64 4098 ... 8192, f32 8194 ... 16384): half-length complex form,
             // one frame per sequence of n / 2 points (k_bs_c2c, RMODE 3), M >= n - 1
             unsigned Mh = 1, l2h = 0;
-            while (Mh < n - 1) { Mh <<= 1; ++l2h; }
-            if (!can && n >= 32 && n % 2 == 0 && (n & (n - 1)) != 0 && bluestein_fused_split(Mh, pl->dtype, &fa3, &fb3, &fc3) &&
+            while (bs_range && Mh < n - 1) { Mh <<= 1; ++l2h; }
+            if (bs_range && !can && n >= 32 && n % 2 == 0 && (n & (n - 1)) != 0 && bluestein_fused_split(Mh, pl->dtype, &fa3, &fb3, &fc3) &&
                 (!ok || per_sample > cost * double(l2h) * double(Mh) / double(n / 2))) {
                 pl->bs_M = Mh;
                 pl->bs_fwd_half = true;

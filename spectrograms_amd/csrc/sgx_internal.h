@@ -304,7 +304,7 @@ struct sgx_plan {
     // inverse path (sgx_istft / sgx_c2r), created on first use: full twiddle table e^{-2 pi i k/n}, frame scratch, flag
     void *d_itw = nullptr, *d_frames = nullptr, *d_flag = nullptr;
     void *d_itwr = nullptr, *d_itw1 = nullptr;  // tuned f32 n_fft = 1024 inverse: conj(W_1024^k) [32][16], W_512^(k1 n2) [32][16]
-    // K_BLUESTEIN: chirp, transformed chirp, length-M twiddles, two frame scratch buffers (grown on demand, sgx_reserve sizes them)
+    // K_BLUESTEIN: chirp, transformed chirp, length-M twiddles (the sequences themselves never leave LDS: no frame scratch)
     void *d_bs_chirp = nullptr, *d_bs_tw = nullptr, *d_bs_wc = nullptr, *d_bs_bhp = nullptr;
     unsigned bs_M = 0;
     bool bs_fwd_half = false;  // K_BLUESTEIN in half-length complex form (even n_fft whose own convolution does not fit LDS)

@@ -4,6 +4,7 @@ reference constructors (src/spectrogram.rs:3479-3506, 3793-3813, 4071-4077, 4129
 from __future__ import annotations
 
 import math
+import re
 from typing import Optional
 
 import numpy as np
@@ -86,6 +87,30 @@ class WindowType:
             else:
                 raise ValueError(f"Unknown normalization mode '{normalize}'. Valid modes: 'sum', 'peak', 'energy'")
         return cls(_ffi.WIN_CUSTOM, 0.0, np.ascontiguousarray(c))
+
+    # "hann" / "hanning" / "hamm" / "hamming" / "rect" / "rectangle" / "blackman" / "kaiser=<x>" / "gaussian=<x>", any case,
+    # surrounding blanks ignored, <x> = digits[.digits] — FromStr for WindowType, src/window.rs:276-338 (same grammar, same
+    # message texts)
+    _SPEC = re.compile(r"^(?:(?P<name>rect|rectangle|hann|hanning|hamm|hamming|blackman)|(?P<param_name>kaiser|gaussian)=(?P<param>\d+(\.\d+)?))$",
+                       re.IGNORECASE | re.ASCII)
+
+    @classmethod
+    def from_str(cls, s: str) -> "WindowType":
+        if not isinstance(s, str):
+            raise TypeError("window specification must be a str")
+        if s == "":
+            raise _ffi.InvalidInputError("Invalid input: Input must not be empty. Must be one of ['rectangular', 'hanning', "
+                                         "'hamming', 'blackman', 'gaussian', 'kaiser']")
+        # (str::trim strips Unicode White_Space; str.strip() does the same for str)
+        m = cls._SPEC.match(s.strip())
+        if m is None:
+            raise _ffi.InvalidInputError(f"Invalid input: Invalid window specification '{s}'")
+        if m.group("name") is not None:
+            name = m.group("name").lower()
+            return {"rect": cls.rectangular, "rectangle": cls.rectangular, "hann": cls.hanning, "hanning": cls.hanning,
+                    "hamm": cls.hamming, "hamming": cls.hamming, "blackman": cls.blackman}[name]
+        value = float(m.group("param"))
+        return cls.kaiser(value) if m.group("param_name").lower() == "kaiser" else cls.gaussian(value)
 
     def __repr__(self) -> str:
         names = ["Rectangular", "Hanning", "Hamming", "Blackman", f"Kaiser(beta={self.param})",

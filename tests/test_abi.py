@@ -67,6 +67,26 @@ def test_custom_window_roundtrip_and_normalisation():
         sg.StftParams(128, 64, sg.WindowType.custom(c))
 
 
+def test_window_type_from_str():
+    """FromStr for WindowType (src/window.rs:276-338): the names, `kaiser=<x>` / `gaussian=<x>`, case and blanks ignored, the
+    reference's three error texts."""
+    W = sg.WindowType
+    for spec, kind in (("hann", W.hanning), ("Hanning", W.hanning), (" HAMM ", W.hamming), ("hamming", W.hamming), ("rect", W.rectangular),
+                       ("Rectangle", W.rectangular), ("blackman", W.blackman)):
+        assert W.from_str(spec) is kind
+    k = W.from_str("kaiser=5.0")
+    assert k.kind == _ffi.WIN_KAISER and k.param == 5.0
+    g = W.from_str("  Gaussian=12 ")
+    assert g.kind == _ffi.WIN_GAUSSIAN and g.param == 12.0
+    with pytest.raises(sg.InvalidInputError, match="Input must not be empty. Must be one of"):
+        W.from_str("")
+    for bad in ("rectangular", "kaiser", "kaiser=", "kaiser=-1", "kaiser=1e3", "kaiser=.5", "gaussian=1.", "hann=3", "tukey", "   "):
+        with pytest.raises(sg.InvalidInputError, match="Invalid window specification '%s'" % bad):
+            W.from_str(bad)
+    # the parsed window builds the same table as the constructor
+    assert np.array_equal(W.make_kaiser(64, 5.0), W._make(W.from_str("kaiser=5.0"), 64, None))
+
+
 @pytest.mark.parametrize("norm", [None, sg.MelNorm.slaney, sg.MelNorm.l1, sg.MelNorm.l2])
 @pytest.mark.parametrize("sr,n_fft,n_mels,fmin,fmax", [(16000, 1024, 80, 0.0, 8000.0), (22050, 400, 64, 20.0, 7600.0),
                                                         (16000, 512, 40, 0.0, 8000.0)])
@@ -132,6 +152,20 @@ def test_raw_abi_rejects_bad_params_without_aborting():
     assert L.sgx_plan_create(C.byref(p), C.byref(h)) == _ffi.SGX_INVALID_INPUT
     assert b"Custom window size (0) must match n_fft (512)" in L.sgx_last_create_error()
     assert L.sgx_plan_create(None, C.byref(h)) == _ffi.SGX_INVALID_INPUT
+
+
+@pytest.mark.parametrize("n_fft", [2 ** 30 + 2, 2 ** 31 + 6, 2 ** 32 - 1, 2 ** 17 + 1])
+def test_huge_frame_lengths_fail_fast(n_fft):
+    """Lengths above every kernel's frame tile: SGX_BACKEND at once — (2^30, 2^31] used to spin in the chirp-z length loop (a 32-bit
+    M shifted to 0), above 2^31 `2 n` wrapped and a tiny convolution length could be selected."""
+    import time
+    L = _ffi.lib()
+    p = _ffi.SgxParams()
+    p.n_fft, p.hop_size, p.sample_rate_hz, p.device, p.centre = n_fft, n_fft // 4, 16000.0, HOST, 1
+    h = C.c_void_p()
+    t0 = time.perf_counter()
+    assert L.sgx_plan_create(C.byref(p), C.byref(h)) == _ffi.SGX_BACKEND and not h.value
+    assert b"n_fft too large" in L.sgx_last_create_error() and time.perf_counter() - t0 < 1.0
 
 
 def test_host_only_plan_refuses_compute_loudly():

@@ -583,12 +583,21 @@ def test_fuzz_chirpz_lengths():
         else:
             kw.update(n_mels=int(rng.integers(4, 41)), fmin=0.0, fmax=8000.0, amp="power")
         plan, got = run_case(n=n, batch=batch, seed=1000 + case, **kw)
-        assert plan.kernel_name == "bluestein", (n_fft, dtype, kw)
+        # the plan's own cost predicate (plan.hip, SGX_BS_COST / SGX_BS_COST_BANK32): chirp-z where the direct sum (primes: n / 2
+        # multiply-adds per sample) or the two-factor kernel (a + b / 2) costs more than cost * log2(M) * M / n — short f32 frames
+        # into a filterbank (n_fft 17 Mel: 14.7 > 8.5) stay on the direct sum, whatever the seed draws
+        m, l2 = 1, 0
+        while m < 2 * n_fft - 1:
+            m, l2 = 2 * m, l2 + 1
+        fa = max([d for d in range(1, int(n_fft ** 0.5) + 1) if n_fft % d == 0])
+        per_sample = n_fft / 2.0 if fa == 1 else fa + (n_fft // fa) / 2.0
+        cost = 0.65 if ("n_mels" in kw and dtype == "float32") else 0.25
+        if per_sample > cost * l2 * m / n_fft or n_fft > 4096:
+            assert plan.kernel_name == "bluestein", (n_fft, dtype, kw)
+        else:
+            assert plan.kernel_name in ("bluestein", "direct_dft", "two_factor_dft"), (plan.kernel_name, n_fft, dtype, kw)
         x = signals(batch, n, np.float32 if dtype == "float32" else np.float64, 1000 + case)
         assert np.array_equal(np.asarray(plan.compute_batch(x[batch - 1:]))[0], np.asarray(got)[batch - 1]), (n_fft, dtype, kw)
-        m = 1
-        while m < 2 * n_fft - 1:
-            m *= 2
         seen_m.add(m)
     assert {64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384} <= seen_m, sorted(seen_m)
 
