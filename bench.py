@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak is ~6290 GB/s
 VALU_PEAK_TFLOPS = 157.3   # FP32 vector peak (same guide)
 FLOPS_PER_FRAME = {"linear_power": 28.1e3, "stft": 26.6e3, "mel_power": 30.1e3, "mel_db": 30.1e3}  # FFT 25.6 k + window 1 k (+ |.|^2 1.5 k, Mel 2 k)
-LEGS = ("mel_power", "mel_db", "config4", "fft2d", "convolve_fft", "chirpz_1009")  # the default run's extra legs (besides the headline workload)
+LEGS = ("mel_power", "mel_db", "config4", "istft", "fft2d", "convolve_fft", "chirpz_1009")  # the default run's extra legs (besides the headline workload)
 IMG_SIDE, IMG_BATCH = 1024, 512  # BASELINE configs[4]
 SR, N_FFT, HOP, N_SAMPLES = 16000.0, 1024, 256, 160000
 WORKLOADS = {  # name -> (kernel workload, utterances per GPU, BASELINE config index)
@@ -63,25 +63,47 @@ def bytes_per_frame(kernel_wl: str, n_frames: int):
     return read, write
 
 
-def kernel_source_stamp() -> str:
+# the kernel sources a measured traffic figure belongs to, per workload family
+STAMP_FILES = {
+    "stft": ("kernels_r32x16.hip", "fft_inreg.h", "r32x16_layout.h"),
+    "2d": ("kernels_r32x16.hip", "kernels_c2c1024.hip", "fft2d.hip", "fft_inreg.h", "r32x16_layout.h"),
+    "istft": ("kernels_c2c1024.hip", "fft_inreg.h"),
+}
+STAMP_FAMILY = {"linear_power": "stft", "mel_power": "stft", "mel_db": "stft", "stft": "stft", "fft2d": "2d", "convolve_fft": "2d", "istft": "istft"}
+
+
+def kernel_source_stamp(family: str = "stft") -> str:
     """Identity of the kernel sources a measurement belongs to (profiles/traffic_latest.json carries the stamp it was taken at)."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "spectrograms_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.startswith("kernels_r32x16") or f in ("fft_inreg.h", "r32x16_layout.h"):
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in sorted(STAMP_FILES[family]):
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
-def measured_traffic(kernel_wl: str):
-    """PMC-measured HBM bytes per launch, or None when the committed measurement predates the current kernel sources."""
+def measured_traffic(workload: str, detail: bool = False):
+    """PMC-measured HBM bytes per step (tools/profile.sh -> tools/summarize_prof.py --traffic), or None when the committed
+    measurement predates the current sources of the kernels it was taken on.  detail: the per-kernel table next to the total."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
     except Exception:
         return None
-    if t.get("kernel_source_stamp") != kernel_source_stamp():
+    e = (t.get("entries") or {}).get(workload)
+    if not e or e.get("stamp") != kernel_source_stamp(STAMP_FAMILY[workload]):
         return None
-    return t.get(kernel_wl)
+    return e if detail else e.get("bytes")
+
+
+def usable_cores() -> int:
+    """CPUs this process may really use: its affinity mask, capped by a cgroup v2 CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # "max" or "<quota> <period>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, -(-int(q) // int(per))))
+    except Exception:
+        pass
+    return n
 
 
 def cpu_baseline(kernel_wl: str, budget_s: float = 10.0):
@@ -143,7 +165,33 @@ def cpu_baseline(kernel_wl: str, budget_s: float = 10.0):
     return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{reps} passes over a {nsig}-utterance batch ({frames} frames, {dt:.1f} s wall, one plan per "
                       f"thread, {cores} threads = the fastest of the thread counts tried); one thread alone: {single:.0f} frames/s",
-            "single_thread_value": single, "pocketfft": cpu_pocketfft(kernel_wl, x[:16])}
+            "single_thread_value": single, "pocketfft": cpu_pocketfft(kernel_wl, x[:16]),
+            "pocketfft_all_cores": cpu_pocketfft_all_cores(kernel_wl, x[:16])}
+
+
+def _pocketfft_worker(job):
+    kernel_wl, x, budget_s = job
+    return cpu_pocketfft(kernel_wl, x, budget_s)["value"] * budget_s  # ~frames done (each worker measures its own wall)
+
+
+def cpu_pocketfft_all_cores(kernel_wl: str, x: np.ndarray, budget_s: float = 3.0):
+    """The optimised-FFT datapoint on every core this process may use: one worker PROCESS per core (fork, started before this
+    process has touched the GPU), each running cpu_pocketfft's single-thread loop over the same utterances for the same wall time —
+    the reference's one-plan-per-thread batch idiom with pocketfft's SIMD butterflies in place of the scalar port's."""
+    import multiprocessing as mp
+
+    cores = usable_cores()
+    try:
+        ctx = mp.get_context("fork")
+        t0 = time.perf_counter()
+        with ctx.Pool(cores) as pool:
+            per = pool.map(_pocketfft_worker, [(kernel_wl, x, budget_s)] * cores)
+        wall = time.perf_counter() - t0
+    except Exception as e:  # a host that refuses the pool: the single-thread figure stands
+        return {"error": repr(e)}
+    return {"value": sum(per) / budget_s, "unit": "frames/s", "cores": cores, "kind": "numpy-pocketfft",
+            "sample": f"{cores} worker processes x {budget_s:.0f} s of the single-thread pocketfft loop each (sum of the workers' own rates; "
+                      f"{wall:.1f} s wall with pool start-up)"}
 
 
 def cpu_pocketfft(kernel_wl: str, x: np.ndarray, budget_s: float = 3.0):
@@ -212,6 +260,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-legs", action="store_true",
                     help="headline workload only: skip the `workloads` legs, the cold-clock run and the measured HBM peak (A/B timing runs)")
     ap.add_argument("--legs", default=",".join(LEGS), help="comma-separated legs of the default run (subset of %s)" % ",".join(LEGS))
+    ap.add_argument("--sustained-s", type=float, default=3.0,
+                    help="seconds of back-to-back headline launches for the `sustained` object (frames/s + shader clock); 0: none")
+    ap.add_argument("--legs-timeout", type=float, default=240.0,
+                    help="seconds the extra legs may take before the line is printed without the unfinished ones (0: no limit)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: the ranks rendezvous over gloo and time an empty step — exercises the launcher, the barrier / "
                          "max-over-ranks timing and the JSON line (tests/test_bench_launcher.py)")
@@ -350,6 +402,173 @@ def stft_leg(torch, sg, dev, name: str, xs256, args, peak):
             "roofline": stft_roofline(kernel_wl, batch, n_frames, kernel_ms, peak)}
 
 
+def istft_leg(torch, sg, dev, xs256, args, peak):
+    """Inverse STFT of the configs[1] batch (src/spectrogram.rs:4860-4946): 256 x [513, 626] complex f32 spectra ->
+    256 x 160 000 f32 samples, one launch of the fused tuned kernel.  Algorithmic bytes: every spectrum value read once, every sample
+    written once."""
+    from spectrograms_amd import _ffi
+
+    params = sg.SpectrogramParams(sg.StftParams(N_FFT, HOP, sg.WindowType.hanning, True), SR)
+    plan = sg.Plan(params, _ffi.AMP_COMPLEX, None, None, "float32")
+    S = plan.compute_batch(xs256[0]).contiguous()
+    y = plan.istft_batch(S)
+    stream = torch.cuda.current_stream(dev)
+
+    def step(i):
+        plan.istft_batch(S, out=y)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+
+    fence()
+    err = float((y[:, 1024:159000] - xs256[0][:, 1024:159000]).abs().max())
+    ph = preheat(step, fence, min(args.preheat_s, 0.2))
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    dt, ms = timed_steps(torch, stream, step, args.steps, fence)
+    frames = S.shape[0] * S.shape[2]
+    alg = float(S.numel() * 8 + y.numel() * 4)
+    achieved = alg / (ms * 1e-3) / 1e9
+    tr = measured_traffic("istft", detail=True)
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": tr["bytes"] if tr else None, "kernel_ms": ms, "kernel_ms_scope": "HIP events over the timed region",
+            "algorithmic_bytes_per_frame": alg / frames, "frames_per_launch": frames}
+    if tr:
+        roof["traffic_over_algorithmic"] = tr["bytes"] / alg
+    if peak and peak.get("copy"):
+        roof["frac_of_measured_copy"] = achieved / peak["copy"]
+    return {"config": "inverse STFT of configs[1]: 256 x [513, 626] complex f32 -> 256 x 160000 f32, n_fft=1024 hop=256 Hanning centre",
+            "kernel": "istft1024", "steps": args.steps, "warmup": args.warmup, "preheat_steps": ph, "ms_per_step": dt / args.steps * 1e3,
+            "value": frames * args.steps / dt, "unit": "frames/s", "roundtrip_max_err": err, "roofline": roof}
+
+
+def sustained_leg(torch, lib, dev, step, fence, frames_per_step: int, seconds: float):
+    """What a caller gets who streams for seconds: `seconds` of back-to-back headline launches (same buffers, same stream as the
+    timed region), in blocks of ~0.25 s with the shader clock probed behind each block (sgx_clock_probe: s_memtime against the 100 MHz
+    counter on every CU, MI355X_MICROARCH.md DVFS item 6).  frames/s over the whole run, probes included."""
+    import ctypes as C
+
+    stream = torch.cuda.current_stream(dev)
+    t_probe = time.perf_counter()
+    for i in range(50):
+        step(i)
+    fence()
+    per = (time.perf_counter() - t_probe) / 50
+    block = max(50, int(0.25 / max(per, 1e-6)))
+    clocks, n = [], 0
+    mhz = C.c_double()
+    fence()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for i in range(block):
+            step(i)
+        n += block
+        if lib.sgx_clock_probe(dev.index, C.c_void_p(stream.cuda_stream), C.byref(mhz)) == 0:  # waits for the stream
+            clocks.append(float(mhz.value))
+        else:
+            fence()
+    fence()
+    dt = time.perf_counter() - t0
+    return {"seconds": dt, "steps": n, "ms_per_step": dt / n * 1e3, "value": frames_per_step * n / dt, "unit": "frames/s",
+            "shader_clock_mhz_mean": sum(clocks) / len(clocks) if clocks else None,
+            "shader_clock_mhz_min": min(clocks) if clocks else None, "shader_clock_mhz_max": max(clocks) if clocks else None,
+            "clock_probes": len(clocks),
+            "how": f"blocks of {block} launches, sgx_clock_probe (one wave per CU, ~20 us) behind each block"}
+
+
+def multi_rank_legs(torch, dist, dev, world, plan, xs, steps, warm, reduce_max, sync, make_comm, label):
+    """BASELINE configs[3] when the job has more than one rank: every rank's shard of utterances through
+    the plan — compute only; with the all-gather of the output shards behind every launch (one all_gather on the launch stream); with
+    the gather of step i overlapped with the compute of step i + 1 (OverlappedGather); and through the C ABI's own communicator
+    (sgx_shard_execute_chunked, 4 chunks: the exchange of chunk k under the compute of chunk k + 1).  Every leg: barrier + synchronize
+    on both sides, max over ranks; `value` = frames of all ranks per second.  A leg that fails reports its error instead of a number.
+    (`--dry-run` drives the same function with CPU tensors over gloo and a stand-in plan: tests/test_bench_launcher.py.)"""
+    from spectrograms_amd.distributed import OverlappedGather
+
+    batch = xs[0].shape[0]
+    n_bins, n_frames = plan.output_shape(xs[0].shape[1])
+    oshape = (batch, n_bins, n_frames)
+    outs = [torch.empty(oshape, dtype=torch.float32, device=dev) for _ in xs]
+    shard_bytes = float(np.prod(oshape)) * 4.0
+    frames_all = batch * n_frames * world
+    res = {}
+
+    def fence():
+        dist.barrier()
+        sync()
+
+    def run(name, step, finish=None, extra=None):
+        try:
+            for i in range(warm):
+                step(i)
+            if finish:
+                finish()
+            fence()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                step(i)
+            if finish:
+                finish()
+            fence()
+            dt = reduce_max(time.perf_counter() - t0)
+            ms = dt / steps * 1e3
+            r = {"config": label, "steps": steps, "warmup": warm, "ms_per_step": ms, "value": frames_all * steps / dt, "unit": "frames/s"}
+            if extra:
+                r.update(extra(ms))
+            res[name] = r
+        except Exception as e:  # the leg's error, not the whole line's
+            res[name] = {"error": repr(e)[:300]}
+
+    run("config4", lambda i: plan.compute_batch(xs[i % len(xs)], out=outs[i % len(xs)]))
+    compute_ms = res["config4"].get("ms_per_step")
+
+    def gather_extra(ms):
+        g = max(ms - (compute_ms or 0.0), 1e-9)
+        return {"shard_MB": shard_bytes / 1e6, "gather_exposed_ms": ms - (compute_ms or 0.0),
+                # every rank sends its shard to, and receives one from, each of the other ranks
+                "GBps_per_rank": shard_bytes * (world - 1) / (g * 1e-3) / 1e9}
+
+    gathered = torch.empty((world * batch, n_bins, n_frames), dtype=torch.float32, device=dev)
+
+    def step_sync(i):
+        plan.compute_batch(xs[i % len(xs)], out=outs[i % len(xs)])
+        dist.all_gather_into_tensor(gathered, outs[i % len(xs)])
+
+    run("config4_gather_sync", step_sync, extra=gather_extra)
+    try:  # the all-gather alone: achieved bytes per second per rank
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            dist.all_gather_into_tensor(gathered, outs[0])
+        fence()
+        gms = reduce_max(time.perf_counter() - t0) / 5 * 1e3
+        res["config4_gather_alone"] = {"ms": gms, "shard_MB": shard_bytes / 1e6, "GBps_per_rank": shard_bytes * (world - 1) / (gms * 1e-3) / 1e9,
+                                       "GBps_per_link": shard_bytes / (gms * 1e-3) / 1e9,
+                                       "note": "per link: one shard per peer over that peer's xGMI link (fully connected node); wall time of 5 back-to-back all-gathers between fences"}
+    except Exception as e:
+        res["config4_gather_alone"] = {"error": repr(e)[:300]}
+    del gathered
+    ov = OverlappedGather(oshape, torch.float32, dev, depth=len(xs))
+
+    def step_ov(i):
+        ov.wait_slot(i)
+        plan.compute_batch(xs[i % len(xs)], out=outs[i % len(xs)])
+        ov.submit(i, outs[i % len(xs)])
+
+    run("config4_gather_overlap", step_ov, finish=ov.finish, extra=gather_extra)
+    del ov
+    try:
+        comm = make_comm()
+        g2 = torch.empty((world * batch, n_bins, n_frames), dtype=torch.float32, device=dev)
+        run("config4_cabi_chunked4", lambda i: comm.execute(plan, xs[i % len(xs)], world * batch, g2, chunks=4), extra=gather_extra)
+        fence()
+        comm.close()
+    except Exception as e:
+        res["config4_cabi_chunked4"] = {"error": repr(e)[:300]}
+    return res
+
+
 def chirpz_leg(torch, sg, dev, xs256, args):
     """A frame length outside the power-of-two / listed sizes (the reference plans every length through RustFFT, src/fft_backend.rs:376-385):
     n_fft 1009 (prime) / hop 252, linear power, the first 64 utterances of the batch — the chirp-z kernel."""
@@ -386,17 +605,23 @@ def chirpz_leg(torch, sg, dev, xs256, args):
                          "note": "bound by its instruction count (VALU issue 71 % of the kernel's cycles, profiles/r03_chirpz_1009_rocprof_summary.txt); peak = FP32 vector"}}
 
 
-def fft2d_legs(torch, sg, dev, which, args, peak):
-    """BASELINE configs[4]: 512 x 1024 x 1024 f32 images, img[r, c] = sin(0.01 r) + cos(0.02 c) + N(0, 0.05^2) (32 distinct noise
-    fields, tiled): `fft2d` alone and `convolve_fft` with gaussian_kernel_2d(9, 2.0).  Algorithmic bytes per image: fft2d 4 MiB
-    read + 1024 * 513 * 8 B written; convolve_fft 4 MiB read + 4 MiB written (kernel spectrum cached by the plan)."""
+def make_images(torch, dev, batch: int = IMG_BATCH):
+    """BASELINE configs[4] input: img[r, c] = sin(0.01 r) + cos(0.02 c) + N(0, 0.05^2), 32 distinct noise fields tiled over the batch."""
     R = C = IMG_SIDE
     rng = np.random.default_rng(7)
     r, c = np.meshgrid(np.arange(R), np.arange(C), indexing="ij")
     base = (np.sin(0.01 * r) + np.cos(0.02 * c)).astype(np.float32)
     nz = 32
     host = base[None] + 0.05 * rng.standard_normal((nz, R, C), dtype=np.float32)
-    x = torch.from_numpy(np.ascontiguousarray(host)).to(dev).repeat(IMG_BATCH // nz, 1, 1)
+    return torch.from_numpy(np.ascontiguousarray(host)).to(dev).repeat(batch // nz, 1, 1)
+
+
+def fft2d_legs(torch, sg, dev, which, args, peak):
+    """BASELINE configs[4]: 512 x 1024 x 1024 f32 images, img[r, c] = sin(0.01 r) + cos(0.02 c) + N(0, 0.05^2) (32 distinct noise
+    fields, tiled): `fft2d` alone and `convolve_fft` with gaussian_kernel_2d(9, 2.0).  Algorithmic bytes per image: fft2d 4 MiB
+    read + 1024 * 513 * 8 B written; convolve_fft 4 MiB read + 4 MiB written (kernel spectrum cached by the plan)."""
+    R = C = IMG_SIDE
+    x = make_images(torch, dev)
     plan = sg.Fft2dPlan(R, C, "float32")
     k = sg.gaussian_kernel_2d(9, 2.0, dtype="float32")
     stream = torch.cuda.current_stream(dev)
@@ -424,10 +649,19 @@ def fft2d_legs(torch, sg, dev, which, args, peak):
         dt, ms = timed_steps(torch, stream, fn, steps, fence)
         ips = IMG_BATCH / (ms * 1e-3)
         achieved = ips * bpi / 1e9
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel_ms": ms, "kernel_ms_scope": "HIP events over the timed region (three launches per step)",
+        tr = measured_traffic(name, detail=True)
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": tr["bytes"] if tr else None,
+                "kernel_ms": ms, "kernel_ms_scope": "HIP events over the timed region (all launches of a step)",
                 "algorithmic_bytes_per_image": bpi, "images_per_step": IMG_BATCH, "valu_frac": flops[name] * ips / (VALU_PEAK_TFLOPS * 1e12),
                 "limiter": "hbm"}
+        if tr:  # the passes' real HBM bytes (PMC): what the multi-pass structure moves, against the algorithmic bytes
+            roof["traffic_per_image"] = tr["bytes"] / IMG_BATCH
+            roof["traffic_over_algorithmic"] = tr["bytes"] / (bpi * IMG_BATCH)
+            roof["traffic_rate_GBps"] = tr["bytes"] / (ms * 1e-3) / 1e9
+            roof["traffic_kernels"] = tr.get("kernels")
+            if peak and peak.get("copy"):
+                roof["traffic_rate_frac_of_measured_copy"] = roof["traffic_rate_GBps"] / peak["copy"]
         if peak and peak.get("copy"):
             roof["frac_of_measured_copy"] = achieved / peak["copy"]
         res[name] = {"config": f"configs[4]: {IMG_BATCH} x {R}x{C} f32 images, {name}" + (" with gaussian_kernel_2d(9, 2.0)" if name != "fft2d" else ""),
@@ -471,13 +705,19 @@ def main() -> int:
         print(f"bench.py: --legs takes a subset of {','.join(LEGS)}", file=sys.stderr)
         return 2
 
-    import torch
-    import torch.distributed as dist
-
     kernel_wl, batch, cfg_idx = WORKLOADS[args.workload]
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if args.dry_run:
         return dry_run(args, rank, world)
+    # the CPU baseline runs FIRST, before this process has touched the GPU: its all-core leg forks worker processes, and a process
+    # that has initialised HIP must not be forked.  (rank 0 at N = 1 only; a bounded sample: ~10 s port + 2 x 3 s pocketfft)
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(kernel_wl)
+
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible — the product path has no CPU fallback", file=sys.stderr)
         return 2
@@ -584,6 +824,9 @@ def main() -> int:
 
     extra = world == 1 and not args.no_legs
     peak = measured_peak(_ffi.lib(), local_rank) if extra else None  # right behind the timed steps: steady clocks
+    sustained = None
+    if extra and args.sustained_s > 0:
+        sustained = sustained_leg(torch, _ffi.lib(), dev, step, fence, batch * n_frames, args.sustained_s)
     frames_per_launch = batch * n_frames
     frames_per_step = frames_per_launch * world
     value = frames_per_step * args.steps / dt
@@ -616,25 +859,65 @@ def main() -> int:
                               "gather_ms": gather_ms,
                               # ring all-gather: every rank sends and receives (world - 1) shards over its links
                               "GBps_per_rank": None if not gather_ms else shard_bytes * (world - 1) / (gather_ms * 1e-3) / 1e9}
+    emitted = []
+
+    def emit():
+        if rank == 0 and not emitted:
+            emitted.append(1)
+            if cpu is not None:
+                line["cpu_baseline"] = cpu
+            print(json.dumps(line), flush=True)
+
+    # A leg that hangs (a first-run RCCL path, say) must not cost the headline line: past `--legs-timeout` seconds the line is
+    # printed with the legs finished so far and the process leaves.
+    watchdog = None
+    if (extra or (world > 1 and not args.no_legs)) and args.legs_timeout > 0:
+        import threading
+
+        def bail():
+            if rank == 0:
+                line["workloads_error"] = f"legs not finished after {args.legs_timeout:.0f} s: line printed without the rest"
+            emit()
+            os._exit(0)
+
+        watchdog = threading.Timer(args.legs_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
+    if sustained is not None:
+        line["sustained"] = sustained
     if extra:
         del outs, xs
         torch.cuda.empty_cache()
-        wl = {}
+        wl = line.setdefault("workloads", {})
         for name in legs:
             if name in ("fft2d", "convolve_fft") or name == args.workload:
                 continue
-            wl[name] = chirpz_leg(torch, sg, dev, xs256, args) if name == "chirpz_1009" else stft_leg(torch, sg, dev, name, xs256, args, peak)
+            if name == "chirpz_1009":
+                wl[name] = chirpz_leg(torch, sg, dev, xs256, args)
+            elif name == "istft":
+                wl[name] = istft_leg(torch, sg, dev, xs256, args, peak)
+            else:
+                wl[name] = stft_leg(torch, sg, dev, name, xs256, args, peak)
             torch.cuda.empty_cache()
         two_d = [l for l in legs if l in ("fft2d", "convolve_fft")]
         if two_d:
             del xs256
             torch.cuda.empty_cache()
             wl.update(fft2d_legs(torch, sg, dev, two_d, args, peak))
-        line["workloads"] = wl
-    if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(kernel_wl)
-        print(json.dumps(line))
+    elif world > 1 and not args.no_legs:
+        # N > 1: BASELINE configs[3] with and without the exchange (every rank takes part; rank 0 reports)
+        del outs, xs
+        torch.cuda.empty_cache()
+        from spectrograms_amd.distributed import ShardComm
+        wl4, b4, _ = WORKLOADS["config4"]
+        mr = multi_rank_legs(torch, dist, dev, world, make_plan(sg, wl4), [torch.cat([x] * (b4 // 256)) for x in xs256],
+                             max(3, min(args.steps, 20)), max(1, min(args.warmup, 3)), reduce_max, lambda: torch.cuda.synchronize(dev),
+                             lambda: ShardComm(dev), f"configs[3]: {b4} x 10 s per GPU x {world} GPUs, mel_power n_fft=1024 hop=256")
+        if rank == 0:
+            line["workloads"] = mr
+    if watchdog is not None:
+        watchdog.cancel()
+    emit()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -673,8 +956,29 @@ def dry_run(args, rank: int, world: int) -> int:
         dist.all_reduce(kmin, op=dist.ReduceOp.MIN)
         dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
     _, batch, cfg_idx = WORKLOADS[args.workload]
+    workloads = None
+    if world > 1 and not args.no_legs:
+        class StandInPlan:  # the launcher's legs without a GPU: a "launch" fills its output
+            def output_shape(self, n):
+                return 8, 5
+
+            def compute_batch(self, x, out=None):
+                out.fill_(float(x[0, 0]))
+                return out
+
+        def no_comm():
+            raise RuntimeError("dry run: no HIP device for the C ABI's communicator")
+
+        def rmax(v):
+            t = torch.tensor([v], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        workloads = multi_rank_legs(torch, dist, "cpu", world, StandInPlan(), [torch.full((4, 64), float(rank + 1)) for _ in range(2)], 3, 1, rmax,
+                                    lambda: None, no_comm, "dry run: stand-in plan, gloo")
     if rank == 0:
         print(json.dumps({"metric": "STFT frames/sec (f32, n_fft=1024 hop=256)", "value": 0.0, "unit": "frames/s", "n_gpus": world,
+                          **({"workloads": workloads} if workloads else {}),
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(dt.item()) / args.steps * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "dry-run (no GPU work)",
                           "rccl_ranks": ranks, "kernel_ms_min": float(kmin.item()), "kernel_ms_max": float(kmax.item()),

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SGX_ABI_VERSION 6
+#define SGX_ABI_VERSION 7
 
 typedef struct sgx_plan sgx_plan; /* opaque */
 
@@ -209,6 +209,16 @@ sgx_status sgx_gather(sgx_comm *comm, const void *send, void *recv, size_t globa
 sgx_status sgx_shard_execute(sgx_plan *plan, sgx_comm *comm, const void *shard_samples, size_t global_batch, size_t n_samples,
                              size_t sample_stride, void *shard_out, void *gathered_out, void *hip_stream);
 
+/* The same, with the gather overlapped with the compute inside the call ("chunked and overlapped with compute"):
+ * the shard is cut into `chunks` (1..64) runs of signals; while run k + 1 computes on `hip_stream`, run k's pieces of every rank
+ * travel on a second stream owned by the communicator (a group of ncclBroadcast per run, each into the piece's own place in
+ * `gathered_out`), ordered by events only.  `hip_stream` waits for the last exchange before the call's work counts as complete,
+ * so the call is asynchronous on `hip_stream` like sgx_shard_execute.  chunks == 1 or gathered_out == NULL: sgx_shard_execute.
+ * The result equals sgx_shard_execute's bit for bit. */
+sgx_status sgx_shard_execute_chunked(sgx_plan *plan, sgx_comm *comm, const void *shard_samples, size_t global_batch,
+                                     size_t n_samples, size_t sample_stride, void *shard_out, void *gathered_out, int32_t chunks,
+                                     void *hip_stream);
+
 /* ---- 2-D FFT path (BASELINE config 5): R2cPlan2d / C2rPlan2d (src/fft_backend.rs:169-246, 614-819), fft2d / ifft2d
  * (src/fft2d.rs:77-185), convolve_fft and the radial filters (src/image_ops.rs:80-432).  Batched: `batch` images of
  * nrows x ncols per call.  Real images are [batch][nrows][ncols] T; half spectra [batch][nrows][ncols/2+1] complex T
@@ -254,6 +264,11 @@ const char *sgx_c2c_last_error(const sgx_c2c *plan);
  * 3: one buffer read and two written per pass (the read : write mix of the linear-power STFT), counted as 3 x `bytes`.
  * Allocates and frees its own buffers on `device` (-1 = current); no plan involved, nothing on the transform path calls it. */
 sgx_status sgx_membench(int32_t device, size_t bytes, int32_t mode, int32_t iters, double *gb_per_s);
+/* The shader clock the device holds right now, in MHz: one wave per CU, enqueued on `hip_stream` behind whatever the caller has
+ * launched there, counts shader cycles against the constant 100 MHz counter for ~20 us; the call waits for the stream and returns
+ * the median over the CUs.  bench.py's `sustained` leg calls it between blocks of back-to-back launches (the clock a caller who
+ * streams for seconds gets, next to the short timed region's). */
+sgx_status sgx_clock_probe(int32_t device, void *hip_stream, double *mhz);
 
 const char *sgx_last_error(const sgx_plan *plan);
 const char *sgx_last_create_error(void);

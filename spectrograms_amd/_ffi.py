@@ -30,8 +30,8 @@ SYMBOLS = [
     "sgx_fft2d_filter", "sgx_fft2d_last_error", "sgx_fft2d_reserve", "sgx_fft2d_device",
     "sgx_reserve", "sgx_plan_device", "sgx_last_dim_mismatch",
     "sgx_c2c_create", "sgx_c2c_destroy", "sgx_c2c_forward", "sgx_c2c_inverse", "sgx_c2c_last_error",
-    "sgx_comm_unique_id", "sgx_comm_create", "sgx_comm_adopt", "sgx_comm_destroy", "sgx_comm_last_error", "sgx_gather", "sgx_shard_execute",
-    "sgx_membench",
+    "sgx_comm_unique_id", "sgx_comm_create", "sgx_comm_adopt", "sgx_comm_destroy", "sgx_comm_last_error", "sgx_gather", "sgx_shard_execute", "sgx_shard_execute_chunked",
+    "sgx_membench", "sgx_clock_probe",
 ]
 
 
@@ -146,7 +146,10 @@ def lib() -> C.CDLL:
     L.sgx_comm_last_error.restype = C.c_char_p
     L.sgx_gather.argtypes = [vp, vp, vp, sz, sz, C.c_int32, vp]
     L.sgx_shard_execute.argtypes = [vp, vp, vp, sz, sz, sz, vp, vp, vp]
+    L.sgx_shard_execute_chunked.argtypes = [vp, vp, vp, sz, sz, sz, vp, vp, C.c_int32, vp]
     L.sgx_membench.argtypes = [C.c_int32, sz, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
+    L.sgx_clock_probe.argtypes = [C.c_int32, C.c_void_p, C.POINTER(C.c_double)]
+    L.sgx_clock_probe.restype = C.c_int32
     _lib = L
     return L
 

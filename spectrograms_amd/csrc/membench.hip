@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "sgx_internal.h"
 
@@ -68,10 +69,59 @@ __global__ __launch_bounds__(256) void k_mb_mix(const v4f *__restrict__ src, v4f
     }
 }
 
+// sgx_clock_probe: one wave per CU stamps the shader clock counter (s_memtime) against the constant 100 MHz counter
+// (s_memrealtime) over ~20 us (MI355X_MICROARCH.md, DVFS give-back item 6).  Every wave leaves after a bounded number of polls.
+__global__ __launch_bounds__(64) void k_clock_probe(unsigned long long *out, unsigned ticks) {
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    for (unsigned spin = 0; spin < (1u << 16) && r1 - r0 < ticks; ++spin) {
+        __builtin_amdgcn_s_sleep(8);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = t1 - t0;
+        out[2 * blockIdx.x + 1] = r1 - r0;
+    }
+}
+
 }  // namespace
 }  // namespace sgx
 
 using namespace sgx;
+
+extern "C" sgx_status sgx_clock_probe(int32_t device, void *hip_stream, double *mhz) {
+    if (!mhz) return SGX_INVALID_INPUT;
+    *mhz = 0.0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SGX_BACKEND;
+    int dev = device;
+    if (dev == -1 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (dev < 0 || dev >= ndev) return SGX_INVALID_INPUT;
+    DeviceGuard dg;
+    if (dg.enter(dev) != hipSuccess) return SGX_BACKEND;
+    const unsigned nwg = std::max(1u, device_cu_count());
+    unsigned long long *h = nullptr;
+    if (hipHostMalloc((void **)&h, 2 * sizeof(unsigned long long) * nwg, hipHostMallocDefault) != hipSuccess) return SGX_BACKEND;
+    for (unsigned i = 0; i < 2 * nwg; ++i) h[i] = 0;
+    hipStream_t s = (hipStream_t)hip_stream;
+    hipLaunchKernelGGL(k_clock_probe, dim3(nwg), dim3(64), 0, s, h, 2000u);
+    sgx_status st = SGX_BACKEND;
+    if (hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess) {
+        std::vector<double> r;
+        for (unsigned i = 0; i < nwg; ++i)
+            if (h[2 * i + 1] > 0) r.push_back(double(h[2 * i]) / double(h[2 * i + 1]) * 100.0);
+        if (!r.empty()) {
+            std::nth_element(r.begin(), r.begin() + r.size() / 2, r.end());
+            *mhz = r[r.size() / 2];
+            st = SGX_OK;
+        }
+    }
+    (void)hipHostFree(h);
+    return st;
+}
 
 extern "C" sgx_status sgx_membench(int32_t device, size_t bytes, int32_t mode, int32_t iters, double *gb_per_s) {
     if (!gb_per_s || mode < 0 || mode > 3 || iters <= 0) return SGX_INVALID_INPUT;

@@ -12,6 +12,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "sgx_internal.h"
 
@@ -23,6 +24,10 @@ struct sgx_comm {
     int device = -1;
     bool owned = false;  // created by sgx_comm_create (destroyed with it) vs adopted from the host
     std::string err;
+    // sgx_shard_execute_chunked: the stream its gathers travel on and the events that order it against the caller's stream
+    hipStream_t gstream = nullptr;
+    std::vector<hipEvent_t> chunk_done;  // chunk k computed (recorded on the caller's stream)
+    hipEvent_t gathered = nullptr;       // last gather issued (recorded on gstream)
 };
 
 namespace {
@@ -159,10 +164,14 @@ sgx_status sgx_comm_adopt(void *nccl_comm, int32_t world_size, int32_t rank, int
 
 void sgx_comm_destroy(sgx_comm *c) {
     if (!c) return;
-    if (c->owned && c->comm && rccl().ok) {
+    {
         DeviceGuard dg;
         (void)dg.enter(c->device);
-        (void)rccl().CommDestroy(c->comm);
+        if (c->gstream) (void)hipStreamSynchronize(c->gstream);
+        for (hipEvent_t e : c->chunk_done) (void)hipEventDestroy(e);
+        if (c->gathered) (void)hipEventDestroy(c->gathered);
+        if (c->gstream) (void)hipStreamDestroy(c->gstream);
+        if (c->owned && c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
     }
     delete c;
 }
@@ -220,6 +229,83 @@ sgx_status sgx_shard_execute(sgx_plan *plan, sgx_comm *c, const void *shard_samp
     }
     if (!gathered_out) return SGX_OK;  // compute-only sharding: no data-path collective
     return sgx_gather(c, dst ? dst : gathered_out, gathered_out, global_batch, per_item, plan->dtype, hip_stream);
+}
+
+// The same job with the gather pipelined behind the compute ("chunked and overlapped with compute"): the
+// rank's shard is cut into `chunks` runs of signals; chunk k is computed on the caller's stream, and its exchange — one grouped
+// ncclBroadcast per rank holding a piece of chunk k, each into that piece's own place in `gathered_out` — is issued on the
+// communicator's second stream behind an event, so it travels over xGMI while chunk k + 1 computes.  (ncclAllGather cannot express
+// it: its receive layout is rank-major per call, the result's is rank-major per SHARD.)  No host synchronisation; the caller's
+// stream waits for the last exchange, so "asynchronous on hip_stream" holds as for sgx_shard_execute.  A signal's bits do not
+// depend on the launch it is computed in, so the gathered result equals the unchunked one bit for bit (tests/c_abi/shard_ranks.c).
+sgx_status sgx_shard_execute_chunked(sgx_plan *plan, sgx_comm *c, const void *shard_samples, size_t global_batch, size_t n_samples,
+                                     size_t sample_stride, void *shard_out, void *gathered_out, int32_t chunks, void *hip_stream) {
+    if (!plan || !c) return SGX_INVALID_INPUT;
+    if (chunks < 1 || chunks > 64) return comm_fail(c, SGX_INVALID_INPUT, "Invalid input: chunks must be in 1..64");
+    if (chunks == 1 || !gathered_out)
+        return sgx_shard_execute(plan, c, shard_samples, global_batch, n_samples, sample_stride, shard_out, gathered_out, hip_stream);
+    const Rccl &r = rccl();
+    if (!r.ok) return comm_fail(c, SGX_BACKEND, "hip -- FFT backend error: " + r.why);
+    if (!c->comm) return comm_fail(c, SGX_INVALID_INPUT, "Invalid input: communicator has no RCCL handle");
+    size_t start = 0, count = 0;
+    if (sgx_shard_range(global_batch, c->world, c->rank, &start, &count) != SGX_OK) return comm_fail(c, SGX_INVALID_INPUT, "Invalid input: bad shard");
+    size_t nb = 0, nf = 0;
+    sgx_status st = sgx_output_shape(plan, n_samples, &nb, &nf);
+    if (st != SGX_OK) return comm_fail(c, st, sgx_last_error(plan));
+    const size_t per_item = nb * nf * (plan->out_mode == OUT_COMPLEX ? 2 : 1);
+    if (sgx_plan_device(plan) != c->device) return comm_fail(c, SGX_INVALID_INPUT, "Invalid input: plan and communicator are on different devices");
+    if (count > 0 && !shard_samples) return comm_fail(c, SGX_INVALID_INPUT, "Invalid input: null buffer");
+    const ncclDataType_t nt = plan->dtype == SGX_F64 ? ncclFloat64 : ncclFloat32;
+    const size_t elem = plan->elem;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    DeviceGuard dg;
+    if (dg.enter(c->device) != hipSuccess) return comm_fail(c, SGX_BACKEND, "hip -- FFT backend error: hipSetDevice failed");
+    auto hip_ok = [&](hipError_t e) { return e == hipSuccess; };
+    if (!c->gstream && !hip_ok(hipStreamCreateWithFlags(&c->gstream, hipStreamNonBlocking)))
+        return comm_fail(c, SGX_BACKEND, "hip -- FFT backend error: hipStreamCreate failed");
+    if (!c->gathered && !hip_ok(hipEventCreateWithFlags(&c->gathered, hipEventDisableTiming)))
+        return comm_fail(c, SGX_BACKEND, "hip -- FFT backend error: hipEventCreate failed");
+    while (c->chunk_done.size() < size_t(chunks)) {
+        hipEvent_t e = nullptr;
+        if (!hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming))) return comm_fail(c, SGX_BACKEND, "hip -- FFT backend error: hipEventCreate failed");
+        c->chunk_done.push_back(e);
+    }
+    // piece k of a shard of n signals: [k n / K, (k + 1) n / K)
+    auto piece = [&](size_t n, int k, size_t *lo, size_t *hi) {
+        *lo = n * size_t(k) / size_t(chunks);
+        *hi = n * size_t(k + 1) / size_t(chunks);
+    };
+    char *gout = static_cast<char *>(gathered_out);
+    char *own = shard_out ? static_cast<char *>(shard_out) : gout + start * per_item * elem;  // where this rank's shard is computed
+    // the exchange stream starts behind whatever the caller has queued (e.g. the last consumer of gathered_out)
+    if (!hip_ok(hipEventRecord(c->gathered, s)) || !hip_ok(hipStreamWaitEvent(c->gstream, c->gathered, 0)))
+        return comm_fail(c, SGX_BACKEND, "hip -- FFT backend error: stream ordering failed");
+    for (int k = 0; k < chunks; ++k) {
+        size_t lo = 0, hi = 0;
+        piece(count, k, &lo, &hi);
+        if (hi > lo) {
+            const char *xin = static_cast<const char *>(shard_samples) + lo * sample_stride * elem;
+            st = sgx_execute(plan, xin, hi - lo, n_samples, sample_stride, own + lo * per_item * elem, (hi - lo) * per_item, SGX_MEM_DEVICE, hip_stream);
+            if (st != SGX_OK) return comm_fail(c, st, sgx_last_error(plan));
+        }
+        if (!hip_ok(hipEventRecord(c->chunk_done[k], s)) || !hip_ok(hipStreamWaitEvent(c->gstream, c->chunk_done[k], 0)))
+            return comm_fail(c, SGX_BACKEND, "hip -- FFT backend error: stream ordering failed");
+        SGX_NCCL(c, r.GroupStart());
+        for (int root = 0; root < c->world; ++root) {
+            size_t rs = 0, rc = 0, plo = 0, phi = 0;
+            (void)sgx_shard_range(global_batch, c->world, root, &rs, &rc);
+            piece(rc, k, &plo, &phi);
+            if (phi == plo) continue;  // (every rank skips the same roots)
+            char *slice = gout + (rs + plo) * per_item * elem;
+            const void *src = root == c->rank ? static_cast<const void *>(own + plo * per_item * elem) : static_cast<const void *>(slice);
+            ncclResult_t e = r.Broadcast(src, slice, (phi - plo) * per_item, nt, root, c->comm, c->gstream);
+            if (e != ncclSuccess) { (void)r.GroupEnd(); return comm_fail(c, SGX_BACKEND, nccl_text(e)); }
+        }
+        SGX_NCCL(c, r.GroupEnd());
+    }
+    if (!hip_ok(hipEventRecord(c->gathered, c->gstream)) || !hip_ok(hipStreamWaitEvent(s, c->gathered, 0)))
+        return comm_fail(c, SGX_BACKEND, "hip -- FFT backend error: stream ordering failed");
+    return SGX_OK;
 }
 
 }  // extern "C"

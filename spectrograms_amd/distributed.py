@@ -115,3 +115,57 @@ class ShardedPlan:
             import torch
             y = gather_outputs(torch.view_as_real(y) if y.is_complex() else y, batch_total, self.group)
         return y
+
+
+class ShardComm:
+    """The C ABI's own RCCL communicator (`sgx_comm_*`, include/spectro_hip.h) for this rank: rank 0 makes the 128-byte id
+    (ncclGetUniqueId), `torch.distributed` carries it to the other ranks (any backend — it is 128 bytes of host data), every rank
+    runs ncclCommInitRank on its own device.  `execute(plan, x_local, batch_total, gathered, chunks)` is `sgx_shard_execute` /
+    `sgx_shard_execute_chunked`: the rank's shard computed straight into its slice of `gathered` and the shards exchanged inside the
+    same call, with `chunks > 1` on the communicator's second stream while the next chunk computes."""
+
+    def __init__(self, device, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self._lib = _ffi.lib()
+        self._h = C.c_void_p()
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        ident = (C.c_ubyte * 128)()
+        if self.rank == 0:
+            st = self._lib.sgx_comm_unique_id(ident)
+            if st != 0:
+                raise _ffi.FFTBackendError((self._lib.sgx_comm_last_error(None) or b"").decode() or "sgx_comm_unique_id failed")
+        box = [bytes(ident)]
+        dist.broadcast_object_list(box, src=0, group=group)
+        dev = torch.device(device)
+        st = self._lib.sgx_comm_create(box[0], self.world, self.rank, dev.index if dev.index is not None else -1, C.byref(self._h))
+        if st != 0:
+            raise _ffi.FFTBackendError((self._lib.sgx_comm_last_error(None) or b"").decode() or "sgx_comm_create failed")
+
+    def execute(self, plan, x_local, batch_total: int, gathered, chunks: int = 1, shard_out=None, stream: int = 0):
+        """x_local: this rank's [count, N] device tensor; gathered: [batch_total, n_bins, n_frames(, 2)] device tensor."""
+        import torch
+
+        s = stream or torch.cuda.current_stream(gathered.device).cuda_stream
+        n = x_local.shape[1] if x_local is not None and x_local.numel() else 0
+        st = self._lib.sgx_shard_execute_chunked(plan._h, self._h, x_local.data_ptr() if n else None, batch_total, x_local.shape[1],
+                                                 x_local.stride(0), shard_out.data_ptr() if shard_out is not None else None,
+                                                 gathered.data_ptr(), int(chunks), C.c_void_p(s))
+        if st != 0:
+            msg = (self._lib.sgx_comm_last_error(self._h) or b"").decode() or f"sgx_shard_execute_chunked failed (status {st})"
+            raise {_ffi.SGX_INVALID_INPUT: _ffi.InvalidInputError, _ffi.SGX_DIM_MISMATCH: _ffi.DimensionMismatchError,
+                   _ffi.SGX_BACKEND: _ffi.FFTBackendError}.get(st, _ffi.InternalError)(msg)
+        return gathered
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.sgx_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

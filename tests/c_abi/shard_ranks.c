@@ -4,7 +4,8 @@
  * Every case compares what every rank gathered with a single launch over the whole batch, bit for bit:
  *   worlds 2 and 3; batches that divide evenly (one ncclAllGather) and ragged ones (a group of ncclBroadcast, incl. a batch smaller
  *   than the world, i.e. ranks with an empty shard); shard computed in place (straight into the rank's slice) and through a separate
- *   shard buffer; per-bin (linear power), filterbank (Mel-80 dB) and complex outputs.
+ *   shard buffer; per-bin (linear power), filterbank (Mel-80 dB) and complex outputs; sgx_shard_execute_chunked with K = 1, 4 and 7
+ *   chunks (the exchange of chunk k on the communicator's own stream while chunk k + 1 computes).
  * Built (hipcc, C mode) and run by tests/test_c_abi.py::test_shard_execute_multi_rank on the GPU box. */
 #include <hip/hip_runtime_api.h>
 #include <math.h>
@@ -39,6 +40,7 @@ typedef struct {
     int world, rank, failed;
     size_t batch;
     int separate; /* 1: compute into a shard buffer, then gather; 0: straight into the rank's slice of the gathered buffer */
+    int chunks;   /* 0: sgx_shard_execute; K >= 1: sgx_shard_execute_chunked with K chunks (gathers on the communicator's own stream) */
     const sgx_params *params;
     const unsigned char *id;
     const float *host_x;  /* [batch][N] */
@@ -68,7 +70,9 @@ static void *rank_main(void *vp) {
         TCHECK(hipMalloc((void **)&dshard, (count ? count : 1) * a->per_item * sizeof(float)) == hipSuccess);
     }
     /* a rank with an empty shard still takes part in the collective */
-    const sgx_status st = sgx_shard_execute(plan, comm, count ? dx : NULL, a->batch, N, N, a->separate ? dshard : NULL, dg, s);
+    const sgx_status st = a->chunks
+                              ? sgx_shard_execute_chunked(plan, comm, count ? dx : NULL, a->batch, N, N, a->separate ? dshard : NULL, dg, a->chunks, s)
+                              : sgx_shard_execute(plan, comm, count ? dx : NULL, a->batch, N, N, a->separate ? dshard : NULL, dg, s);
     if (st != SGX_OK) fprintf(stderr, "rank %d: sgx_shard_execute -> %d: %s\n", a->rank, (int)st, sgx_comm_last_error(comm));
     TCHECK(st == SGX_OK);
     TCHECK(hipStreamSynchronize(s) == hipSuccess);
@@ -92,7 +96,7 @@ static void *rank_main(void *vp) {
     return NULL;
 }
 
-static int run_case(const sgx_params *p, const float *x, size_t batch, int world, int separate, const char *what) {
+static int run_case_k(const sgx_params *p, const float *x, size_t batch, int world, int separate, int chunks, const char *what) {
     sgx_plan *plan = NULL;
     CHECK(sgx_plan_create(p, &plan) == SGX_OK);
     size_t nb = 0, nf = 0;
@@ -118,7 +122,7 @@ static int run_case(const sgx_params *p, const float *x, size_t batch, int world
     rank_arg args[8];
     const int ag0 = fake_rccl_allgathers, bc0 = fake_rccl_broadcasts, gr0 = fake_rccl_groups;
     for (int r = 0; r < world; ++r) {
-        rank_arg a = {world, r, 0, batch, separate, p, id, x, ref, per_item, &bar};
+        rank_arg a = {world, r, 0, batch, separate, chunks, p, id, x, ref, per_item, &bar};
         args[r] = a;
         CHECK(pthread_create(&th[r], NULL, rank_main, &args[r]) == 0);
     }
@@ -130,16 +134,29 @@ static int run_case(const sgx_params *p, const float *x, size_t batch, int world
     pthread_barrier_destroy(&bar);
     free(ref);
     const int ag = fake_rccl_allgathers - ag0, bc = fake_rccl_broadcasts - bc0, gr = fake_rccl_groups - gr0;
-    printf("%-14s world %d batch %zu %-9s: %s  (ncclAllGather x%d, ncclBroadcast x%d in %d groups)\n", what, world, batch,
-           separate ? "separate" : "in-place", failed ? "FAILED" : "ok", ag, bc, gr);
+    printf("%-14s world %d batch %zu %-9s chunks %d: %s  (ncclAllGather x%d, ncclBroadcast x%d in %d groups)\n", what, world, batch,
+           separate ? "separate" : "in-place", chunks, failed ? "FAILED" : "ok", ag, bc, gr);
     CHECK(!failed);
-    if (batch % (size_t)world == 0) {
+    if (chunks > 1) {
+        /* one group per chunk and rank; in it one broadcast per rank that holds a piece [k n / K, (k + 1) n / K) of that chunk */
+        int pieces = 0;
+        for (int r = 0; r < world; ++r) {
+            size_t rs = 0, rc = 0;
+            CHECK(sgx_shard_range(batch, world, r, &rs, &rc) == SGX_OK);
+            for (int k = 0; k < chunks; ++k) pieces += rc * (size_t)(k + 1) / (size_t)chunks > rc * (size_t)k / (size_t)chunks;
+        }
+        CHECK(ag == 0 && gr == chunks * world && bc == pieces * world);
+    } else if (batch % (size_t)world == 0) {
         CHECK(ag == world && bc == 0); /* equal shards: one all-gather per rank */
     } else {
         size_t roots = batch < (size_t)world ? batch : (size_t)world; /* ranks with a non-empty shard */
         CHECK(ag == 0 && gr == world && bc == (int)(roots * (size_t)world));
     }
     return 0;
+}
+
+static int run_case(const sgx_params *p, const float *x, size_t batch, int world, int separate, const char *what) {
+    return run_case_k(p, x, batch, world, separate, 0, what);
 }
 
 int main(void) {
@@ -167,6 +184,18 @@ int main(void) {
             if (run_case(&mel, x, 7, world, separate, "Mel-80 dB")) return 1;
             if (run_case(&cpx, x, 5, world, separate, "complex STFT")) return 1;
         }
+    /* sgx_shard_execute_chunked: K = 1 (the plain path) and K = 4 (compute on the caller's stream, each chunk's exchange on the
+     * communicator's stream behind an event), equal and ragged shards, chunks with no signals (7 signals over 3 ranks x 4 chunks), ranks
+     * with an empty shard — bit for bit against one launch */
+    for (int world = 2; world <= 3; ++world)
+        for (int separate = 0; separate <= 1; ++separate) {
+            if (run_case_k(&lin, x, 6, world, separate, 1, "linear power")) return 1;
+            if (run_case_k(&lin, x, 6, world, separate, 4, "linear power")) return 1;
+            if (run_case_k(&mel, x, 7, world, separate, 4, "Mel-80 dB")) return 1;
+            if (run_case_k(&cpx, x, 5, world, separate, 4, "complex STFT")) return 1;
+        }
+    if (run_case_k(&mel, x, 2, 3, 0, 4, "Mel-80 dB")) return 1;
+    if (run_case_k(&mel, x, 7, 2, 0, 7, "Mel-80 dB")) return 1;
     if (run_case(&mel, x, 2, 3, 0, "Mel-80 dB")) return 1; /* batch < world: rank 2 has nothing to compute and still gathers */
     if (run_case(&lin, x, 1, 2, 1, "linear power")) return 1;
     free(x);

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     L = C.CDLL(_ffi.LIB_PATH)
     for s in declared:
         assert hasattr(L, s), s
-    assert _ffi.lib().sgx_abi_version() == 6
+    assert _ffi.lib().sgx_abi_version() == 7
 
 
 def test_params_struct_layout_matches_header():

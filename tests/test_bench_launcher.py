@@ -27,6 +27,17 @@ def test_direct_multi_rank_run_spawns_its_ranks():
     # what the multi-rank line must carry so that the driver's scaling records can be audited: how many ranks the process group
     # really has, and the spread of the per-rank launch times
     assert d["rccl_ranks"] == 2 and 0 < d["kernel_ms_min"] <= d["kernel_ms_max"]
+    # N > 1 carries BASELINE configs[3] with and without the exchange (bench.multi_rank_legs, here on a stand-in plan over gloo): compute
+    # only, all-gather behind every launch, gather overlapped with the next launch, the all-gather alone with its per-rank rate, and
+    # the C ABI's chunked path — which has no device here and must report its error without taking the line down
+    w = d["workloads"]
+    assert set(w) == {"config4", "config4_gather_sync", "config4_gather_alone", "config4_gather_overlap", "config4_cabi_chunked4"}
+    for k in ("config4", "config4_gather_sync", "config4_gather_overlap"):
+        assert w[k]["value"] > 0 and w[k]["ms_per_step"] > 0 and w[k]["steps"] == 3, w[k]
+    for k in ("config4_gather_sync", "config4_gather_overlap"):
+        assert w[k]["GBps_per_rank"] > 0 and w[k]["shard_MB"] == 4 * 8 * 5 * 4 / 1e6
+    assert w["config4_gather_alone"]["GBps_per_rank"] > 0 and w["config4_gather_alone"]["GBps_per_link"] > 0
+    assert "no HIP device" in w["config4_cabi_chunked4"]["error"]
 
 
 def test_two_ranks_on_one_device_are_refused():

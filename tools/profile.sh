@@ -8,7 +8,8 @@ OUT=$ROOT/gpurun_out/prof_${TAG}_${WL}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # the stats pass launches 800 times: the clocks need ~300 launches from idle; summarize_prof.py reports the second half's average
-timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/tools/prof_driver.py $WL 800 > $OUT/stats.log 2>&1
+case $WL in fft2d|convolve_fft) NST=120;; istft) NST=400;; *) NST=800;; esac
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/tools/prof_driver.py $WL $NST > $OUT/stats.log 2>&1
 DRV="python3 $ROOT/tools/prof_driver.py $WL 12"
 pmc() { name=$1; shift; timeout 180 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- $DRV > $OUT/$name.log 2>&1; }
 pmc sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
@@ -19,5 +20,5 @@ pmc write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 pmc tcp TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_LATENCY_sum
 pmc ta TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_FLAT_WRITE_WAVEFRONTS_sum
 cd $ROOT
-python3 tools/summarize_prof.py $OUT --traffic $WL > $OUT/summary.txt 2>&1
+python3 tools/summarize_prof.py $OUT --traffic $WL --iters 12 > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
