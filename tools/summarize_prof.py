@@ -6,6 +6,7 @@ bytes, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-byte read 
 profiles/traffic_latest.json, stamped with the hash of the kernel sources the library was built from (bench.py reports
 `roofline.traffic` only while that stamp matches the sources it runs).  No number in that file is typed by hand."""
 import csv
+import re
 import glob
 import json
 import os
@@ -37,7 +38,8 @@ def write_traffic(workload: str, per_kernel: dict, sums: dict, durations: dict, 
         fetch = f_sum / f_n * 1024.0  # bytes per dispatch as the counter reports them
         write = w_sum / w_n * 1024.0
         b = (2.0 * fetch + write) * per_step
-        short = k.split("(")[0][-90:]
+        m = re.search(r"(k_\w+(?:<[^>]*>)?)", k)
+        short = m.group(1) if m else k[:90]
         kernels[short] = {"dispatches_per_step": per_step, "FETCH_SIZE_bytes_per_dispatch": fetch, "WRITE_SIZE_bytes_per_dispatch": write,
                           "bytes_per_step": int(round(b)), "steady_avg_us": durations.get(k)}
         total += b
