@@ -252,7 +252,7 @@ __device__ __forceinline__ JobOfs job_offsets(unsigned j, unsigned n_frames) {
 struct PwAddr {
     float *up, *down;  // up[i * pstep] = bin c + 32 i; down[(7 - i) * pstep] = its mirror (both for c1 and, + c2off, for c2)
 };
-template <int MODE, int AMP, bool PWT, int PS = 0>
+template <int MODE, int AMP, bool PWT>
 __device__ __forceinline__ void pass2_compute(v2f (&A)[16], v2f (&B)[16], bool j0, float eps, const v4f *tw, __amdgpu_buffer_rsrc_t ro,
                                               unsigned oa1, unsigned ob1, unsigned oa2, unsigned ob2, unsigned omid, unsigned step,
                                               float *pw_c1, float *pw_m1, float *pw_c2, float *pw_m2, float *pw_mid SGX_STAMP_PARAMS) {
@@ -277,7 +277,7 @@ __device__ __forceinline__ void pass2_compute(v2f (&A)[16], v2f (&B)[16], bool j
         asm volatile("" ::: "memory");  // keeps this a branch (the compiler turned the selects into 48 v_cndmask per tile)
     }
     SGX_STAMP(9);  // 16-point transforms
-    constexpr int PSTEP = PS ? PS : PWT ? 32 * 16 : 32;  // floats between bins k and k + 32 in the |X|^2 tile
+    constexpr int PSTEP = PWT ? 32 * 16 : 32;  // floats between bins k and k + 32 in the |X|^2 tile
     auto emit = [&](unsigned voff, unsigned soff, float *pwp, v2f X, bool conj) {
 #ifdef SGX_ABL_NOSTORE  // timing experiment only: keep the value alive, drop the store
         asm volatile("" ::"v"(X), "v"(voff));
@@ -1144,252 +1144,6 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
 #endif
 }
 
-// ====================================================================================================================
-// k_w4 — filterbank outputs at n_fft 1024, hop <= 256 (round 4): the same transform with NO workgroup barrier in its loop.
-//
-// k_r32x16 moves its 8 waves through every phase together, so the CU's vector units wait while the LDS serves the exchange and
-// the LDS waits while the butterflies run: measured time = VALU cycles + LDS cycles.  What forces the lockstep is
-// pass 2's lane map — lane (job, frame 0..15) gathers ONE job of all 16 frames into a wave so that a store covers 16 consecutive
-// frames of a bin — and the 16-frame band stage.  A filterbank output needs neither: here a wave owns a tile of 4 consecutive
-// frames and a private 16 KiB of LDS; lane (frame pf = lane >> 4, x = lane & 15) is column n2 = x of its frame in pass 1 and job
-// j = x of the SAME frame in pass 2, so the exchange stays inside the wave (LDS serves a wave's instructions in order: no barrier,
-// no wait), the |X|^2 tile is the wave's own, and the band stage runs over the wave's 4 frames (lane = band slot x frame pair).
-// The 8 waves of a CU share only the read-only tables and drift apart, so one wave's LDS phases meet another's arithmetic.
-//   ex      [frame][row k1][16-byte chunk c ^ ((k1 >> 1) & 7)]: frame stride 4096, XOR-swizzled chunks — a 16-lane read group of
-//           ds_read_b128 is jobs {0..3, 12..15} of one frame + jobs {4..11} of the next (or the reverse): all 64 banks once, for
-//           rows j and for rows 32 - j (checked in tests/test_rr_layout.py::test_w4_exchange_is_conflict_free)
-//   samples the wave's own 3 hop + 1024 samples, 7 x 16 bytes per lane, one tile ahead in registers
-//   bands   dealt in descending length, 32 per segment (plan.hip build_band_schedule_w4): 40 + 12 + 8 steps for Mel-80 against 40
-//           + 8 per wave of k_r32x16's 16-frame stage — 25 % more band arithmetic, no barrier before or after it
-// Same arithmetic in the same order as k_r32x16 (pass 1, pass 2, real split and the band sums are the same functions): a frame's
-// bits do not depend on which of the two kernels ran it.
-// ====================================================================================================================
-__host__ __device__ constexpr unsigned pw4_index(unsigned k, unsigned f) { return (k >> 1) * 8u + (f >> 1) * 4u + (k & 1u) * 2u + (f & 1u); }
-
-// NQ groups of 4 steps: all 3 NQ operand reads are requested together, then summed in order.  (hipcc's own loop does this only for
-// runs of 32 steps and falls back to one exposed LDS round trip per 4 steps for the rest — the 12- and 8-step segments of a Mel-80
-// bank — which made the stage 32 us of the launch.)
-template <int NQ>
-__device__ __forceinline__ void band_block(const v4f *wr, const v4f *pr, unsigned t, v2f &acc) {
-    v4f w[NQ], qa[NQ], qb[NQ];
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-#ifdef SGX_W4_ABL_W  // timing experiments only (wrong results)
-        w[i] = (v4f){1.f, 0.5f, 0.25f, (float)t};
-#else
-        w[i] = wr[(t >> 2) + i];
-#endif
-#ifdef SGX_W4_ABL_P
-        qa[i] = (v4f){(float)t, 1.f, 2.f, 3.f};
-        qb[i] = (v4f){4.f, 5.f, (float)i, 7.f};
-#else
-        qa[i] = pr[((t >> 1) + 2 * i) * 2u];
-        qb[i] = pr[((t >> 1) + 2 * i) * 2u + 2u];
-#endif
-    }
-#ifdef SGX_W4_ABL_CHAIN2  // timing experiment only: two interleaved partial sums (not the reference's order)
-    v2f a2 = {0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-        acc = mul_add_unfused(w[i].x, (v2f){qa[i].x, qa[i].y}, acc);
-        a2 = mul_add_unfused(w[i].y, (v2f){qa[i].z, qa[i].w}, a2);
-        acc = mul_add_unfused(w[i].z, (v2f){qb[i].x, qb[i].y}, acc);
-        a2 = mul_add_unfused(w[i].w, (v2f){qb[i].z, qb[i].w}, a2);
-    }
-    acc = acc + a2;
-    return;
-#endif
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) {  // qa = (bin t: frames 2 fp, 2 fp + 1; bin t + 1: the same two frames), qb = bins t + 2, t + 3
-        acc = mul_add_unfused(w[i].x, (v2f){qa[i].x, qa[i].y}, acc);
-        acc = mul_add_unfused(w[i].y, (v2f){qa[i].z, qa[i].w}, acc);
-        acc = mul_add_unfused(w[i].z, (v2f){qb[i].x, qb[i].y}, acc);
-        acc = mul_add_unfused(w[i].w, (v2f){qb[i].z, qb[i].w}, acc);
-    }
-}
-
-template <int AMP, int NSEG>
-__device__ __forceinline__ void mel_tile_w4(const StftArgs &a, const float *pw, const unsigned *sched, unsigned b, unsigned f0, unsigned nf,
-                                            float eps, unsigned lane) {
-    const unsigned slot = lane >> 1, fp = lane & 1u;
-    constexpr unsigned kDrop = 0x80000000u;  // past the descriptor's range: the hardware drops the store
-    const unsigned obytes = (a.n_out * a.n_frames - f0) * 4u;
-    const __amdgpu_buffer_rsrc_t ro = make_rsrc((const float *)a.out + (size_t)b * a.n_out * a.n_frames + f0, obytes);
-    // a lane's two frames are neighbours in memory: one 8-byte store when both exist, a 4-byte one for the first alone (an odd frame
-    // count's last tile) — the other of the two is dropped by the range check
-    const unsigned fo2 = 2u * fp + 1u < nf ? 8u * fp : kDrop, fo1 = (2u * fp < nf && 2u * fp + 1u >= nf) ? 8u * fp : kDrop;
-    const uint4 *info = (const uint4 *)(sched + kSchedHdr) + slot;
-    uint4 rec[NSEG];  // all records up front: one LDS round trip for the stage's control data
-#pragma unroll
-    for (int q = 0; q < NSEG; ++q) rec[q] = info[q * 32];
-    // (a fixed trip count and unconditional stores: the compiler counts the stage's 2 NSEG stores behind the next tile's sample loads)
-#pragma unroll
-    for (int seg = 0; seg < NSEG; ++seg) {
-        const uint4 cur = rec[seg];
-        const unsigned L = __builtin_amdgcn_readfirstlane(cur.x);  // a multiple of 8
-        const v4f *wr = (const v4f *)((const float *)sched + cur.y);
-        const v4f *pr = (const v4f *)(pw + (cur.z >> 1) * 8u) + fp;  // kstart is even
-        v2f acc = {0.0f, 0.0f};
-        unsigned t = 0;
-        for (; t + 32u <= L; t += 32u) band_block<8>(wr, pr, t, acc);
-        const unsigned rem = (L - t) >> 3;  // 0..3 runs of 8 steps
-        if (rem == 3u) band_block<6>(wr, pr, t, acc);
-        else if (rem == 2u) band_block<4>(wr, pr, t, acc);
-        else if (rem == 1u) band_block<2>(wr, pr, t, acc);
-        const bool have = cur.w != 0xffffffffu;
-        const unsigned bo = cur.w * a.n_frames * 4u;
-#ifdef SGX_W4_ABL_STORE  // timing experiment only
-        asm volatile("" ::"v"(acc), "v"(bo), "v"(have));
-        continue;
-#endif
-        const v2f r = (v2f){amp_f32<AMP>(acc.x, eps), amp_f32<AMP>(acc.y, eps)};
-        const float r0 = r.x;  // (a scalar first: __builtin_bit_cast of a vector component other than .x reads the first element — hipcc 7.2)
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, r), ro, (int)((have && fo2 != kDrop) ? bo + fo2 : kDrop), 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, r0), ro, (int)((have && fo1 != kDrop) ? bo + fo1 : kDrop), 0, 0);
-    }
-}
-
-template <int AMP, bool XSPAD, int NSEG>
-__global__ __launch_bounds__(512, 2) void k_w4(StftArgs a, unsigned per_xcd, unsigned total, unsigned slots, unsigned tiles4) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
-    const unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    unsigned char *reg = smem_all + wv * kW4Region;
-    unsigned char *tabs = smem_all + kW4Tabs;
-    if (threadIdx.x < 256u) ((v4f *)(tabs + kWinOff))[threadIdx.x] = ((const v4f *)a.window)[threadIdx.x];
-    for (unsigned i = threadIdx.x; i < 16u * 17u; i += 512u) ((v4f *)(tabs + kTw2Off))[i] = ((const v4f *)a.tw2)[i];
-    unsigned *sched = (unsigned *)(tabs + kMelOff);
-    for (unsigned i = threadIdx.x; i < a.mel_sched4_words; i += 512u) sched[i] = a.mel_sched4[i];
-
-    // XCD x owns the contiguous run of tiles [x per_xcd, (x + 1) per_xcd); its 8 * slots resident waves walk it with that stride, so the
-    // tiles in flight on one XCD are neighbours (they share the 768-sample halo in its L2)
-    const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-    const unsigned lo = xcd * per_xcd, hi = min(lo + per_xcd, total), stride = slots * 8u;
-    unsigned wid = lo + slot * 8u + wv;
-
-    const unsigned pf = lane >> 4, x = lane & 15u;  // frame of the tile; column n2 (pass 1) / job j (pass 2)
-    const unsigned ra = x, rb = x == 0 ? 16u : 32u - x;
-    const float eps = (float)a.eps;
-    const v4f *twj = (const v4f *)(tabs + kTw2Off) + x * 17u;
-    v2f twa[4], twb[8];
-    load_tw1(a, x, twa, twb);
-    const unsigned hop = XSPAD ? 256u : a.hop;
-    const unsigned row_bytes = (unsigned)a.n_samples * 4u;  // host: n_samples < 2^29
-    constexpr unsigned RS = XSPAD ? 1024u + 128u : 1024u;  // LDS bytes per round of 64 chunks (hop 256: 128 B of padding per KiB, so that the
-                                                            // two frames of a 32-lane read group sit on different bank halves)
-    v4f creg[7];
-    auto load_tile = [&](unsigned w) {
-        const unsigned b = w / tiles4, f0 = (w - b * tiles4) * 4u;
-        const __amdgpu_buffer_rsrc_t rx = make_rsrc((const float *)a.x + (size_t)b * a.sample_stride, row_bytes);
-        // first sample of the tile relative to the row: negative in the left padding — as an unsigned byte offset far out of range, so
-        // the hardware returns 0 there as it does past the end of the row (S1: zero padding)
-        const int vo = ((int)(f0 * hop) - (int)a.pad + 4 * (int)lane) * 4;
-#ifdef SGX_W4_NOLOAD  // timing experiment only (wrong results)
-#pragma unroll
-        for (int r = 0; r < 7; ++r) creg[r] = (v4f){(float)vo, 1.f, 2.f, (float)r};
-        return;
-#endif
-#pragma unroll
-        for (int r = 0; r < 7; ++r) creg[r] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rx, vo + r * 1024, 0, 0));
-    };
-    if (wid < hi) load_tile(wid);
-    __syncthreads();  // tables visible — the only barrier of the kernel
-#ifndef SGX_W4_STAGGER
-#define SGX_W4_STAGGER 0  // wave w starts w * SGX_W4_STAGGER * 64 cycles late (A/B: spreads the 8 waves of a CU over the tile period)
-#endif
-    for (unsigned q = 0; q < wv * SGX_W4_STAGGER; ++q) __builtin_amdgcn_s_sleep(1);
-
-    const unsigned xaddr = lds_addr(reg) + pf * hop * 4u + x * 8u + (XSPAD ? pf * 128u : 0u);
-    const unsigned waddr = lds_addr(tabs + kWinOff) + x * 8u;
-    unsigned char *exf = reg + pf * 4096u;
-    // ex write bases: the value of (row k1, column n2) goes to chunk (n2 >> 1) ^ ((k1 >> 1) & 7) of its row
-    unsigned char *exw[8];
-#pragma unroll
-    for (int m = 0; m < 8; ++m) exw[m] = exf + ((((x >> 1) ^ (unsigned)m) << 4) | ((x & 1u) << 3));
-    const unsigned offa = ra * 128u + (((ra >> 1) & 7u) << 4), offb = rb * 128u + (((rb >> 1) & 7u) << 4);
-    float *pwf = (float *)(reg + kW4PwOff);
-#ifdef SGX_STAMPS
-    unsigned long long st_acc[16] = {0}, st_prev;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
-#endif
-
-    while (wid < hi) {
-        const unsigned b = wid / tiles4, f0 = (wid - b * tiles4) * 4u;
-        const unsigned nf = min(4u, a.n_frames - f0);
-        v2f xr[32];
-        {
-            v2f e[16], o[16], we[16], wo[16];
-#pragma unroll
-            for (int r = 0; r < 7; ++r) *(v4f *)(reg + r * RS + lane * 16u) = creg[r];
-            asm volatile("" ::: "memory");  // the column reads below are asm: keep them behind the staging stores (the LDS serves a wave in order)
-            SGX_STAMP(0);  // wait for the samples + staging writes
-            read_cols<XSPAD, 0>(e, we, xaddr, waddr, std::make_integer_sequence<int, 16>{});
-            read_cols<XSPAD, 1>(o, wo, xaddr, waddr, std::make_integer_sequence<int, 16>{});
-            tie16<15>(e);
-            tie16<-1>(we);
-            Fft<16, true>::run(e, we);
-            tie16<0>(o);
-            tie16<-1>(wo);
-            Fft<16, true>::run(o, wo);
-            Comb<32, 0, v2f>::run(xr, e, o);
-        }
-        SGX_STAMP(2);  // column / window reads + 32-point transform
-#pragma unroll
-        for (int k1 = 0; k1 < 32; ++k1) {  // twiddle by W_512^(k1 n2) and write row k1 of this lane's column
-            const int qa = k1 >> 3, qb = k1 & 7;
-            v2f r = xr[k1];
-            if (qb) r = cmulv(r, twb[qb]);
-            if (qa) r = cmulv(r, twa[qa]);
-            *(v2f *)(exw[(k1 >> 1) & 7] + k1 * 128) = r;
-        }
-        SGX_STAMP(4);  // twiddles + ex writes
-        const unsigned next = wid + stride;
-        if (next < hi) load_tile(next);  // in flight during pass 2 and the band stage
-        SGX_STAMP(5);  // load issue
-        v2f A[16], B[16];
-        {
-            const unsigned char *fb = reg + pf * 4096u;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const v4f q = *(const v4f *)(fb + (offa ^ ((unsigned)c << 4)));
-                A[2 * c] = (v2f){q.x, q.y};
-                A[2 * c + 1] = (v2f){q.z, q.w};
-            }
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const v4f q = *(const v4f *)(fb + (offb ^ ((unsigned)c << 4)));
-                B[2 * c] = (v2f){q.x, q.y};
-                B[2 * c + 1] = (v2f){q.z, q.w};
-            }
-        }
-        SGX_STAMP(7);  // row reads
-        // the |X|^2 tile overlays the exchange rows just read (same wave: the reads above are served before the writes below)
-        if (lane < 44u) pwf[pw4_index(513u + (lane >> 2), lane & 3u)] = 0.0f;  // bins 513..523 are read with zero weights
-        {
-            const unsigned c1 = x == 0 ? 16u : x, c2 = x == 0 ? 0u : x + 256u;
-            auto slot_of = [&](unsigned k) { return pwf + pw4_index(k, pf); };  // bins k + 32 i follow at i * 128 floats
-            const __amdgpu_buffer_rsrc_t none = make_rsrc(a.out, 0u);  // (pass2_compute's per-bin outputs: unused for OUT_MEL)
-            pass2_compute<OUT_MEL, AMP, true, 128>(A, B, x == 0, eps, twj, none, 0u, 0u, 0u, 0u, 0u, 0u, slot_of(c1),
-                                                   slot_of(512u - 224u - c1), slot_of(c2), slot_of(512u - 224u - c2), slot_of(256u) SGX_STAMP_ARGS);
-        }
-#ifdef SGX_W4_NOBAND  // timing experiment only (wrong results): the transform without its band stage
-        asm volatile("" ::"v"(pwf[lane]));
-#else
-        mel_tile_w4<AMP, NSEG>(a, pwf, sched, b, f0, nf, eps, lane);
-#endif
-        SGX_STAMP(13);  // band stage
-        wid = next;
-#ifdef SGX_STAMPS
-        st_acc[15] += 1;
-#endif
-    }
-#ifdef SGX_STAMPS
-    if (lane == 0) {
-        for (int q = 0; q < 16; ++q) atomicAdd(&g_stamps[q], st_acc[q]);
-        atomicAdd(&g_stamps[16], 1ull);
-    }
-#endif
-}
-
 // Packed tiles pay 5 more vector instructions per sample pair and give up the staged loads and the wide stores — measured 1.0-1.1 G
 // frames/s (linear power and Mel-80 dB, 4 ... 40 frames per signal) against 1.4-1.5 G x the filled share of one-signal tiles
 // (profiles/bench_r03_short_signals.txt): packed once a quarter or more of the one-signal tiles' slots would be empty (626 frames: 2
@@ -1433,27 +1187,6 @@ hipError_t launch_variant(const StftArgs &a0, hipStream_t s) {
         if (pack && a.n_fft == 512u) return go(k_r32x16<MODE, AMP, 0, false, false, false, 128, true>);  // (128: any hop, the mode's marker)
     if (pack) return go(k_r32x16<MODE, AMP, 0, false, false, MODE == OUT_MEL, 0, true>);
     if constexpr (MODE == OUT_MEL) {
-#ifndef SGX_W4
-#define SGX_W4 1  // 0: filterbank outputs at n_fft 1024 stay on k_r32x16's 16-frame tiles (A/B; plan.hip's SGX_W4_DEFAULT names the kernel)
-#endif
-        if (SGX_W4 && pwt && a.mel_sched4 && a.n_fft == 1024u && a.hop <= 256u && !(a.hop & 1u)) {
-            const unsigned tiles4 = (a.n_frames + 3u) / 4u;
-            const unsigned long long total64 = (unsigned long long)tiles4 * a.batch;
-            if (total64 < 0x7ffffff0ull) {
-                const unsigned tot = (unsigned)total64, pxcd = (tot + 7u) / 8u;
-                const unsigned ns = std::min(cu_slots, (pxcd + 7u) / 8u);
-                const unsigned lds = (unsigned)kW4Tabs + (unsigned)kMelOff + ((a.mel_sched4_words * 4u + 15u) & ~15u) + 64u;
-                auto go4 = [&](auto kernel) -> hipError_t {
-                    hipError_t e = set_max_dynamic_lds((const void *)kernel, kW4LdsBytes);
-                    if (e != hipSuccess) return e;
-                    hipLaunchKernelGGL(kernel, dim3(ns * 8), dim3(512), lds, s, a, pxcd, tot, ns, tiles4);
-                    return hipGetLastError();
-                };
-                // (the band stage's segment count is a compile-time trip count: 3 covers 96 bands — Mel-80 —, 4 the rest)
-                if (a.n_mels <= 96u) return a.hop == 256u ? go4(k_w4<AMP, true, 3>) : go4(k_w4<AMP, false, 3>);
-                return a.hop == 256u ? go4(k_w4<AMP, true, 4>) : go4(k_w4<AMP, false, 4>);
-            }
-        }
         if (pwt) {
             if (a.n_fft == 512u) {  // two frames per transform
                 if (a.hop == 64u) return go(k_r32x16<MODE, AMP, 3, false, false, true, 64>);

@@ -27,19 +27,5 @@ constexpr int kLdsBytes = 2 * kExBytes + kMelOff + kMelMaxWords * 4;  // 156416 
 constexpr int kSchedHdr = 4;
 constexpr int kSchedSegs = 4;  // the kernel always runs this many segments (empty ones have L = 0, band = none): n_mels <= 128
 
-// ---- k_w4: the barrier-free form of the tuned kernel for filterbank outputs at n_fft 1024 (kernels_r32x16.hip) -------------
-// Every wave owns a tile of 4 consecutive frames and a private 16 KiB LDS region and runs pass 1 -> exchange -> pass 2 -> |X|^2 ->
-// band stage on it alone; the 8 waves of a CU share only the read-only tables.
-constexpr int kW4Region = 16384;   // per wave: staged samples (<= 7552 B incl. padding) / ex [4 frames][32 rows][128 B] / |X|^2 tile
-constexpr int kW4PwOff = 7680;     // |X|^2 tile [bin pair][frame pair][bin parity][frame parity] (524 bins x 4 frames) above the staged samples
-constexpr int kW4Tabs = 8 * kW4Region;  // window, tw2 (as above), then the schedule
-constexpr int kW4MaxWords = 4096;
-constexpr int kW4LdsBytes = kW4Tabs + kMelOff + kW4MaxWords * 4;  // 155904 of the CU's 163840
-// Schedule: [0] nseg [1] total words [2..3] 0; rec [seg][slot 0..31], seg <= kW4Segs (one read ahead) = {L of the segment (multiple
-// of 4), word offset of the slot's weight row, kstart (even), band (0xffffffff: none)}; weight rows of lpad floats, lpad / 4 odd.
-// Lane (slot = lane >> 1, fp = lane & 1) sums frames (2 fp, 2 fp + 1) of its slot's band; the bands are dealt in descending
-// length, 32 per segment, so a segment's trip count is its longest band's.
-constexpr int kW4Segs = 4;  // n_mels <= 128
-
 }  // namespace r32x16
 }  // namespace sgx
