@@ -388,7 +388,7 @@ sgx_status grow(sgx_plan *pl, void **buf, size_t *have, size_t need);
 // A padding step has weight +0: it adds +0 to the running sum as long as |X|^2 of that bin is finite.  A non-finite |X|^2
 // (possible only with non-finite or > 1e19 samples, which poison the whole frame's spectrum anyway) within the padded cover
 // of a band — up to 11 bins past its last — makes that band NaN where the reference's CSR sum would not look at the bin.
-void build_band_schedule(sgx_plan *pl) {
+void build_band_schedule(sgx_plan *pl, unsigned NW = 4, unsigned kSegs = r32x16::kSchedSegs, unsigned max_words = r32x16::kMelMaxWords) {
     pl->h_mel_sched.clear();
     pl->mel_sched_words = 0;
     if (pl->out_mode != OUT_MEL || pl->mel_ptr.size() != size_t(pl->p.n_mels) + 1) return;
@@ -427,26 +427,25 @@ void build_band_schedule(sgx_plan *pl) {
 #endif
             }
         }
-        std::vector<std::vector<unsigned>> per_wave(4);
-        unsigned load[4] = {0, 0, 0, 0};
+        std::vector<std::vector<unsigned>> per_wave(NW);
+        std::vector<unsigned> load(NW, 0u);
         for (unsigned g = 0; g < ngroups; ++g) {  // groups are already in descending length order
             unsigned best = 0;
-            for (unsigned w = 1; w < 4; ++w) if (load[w] < load[best]) best = w;
+            for (unsigned w = 1; w < NW; ++w) if (load[w] < load[best]) best = w;
             per_wave[best].push_back(g);
             load[best] += groups[g].L + 8;  // + the per-segment epilogue
         }
         unsigned nseg = 0;
         for (auto &v : per_wave) nseg = std::max<unsigned>(nseg, unsigned(v.size()));
-        const unsigned kSegs = r32x16::kSchedSegs;
-        std::vector<uint32_t> words(r32x16::kSchedHdr + (kSegs + 1) * 32 * 4, 0);
+        std::vector<uint32_t> words(r32x16::kSchedHdr + (kSegs + 1) * NW * 8 * 4, 0);
         words[0] = nseg;
         bool ok = nseg <= kSegs;
         for (unsigned seg = 0; ok && seg <= kSegs; ++seg)
-            for (unsigned w = 0; w < 4; ++w) {
-                const size_t ro = r32x16::kSchedHdr + ((seg * 4 + w) * 8) * 4;
+            for (unsigned w = 0; w < NW; ++w) {
+                const size_t ro = r32x16::kSchedHdr + ((seg * NW + w) * 8) * 4;
                 const bool have = seg < per_wave[w].size();
                 const Group *G = have ? &groups[per_wave[w][seg]] : nullptr;
-                const unsigned L = have ? G->L : 0, lpad = ((L / 4) & 1u) ? L : L + 4;  // lpad / 4 odd: the 8 slots' rows start on different banks
+                const unsigned L = have ? G->L : 0, lpad = L == 0 ? 0u : ((L / 4) & 1u) ? L : L + 4;  // lpad / 4 odd: the 8 slots' rows start on different banks (an empty segment reads no weights)
                 const unsigned woff = unsigned((words.size() + 3) & ~size_t(3));
                 words.resize(woff + 8 * size_t(lpad), 0);
                 for (unsigned q = 0; q < 8; ++q) {
@@ -474,7 +473,7 @@ void build_band_schedule(sgx_plan *pl) {
             }
         words.resize(words.size() + 4, 0);
         words[1] = uint32_t(words.size());
-        if (ok && words.size() + 16 <= size_t(r32x16::kMelMaxWords)) {  // (+16: the kernel's read-ahead stays inside the LDS table)
+        if (ok && words.size() + 16 <= size_t(max_words)) {  // (+16: the kernel's read-ahead stays inside the LDS table)
             pl->mel_sched_words = unsigned(words.size());
             pl->h_mel_sched = std::move(words);
         }
@@ -577,7 +576,7 @@ sgx_status build_device_tables(sgx_plan *pl) {
             if ((st = upload<uint32_t>(pl, &pl->d_mm_blk, blk)) != SGX_OK) return st;
         }
         // Band schedule of the tuned kernel: built on the host at plan creation (build_band_schedule), uploaded here
-        if (std::is_same<T, float>::value && pl->kind == K_R32X16_F32 && !pl->h_mel_sched.empty() && !pl->d_mm_frag) {
+        if (std::is_same<T, float>::value && (pl->kind == K_R32X16_F32 || pl->kind == K_R32X32_F32) && !pl->h_mel_sched.empty() && !pl->d_mm_frag) {
             if ((st = upload<uint32_t>(pl, &pl->d_mel_sched, pl->h_mel_sched)) != SGX_OK) return st;
         }
     }
@@ -622,6 +621,32 @@ sgx_status build_device_tables(sgx_plan *pl) {
         } else {  // n_fft 512, two frames per transform: the pair (w[i], w[i]) multiplies z[i] = a[i] + i b[i]
             for (unsigned i = 0; i < 512; ++i) wh[2 * i] = wh[2 * i + 1] = 0.5f * float(pl->window[i]);
         }
+        if ((st = upload<float>(pl, &pl->d_window_half, wh)) != SGX_OK) return st;
+        if ((st = upload<float>(pl, &pl->d_ones_half, oh)) != SGX_OK) return st;
+    }
+    if (pl->kind == K_R32X32_F32) {
+        // tw1[k1][n2] = W_1024^(k1 n2), 32 x 32 (pass-1 twiddles); tw2[J][i], i < 16: the pair job J splits i-th is (Z[k], Z[1024 - k]) with
+        // k = c1 + 64 i (i < 8) or c2 + 64 (i - 8), c1 = J, c2 = J + 512 (job 0: 0 and 32); entry = (W', W'^perp), W' = -i W_2048^k
+        std::vector<float> t1(2 * 32 * 32), t2(32 * 17 * 4, 0.0f);
+        for (unsigned k1 = 0; k1 < 32; ++k1)
+            for (unsigned n2 = 0; n2 < 32; ++n2) {
+                const double a = -2.0 * kPi * double(k1 * n2) / 1024.0;
+                t1[2 * (k1 * 32 + n2)] = float(std::cos(a));
+                t1[2 * (k1 * 32 + n2) + 1] = float(std::sin(a));
+            }
+        for (unsigned J = 0; J < 32; ++J)
+            for (unsigned i = 0; i < 16; ++i) {
+                const unsigned c1 = J == 0 ? 0u : J, c2 = J == 0 ? 32u : J + 512u;
+                const unsigned k = i < 8 ? c1 + 64 * i : c2 + 64 * (i - 8);
+                const double a = -2.0 * kPi * double(k) / 2048.0;
+                const float wr = float(std::cos(a)), wi = float(std::sin(a));
+                float *q = &t2[4 * (J * 17 + i)];
+                q[0] = wi; q[1] = -wr; q[2] = wr; q[3] = wi;
+            }
+        if ((st = upload<float>(pl, &pl->d_tw1, t1)) != SGX_OK) return st;
+        if ((st = upload<float>(pl, &pl->d_tw2, t2)) != SGX_OK) return st;
+        std::vector<float> wh(2048), oh(2048, 0.5f);
+        for (unsigned i = 0; i < 2048; ++i) wh[i] = 0.5f * float(pl->window[i]);  // exact scaling of the f32 window
         if ((st = upload<float>(pl, &pl->d_window_half, wh)) != SGX_OK) return st;
         if ((st = upload<float>(pl, &pl->d_ones_half, oh)) != SGX_OK) return st;
     }
@@ -748,6 +773,7 @@ bool set_geometry(const sgx_plan *pl, StftArgs &a, KernelKind kind) {
     bool ok = false;
     switch (kind) {
     case K_R32X16_F32: ok = plan_geometry_r32x16_f32(a); break;
+    case K_R32X32_F32: ok = plan_geometry_r32x32_f32(a); break;
     case K_LDS_RADIX2: ok = plan_geometry_lds_radix2(a, pl->dtype); break;
     case K_DIRECT_DFT: ok = plan_geometry_direct_dft(a, pl->dtype); break;
     case K_TWO_FACTOR: ok = plan_geometry_two_factor(a, pl->dtype); break;
@@ -782,6 +808,7 @@ hipError_t launch(sgx_plan *pl, const StftArgs &a, KernelKind kind, hipStream_t 
     switch (kind) {
     case K_BLUESTEIN: return launch_bluestein_plan(pl, a, s);
     case K_R32X16_F32: return launch_r32x16_f32(a, s);
+    case K_R32X32_F32: return launch_r32x32_f32(a, s);
     case K_LDS_RADIX2: return launch_lds_radix2(a, pl->dtype, s);
     case K_TWO_FACTOR: return launch_two_factor(a, pl->dtype, s);
     case K_REG_RADIX: return launch_reg_radix(a, pl->dtype, s);
@@ -830,13 +857,13 @@ bool resolve_geometry(const sgx_plan *pl, StftArgs &a, KernelKind &kind) {
     if (set_geometry(pl, a, kind)) return true;
     const bool p2 = (a.n_fft & (a.n_fft - 1)) == 0;
     bool ok = false;
-    if (kind == K_R32X16_F32) ok = set_geometry(pl, a, kind = K_REG_RADIX);
+    if (kind == K_R32X16_F32 || kind == K_R32X32_F32) ok = set_geometry(pl, a, kind = K_REG_RADIX);
     if (!ok && p2 && kind != K_LDS_RADIX2) ok = set_geometry(pl, a, kind = K_LDS_RADIX2);
     if (!ok && !p2 && kind == K_REG_RADIX) ok = set_geometry(pl, a, kind = K_TWO_FACTOR);
     if (!ok) ok = set_geometry(pl, a, kind = K_DIRECT_DFT);
     return ok;
 }
-int chain_pos(KernelKind k) { return k == K_R32X16_F32 ? 0 : k == K_REG_RADIX ? 1 : k == K_DIRECT_DFT ? 3 : 2; }  // (K_BLUESTEIN is chosen after the chain, at creation)
+int chain_pos(KernelKind k) { return (k == K_R32X16_F32 || k == K_R32X32_F32) ? 0 : k == K_REG_RADIX ? 1 : k == K_DIRECT_DFT ? 3 : 2; }  // (K_BLUESTEIN is chosen after the chain, at creation)
 
 sgx_status run_device(sgx_plan *pl, const void *x, size_t batch, size_t n_samples, size_t stride, void *out,
                       size_t n_frames, hipStream_t s, int iters, float *ms) {
@@ -866,7 +893,7 @@ sgx_status run_device(sgx_plan *pl, const void *x, size_t batch, size_t n_sample
     }
     if (!resolve_geometry(pl, a1, kind))
         return set_err(pl, SGX_BACKEND, "hip -- FFT backend error: n_fft too large for the on-chip frame tile");
-    if (kind == K_R32X16_F32) a1.window = pl->d_window_half;
+    if (kind == K_R32X16_F32 || kind == K_R32X32_F32) a1.window = pl->d_window_half;
     if (ms) SGX_HIP(pl, hipEventRecord(pl->ev0, s));
     const unsigned skip = pl->p.n_mfcc - pl->n_final * (mfcc ? 1u : 0u);
     for (int i = 0; i < iters; ++i) {
@@ -1071,6 +1098,7 @@ const char *sgx_kernel_name(const sgx_plan *plan) {
     if (!plan) return "";
     switch (plan->kind) {
     case K_R32X16_F32: return "r32x16_f32";
+    case K_R32X32_F32: return "r32x32_f32";
     case K_LDS_RADIX2: return "lds_radix2";
     case K_TWO_FACTOR: return "two_factor_dft";
     case K_REG_RADIX: return "reg_radix";
@@ -1122,7 +1150,9 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
     pl->kind = (pow2 || params->n_fft % 2 == 0) ? K_REG_RADIX : K_TWO_FACTOR;  // (even sizes outside the register-tiled list fall through)
     if (params->dtype == SGX_F32 && params->n_fft == 1024 && (SGX_ODDHOP || params->hop_size % 2 == 0)) pl->kind = K_R32X16_F32;
     if (params->dtype == SGX_F32 && params->n_fft == 512 && (params->hop_size == 64 || params->hop_size == 128 || params->hop_size == 160 || params->hop_size == 256)) pl->kind = K_R32X16_F32;  // per-bin outputs (else falls back)
+    if (params->dtype == SGX_F32 && params->n_fft == 2048 && params->hop_size % 2 == 0) pl->kind = K_R32X32_F32;  // (odd hops: register-tiled kernel)
     if (pl->kind == K_R32X16_F32) build_band_schedule(pl);  // before the kind is resolved: plan_geometry_r32x16_f32 asks for it
+    if (pl->kind == K_R32X32_F32) build_band_schedule(pl, 8, r32x32::kSegs2, r32x32::kSch2MaxWords);
     {
         StftArgs probe;
         fill_args(pl, probe, nullptr, nullptr, 1, params->n_fft, params->n_fft, 1);
@@ -1134,11 +1164,11 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
             per_bin_args(pl, lin);
             KernelKind kind_lin = pl->kind;
             const bool ok_lin = resolve_geometry(pl, lin, kind_lin);
-            const bool long_frames = ok && kind != K_R32X16_F32 && size_t(params->n_fft) * pl->elem >= SGX_SPLIT_BANK_BYTES;
+            const bool long_frames = ok && kind != K_R32X16_F32 && kind != K_R32X32_F32 && size_t(params->n_fft) * pl->elem >= SGX_SPLIT_BANK_BYTES;
             // f64 at the composite sizes (25-, 30-, 32-point first passes at one wave per SIMD): the fused stage never wins there —
             // 64 x 10 s, fused vs split: 400 198 vs 163 us, 800 193 vs 148, 1440 240 vs 173, ties at 240 / 480 / 960 / 1000 (f32: fused wins)
             const bool f64_mixed = ok && kind == K_REG_RADIX && pl->dtype == SGX_F64 && !pow2;
-            const bool further_up = ok_lin && kind_lin != K_R32X16_F32 && (!ok || chain_pos(kind_lin) < chain_pos(kind));
+            const bool further_up = ok_lin && kind_lin != K_R32X16_F32 && kind_lin != K_R32X32_F32 && (!ok || chain_pos(kind_lin) < chain_pos(kind));
             if (ok_lin && (long_frames || f64_mixed || further_up)) {
                 pl->split_bank = true;
                 kind = kind_lin;
@@ -1351,7 +1381,7 @@ sgx_status sgx_r2c(sgx_plan *plan, const void *in, size_t in_len, void *out, siz
         kind = K_DIRECT_DFT;
         if (!set_geometry(plan, a, kind)) return set_err(plan, SGX_BACKEND, "hip -- FFT backend error: n_fft too large");
     }
-    if (kind == K_R32X16_F32) a.window = plan->d_ones_half;
+    if (kind == K_R32X16_F32 || kind == K_R32X32_F32) a.window = plan->d_ones_half;
     SGX_HIP(plan, launch(plan, a, kind, nullptr));
     SGX_HIP(plan, hipMemcpy(out, plan->d_out, 2 * nb * plan->elem, hipMemcpyDeviceToHost));
     return SGX_OK;

@@ -28,4 +28,18 @@ constexpr int kSchedHdr = 4;
 constexpr int kSchedSegs = 4;  // the kernel always runs this many segments (empty ones have L = 0, band = none): n_mels <= 128
 
 }  // namespace r32x16
+
+// ---- k_r32x32: the tuned f32 n_fft = 2048 kernel (kernels_r32x32.hip), one 16-frame tile per 512-thread workgroup ----------
+namespace r32x32 {
+constexpr int kFS2 = 8192 + 16;        // LDS bytes per frame of ex[f][32][32] (odd multiple of 16: conflict-free b128 row reads)
+constexpr int kEx2 = 16 * kFS2;        // 131328: exchange buffer; also holds the staged samples (<= 40960 B) and the |X|^2 tile
+constexpr int kPw2Off = kEx2 - 518 * 128;  // 65024: |X|^2 tile, 1036 bins x 16 frames (pwt2_index), above the staged samples
+constexpr int kWin2Off = 0;            // tables behind the exchange buffer: float2 win[1024] = (w[2n], w[2n+1]) / 2
+constexpr int kTw22Off = 8192;         // float4 tw2[32 jobs][17]: entry i of job J = (W', W'^perp) of the i-th pair it splits
+constexpr int kSch2Off = kTw22Off + 32 * 17 * 16;  // 16896: band schedule, 8 waves x 8 slots (format of r32x16's, record stride 64 per segment)
+constexpr int kLds2Base = kEx2 + kSch2Off;         // 148224
+constexpr int kLds2Max = 163840;
+constexpr int kSch2MaxWords = (kLds2Max - kLds2Base - 64) / 4;  // 3888
+constexpr int kSegs2 = 3;              // 16 groups of 8 bands dealt to 8 waves by length: up to 3 per wave at n_mels = 128
+}  // namespace r32x32
 }  // namespace sgx

@@ -133,9 +133,65 @@ def test_pow2_sizes(n_fft, hop, amp, dtype):
     (unaligned frames), the LDS radix-2 kernel below 32 points."""
     plan, _ = run_case(n=max(6000, 3 * n_fft), n_fft=n_fft, hop=hop, amp=amp, dtype=dtype)
     fits = n_fft <= (4096 if dtype == "float64" else 8192)  # an 8192-point f64 tile (164 KB with its tables) exceeds the CU's LDS
-    tuned = dtype == "float32" and (n_fft == 1024 or (n_fft == 512 and hop in (64, 128, 160, 256)))
+    tuned = dtype == "float32" and (n_fft == 1024 or (n_fft == 512 and hop in (64, 128, 160, 256)) or (n_fft == 2048 and hop % 2 == 0))
     if 32 <= n_fft and fits and not tuned:
         assert plan.kernel_name == "reg_radix"
+
+
+# ------------------------------------------------------------------ n_fft 2048, f32: the tuned kernel k_r32x32 (round 4)
+@pytest.mark.parametrize("hop", [512, 256, 1024, 2048, 100, 544, 546, 600, 2])
+@pytest.mark.parametrize("amp,floor,n_mels", [("complex", None, None), ("power", None, None), ("magnitude", None, None), ("db", -80.0, None),
+                                              ("power", None, 80), ("db", -80.0, 80), ("magnitude", None, 40)])
+def test_tuned_2048(hop, amp, floor, n_mels):
+    """The reference's music default n_fft 2048 / hop 512 (src/spectrogram.rs:4243-4248) and its neighbours on k_r32x32: staged samples up to
+    hop 544, per-lane columns above; every output mode; frame counts that are not multiples of the 16-frame tile; centre on and off; a
+    signal's bits independent of its batch."""
+    n = 23 * 1024 + 77 if hop >= 100 else 6000
+    kw = dict(n_fft=2048, hop=hop, amp=amp, floor=floor, dtype="float32")
+    if n_mels:
+        kw.update(n_mels=n_mels, fmin=0.0, fmax=8000.0)
+    plan, got = run_case(n=n, batch=3, **kw)
+    assert plan.kernel_name == "r32x32_f32"
+    x = signals(3, n, np.float32, 0)
+    assert np.array_equal(np.asarray(plan.compute_batch(x[2:3]))[0], np.asarray(got)[2])
+    run_case(n=n, batch=2, centre=False, **kw)
+
+
+@pytest.mark.parametrize("n", [1, 5, 1023, 1024, 1025, 2047, 2048, 2049, 2559, 2560, 2561, 8193, 10239, 10240, 10241])
+@pytest.mark.parametrize("centre", [True, False])
+def test_ragged_lengths_2048(n, centre):
+    if not centre and n < 2048:
+        n += 2048
+    run_case(n=n, batch=2, n_fft=2048, hop=512, centre=centre, amp="complex")
+    run_case(n=n, batch=2, n_fft=2048, hop=512, centre=centre, n_mels=80, fmin=0.0, fmax=8000.0, amp="db", floor=-80.0)
+
+
+def test_tuned_2048_full_size():
+    """64 x 10 s at n_fft 2048 / hop 512 (the shape of profiles/bench_r04_sweep.txt): oracle on four rows incl. the last; every row
+    equal to its own B = 1 launch, bit for bit."""
+    torch = pytest.importorskip("torch")
+    base = H.cfg2_batch(64)
+    x = torch.from_numpy(base).cuda()
+    params = sg.SpectrogramParams(sg.StftParams(2048, 512, sg.WindowType.hanning, True), 16000.0)
+    for plan, op in ((sg.SpectrogramPlanner().linear_power_plan(params, dtype="float32"), orc.Params(n_fft=2048, hop=512)),
+                     (sg.SpectrogramPlanner().mel_db_plan(params, sg.MelParams(80, 0.0, 8000.0), sg.LogParams(-80.0), dtype="float32"),
+                      orc.Params(n_fft=2048, hop=512, n_mels=80, amp="db", floor_db=-80.0))):
+        assert plan.kernel_name == "r32x32_f32"
+        out = plan.compute_batch(x)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        assert np.all(np.isfinite(got))
+        for b in (0, 1, 31, 63):
+            ref = orc.spectrogram_batch(op, base[b:b + 1].astype(np.float64))[0]
+            if op.amp == "db":
+                pw = orc.spectrogram_batch(orc.Params(n_fft=2048, hop=512, n_mels=80), base[b:b + 1].astype(np.float64))[0]
+                m = pw > 1e-4 * pw.max()
+                assert np.max(np.abs(got[b][m] - ref[m])) < 1e-3
+            else:
+                m = ref > 1e-4 * ref.max()
+                assert np.max(np.abs(got[b][m] - ref[m]) / ref[m]) < 1e-4
+            one = plan.compute_batch(x[b:b + 1])
+            assert torch.equal(one[0], out[b])
 
 
 @pytest.mark.parametrize("amp,floor", [("power", None), ("magnitude", None), ("db", -80.0)])
@@ -487,7 +543,7 @@ def test_full_size_register_tiled_kernel(cfg2_x, n_fft, hop, dtype):
     x = cfg2_x if dtype == "float32" else cfg2_x.astype(np.float64)
     got = plan.compute_batch(x)
     # (f32 512 at hops 64 / 128 / 160 takes the tuned kernel's two-frames-per-transform mode)
-    assert plan.kernel_name == ("r32x16_f32" if (n_fft, dtype) == (512, "float32") else "reg_radix")
+    assert plan.kernel_name == {(512, "float32"): "r32x16_f32", (2048, "float32"): "r32x32_f32"}.get((n_fft, dtype), "reg_radix")
     nf = (160000 + 2 * (n_fft // 2) - n_fft) // hop + 1
     assert got.shape == (256, n_fft // 2 + 1, nf)
     ref = orc.spectrogram_batch(op, x, nthreads=orc.max_threads())
