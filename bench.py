@@ -264,6 +264,9 @@ def parse_args(argv=None):
                     help="seconds of back-to-back headline launches for the `sustained` object (frames/s + shader clock); 0: none")
     ap.add_argument("--legs-timeout", type=float, default=240.0,
                     help="seconds the extra legs may take before the line is printed without the unfinished ones (0: no limit)")
+    ap.add_argument("--rehearse-multi-rank", action="store_true",
+                    help="with --gpus 1: open a ONE-rank RCCL process group and run the N > 1 legs (config 4 compute / gather / C-ABI chunked) "
+                         "instead of the single-GPU ones — every call the driver's 8-GPU run makes, against the real RCCL, on one GPU")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: the ranks rendezvous over gloo and time an empty step — exercises the launcher, the barrier / "
                          "max-over-ranks timing and the JSON line (tests/test_bench_launcher.py)")
@@ -728,6 +731,10 @@ def main() -> int:
     dev = torch.device("cuda", local_rank)
     rccl_ranks = 1
     device_note = None
+    rehearse = args.rehearse_multi_rank and world == 1
+    if rehearse:
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         rccl_ranks = dist.get_world_size()
@@ -822,7 +829,7 @@ def main() -> int:
         dist.all_reduce(kmin, op=dist.ReduceOp.MIN)
         dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
 
-    extra = world == 1 and not args.no_legs
+    extra = world == 1 and not args.no_legs and not rehearse
     peak = measured_peak(_ffi.lib(), local_rank) if extra else None  # right behind the timed steps: steady clocks
     sustained = None
     if extra and args.sustained_s > 0:
@@ -871,7 +878,7 @@ def main() -> int:
     # A leg that hangs (a first-run RCCL path, say) must not cost the headline line: past `--legs-timeout` seconds the line is
     # printed with the legs finished so far and the process leaves.
     watchdog = None
-    if (extra or (world > 1 and not args.no_legs)) and args.legs_timeout > 0:
+    if (extra or rehearse or (world > 1 and not args.no_legs)) and args.legs_timeout > 0:
         import threading
 
         def bail():
@@ -904,7 +911,7 @@ def main() -> int:
             del xs256
             torch.cuda.empty_cache()
             wl.update(fft2d_legs(torch, sg, dev, two_d, args, peak))
-    elif world > 1 and not args.no_legs:
+    elif (world > 1 and not args.no_legs) or rehearse:
         # N > 1: BASELINE configs[3] with and without the exchange (every rank takes part; rank 0 reports)
         del outs, xs
         torch.cuda.empty_cache()
@@ -918,7 +925,7 @@ def main() -> int:
     if watchdog is not None:
         watchdog.cancel()
     emit()
-    if world > 1:
+    if world > 1 or rehearse:
         dist.barrier()
         dist.destroy_process_group()
     return 0
