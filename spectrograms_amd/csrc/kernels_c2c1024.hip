@@ -332,152 +332,34 @@ struct IstftArgs {
 // in dwords must spread them over the 32 write banks: 4624 B = 1156 dwords = 4 (mod 32) gives 8 distinct bank pairs (2-way,
 // the best a 16-byte aligned stride allows; 4640 B = 8 (mod 32) was 4-way: SQ_LDS_BANK_CONFLICT 48 % of the LDS cycles);
 // 4624 / 16 = 289 = 1 (mod 16) keeps the pass-2 ds_read_b128 (lanes over k1, 144-byte rows) conflict-free.
-constexpr int kISeq = kRSeq + 16;
+constexpr int kISeq = kRSeq + 16;  // (kept: the first fused inverse kernel's stride; k_istft1024c uses kBFS below)
 // NF frames per workgroup of 16 NF threads: 16 -> 74 240 B, two workgroups per CU; 32 -> 148 480 B, one workgroup of 8 waves
 // (the real frames, NF * 4 KiB, overlay the exchange buffer).  32 halves the share of halo frames (3 of 32 instead of 3 of 16
 // at hop 256) and doubles the load segments to 256 bytes, but measures slower (see launch_istft1024): 16 is the default.
 
-// Overlap-add of a tile's NF windowed real frames fr[NF][1024] (LDS) into the output signal.
-// `w`: the window as the caller holds it in LDS (a global pointer here put a vector-memory round trip — and, with the next tile's
-// spectrum pairs in flight, a wait for all of those — in front of every tile's normalisation sums: 312 -> 299 us)
-template <unsigned NF, unsigned NT>
-__device__ __forceinline__ void istft_ola(const IstftArgs &a, const unsigned char *smem, const float *w, unsigned tid, unsigned b, long long h0,
-                                          long long fbase) {
-        // overlap-add, one thread per offset `off` inside a hop block, walking the tile's hop blocks: no division per sample.
-        // Position pos = (h0 + hb) hop + off receives frames f in [fh - q + 1, fh] (fh = h0 + hb, q = ceil((1024 - off) / hop)),
-        // clipped to [0, n_frames): ascending f as the reference adds them (:4906-4925), frame sample j = (fh - f) hop + off.
-        const float *fr = (const float *)smem;
-        float *o = (float *)a.out + (size_t)b * a.out_len;
-        const unsigned long long p0 = (unsigned long long)h0 * a.hop;
-        const long long last = (long long)a.n_frames - 1;
-        // Interior tiles (47 of 49 per signal at hop 256) with hop | 1024: every position of the tile is inside the output, every
-        // frame exists and q = 1024 / hop frames overlap every offset, so the walk needs no per-block bounds, frame clipping or
-        // edge normalisation — same sums in the same (ascending-frame) order.
-        const bool interior = fbase >= 0 && fbase + (long long)(NF - 1u) <= last && p0 >= a.start &&
-                              p0 + (unsigned long long)a.nbk * a.hop <= a.start + a.out_len && (1024u % a.hop) == 0u;
-        if (interior && a.hop < NT) {
-            // fewer offsets than threads: all NT threads walk the tile's nbk * hop positions (consecutive threads = consecutive
-            // positions), the norm of an offset comes from a table built once per tile in the 2304 dead bytes between the real
-            // frames and the twiddle table (hop < 256 entries)
-            const unsigned q = 1024u / a.hop, fstride = 1024u - a.hop;
-            float *nt = (float *)(smem + NF * 4096u);
-            if (tid < a.hop) {
-                float nrm = 0.f;
-                for (unsigned i = q; i-- > 0;) {
-                    const float wj = w[i * a.hop + tid];
-                    nrm = __fadd_rn(nrm, __fmul_rn(wj, wj));
-                }
-                nt[tid] = nrm;
-            }
-            __syncthreads();
-            const unsigned dq = NT / a.hop, dr = NT - dq * a.hop;
-            unsigned hb = tid / a.hop, off = tid - hb * a.hop;
-            for (; hb < a.nbk; hb += dq, off += dr) {
-                if (off >= a.hop) {
-                    off -= a.hop;
-                    if (++hb >= a.nbk) break;
-                }
-                const float *src = fr + (a.ov + 1u - q + hb) * 1024u + (q - 1u) * a.hop + off;  // frame fh - q + 1, sample j
-                float acc = 0.f;
-                for (unsigned i = 0; i < q; ++i) acc += src[i * fstride];
-                const float nrm = nt[off];
-                if (nrm > 1e-10f) acc /= nrm;
-                o[(p0 - a.start) + (size_t)hb * a.hop + off] = acc;
-            }
-            return;
-        }
-        if (interior) {
-            const unsigned q = 1024u / a.hop, fstride = 1024u - a.hop;
-            for (unsigned off = tid; off < a.hop; off += NT) {
-                float nrm = 0.f;
-                for (unsigned i = q; i-- > 0;) {
-                    const float wj = w[i * a.hop + off];
-                    nrm = __fadd_rn(nrm, __fmul_rn(wj, wj));
-                }
-                const float *src = fr + (a.ov + 1u - q) * 1024u + (q - 1u) * a.hop + off;  // frame fh - q + 1 of block 0, sample j
-                float *op = o + (p0 - a.start) + off;
-                const bool div = nrm > 1e-10f;
-                if (q == 4u) {
-                    for (unsigned hb = 0; hb < a.nbk; ++hb) {
-                        float acc = 0.f;
-                        acc += src[0];
-                        acc += src[fstride];
-                        acc += src[2u * fstride];
-                        acc += src[3u * fstride];
-                        if (div) acc /= nrm;
-                        *op = acc;
-                        src += 1024u;
-                        op += a.hop;
-                    }
-                } else {
-                    for (unsigned hb = 0; hb < a.nbk; ++hb) {
-                        float acc = 0.f;
-                        for (unsigned i = 0; i < q; ++i) acc += src[i * fstride];
-                        if (div) acc /= nrm;
-                        *op = acc;
-                        src += 1024u;
-                        op += a.hop;
-                    }
-                }
-            }
-            return;
-        }
-        for (unsigned off = tid; off < a.hop; off += NT) {
-            const unsigned q = (1024u - off + a.hop - 1u) / a.hop;  // frames overlapping this offset (>= 1)
-            float nrm_full = 0.f;  // sum of w^2 over the q frames, same order: the value of every interior position
-            for (unsigned i = q; i-- > 0;) {
-                const float wj = w[i * a.hop + off];
-                nrm_full = __fadd_rn(nrm_full, __fmul_rn(wj, wj));
-            }
-            for (unsigned hb = 0; hb < a.nbk; ++hb) {
-                const unsigned long long pos = p0 + (unsigned long long)hb * a.hop + off;
-                if (pos < a.start || pos - a.start >= a.out_len) continue;
-                const long long fh = h0 + hb;
-                const long long f_lo = max(fh - (long long)q + 1, 0ll), f_hi = min(fh, last);
-                float acc = 0.f, nrm;
-                const float *src = fr + (unsigned)(f_lo - fbase) * 1024u + (unsigned)(fh - f_lo) * a.hop + off;
-                const unsigned cnt = f_hi >= f_lo ? (unsigned)(f_hi - f_lo + 1) : 0u;
-                for (unsigned i = 0; i < cnt; ++i) acc += src[(int)i * (1024 - (int)a.hop)];  // next frame: row + 1, j - hop
-                if (cnt == q) {
-                    nrm = nrm_full;
-                } else {  // signal edges: fewer frames
-                    nrm = 0.f;
-                    for (long long f = f_lo; f <= f_hi; ++f) {
-                        const float wj = w[(unsigned)(fh - f) * a.hop + off];
-                        nrm = __fadd_rn(nrm, __fmul_rn(wj, wj));
-                    }
-                }
-                if (nrm > 1e-10f) acc /= nrm;
-                o[pos - a.start] = acc;
-            }
-        }
-    }
-
-
 // ---------------------------------------------------------------------------------------------------------------------
-// k_istft1024b: the same fused inverse STFT with the forward kernel's dataflow run backwards, so that every (k, 512 - k) pair
-// of a frame's spectrum is loaded ONCE and folded ONCE (k_istft1024 loads and folds each pair in two lanes):
+// k_istft1024c (round 4): the fused inverse STFT without halo frames.
 //   A  lane (jq, f), job j = wave + 4 jq, owns rows j and 32 - j (job 0: rows 0 and 16) of v[k1 + 32 k2], v = conj(Z'):
 //      16 pairs P = X[k], Q = X[512 - k] with S = P + conj Q, T = conj(W^k)(P - conj Q): v[k] = conj(S + i T) and
 //      v[512 - k] = S - i T (conj(W^k) from an LDS copy of the plan's table); 16-point transforms of both rows;
 //      ds_write_b128 to ex[f][k1][n2].
 //   B  lane (f, n2): column n2 of the 32 rows, twiddle W_512^(k1 n2) (two per-lane register tables), 32-point transform:
 //      y[n2 + 16 n1] -> (x[2n], x[2n+1]) = conj(y) / 1024, times the window, real frames fr[f][1024] over the dead ex.
-//   C  overlap-add (istft_ola).
+//   C  overlap-add with a CARRY: a tile is 16 NEW frames F .. F + 15 and the 16 hop blocks F .. F + 15 of the output; a block h
+//      takes frames h - ov .. h, so its first `ov` blocks start from the partial sums the previous tile left in LDS (<= 1023 floats)
+//      and the partial sums of blocks F + 16 .. F + 15 + ov are left for the next one — frames are added in ascending order exactly
+//      as before (src/spectrogram.rs:4906-4925), the carry is just the sum so far.  Rounds 1-3 recomputed the `ov` frames in front
+//      of every tile instead (3 of 16 at hop 256: 19 % of the loads and of the transforms).
+// A workgroup walks RUNS of consecutive tiles of one signal (the launcher cuts every signal into equal runs so that all workgroups
+// get one); a run that starts inside a signal first passes over the tile in front of it without storing, which builds its carry.
 // DFT_512 over m = k1 + 32 k2 -> n = n2 + 16 n1:  W^(mn) = W_16^(k2 n2) W_512^(k1 n2) W_32^(k1 n1).
 constexpr int kBFS = 4240;               // bytes per frame of ex[f][32][16] (1060 dwords = 4 mod 32: conflict-free b128 writes)
 constexpr int kBTw = 16 * kBFS;          // 67 840: conj(W_1024^k), k < 512 (4096 B)
-constexpr int kBWin = kBTw + 4096;       // 71 936: the window (4096 B): 32 ds_read_b64 per lane instead of 32 more loads through the
-                                         // in-order vector-memory pipe
-constexpr int kBLds = kBWin + 4096;      // 76 032 B -> two workgroups per CU
+constexpr int kBWin = kBTw + 4096;       // 71 936: the window (4096 B)
+constexpr int kBCarry = kBWin + 4096;    // 76 032: the carry, ov * hop <= 1023 floats
+constexpr int kBLds = kBCarry + 4096;    // 80 128 B -> two workgroups per CU (160 256 of 163 840)
 
-#ifndef SGX_ISTFT_NT
-#define SGX_ISTFT_NT 0
-#endif
-#ifndef SGX_ISTFT_REQPOS
-#define SGX_ISTFT_REQPOS 0  // where the next tile's pairs are requested: 0 after the fold, 1 after the 32-point transforms, 2 after the frame writes, 3 after the overlap-add
-#endif
-#ifdef SGX_IS_STAMPS  // diagnostic build only (tools/stamps_istft.py): a wave's cycles per phase of k_istft1024b
+#ifdef SGX_IS_STAMPS  // diagnostic build only (tools/stamps_istft.py): a wave's cycles per phase
 __device__ unsigned long long g_is_stamps[16];
 #define IS_STAMP(i)                                                                \
     do {                                                                           \
@@ -491,27 +373,145 @@ __device__ unsigned long long g_is_stamps[16];
 #else
 #define IS_STAMP(i)
 #endif
-// Persistent form (round 3): a workgroup walks its XCD's run of tiles (neighbouring tiles share their 3 halo frames in L2) and
-// requests the NEXT tile's 33 spectrum pairs per lane as soon as the current tile's have been folded, so that they are in flight during
-// the 32-point transforms, the windowing and the overlap-add.  Measured: 310-322 us per 256 x [513, 626] against 312 us for one tile
-// per workgroup — no gain: the phase stamps (profiles/r03_istft_stamps_pmc.txt) show a third of a wave's time going into ISSUING those 33
-// loads (~300 cycles each) and another quarter into the overlap-add behind them; VALU issue is 33 %.  The access pattern itself reads
-// at 5 TB/s with 32 waves per CU (tools/ubench/istft_read_pattern.hip: 130 us for the whole spectrum): a CU drains one 512-byte
-// wave-load per ~44 cycles, and here all 8 waves of a CU (2 workgroups at 76 KB of LDS) request their 33 loads together and then
-// compute together.  Spreading the requests over the tile's phases (sched_barrier-pinned groups of 4 loads) spills and loses
-// (309-319 us); non-temporal loads lose (355 us).
-__global__ __launch_bounds__(256, 2) void k_istft1024b(IstftArgs a, const v2f *twr, const v2f *tw1, unsigned per_xcd, unsigned total,
-                                                       unsigned slots) {
-    constexpr unsigned NF = 16, NT = 256;
+
+// Overlap-add of a tile's 16 windowed real frames fr[16][1024] (LDS rows = frames F .. F + 15) with the carry.
+//   phase 1: output blocks hb = 0 .. 15 (h = F + hb): sum = carry (frames before F, if the offset reaches back that far) + this
+//            tile's frames max(F, h - q + 1) .. h in ascending order; norm = sum of w^2 over the frames that exist; store.
+//   phase 2: blocks hb = 16 .. 15 + ov: the sums of this tile's frames h - q + 1 .. F + 15 go to the carry.
+// A thread owns offsets (hop >= NT: off = tid, tid + NT, ...; hop < NT: off = tid mod hop and every (NT / hop)-th block).
+// Interior tiles at hop 256 / 512 / 1024 (every position inside the output, every frame there, q = 1024 / HOP frames over every
+// offset): the same sums with every index a compile-time constant, so that a thread's 16 x q frame reads are all in flight together
+// (the general walk below exposes an LDS round trip per frame added).
+template <unsigned HOP, unsigned NT>
+__device__ __forceinline__ void istft_ola_carry_fast(const IstftArgs &a, const unsigned char *smem, const float *w, float *carry, unsigned tid,
+                                                     unsigned b, unsigned F, bool store) {
+    constexpr unsigned Q = 1024u / HOP, OV = Q - 1u;
+    const float *fr = (const float *)smem;
+    float *o = (float *)a.out + (size_t)b * a.out_len + ((unsigned long long)F * HOP - a.start);
+#pragma unroll
+    for (unsigned k = 0; k < HOP / NT; ++k) {
+        const unsigned off = tid + k * NT;
+        if (store) {
+            float nrm = 0.f;  // ascending frame = descending sample index: the reference's order
+#pragma unroll
+            for (unsigned i = Q; i-- > 0;) {
+                const float wj = w[i * HOP + off];
+                nrm = __fadd_rn(nrm, __fmul_rn(wj, wj));
+            }
+            const bool div = nrm > 1e-10f;
+#pragma unroll
+            for (unsigned hb = 0; hb < 16u; ++hb) {
+                float acc = hb < OV ? carry[hb * HOP + off] : 0.f;
+#pragma unroll
+                for (unsigned d = (hb < OV ? hb : OV) + 1u; d-- > 0;) acc += fr[(hb - d) * 1024u + d * HOP + off];  // frames hb - d, ascending
+                o[hb * HOP + off] = div ? acc / nrm : acc;
+            }
+        }
+    }
+    __syncthreads();  // every carry value has been read
+#pragma unroll
+    for (unsigned k = 0; k < HOP / NT; ++k) {
+        const unsigned off = tid + k * NT;
+#pragma unroll
+        for (unsigned hb2 = 0; hb2 < OV; ++hb2) {
+            float acc = 0.f;
+#pragma unroll
+            for (unsigned d = OV; d > hb2; --d) acc += fr[(16u + hb2 - d) * 1024u + d * HOP + off];  // rows 16 + hb2 - d <= 15
+            carry[hb2 * HOP + off] = acc;
+        }
+    }
+}
+
+template <unsigned NT>
+__device__ __forceinline__ void istft_ola_carry(const IstftArgs &a, const unsigned char *smem, const float *w, float *carry, unsigned tid, unsigned b,
+                                                unsigned F, bool store) {
+    const float *fr = (const float *)smem;
+    float *o = (float *)a.out + (size_t)b * a.out_len;
+    const unsigned hop = a.hop, ov = a.ov;
+    const unsigned long long p0 = (unsigned long long)F * hop;
+    // interior tile: every frame of the tile and the `ov` before it exist, every position lies inside the output
+    const bool interior = F >= ov && F + 15u < a.n_frames && p0 >= a.start && p0 + 16ull * hop <= a.start + a.out_len;
+    if (interior) {  // (uniform)
+        if (hop == 256u) return istft_ola_carry_fast<256, NT>(a, smem, w, carry, tid, b, F, store);
+        if (hop == 512u) return istft_ola_carry_fast<512, NT>(a, smem, w, carry, tid, b, F, store);
+        if (hop == 1024u) return istft_ola_carry_fast<1024, NT>(a, smem, w, carry, tid, b, F, store);
+    }
+    const bool small = hop < NT;
+    const unsigned nrep = small ? NT / hop : 1u, g = small ? tid / hop : 0u, ostep = small ? hop : NT;
+    const unsigned off0 = small ? tid - g * hop : tid;
+    if (g < nrep && store) {  // (a run's first pass over the tile in front of it only builds the carry)
+        for (unsigned off = off0; off < hop; off += ostep) {
+            const unsigned q = (1024u - off + hop - 1u) / hop;  // frames overlapping this offset: h - q + 1 .. h
+            float nrm_full = 0.f;  // sum of w^2 over the q frames, ascending frame = descending sample index: the reference's order
+            for (unsigned i = q; i-- > 0;) {
+                const float wj = w[i * hop + off];
+                nrm_full = __fadd_rn(nrm_full, __fmul_rn(wj, wj));
+            }
+            for (unsigned hb = g; hb < 16u; hb += nrep) {
+                const unsigned h = F + hb;
+                const unsigned long long pos = p0 + (unsigned long long)hb * hop + off;
+                // frames h - q + 1 .. h; those before F are in the carry
+                const unsigned back = q - 1u;  // how far the offset reaches back
+                float acc = hb < back ? carry[hb * hop + off] : 0.f;
+                const unsigned r_lo = hb < back ? 0u : hb - back;  // first row (frame - F) of this tile taking part
+                const float *src = fr + r_lo * 1024u + (hb - r_lo) * hop + off;
+                for (unsigned r = r_lo; r <= hb; ++r) {  // next frame: row + 1, sample index - hop
+                    acc += *src;
+                    src += 1024 - (int)hop;
+                }
+                float nrm = nrm_full;
+                if (!interior) {
+                    if (pos < a.start || pos - a.start >= a.out_len) continue;
+                    // signal edges: only the frames that exist (0 <= f < n_frames) count, ascending
+                    const long long f_lo = (long long)h - (long long)back < 0 ? 0ll : (long long)h - (long long)back;
+                    const long long f_hi = h < a.n_frames ? (long long)h : (long long)a.n_frames - 1;
+                    if ((unsigned)(f_hi - f_lo + 1) != q || f_hi < f_lo) {
+                        nrm = 0.f;
+                        for (long long f = f_lo; f <= f_hi; ++f) {
+                            const float wj = w[(unsigned)((long long)h - f) * hop + off];
+                            nrm = __fadd_rn(nrm, __fmul_rn(wj, wj));
+                        }
+                    }
+                }
+                if (nrm > 1e-10f) acc /= nrm;
+                o[pos - a.start] = acc;
+            }
+        }
+    }
+    __syncthreads();  // every carry value has been read
+    if (g < nrep) {
+        for (unsigned off = off0; off < hop; off += ostep) {
+            const unsigned q = (1024u - off + hop - 1u) / hop;
+            for (unsigned hb2 = g; hb2 < ov; hb2 += nrep) {
+                const unsigned hb = 16u + hb2, back = q - 1u;
+                float acc = 0.f;
+                if (hb <= 15u + back) {  // the offset reaches back into this tile: rows hb - back .. 15
+                    const unsigned r_lo = hb - back;
+                    const float *src = fr + r_lo * 1024u + (hb - r_lo) * hop + off;
+                    for (unsigned r = r_lo; r < 16u; ++r) {
+                        acc += *src;
+                        src += 1024 - (int)hop;
+                    }
+                }
+                carry[hb2 * hop + off] = acc;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_istft1024c(IstftArgs a, const v2f *twr, const v2f *tw1, unsigned per_xcd, unsigned total_runs,
+                                                       unsigned slots, unsigned runs_per_signal, unsigned run_len) {
+    constexpr unsigned NT = 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned tid = threadIdx.x;
     v2f *twl = (v2f *)(smem + kBTw);
     twl[tid] = twr[tid];
     twl[tid + 256u] = twr[tid + 256u];
     ((v4f *)(smem + kBWin))[tid] = ((const v4f *)a.win)[tid];
+    float *carry = (float *)(smem + kBCarry);
     __syncthreads();
     const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-    const unsigned lo = xcd * per_xcd, hi = min(lo + per_xcd, total);
+    const unsigned lo = xcd * per_xcd, hi = min(lo + per_xcd, total_runs);
     const unsigned lane = tid & 63u, jq = lane >> 4, fl = lane & 15u;
     const unsigned j = (tid >> 6) + 4u * jq;
     const bool j0 = j == 0u;
@@ -521,10 +521,9 @@ __global__ __launch_bounds__(256, 2) void k_istft1024b(IstftArgs a, const v2f *t
     const unsigned ka = j0 ? 16u : j, kb = j0 ? 0u : j + 256u;
     const unsigned st = 32u * nf8;  // byte offsets are stepped by 32 bins (no per-load multiply)
     v2f P[16], Q[16], X256;
-    auto request = [&](unsigned w) {
-        const unsigned t = w % a.tiles, b = w / a.tiles;
-        const long long f = (long long)t * a.nbk - (long long)a.ov + fl;
-        const unsigned fcl = (f >= 0 && f < (long long)a.n_frames) ? (unsigned)f : 0u;  // a frame outside the signal reads frame 0 and is zeroed in the fold
+    auto request = [&](unsigned b, unsigned t) {
+        const unsigned f = 16u * t + fl;
+        const unsigned fcl = f < a.n_frames ? f : 0u;  // a frame past the signal reads frame 0 and is zeroed in the fold
         const unsigned char *inb = (const unsigned char *)a.spec + (size_t)b * 513u * a.n_frames * 8u;
         unsigned oa = ka * nf8 + fcl * 8u, oy = (512u - ka) * nf8 + fcl * 8u;
 #pragma unroll
@@ -533,31 +532,46 @@ __global__ __launch_bounds__(256, 2) void k_istft1024b(IstftArgs a, const v2f *t
                 oa = kb * nf8 + fcl * 8u;
                 oy = (512u - kb) * nf8 + fcl * 8u;
             }
-#if SGX_ISTFT_NT  // experiment: streaming (non-temporal) loads — every pair is read once
-            P[p] = __builtin_nontemporal_load((const v2f *)(inb + oa));
-            Q[p] = __builtin_nontemporal_load((const v2f *)(inb + oy));
-#else
             P[p] = *(const v2f *)(inb + oa);
             Q[p] = *(const v2f *)(inb + oy);
-#endif
             oa += st;
             oy -= st;
         }
         X256 = *(const v2f *)(inb + 256u * nf8 + fcl * 8u);
     };
-    unsigned w = lo + slot;
-    if (w < hi) request(w);
+    // run rid = signal rid / R, tiles [t0, t1) of it; a run inside a signal starts one tile early (carry only, nothing stored)
+    auto run_of = [&](unsigned rid, unsigned &b, unsigned &t0, unsigned &t1, unsigned &ts) {
+        b = rid / runs_per_signal;
+        t0 = (rid - b * runs_per_signal) * run_len;
+        t1 = min(a.tiles, t0 + run_len);
+        ts = t0 > 0u ? t0 - 1u : 0u;
+    };
+    unsigned rid = lo + slot, b = 0, t0 = 0, t1 = 0, t = 0;
+    if (rid < hi) {
+        run_of(rid, b, t0, t1, t);
+        if (t0 >= t1) rid = hi;  // (an empty run: the launcher makes none, kept for safety)
+    }
+    bool fresh = true;  // the run has just started: its carry is zero
+    if (rid < hi) request(b, t);
 #ifdef SGX_IS_STAMPS
     unsigned long long st_acc[12] = {0}, st_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
 #endif
-    for (; w < hi; w += slots) {
-        const unsigned t = w % a.tiles, b = w / a.tiles;
-        const long long h0 = (long long)t * a.nbk;      // first hop block of this tile
-        const long long fbase = h0 - (long long)a.ov;   // frame held in row 0
+    while (rid < hi) {
+        const unsigned F = 16u * t;
+        // where the walk goes next: the next tile of the run, or the first tile of the workgroup's next run
+        unsigned nrid = rid, nb = b, nt0 = t0, nt1 = t1, nt = t + 1u;
+        if (nt >= t1) {
+            nrid = rid + slots;
+            if (nrid < hi) run_of(nrid, nb, nt0, nt1, nt);
+        }
+        if (fresh) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) carry[tid + 256u * q] = 0.f;  // (ordered before its first use by the barriers below)
+        }
         {
-            const long long f = fbase + fl;
-            const bool valid = f >= 0 && f < (long long)a.n_frames;
+            const unsigned f = F + fl;
+            const bool valid = f < a.n_frames;
             const float vm = valid ? 1.f : 0.f;
             v2f PA[16], QB[16];
             const v2f *tp = twl + ka;
@@ -591,9 +605,7 @@ __global__ __launch_bounds__(256, 2) void k_istft1024b(IstftArgs a, const v2f *t
             for (int i = 1; i < 8; ++i) A[8 + i] = j0 ? QB[16 - i] : PA[8 + i];  // job 0: v[512 - 32 (8 - i)] = v[32 (8 + i)]
             IS_STAMP(0);  // wait for the pairs + fold
             // the pairs are consumed: the next tile's go out now and land during the rest of this tile
-#if SGX_ISTFT_REQPOS == 0
-            if (w + slots < hi) request(w + slots);
-#endif
+            if (nrid < hi) request(nb, nt);
             IS_STAMP(1);  // request issue
             Fft<16, false>::run(A, A);
             Fft<16, false>::run(B, B);
@@ -627,9 +639,6 @@ __global__ __launch_bounds__(256, 2) void k_istft1024b(IstftArgs a, const v2f *t
             }
             Fft<32, false>::run(v, v);
         }
-#if SGX_ISTFT_REQPOS == 1
-        if (w + slots < hi) request(w + slots);
-#endif
         IS_STAMP(4);  // column reads, twiddles, 32-point transform
         __syncthreads();  // exchange buffer consumed: overlay the real frames
         IS_STAMP(5);
@@ -643,22 +652,18 @@ __global__ __launch_bounds__(256, 2) void k_istft1024b(IstftArgs a, const v2f *t
                 fr2[16 * n1] = (v2f){__fmul_rn(sc.x, ww.x), __fmul_rn(sc.y, ww.y)};
             }
         }
-#if SGX_ISTFT_REQPOS == 2
-        if (w + slots < hi) request(w + slots);
-#endif
         IS_STAMP(6);  // scale, window, frame writes
         __syncthreads();
         IS_STAMP(7);
-        istft_ola<NF, NT>(a, smem, (const float *)(smem + kBWin), tid, b, h0, fbase);
-#if SGX_ISTFT_REQPOS == 3
-        if (w + slots < hi) request(w + slots);
-#endif
-        IS_STAMP(8);  // overlap-add, normalise, stores
-        __syncthreads();  // the frames are consumed: the next tile's exchange rows may overwrite them
+        istft_ola_carry<NT>(a, smem, (const float *)(smem + kBWin), carry, tid, b, F, t >= t0);
+        IS_STAMP(8);  // overlap-add, normalise, stores, carry
+        __syncthreads();  // the frames are consumed and the carry is complete: the next tile may overwrite / read them
         IS_STAMP(9);
 #ifdef SGX_IS_STAMPS
         st_acc[10] += 1;
 #endif
+        fresh = nrid != rid;
+        rid = nrid; b = nb; t0 = nt0; t1 = nt1; t = nt;
     }
 #ifdef SGX_IS_STAMPS
     if ((threadIdx.x & 63u) == 0) {
@@ -679,21 +684,25 @@ hipError_t launch_istft1024(const void *spec, void *out, const void *win, unsign
     a.n_frames = n_frames; a.hop = hop; a.batch = batch;
     a.ov = 1023u / hop;
     if (a.ov >= 16) return hipErrorInvalidConfiguration;
-    // measured in round 1 (256 x 626 frames, hop 256): one 8-wave workgroup of 32 frames per CU keeps every wave in the same
-    // phase (512 us); two independent 4-wave workgroups of 16 frames overlap their load / transform / store phases (316 us)
-    a.nbk = 16u - a.ov;
+    a.nbk = 16u;
     const unsigned long long full = (unsigned long long)(n_frames - 1) * hop + 1024ull;
     const unsigned long long blocks = (full + hop - 1) / hop;
-    a.tiles = (unsigned)((blocks + a.nbk - 1) / a.nbk);
+    a.tiles = (unsigned)((blocks + 15u) / 16u);  // 16 hop blocks (and the 16 frames that start in them) per tile
     a.start = start; a.out_len = out_len; a.scale = scale; a.bad_flag = bad_flag;
-    const unsigned long long g = (unsigned long long)a.tiles * batch;
-    if (g == 0 || g >= 0x7fffffffull) return hipErrorInvalidConfiguration;
-    hipError_t e = set_max_dynamic_lds((const void *)k_istft1024b, kBLds);
+    if ((unsigned long long)a.tiles * batch >= 0x7fffffffull || a.tiles == 0) return hipErrorInvalidConfiguration;
+    hipError_t e = set_max_dynamic_lds((const void *)k_istft1024c, kBLds);
     if (e != hipSuccess) return e;
-    // persistent workgroups: two per CU (LDS), each XCD's share of them walking that XCD's contiguous run of tiles
-    const unsigned total = (unsigned)g, per_xcd = (total + 7u) / 8u;
-    const unsigned slots = std::max(1u, std::min(per_xcd, 2u * device_cu_count() / 8u));
-    hipLaunchKernelGGL(k_istft1024b, dim3(8u * slots), dim3(256), kBLds, s, a, (const v2f *)twr, (const v2f *)tw1, per_xcd, total, slots);
+    // Runs: every signal is cut into R equal runs of consecutive tiles so that the 2 workgroups per CU all get work; a run inside a
+    // signal costs one extra tile (its carry), so R stays as small as that allows and a run keeps at least 4 tiles.
+    const unsigned wgs = 2u * device_cu_count();
+    unsigned R = (wgs + batch - 1u) / batch;
+    R = std::max(1u, std::min(R, std::max(1u, a.tiles / 4u)));
+    const unsigned run_len = (a.tiles + R - 1u) / R;
+    R = (a.tiles + run_len - 1u) / run_len;  // no empty runs
+    const unsigned total_runs = R * batch, per_xcd = (total_runs + 7u) / 8u;
+    const unsigned slots = std::max(1u, std::min(per_xcd, wgs / 8u));
+    hipLaunchKernelGGL(k_istft1024c, dim3(8u * slots), dim3(256), kBLds, s, a, (const v2f *)twr, (const v2f *)tw1, per_xcd, total_runs, slots, R,
+                       run_len);
     return hipGetLastError();
 }
 

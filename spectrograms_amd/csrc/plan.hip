@@ -979,11 +979,11 @@ sgx_status inverse_tables(sgx_plan *pl) {
             pl->bs_half.M = h.M;
         }
     }
-    // The fused tuned kernel recomputes ov = floor(1023 / hop) halo frames per 16-frame tile.  Up to ov = 10 (hop >= 94) that beats
-    // the register-tiled rows + overlap-add through a frame scratch; below, the halo wins (256 x 10 s: hop 100 1.62 vs 1.68 ms,
-    // hop 80 2.93 vs 2.04 ms, hop 64 — one new hop block per tile — 11.3 vs 2.5 ms).
+    // The fused tuned kernel carries the overlap from tile to tile (k_istft1024c: no halo frames), which needs ov = floor(1023 / hop) < 16
+    // hop blocks of carry: hop >= 64.  (Rounds 1-3 recomputed the halo frames and left hops below 94 to the register-tiled rows +
+    // overlap-add through a frame scratch; with the carry, 256 x 10 s: hop 90 1.77 -> 0.86 ms, hop 80 2.03 -> 0.91, hop 64 2.44 -> 1.08.)
 #ifndef SGX_ISTFT1024_MIN_HOP
-#define SGX_ISTFT1024_MIN_HOP 94
+#define SGX_ISTFT1024_MIN_HOP 64
 #endif
     if (std::is_same<T, float>::value && n == 1024 && pl->p.hop_size >= SGX_ISTFT1024_MIN_HOP) {  // tables of the fused tuned kernel
         std::vector<float> tr(2 * 32 * 16), t1(2 * 32 * 16);
