@@ -408,7 +408,8 @@ __device__ __forceinline__ void istft_ola_carry_fast(const IstftArgs &a, const u
             }
         }
     }
-    __syncthreads();  // every carry value has been read
+    // (HOP >= NT: an offset belongs to ONE thread, which has read its carry values above before it overwrites them here — no barrier)
+    static_assert(HOP >= NT && HOP % NT == 0, "fast overlap-add: one owner per offset");
 #pragma unroll
     for (unsigned k = 0; k < HOP / NT; ++k) {
         const unsigned off = tid + k * NT;

@@ -95,6 +95,16 @@ int main(void) {
         CHECK(hipDeviceSynchronize() == hipSuccess);
         CHECK(hipMemcpy(g, dg, B * nb * nf * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess);
         CHECK(memcmp(g, out, B * nb * nf * sizeof(float)) == 0);
+        /* the chunked form (ABI 7): compute on the caller's stream, each chunk's exchange on the communicator's own stream, ordered by
+         * events — here through the real RCCL with one rank, in place and through the shard buffer */
+        for (int chunks = 1; chunks <= 4; chunks += 3) {
+            CHECK(hipMemset(dg, 0, B * nb * nf * sizeof(float)) == hipSuccess);
+            CHECK(sgx_shard_execute_chunked(plan, comm, dx, B, N, N, chunks == 4 ? dout : NULL, dg, chunks, NULL) == SGX_OK);
+            CHECK(hipDeviceSynchronize() == hipSuccess);
+            CHECK(hipMemcpy(g, dg, B * nb * nf * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess);
+            CHECK(memcmp(g, out, B * nb * nf * sizeof(float)) == 0);
+        }
+        CHECK(sgx_shard_execute_chunked(plan, comm, dx, B, N, N, NULL, dg, 65, NULL) == SGX_INVALID_INPUT);
         free(g);
         (void)hipFree(dg);
         sgx_comm_destroy(comm);
