@@ -118,7 +118,7 @@ __device__ __forceinline__ void mel_tile_sched8(const StftArgs &a, const float *
     // (fixed trip count, unconditional stores: the compiler counts them behind the next tile's sample loads instead of waiting vmcnt(0))
 #pragma unroll
     for (unsigned seg = 0; seg < (unsigned)kSegs2; ++seg) {
-        const uint4 nxt = info[(seg + 1u) * 64u];  // the table holds kSegs2 + 1 segments
+        const uint4 nxt = seg + 1u < (unsigned)kSegs2 ? info[(seg + 1u) * 64u] : cur;  // fetched ahead (the table holds exactly kSegs2 segments)
         const unsigned L = __builtin_amdgcn_readfirstlane(cur.x);
         const v4f *wr = (const v4f *)((const float *)sched + cur.y);
         const v4f *pr = (const v4f *)(pwT + (cur.z >> 1) * 32u) + fp;  // kstart is even

@@ -388,7 +388,8 @@ sgx_status grow(sgx_plan *pl, void **buf, size_t *have, size_t need);
 // A padding step has weight +0: it adds +0 to the running sum as long as |X|^2 of that bin is finite.  A non-finite |X|^2
 // (possible only with non-finite or > 1e19 samples, which poison the whole frame's spectrum anyway) within the padded cover
 // of a band — up to 11 bins past its last — makes that band NaN where the reference's CSR sum would not look at the bin.
-void build_band_schedule(sgx_plan *pl, unsigned NW = 4, unsigned kSegs = r32x16::kSchedSegs, unsigned max_words = r32x16::kMelMaxWords) {
+// (NW waves; `ahead` = 1: one more, empty, segment of records behind the last — k_r32x16 fetches a record ahead unconditionally)
+void build_band_schedule(sgx_plan *pl, unsigned NW = 4, unsigned kSegs = r32x16::kSchedSegs, unsigned max_words = r32x16::kMelMaxWords, unsigned ahead = 1) {
     pl->h_mel_sched.clear();
     pl->mel_sched_words = 0;
     if (pl->out_mode != OUT_MEL || pl->mel_ptr.size() != size_t(pl->p.n_mels) + 1) return;
@@ -437,10 +438,10 @@ void build_band_schedule(sgx_plan *pl, unsigned NW = 4, unsigned kSegs = r32x16:
         }
         unsigned nseg = 0;
         for (auto &v : per_wave) nseg = std::max<unsigned>(nseg, unsigned(v.size()));
-        std::vector<uint32_t> words(r32x16::kSchedHdr + (kSegs + 1) * NW * 8 * 4, 0);
+        std::vector<uint32_t> words(r32x16::kSchedHdr + (kSegs + ahead) * NW * 8 * 4, 0);
         words[0] = nseg;
         bool ok = nseg <= kSegs;
-        for (unsigned seg = 0; ok && seg <= kSegs; ++seg)
+        for (unsigned seg = 0; ok && seg < kSegs + ahead; ++seg)
             for (unsigned w = 0; w < NW; ++w) {
                 const size_t ro = r32x16::kSchedHdr + ((seg * NW + w) * 8) * 4;
                 const bool have = seg < per_wave[w].size();
@@ -1152,7 +1153,7 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
     if (params->dtype == SGX_F32 && params->n_fft == 512 && (params->hop_size == 64 || params->hop_size == 128 || params->hop_size == 160 || params->hop_size == 256)) pl->kind = K_R32X16_F32;  // per-bin outputs (else falls back)
     if (params->dtype == SGX_F32 && params->n_fft == 2048 && params->hop_size % 2 == 0) pl->kind = K_R32X32_F32;  // (odd hops: register-tiled kernel)
     if (pl->kind == K_R32X16_F32) build_band_schedule(pl);  // before the kind is resolved: plan_geometry_r32x16_f32 asks for it
-    if (pl->kind == K_R32X32_F32) build_band_schedule(pl, 8, r32x32::kSegs2, r32x32::kSch2MaxWords);
+    if (pl->kind == K_R32X32_F32) build_band_schedule(pl, 8, r32x32::kSegs2, r32x32::kSch2MaxWords, 0);
     {
         StftArgs probe;
         fill_args(pl, probe, nullptr, nullptr, 1, params->n_fft, params->n_fft, 1);

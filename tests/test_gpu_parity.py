@@ -141,7 +141,8 @@ def test_pow2_sizes(n_fft, hop, amp, dtype):
 # ------------------------------------------------------------------ n_fft 2048, f32: the tuned kernel k_r32x32 (round 4)
 @pytest.mark.parametrize("hop", [512, 256, 1024, 2048, 100, 544, 546, 600, 2])
 @pytest.mark.parametrize("amp,floor,n_mels", [("complex", None, None), ("power", None, None), ("magnitude", None, None), ("db", -80.0, None),
-                                              ("power", None, 80), ("db", -80.0, 80), ("magnitude", None, 40)])
+                                              ("power", None, 80), ("db", -80.0, 80), ("magnitude", None, 40), ("power", None, 128),
+                                              ("db", -80.0, 24)])
 def test_tuned_2048(hop, amp, floor, n_mels):
     """The reference's music default n_fft 2048 / hop 512 (src/spectrogram.rs:4243-4248) and its neighbours on k_r32x32: staged samples up to
     hop 544, per-lane columns above; every output mode; frame counts that are not multiples of the 16-frame tile; centre on and off; a
