@@ -928,7 +928,7 @@ sgx_status grow(sgx_plan *pl, void **buf, size_t *have, size_t need) {
 
 void free_device(sgx_plan *pl) {
     void **bufs[] = {&pl->d_window, &pl->d_tw, &pl->d_tw1, &pl->d_tw2, &pl->d_mel_ptr, &pl->d_mel_col,
-                     &pl->d_mel_val, &pl->d_dct, &pl->d_lifter, &pl->d_melbuf, &pl->d_pwbuf, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_mm_frag, &pl->d_mm_blk, &pl->d_mel_sched, &pl->d_itw, &pl->d_itwr, &pl->d_itw1, &pl->d_frames, &pl->d_flag, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half, &pl->d_bs_chirp, &pl->d_bs_tw, &pl->d_bs_wc, &pl->d_bs_bhp, &pl->bs_half.chirp, &pl->bs_half.bhp, &pl->bs_half.tw};
+                     &pl->d_mel_val, &pl->d_dct, &pl->d_lifter, &pl->d_melbuf, &pl->d_pwbuf, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_mm_frag, &pl->d_mm_blk, &pl->d_mel_sched, &pl->d_itw, &pl->d_itwr, &pl->d_itw1, &pl->d_itwr2, &pl->d_itw12, &pl->d_frames, &pl->d_flag, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half, &pl->d_bs_chirp, &pl->d_bs_tw, &pl->d_bs_wc, &pl->d_bs_bhp, &pl->bs_half.chirp, &pl->bs_half.bhp, &pl->bs_half.tw};
     for (void **b : bufs)
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
@@ -1000,6 +1000,22 @@ sgx_status inverse_tables(sgx_plan *pl) {
         if ((st = upload<float>(pl, &pl->d_itwr, tr)) != SGX_OK) return st;
         if ((st = upload<float>(pl, &pl->d_itw1, t1)) != SGX_OK) return st;
     }
+    if (std::is_same<T, float>::value && n == 2048 && pl->p.hop_size >= 128) {  // tables of the fused tuned n_fft 2048 kernel (ov = 2047 / hop < 16)
+        std::vector<float> tr(2 * 1024), t1(2 * 32 * 32);
+        for (unsigned k = 0; k < 1024; ++k) {
+            const double a = 2.0 * kPi * double(k) / 2048.0;  // conj(W_2048^k)
+            tr[2 * k] = float(std::cos(a));
+            tr[2 * k + 1] = float(std::sin(a));
+        }
+        for (unsigned k1 = 0; k1 < 32; ++k1)
+            for (unsigned n2 = 0; n2 < 32; ++n2) {
+                const double b2 = -2.0 * kPi * double(k1 * n2) / 1024.0;  // W_1024^(k1 n2)
+                t1[2 * (k1 * 32 + n2)] = float(std::cos(b2));
+                t1[2 * (k1 * 32 + n2) + 1] = float(std::sin(b2));
+            }
+        if ((st = upload<float>(pl, &pl->d_itwr2, tr)) != SGX_OK) return st;
+        if ((st = upload<float>(pl, &pl->d_itw12, t1)) != SGX_OK) return st;
+    }
     SGX_HIP(pl, hipMalloc(&pl->d_flag, sizeof(unsigned)));
     return SGX_OK;
 }
@@ -1055,6 +1071,11 @@ sgx_status run_istft(sgx_plan *pl, const void *spec, size_t batch, size_t n_fram
     const size_t pad = pl->p.centre ? n / 2 : 0;
     const size_t full = (n_frames - 1) * size_t(pl->p.hop_size) + n;
     const size_t start = out_len == full ? 0 : pad;  // untrimmed when the centred signal would be empty (:4933)
+    if (pl->d_itwr2 && n_frames * 1025ull * 8ull < 0x7fffffffull) {  // fused tuned kernel at n_fft 2048 (kernels_istft2048.hip)
+        SGX_HIP(pl, launch_istft2048(spec, out, pl->d_window, unsigned(n_frames), pl->p.hop_size, unsigned(batch), start, out_len, 1.0f / 2048.0f,
+                                     (unsigned *)pl->d_flag, pl->d_itwr2, pl->d_itw12, s));
+        return SGX_OK;
+    }
     // fused register-tiled kernel (every length with a pass split, hop <= n_fft, at most half a tile of halo frames): the windowed
     // frames never leave the chip
     if (n_frames <= 0xffffffffull && batch <= 0xffffffffull) {
@@ -1472,7 +1493,7 @@ sgx_status sgx_reserve(sgx_plan *plan, size_t batch, size_t n_samples, int32_t h
     if (inverse) {  // sgx_istft of `batch` spectra whose frame count is that of n_samples-long signals
         // the same tests run_istft applies: tuned n_fft = 1024 kernel, else the fused register-tiled kernel; only the unfused
         // fallback (rows + overlap-add) touches the frame scratch
-        const bool fused = (plan->d_itwr && nf * 513ull * 8ull < 0x7fffffffull) ||
+        const bool fused = (plan->d_itwr && nf * 513ull * 8ull < 0x7fffffffull) || (plan->d_itwr2 && nf * 1025ull * 8ull < 0x7fffffffull) ||
                            (nf <= 0xffffffffull && batch <= 0xffffffffull &&
                             istft_reg_fuses(plan->d_window, plan->p.n_fft, unsigned(nf), plan->p.hop_size, unsigned(batch), plan->dtype));
         if (!fused && (st = grow(plan, &plan->d_frames, &plan->d_frames_bytes, batch * nf * plan->p.n_fft * plan->elem)) != SGX_OK) return st;

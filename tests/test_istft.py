@@ -33,7 +33,10 @@ CASES = [(512, 128, True, "hanning"), (512, 256, True, "hanning"), (400, 100, Fa
          (251, 62, True, "hanning"), (1009, 252, True, "hamming"), (1023, 256, False, "hamming"), (1006, 300, True, "blackman"),
          # short 2 x prime lengths the forward cost model leaves on the direct / two-factor kernels: their inverse rows take the LDS-tile
          # rows (launch_c2r_rows), not half-length chirp-z tables
-         (34, 9, True, "hanning"), (62, 16, False, "hamming"), (46, 46, True, "rectangular")]
+         (34, 9, True, "hanning"), (62, 16, False, "hamming"), (46, 46, True, "rectangular"),
+         # n_fft 2048: the fused tuned kernel k_istft2048 from hop 128 (round 4), the register-tiled rows below
+         (2048, 512, True, "hanning"), (2048, 256, False, "hamming"), (2048, 300, True, "blackman"), (2048, 128, True, "hanning"),
+         (2048, 1024, True, "hamming"), (2048, 2048, False, "rectangular"), (2048, 100, True, "hanning")]
 
 
 @pytest.mark.parametrize("n_fft,hop,centre,window", CASES)
@@ -268,3 +271,27 @@ def test_gpu_istft_fuzz_shapes():
         wgt = np.minimum(1.0, nrm)[None, :]
         tol = 1e-10 if dtype == "float64" else 3e-5
         assert np.max(np.abs(got - ref) * wgt) < tol * max(1.0, np.max(np.abs(ref) * wgt)), (n_fft, hop, centre, window, dtype)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hop,centre,n,batch", [(512, True, 100000, 5), (512, False, 33333, 3), (640, True, 70001, 2), (128, True, 20000, 2),
+                                               (2048, True, 50000, 4), (512, True, 2047, 2), (512, True, 1, 1)])
+def test_gpu_istft_2048_long_signals(hop, centre, n, batch):
+    """k_istft2048 over many tiles per signal (runs that start inside a signal build their carry from the tile in front), frame
+    counts that are not multiples of 16, signals shorter than a frame; round trip and the oracle."""
+    rng = np.random.default_rng(11)
+    if not centre and n < 2048:
+        n = 2048 + n
+    x = rng.standard_normal((batch, n)).astype(np.float32)
+    # without centring (or with hop = n_fft) a Hann envelope falls to 5e-12 at the frame ends and the division amplifies f32
+    # rounding there: Hamming then
+    wname = "hanning" if centre and hop < 2048 else "hamming"
+    params = sg.SpectrogramParams(sg.StftParams(2048, hop, getattr(sg.WindowType, wname), centre), 16000.0)
+    plan = sg.Plan(params, _ffi.AMP_COMPLEX, None, None, "float32")
+    S = plan.compute_batch(x)
+    y = plan.istft_batch(np.ascontiguousarray(S))
+    ref = np.stack([orc.istft(s.astype(np.complex128), 2048, hop, wname, centre) for s in np.asarray(S)])
+    assert y.shape == ref.shape
+    assert np.max(np.abs(y - ref)) < 2e-5 * max(1.0, np.max(np.abs(ref)))
+    one = plan.istft_batch(np.ascontiguousarray(np.asarray(S)[batch - 1:]))
+    assert np.array_equal(one[0], y[batch - 1])
