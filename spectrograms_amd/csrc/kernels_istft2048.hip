@@ -196,7 +196,7 @@ __global__ __launch_bounds__(512, 2) void k_istft2048(Ist2Args a, const v2f *twr
         b = rid / runs_per_signal;
         t0 = (rid - b * runs_per_signal) * run_len;
         t1 = min(a.tiles, t0 + run_len);
-        ts = t0 > 0u ? t0 - 1u : 0u;
+        ts = (t0 > 0u && a.ov) ? t0 - 1u : t0;
     };
     unsigned rid = lo + slot, b = 0, t0 = 0, t1 = 0, t = 0;
     if (rid < hi) {
@@ -324,12 +324,10 @@ hipError_t launch_istft2048(const void *spec, void *out, const void *win, unsign
     if ((unsigned long long)a.tiles * batch >= 0x7fffffffull || a.tiles == 0) return hipErrorInvalidConfiguration;
     hipError_t e = set_max_dynamic_lds((const void *)k_istft2048, kI2Lds);
     if (e != hipSuccess) return e;
-    // runs: every signal is cut into R equal runs of consecutive tiles so that all CUs get work; a run inside a signal costs one extra tile
+    // runs of consecutive tiles, one workgroup per CU (istft_carry_runs, sgx_internal.h)
     const unsigned wgs = device_cu_count();
-    unsigned R = (wgs + batch - 1u) / batch;
-    R = std::max(1u, std::min(R, std::max(1u, a.tiles / 4u)));
-    const unsigned run_len = (a.tiles + R - 1u) / R;
-    R = (a.tiles + run_len - 1u) / run_len;  // no empty runs
+    unsigned R, run_len;
+    istft_carry_runs(a.tiles, batch, wgs, a.ov, R, run_len);
     const unsigned total_runs = R * batch, per_xcd = (total_runs + 7u) / 8u;
     const unsigned slots = std::max(1u, std::min(per_xcd, wgs / 8u));
     hipLaunchKernelGGL(k_istft2048, dim3(8u * slots), dim3(512), kI2Lds, s, a, (const v2f *)twr, (const v2f *)tw1, per_xcd, total_runs, slots, R, run_len);

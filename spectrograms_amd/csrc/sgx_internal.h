@@ -235,6 +235,27 @@ inline hipError_t set_max_dynamic_lds(const void *fn, int bytes) {
 
 // Compute units of the CURRENT device (the entry points have made the plan's device current), looked up once per device: a
 // process may drive GPUs with different CU counts or partition modes, and the persistent grids are sized per device.
+// Inverse STFT with the overlap carried in LDS (k_istft1024c, k_istft2048): every signal's `tiles` are cut into R equal runs of
+// consecutive tiles, one run per workgroup visit.  A run that starts inside a signal first passes over the tile in front of it to
+// build its carry (nothing when the frames do not overlap: ov == 0), so the time is about rounds x (run_len + warm-up) tile periods,
+// rounds = ceil(R * batch / workgroups): the R with the smallest product, the smallest such R.
+inline void istft_carry_runs(unsigned tiles, unsigned batch, unsigned wgs, unsigned ov, unsigned &R, unsigned &run_len) {
+    unsigned long long best = ~0ull;
+    R = 1;
+    for (unsigned r = 1; r <= tiles; ++r) {
+        const unsigned len = (tiles + r - 1u) / r;
+        if ((tiles + len - 1u) / len != r) continue;  // (the same cut as a smaller r: no empty runs)
+        const unsigned long long rounds = ((unsigned long long)r * batch + wgs - 1u) / wgs;
+        const unsigned long long cost = rounds * (len + ((r > 1u && ov) ? 1u : 0u));
+        if (cost < best) {
+            best = cost;
+            R = r;
+        }
+        if (rounds > 1u && len <= 2u) break;  // shorter runs only add rounds and warm-up tiles from here
+    }
+    run_len = (tiles + R - 1u) / R;
+}
+
 inline unsigned device_cu_count() {
     static std::mutex mu;
     static int cached[64] = {0};

@@ -295,3 +295,23 @@ def test_gpu_istft_2048_long_signals(hop, centre, n, batch):
     assert np.max(np.abs(y - ref)) < 2e-5 * max(1.0, np.max(np.abs(ref)))
     one = plan.istft_batch(np.ascontiguousarray(np.asarray(S)[batch - 1:]))
     assert np.array_equal(one[0], y[batch - 1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_fft,hop,n,batch", [(1024, 1024, 300000, 2), (2048, 2048, 400000, 2), (1024, 256, 300000, 3), (2048, 512, 400000, 1),
+                                               (1024, 512, 40000, 40), (2048, 1024, 160000, 64)])
+def test_gpu_istft_run_cuts(n_fft, hop, n, batch):
+    """Few long signals: the launcher cuts them into many short runs (istft_carry_runs); hop = n_fft has no carry and no warm-up tile.
+    Whatever the cut, a signal's samples are the same bits as when it is inverted alone (one run per signal at batch 1 ... many)."""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((batch, n)).astype(np.float32)
+    params = sg.SpectrogramParams(sg.StftParams(n_fft, hop, sg.WindowType.hamming, True), 16000.0)
+    plan = sg.Plan(params, _ffi.AMP_COMPLEX, None, None, "float32")
+    S = np.ascontiguousarray(plan.compute_batch(x))
+    y = plan.istft_batch(S)
+    ref = orc.istft(S[0].astype(np.complex128), n_fft, hop, "hamming", True)
+    assert np.max(np.abs(y[0] - ref)) < 2e-5 * max(1.0, np.max(np.abs(ref)))
+    m = min(y.shape[1], n)
+    assert np.max(np.abs(y[:, :m] - x[:, :m])) < 1e-4
+    big = plan.istft_batch(np.ascontiguousarray(np.concatenate([S] * 3)[: 3 * batch - 1]))  # another batch size: another cut
+    assert np.array_equal(big[:batch], y) and np.array_equal(big[batch:2 * batch], y)
