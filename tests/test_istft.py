@@ -315,3 +315,25 @@ def test_gpu_istft_run_cuts(n_fft, hop, n, batch):
     assert np.max(np.abs(y[:, :m] - x[:, :m])) < 1e-4
     big = plan.istft_batch(np.ascontiguousarray(np.concatenate([S] * 3)[: 3 * batch - 1]))  # another batch size: another cut
     assert np.array_equal(big[:batch], y) and np.array_equal(big[batch:2 * batch], y)
+
+
+@pytest.mark.gpu
+def test_gpu_istft_fuzz_tuned_shapes():
+    """Random hops, lengths and batch sizes through the fused inverse kernels (n_fft 1024 from hop 64, 2048 from hop 128: every
+    run cut istft_carry_runs can produce, general and compile-time overlap-add) and the register-tiled fallback below those hops."""
+    rng = np.random.default_rng(2024)
+    for it in range(40):
+        n_fft = int(rng.choice([1024, 2048]))
+        hop = int(rng.choice([n_fft // 8, n_fft // 4, n_fft // 2, n_fft, int(rng.integers(40, n_fft + 1))]))
+        centre = bool(rng.integers(0, 2))
+        batch = int(rng.choice([1, 2, 3, 7, 33, 130]))
+        n = int(rng.integers(n_fft, 40 * n_fft)) if batch > 7 else int(rng.integers(n_fft, 400 * n_fft))
+        x = rng.standard_normal((batch, n)).astype(np.float32)
+        params = sg.SpectrogramParams(sg.StftParams(n_fft, hop, sg.WindowType.hamming, centre), 16000.0)
+        plan = sg.Plan(params, _ffi.AMP_COMPLEX, None, None, "float32")
+        S = np.ascontiguousarray(plan.compute_batch(x))
+        y = plan.istft_batch(S)
+        for b in sorted({0, batch - 1, batch // 2}):
+            ref = orc.istft(S[b].astype(np.complex128), n_fft, hop, "hamming", centre)
+            assert y[b].shape == ref.shape, (n_fft, hop, centre, batch, n)
+            assert np.max(np.abs(y[b] - ref)) < 2e-5 * max(1.0, np.max(np.abs(ref))), (it, n_fft, hop, centre, batch, n, b)
