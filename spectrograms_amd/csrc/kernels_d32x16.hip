@@ -1,0 +1,289 @@
+// kernels_d32x16.hip — tuned f64, n_fft = 1024 STFT kernel for gfx950 (round 4): BASELINE's shape in the reference's other `Sample`
+// type (src/sample.rs:23-86; f64 is the default dtype of the Python API and configs[0]'s type).
+//
+// k_r32x32's construction (kernels_r32x32.hip) at 512 complex f64 points — the same bytes per frame, so the same tile: 16 consecutive
+// frames of one signal, one persistent 512-thread workgroup per CU, a 128 KiB exchange buffer ex[f][k1][n2] of 16-byte elements.
+//
+//   pass 1  lane (f = 0..15, n2 = 0..31) owns z[32 n1 + n2], n1 = 0..15, of frame f, z[n] = w[2n] x[2n] + i w[2n+1] x[2n+1] (window
+//           pre-scaled by 1/2 on the host — exact); window multiply fused into the first butterflies; one 16-point FFT in registers;
+//           twiddle W_512^(k1 n2) from two short per-lane register tables; one ds_write_b128 per value.
+//   pass 2  16 rows of 32 points.  The real split pairs Z[k] with Z[512 - k] = row 16 - k1, element 31 - k2, and the even-indexed outputs
+//           of row r pair with the odd-indexed outputs of row 16 - r.  A half row (one decimation-in-frequency step as the row is read,
+//           then a 16-point FFT: 64 data registers in f64) is one lane's work, so the two partner halves sit in lanes l and l + 32 of
+//           one wave: lane l (half 0) takes the even outputs of row r, lane l + 32 the odd outputs of row 16 - r, and after the
+//           transforms they trade the upper 8 values with v_permlane32_swap_b32 (32 instructions; no LDS).  Each then splits 8 pairs
+//           = 16 bins: own H[u] = Z[kb + 32 u] with the partner's Z[512 - kb - 32 u], kb = r (half 0) or 32 - r (half 1).  Row 0's two
+//           halves pair inside themselves (kb = 0 and 16): rearranged once under a branch their 32 lanes take.
+//           16 rows x 2 halves x 16 frames = the 512 lanes.
+//   store   the 16 lanes of a (row, half) hold one bin of 16 consecutive frames: 128-byte runs of the frame-contiguous layout (S9).
+//
+// Samples: the tile's 15 hop + 1024 samples once, 16-byte buffer loads through the row's descriptor (out-of-range dwords read 0: the
+// zero centre padding, spectrogram.rs:1301-1320), one tile ahead, staged in LDS over the idle exchange buffer (hop <= 272); longer hops
+// load their columns per lane.  Per-bin outputs (power / magnitude / dB) and the complex STFT; filterbank outputs stay on k_reg_radix.
+// Reference semantics: spectrogram.rs:1301-1334, :2068-2080.
+#include <type_traits>
+#include <utility>
+
+#include "buffer_ops.h"
+#include "fft_inreg.h"
+#include "sgx_internal.h"
+
+namespace sgx {
+namespace {
+
+using namespace inreg;
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+
+constexpr int kDFS = 8192 + 16;       // LDS bytes per frame of ex[f][16][32] (odd multiple of 16: conflict-free b128 row reads over frames)
+constexpr int kDEx = 16 * kDFS;       // 131328: exchange buffer; also holds the staged samples (<= 40960 B)
+constexpr int kDWinOff = 0;           // tables behind it: v2d win[512] = (w[2n], w[2n+1]) / 2
+constexpr int kDTw2Off = 8192;        // v2d tw2[32][8]: entry u of lane kind kb = W' = -i W_1024^(kb + 32 u)
+constexpr int kDLds = kDEx + kDTw2Off + 32 * 8 * 16;  // 143616
+
+template <int AMP>
+__device__ __forceinline__ double amp_f64(double p, double eps) {
+    if constexpr (AMP == AMP_MAGNITUDE) return sqrt(p);
+    else if constexpr (AMP == AMP_DB) return 10.0 * log10(fmax(p, eps));
+    else return p;
+}
+
+// lanes l and l ^ 32 trade a complex value; each receives the other's as (im, re)
+__device__ __forceinline__ void trade32(v2d &v) {
+    const double vx = v.x, vy = v.y;  // (scalars first: __builtin_bit_cast of the vector-element lvalue v.y reads element 0 with this clang)
+    v2u re = __builtin_bit_cast(v2u, vx), im = __builtin_bit_cast(v2u, vy);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        // vdst's lanes 32..63 <-> src0's lanes 0..31.  First: re = {a.re | a.im}, im = {b.re | b.im}; second (im, re): im = {b.re | a.re}, re = {b.im | a.im}
+        const v2u s1 = __builtin_amdgcn_permlane32_swap(re[c], im[c], false, false);
+        const v2u s2 = __builtin_amdgcn_permlane32_swap(s1.y, s1.x, false, false);
+        im[c] = s2.x;
+        re[c] = s2.y;
+    }
+    v.x = __builtin_bit_cast(double, re);
+    v.y = __builtin_bit_cast(double, im);
+}
+
+template <int MODE, int AMP, int ROUNDS>
+__global__ __launch_bounds__(512, 2) void k_d32x16(StftArgs a, unsigned per_xcd, unsigned total, unsigned slots) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned tid = threadIdx.x;
+    unsigned char *tabs = smem + kDEx;
+    ((v4f *)(tabs + kDWinOff))[tid] = ((const v4f *)a.window)[tid];  // 1024 doubles
+    if (tid < 256u) ((v4f *)(tabs + kDTw2Off))[tid] = ((const v4f *)a.tw2)[tid];
+
+    // XCD x owns the contiguous run of tiles [x per_xcd, (x + 1) per_xcd); its `slots` resident workgroups walk it with that stride
+    const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const unsigned lo = xcd * per_xcd, hi = min(lo + per_xcd, total);
+    unsigned wid = lo + slot;
+
+    const unsigned p1f = tid >> 5, n2 = tid & 31u;  // pass-1 identity
+    const unsigned wave = tid >> 6, lane = tid & 63u, half = lane >> 5, p2f = lane & 15u;
+    const unsigned r = wave + 8u * ((lane >> 4) & 1u);  // pass-2 job: row r (half 0: its even outputs) with row 16 - r (half 1: its odd outputs)
+    const unsigned row = half ? ((16u - r) & 15u) : r;
+    const bool j0 = r == 0u;
+    const unsigned kb = half ? (j0 ? 16u : 32u - r) : r;  // own H[u] = Z[kb + 32 u]
+    const double eps = a.eps;
+    constexpr unsigned ES = MODE == OUT_COMPLEX ? 16u : 8u;
+    const unsigned step = 32u * a.n_frames * ES;  // uniform: 32 bins further
+    const v2d *twj = (const v2d *)(tabs + kDTw2Off) + kb * 8u;
+    v2d twa[4], twb[4];  // W_512^(k1 n2) = twa[k1 >> 2] * twb[k1 & 3]
+    {
+        const v2d *t1 = (const v2d *)a.tw1 + n2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            twa[q] = t1[32 * 4 * q];
+            twb[q] = t1[32 * q];
+        }
+    }
+    const double sg = half ? -1.0 : 1.0, hb = half ? 1.0 : 0.0;
+
+    constexpr int NCR = ROUNDS > 0 ? ROUNDS : 1;
+    v4f creg[NCR];
+    v2d xd[ROUNDS > 0 ? 1 : 16];
+    const unsigned hop = a.hop;
+    const unsigned row_bytes = (unsigned)a.n_samples * 8u;  // host: n_samples < 2^29
+    auto load_tile = [&](unsigned w) {
+        const unsigned b = w / a.tiles, f0 = (w - b * a.tiles) * 16u;
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc((const double *)a.x + (size_t)b * a.sample_stride, row_bytes);
+        // first sample of the tile relative to the row: negative in the left padding — as an unsigned byte offset far out of range, so
+        // the hardware returns 0 there as it does past the end of the row (S1)
+        const int tile_lo = (int)(f0 * hop) - (int)a.pad;
+        if constexpr (ROUNDS > 0) {
+            const int vo = (tile_lo + 2 * (int)tid) * 8;
+#pragma unroll
+            for (int q = 0; q < ROUNDS; ++q) creg[q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rx, vo + q * 8192, 0, 0));
+        } else {
+            const int vo = ((int)(p1f * hop) + tile_lo + 2 * (int)n2) * 8;  // (even hop: a pair never straddles the row start)
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                int o = vo + n1 * 512;
+                asm("" : "+v"(o));  // the whole offset in the lane register: an immediate part is added without wrapping (buffer_ops.h)
+                xd[n1] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rx, o, 0, 0));
+            }
+        }
+    };
+    if (wid < hi) load_tile(wid);
+    __syncthreads();  // tables visible
+
+    const unsigned char *xs = smem + p1f * hop * 8u + n2 * 16u;
+    const v2d *w2 = (const v2d *)(tabs + kDWinOff) + n2;
+
+    while (wid < hi) {
+        const unsigned b = wid / a.tiles, f0 = (wid - b * a.tiles) * 16u;
+        const unsigned nf = min(16u, a.n_frames - f0);
+        v2d xr[16];
+        {
+            // even and odd n1 apart (the 16-point transform's first split), so that at most half of the 32 operands are live at once
+            v2d e[8], we[8], o[8], wo[8];
+            if constexpr (ROUNDS > 0) {
+#pragma unroll
+                for (int q = 0; q < ROUNDS; ++q) *(v4f *)(smem + (q * 512u + tid) * 16u) = creg[q];
+                __syncthreads();  // barrier 1: the staged samples are complete
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    e[k] = *(const v2d *)(xs + k * 1024);
+                    we[k] = w2[64 * k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    e[k] = xd[2 * k];
+                    we[k] = w2[64 * k];
+                }
+            }
+            Fft<8, true, v2d>::run(e, we);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if constexpr (ROUNDS > 0) o[k] = *(const v2d *)(xs + k * 1024 + 512);
+                else o[k] = xd[2 * k + 1];
+                wo[k] = w2[64 * k + 32];
+            }
+            Fft<8, true, v2d>::run(o, wo);
+            Comb<16, 0, v2d>::run(xr, e, o);
+        }
+        // barrier 2: every wave has read its columns: pass 1 may write ex
+        if constexpr (ROUNDS > 0) __syncthreads();
+        {
+            unsigned char *dst = smem + p1f * kDFS + n2 * 16u;
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) {  // twiddle by W_512^(k1 n2), write row k1 of this lane's column
+                const int qa = k1 >> 2, qb = k1 & 3;
+                v2d v = xr[k1];
+                if (qb) v = cmulv(v, twb[qb]);
+                if (qa) v = cmulv(v, twa[qa]);
+                *(v2d *)(dst + k1 * 512) = v;
+            }
+        }
+        const unsigned next = wid + slots;
+        if (next < hi) load_tile(next);  // in flight during pass 2
+        __syncthreads();  // barrier 3: ex complete
+        // pass 2.  A lane whose frame does not exist (last tile of a signal) mirrors the tile's last frame: same values to the same
+        // addresses, so every lane stores unconditionally and the compiler counts the stores behind the next tile's loads.
+        const unsigned fe = min(p2f, nf - 1u);
+        v2d H[16];
+        {
+            const unsigned char *rp = smem + fe * kDFS + row * 512u;
+            double hbl = hb;
+            asm volatile("" : "+v"(hbl));  // (not loop-invariant: the 15 lane twiddles below would otherwise be kept in 60 registers across tiles)
+            // one decimation-in-frequency step: even outputs x[n] + x[n + 16]; odd: (x[n] - x[n + 16]) W_32^n.  Four points at a time: the
+            // scheduler would otherwise put all 32 reads (128 registers) in flight
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                const v2d x0 = *(const v2d *)(rp + n * 16), x1 = *(const v2d *)(rp + n * 16 + 256);
+                v2d d = pfma(x1, (v2d){sg, sg}, x0);
+                if (n > 0) {
+                    const double c = kCos64[2 * n], s = -kSin64[2 * n];     // W_32^n
+                    const v2d t = {__builtin_fma(hbl, c - 1.0, 1.0), hbl * s};  // half 0: 1; half 1: W_32^n
+                    d = cmulv(d, t);
+                }
+                H[n] = d;
+                if ((n & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();  // barrier 4: ex consumed: the next staging may overwrite it
+        Fft<16, false, v2d>::run(H, H);
+        const v2d h8 = H[8];
+        v2d R[8];  // R[j] = the partner's H[8 + j] as (im, re)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            R[j] = H[8 + j];
+            trade32(R[j]);
+        }
+        if (j0) {
+            // row 0: both halves pair inside themselves.  Half 0 (E[m] = Z[32 m]): E[u] with E[16 - u] (u = 0: Z[0] with itself gives bins 0 and
+            // 512; E[8] = Z[256] pairs with itself, below).  Half 1 (O[m] = Z[16 + 32 m]): O[u] with O[15 - u].
+#pragma unroll
+            for (int j = 0; j < 7; ++j) R[j] = swp(half ? H[8 + j] : H[9 + j]);
+            R[7] = swp(half ? H[15] : H[0]);
+            asm volatile("" ::: "memory");  // keeps this a branch
+        }
+        const unsigned p2ofs = f0 + fe;
+        const __amdgpu_buffer_rsrc_t ro = make_rsrc((unsigned char *)a.out + (size_t)b * 513u * a.n_frames * ES, 513u * a.n_frames * ES);
+        // bins kb + 32 u upwards; the mirrored bins 512 - kb - 32 u count down: lane part 7 steps low, scalar part (7 - u) steps
+        const unsigned oa = (kb * a.n_frames + p2ofs) * ES, ob = ((512u - 224u - kb) * a.n_frames + p2ofs) * ES;
+        auto emit = [&](unsigned voff, unsigned soff, v2d X, bool conj) {
+            if constexpr (MODE == OUT_COMPLEX) {
+                const v2d V = conj ? (v2d){X.x, -X.y} : X;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, V), ro, (int)voff, (int)soff, 0);
+            } else {
+                const double p = __builtin_fma(X.x, X.x, X.y * X.y);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, amp_f64<AMP>(p, eps)), ro, (int)voff, (int)soff, 0);
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            // pair (P, Q) = (Z[k], Z[512 - k]): E = (P.x + Q.x, P.y - Q.y), D = (P.x - Q.x, P.y + Q.y), T = W' D with W' = -i W_1024^k:
+            //   X[k] = E + T, X[512 - k] = conj(E - T)   (window pre-halved: no 1/2)
+            const v2d P = H[u], Q = swp(R[7 - u]);
+            const v2d E = pfma(Q, (v2d){1.0, -1.0}, P), D = pfma(Q, (v2d){-1.0, 1.0}, P);
+            const v2d T = cmulv(D, twj[u]);
+            emit(oa, u * step, E + T, false);
+            emit(ob, (7 - u) * step, E - T, true);
+        }
+        if (j0 && half == 0u) emit((256u * a.n_frames + p2ofs) * ES, 0u, h8 * (v2d){2.0, -2.0}, false);  // X[256] = 2 conj(Z[256])
+        wid = next;
+    }
+}
+
+template <int MODE, int AMP>
+hipError_t launch_variant_d(const StftArgs &a, hipStream_t s) {
+    const unsigned total = a.tiles * a.batch;
+    const unsigned per_xcd = (total + 7u) / 8u;
+    const unsigned cu_slots = std::max(1u, device_cu_count() / 8u);
+    const unsigned nslots = per_xcd < cu_slots ? per_xcd : cu_slots;  // one 512-thread workgroup per CU
+    const unsigned chunks = (15u * a.hop + 1024u + 1u) >> 1;         // 16-byte chunks of a tile's samples
+    auto go = [&](auto kernel) -> hipError_t {
+        hipError_t e = set_max_dynamic_lds((const void *)kernel, kDLds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kernel, dim3(nslots * 8), dim3(512), kDLds, s, a, per_xcd, total, nslots);
+        return hipGetLastError();
+    };
+    if (chunks <= 5u * 512u) return go(k_d32x16<MODE, AMP, 5>);
+    return go(k_d32x16<MODE, AMP, 0>);
+}
+
+}  // namespace
+
+bool plan_geometry_d32x16_f64(StftArgs &a) {
+    if (a.n_fft != 1024 || (a.hop & 1u) || a.out_mode == OUT_MEL) return false;  // (filterbank outputs: k_reg_radix)
+    if (a.n_samples >= (1ull << 28)) return false;                                        // 32-bit byte offsets into a sample row
+    if ((unsigned long long)a.n_frames * 513ull * 16ull >= 0x7fffffffull) return false;  // and into one output signal
+    a.ft = 16;
+    return true;
+}
+
+hipError_t launch_d32x16_f64(const StftArgs &a, hipStream_t s) {
+    const unsigned long long total64 = (unsigned long long)a.tiles * a.batch;
+    if (total64 == 0 || total64 >= 0x7ffffff0ull) return hipErrorInvalidConfiguration;
+    if (a.out_mode == OUT_COMPLEX) return launch_variant_d<OUT_COMPLEX, AMP_POWER>(a, s);
+    if (a.out_mode != OUT_LINEAR) return hipErrorInvalidConfiguration;
+    if (a.amp == AMP_MAGNITUDE) return launch_variant_d<OUT_LINEAR, AMP_MAGNITUDE>(a, s);
+    if (a.amp == AMP_DB) return launch_variant_d<OUT_LINEAR, AMP_DB>(a, s);
+    return launch_variant_d<OUT_LINEAR, AMP_POWER>(a, s);
+}
+
+}  // namespace sgx

@@ -651,6 +651,29 @@ sgx_status build_device_tables(sgx_plan *pl) {
         if ((st = upload<float>(pl, &pl->d_window_half, wh)) != SGX_OK) return st;
         if ((st = upload<float>(pl, &pl->d_ones_half, oh)) != SGX_OK) return st;
     }
+    if (pl->kind == K_D32X16_F64) {
+        // tw1[k1][n2] = W_512^(k1 n2), 16 x 32 (pass-1 twiddles); tw2[kb][u] = W' = -i W_1024^(kb + 32 u): the pair (Z[k], Z[512 - k]) a lane of
+        // kind kb splits u-th (kernels_d32x16.hip)
+        std::vector<double> t1(2 * 16 * 32), t2(32 * 8 * 2);
+        for (unsigned k1 = 0; k1 < 16; ++k1)
+            for (unsigned n2 = 0; n2 < 32; ++n2) {
+                const double a = -2.0 * kPi * double(k1 * n2) / 512.0;
+                t1[2 * (k1 * 32 + n2)] = std::cos(a);
+                t1[2 * (k1 * 32 + n2) + 1] = std::sin(a);
+            }
+        for (unsigned kb = 0; kb < 32; ++kb)
+            for (unsigned u = 0; u < 8; ++u) {
+                const double a = -2.0 * kPi * double(kb + 32 * u) / 1024.0;
+                t2[2 * (kb * 8 + u)] = std::sin(a);       // W' = -i (wr + i wi) = (wi, -wr)
+                t2[2 * (kb * 8 + u) + 1] = -std::cos(a);
+            }
+        if ((st = upload<double>(pl, &pl->d_tw1, t1)) != SGX_OK) return st;
+        if ((st = upload<double>(pl, &pl->d_tw2, t2)) != SGX_OK) return st;
+        std::vector<double> wh(1024), oh(1024, 0.5);
+        for (unsigned i = 0; i < 1024; ++i) wh[i] = 0.5 * double(pl->window[i]);  // exact scaling
+        if ((st = upload<double>(pl, &pl->d_window_half, wh)) != SGX_OK) return st;
+        if ((st = upload<double>(pl, &pl->d_ones_half, oh)) != SGX_OK) return st;
+    }
     if (pl->kind == K_BLUESTEIN && pl->bs_fwd_half) {  // half-length complex form: tables of length n / 2 (shared with the inverse rows)
         BsHostTables h;
         if (!bluestein_host_tables(n / 2, pl->dtype, h)) return set_err(pl, SGX_INTERNAL, "Internal error: chirp-z plan without a pass split");
@@ -775,6 +798,7 @@ bool set_geometry(const sgx_plan *pl, StftArgs &a, KernelKind kind) {
     switch (kind) {
     case K_R32X16_F32: ok = plan_geometry_r32x16_f32(a); break;
     case K_R32X32_F32: ok = plan_geometry_r32x32_f32(a); break;
+    case K_D32X16_F64: ok = plan_geometry_d32x16_f64(a); break;
     case K_LDS_RADIX2: ok = plan_geometry_lds_radix2(a, pl->dtype); break;
     case K_DIRECT_DFT: ok = plan_geometry_direct_dft(a, pl->dtype); break;
     case K_TWO_FACTOR: ok = plan_geometry_two_factor(a, pl->dtype); break;
@@ -810,6 +834,7 @@ hipError_t launch(sgx_plan *pl, const StftArgs &a, KernelKind kind, hipStream_t 
     case K_BLUESTEIN: return launch_bluestein_plan(pl, a, s);
     case K_R32X16_F32: return launch_r32x16_f32(a, s);
     case K_R32X32_F32: return launch_r32x32_f32(a, s);
+    case K_D32X16_F64: return launch_d32x16_f64(a, s);
     case K_LDS_RADIX2: return launch_lds_radix2(a, pl->dtype, s);
     case K_TWO_FACTOR: return launch_two_factor(a, pl->dtype, s);
     case K_REG_RADIX: return launch_reg_radix(a, pl->dtype, s);
@@ -858,13 +883,13 @@ bool resolve_geometry(const sgx_plan *pl, StftArgs &a, KernelKind &kind) {
     if (set_geometry(pl, a, kind)) return true;
     const bool p2 = (a.n_fft & (a.n_fft - 1)) == 0;
     bool ok = false;
-    if (kind == K_R32X16_F32 || kind == K_R32X32_F32) ok = set_geometry(pl, a, kind = K_REG_RADIX);
+    if (kind_is_tuned(kind)) ok = set_geometry(pl, a, kind = K_REG_RADIX);
     if (!ok && p2 && kind != K_LDS_RADIX2) ok = set_geometry(pl, a, kind = K_LDS_RADIX2);
     if (!ok && !p2 && kind == K_REG_RADIX) ok = set_geometry(pl, a, kind = K_TWO_FACTOR);
     if (!ok) ok = set_geometry(pl, a, kind = K_DIRECT_DFT);
     return ok;
 }
-int chain_pos(KernelKind k) { return (k == K_R32X16_F32 || k == K_R32X32_F32) ? 0 : k == K_REG_RADIX ? 1 : k == K_DIRECT_DFT ? 3 : 2; }  // (K_BLUESTEIN is chosen after the chain, at creation)
+int chain_pos(KernelKind k) { return kind_is_tuned(k) ? 0 : k == K_REG_RADIX ? 1 : k == K_DIRECT_DFT ? 3 : 2; }  // (K_BLUESTEIN is chosen after the chain, at creation)
 
 sgx_status run_device(sgx_plan *pl, const void *x, size_t batch, size_t n_samples, size_t stride, void *out,
                       size_t n_frames, hipStream_t s, int iters, float *ms) {
@@ -894,7 +919,7 @@ sgx_status run_device(sgx_plan *pl, const void *x, size_t batch, size_t n_sample
     }
     if (!resolve_geometry(pl, a1, kind))
         return set_err(pl, SGX_BACKEND, "hip -- FFT backend error: n_fft too large for the on-chip frame tile");
-    if (kind == K_R32X16_F32 || kind == K_R32X32_F32) a1.window = pl->d_window_half;
+    if (kind_is_tuned(kind)) a1.window = pl->d_window_half;
     if (ms) SGX_HIP(pl, hipEventRecord(pl->ev0, s));
     const unsigned skip = pl->p.n_mfcc - pl->n_final * (mfcc ? 1u : 0u);
     for (int i = 0; i < iters; ++i) {
@@ -1121,6 +1146,7 @@ const char *sgx_kernel_name(const sgx_plan *plan) {
     switch (plan->kind) {
     case K_R32X16_F32: return "r32x16_f32";
     case K_R32X32_F32: return "r32x32_f32";
+    case K_D32X16_F64: return "d32x16_f64";
     case K_LDS_RADIX2: return "lds_radix2";
     case K_TWO_FACTOR: return "two_factor_dft";
     case K_REG_RADIX: return "reg_radix";
@@ -1173,6 +1199,7 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
     if (params->dtype == SGX_F32 && params->n_fft == 1024 && (SGX_ODDHOP || params->hop_size % 2 == 0)) pl->kind = K_R32X16_F32;
     if (params->dtype == SGX_F32 && params->n_fft == 512 && (params->hop_size == 64 || params->hop_size == 128 || params->hop_size == 160 || params->hop_size == 256)) pl->kind = K_R32X16_F32;  // per-bin outputs (else falls back)
     if (params->dtype == SGX_F32 && params->n_fft == 2048 && params->hop_size % 2 == 0) pl->kind = K_R32X32_F32;  // (odd hops: register-tiled kernel)
+    if (params->dtype == SGX_F64 && params->n_fft == 1024 && params->hop_size % 2 == 0) pl->kind = K_D32X16_F64;  // per-bin and complex outputs (filterbanks, odd hops: register-tiled kernel)
     if (pl->kind == K_R32X16_F32) build_band_schedule(pl);  // before the kind is resolved: plan_geometry_r32x16_f32 asks for it
     if (pl->kind == K_R32X32_F32) build_band_schedule(pl, 8, r32x32::kSegs2, r32x32::kSch2MaxWords, 0);
     {
@@ -1186,11 +1213,11 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
             per_bin_args(pl, lin);
             KernelKind kind_lin = pl->kind;
             const bool ok_lin = resolve_geometry(pl, lin, kind_lin);
-            const bool long_frames = ok && kind != K_R32X16_F32 && kind != K_R32X32_F32 && size_t(params->n_fft) * pl->elem >= SGX_SPLIT_BANK_BYTES;
+            const bool long_frames = ok && !kind_is_tuned(kind) && size_t(params->n_fft) * pl->elem >= SGX_SPLIT_BANK_BYTES;
             // f64 at the composite sizes (25-, 30-, 32-point first passes at one wave per SIMD): the fused stage never wins there —
             // 64 x 10 s, fused vs split: 400 198 vs 163 us, 800 193 vs 148, 1440 240 vs 173, ties at 240 / 480 / 960 / 1000 (f32: fused wins)
             const bool f64_mixed = ok && kind == K_REG_RADIX && pl->dtype == SGX_F64 && !pow2;
-            const bool further_up = ok_lin && kind_lin != K_R32X16_F32 && kind_lin != K_R32X32_F32 && (!ok || chain_pos(kind_lin) < chain_pos(kind));
+            const bool further_up = ok_lin && !kind_is_tuned(kind_lin) && (!ok || chain_pos(kind_lin) < chain_pos(kind));
             if (ok_lin && (long_frames || f64_mixed || further_up)) {
                 pl->split_bank = true;
                 kind = kind_lin;
@@ -1403,7 +1430,7 @@ sgx_status sgx_r2c(sgx_plan *plan, const void *in, size_t in_len, void *out, siz
         kind = K_DIRECT_DFT;
         if (!set_geometry(plan, a, kind)) return set_err(plan, SGX_BACKEND, "hip -- FFT backend error: n_fft too large");
     }
-    if (kind == K_R32X16_F32 || kind == K_R32X32_F32) a.window = plan->d_ones_half;
+    if (kind_is_tuned(kind)) a.window = plan->d_ones_half;
     SGX_HIP(plan, launch(plan, a, kind, nullptr));
     SGX_HIP(plan, hipMemcpy(out, plan->d_out, 2 * nb * plan->elem, hipMemcpyDeviceToHost));
     return SGX_OK;

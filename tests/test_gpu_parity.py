@@ -134,7 +134,10 @@ def test_pow2_sizes(n_fft, hop, amp, dtype):
     plan, _ = run_case(n=max(6000, 3 * n_fft), n_fft=n_fft, hop=hop, amp=amp, dtype=dtype)
     fits = n_fft <= (4096 if dtype == "float64" else 8192)  # an 8192-point f64 tile (164 KB with its tables) exceeds the CU's LDS
     tuned = dtype == "float32" and (n_fft == 1024 or (n_fft == 512 and hop in (64, 128, 160, 256)) or (n_fft == 2048 and hop % 2 == 0))
-    if 32 <= n_fft and fits and not tuned:
+    tuned64 = dtype == "float64" and n_fft == 1024 and hop % 2 == 0
+    if tuned64:
+        assert plan.kernel_name == "d32x16_f64"
+    elif 32 <= n_fft and fits and not tuned:
         assert plan.kernel_name == "reg_radix"
 
 
@@ -157,6 +160,32 @@ def test_tuned_2048(hop, amp, floor, n_mels):
     assert np.array_equal(np.asarray(plan.compute_batch(x[2:3]))[0], np.asarray(got)[2])
     run_case(n=n, batch=2, centre=False, **kw)
 
+
+
+# ------------------------------------------------------------------ n_fft 1024, f64: the tuned kernel k_d32x16 (round 4)
+@pytest.mark.parametrize("hop", [256, 128, 512, 1024, 64, 272, 274, 600, 2])
+@pytest.mark.parametrize("amp,floor", [("complex", None), ("power", None), ("magnitude", None), ("db", -80.0)])
+def test_tuned_f64_1024(hop, amp, floor):
+    """BASELINE's shape in f64 on k_d32x16 (half rows in lane pairs traded with v_permlane32_swap): staged samples up to hop 272, per-lane
+    columns above; per-bin and complex outputs; frame counts that are not multiples of the 16-frame tile; centre on and off; a signal's
+    bits independent of its batch.  Filterbank outputs and odd hops stay on the register-tiled kernel."""
+    n = 23 * 512 + 77 if hop >= 64 else 3000
+    kw = dict(n_fft=1024, hop=hop, amp=amp, floor=floor, dtype="float64")
+    plan, got = run_case(n=n, batch=3, **kw)
+    assert plan.kernel_name == "d32x16_f64"
+    x = signals(3, n, np.float64, 0)
+    assert np.array_equal(np.asarray(plan.compute_batch(x[2:3]))[0], np.asarray(got)[2])
+    run_case(n=n, batch=2, centre=False, **kw)
+    assert run_case(n=n, batch=2, n_fft=1024, hop=hop, n_mels=40, fmin=0.0, fmax=8000.0, amp="power", dtype="float64")[0].kernel_name == "reg_radix"
+
+
+@pytest.mark.parametrize("n", [1, 5, 511, 512, 513, 1023, 1024, 1025, 1279, 1280, 1281, 4097, 5119, 5120, 5121])
+@pytest.mark.parametrize("centre", [True, False])
+def test_ragged_lengths_f64_1024(n, centre):
+    if not centre and n < 1024:
+        n += 1024
+    run_case(n=n, batch=2, n_fft=1024, hop=256, centre=centre, amp="complex", dtype="float64")
+    run_case(n=n, batch=3, n_fft=1024, hop=256, centre=centre, amp="power", dtype="float64")
 
 @pytest.mark.parametrize("n", [1, 5, 1023, 1024, 1025, 2047, 2048, 2049, 2559, 2560, 2561, 8193, 10239, 10240, 10241])
 @pytest.mark.parametrize("centre", [True, False])
@@ -544,7 +573,7 @@ def test_full_size_register_tiled_kernel(cfg2_x, n_fft, hop, dtype):
     x = cfg2_x if dtype == "float32" else cfg2_x.astype(np.float64)
     got = plan.compute_batch(x)
     # (f32 512 at hops 64 / 128 / 160 takes the tuned kernel's two-frames-per-transform mode)
-    assert plan.kernel_name == {(512, "float32"): "r32x16_f32", (2048, "float32"): "r32x32_f32"}.get((n_fft, dtype), "reg_radix")
+    assert plan.kernel_name == {(512, "float32"): "r32x16_f32", (2048, "float32"): "r32x32_f32", (1024, "float64"): "d32x16_f64"}.get((n_fft, dtype), "reg_radix")
     nf = (160000 + 2 * (n_fft // 2) - n_fft) // hop + 1
     assert got.shape == (256, n_fft // 2 + 1, nf)
     ref = orc.spectrogram_batch(op, x, nthreads=orc.max_threads())
