@@ -19,29 +19,28 @@
 //
 // Samples: the tile's 15 hop + 1024 samples once, 16-byte buffer loads through the row's descriptor (out-of-range dwords read 0: the
 // zero centre padding, spectrogram.rs:1301-1320), one tile ahead, staged in LDS over the idle exchange buffer (hop <= 272); longer hops
-// load their columns per lane.  Per-bin outputs (power / magnitude / dB) and the complex STFT; filterbank outputs stay on k_reg_radix.
+// load their columns per lane.  Filterbank outputs: |X|^2 to LDS (pwd_index), reduced per (band, frame pair) in ascending-bin order
+// (spectrogram.rs:102-117) along a host-built schedule over the 8 waves.
 // Reference semantics: spectrogram.rs:1301-1334, :2068-2080.
 #include <type_traits>
 #include <utility>
 
 #include "buffer_ops.h"
 #include "fft_inreg.h"
+#include "r32x16_layout.h"
 #include "sgx_internal.h"
 
 namespace sgx {
 namespace {
 
 using namespace inreg;
+using namespace d32x16;
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
-constexpr int kDFS = 8192 + 16;       // LDS bytes per frame of ex[f][16][32] (odd multiple of 16: conflict-free b128 row reads over frames)
-constexpr int kDEx = 16 * kDFS;       // 131328: exchange buffer; also holds the staged samples (<= 40960 B)
-constexpr int kDWinOff = 0;           // tables behind it: v2d win[512] = (w[2n], w[2n+1]) / 2
-constexpr int kDTw2Off = 8192;        // v2d tw2[32][8]: entry u of lane kind kb = W' = -i W_1024^(kb + 32 u)
-constexpr int kDLds = kDEx + kDTw2Off + 32 * 8 * 16;  // 143616
+__host__ __device__ constexpr unsigned pwd_index(unsigned k, unsigned f) { return (k >> 1) * 32u + (f >> 1) * 4u + (k & 1u) * 2u + (f & 1u); }
 
 template <int AMP>
 __device__ __forceinline__ double amp_f64(double p, double eps) {
@@ -66,6 +65,45 @@ __device__ __forceinline__ void trade32(v2d &v) {
     v.y = __builtin_bit_cast(double, im);
 }
 
+__device__ __forceinline__ v2d mul_add_unfused_d(double w, v2d p, v2d acc) {  // the reference's `acc += w * x`: two roundings (spectrogram.rs:102-117)
+    return (v2d){__dadd_rn(__dmul_rn(w, p.x), acc.x), __dadd_rn(__dmul_rn(w, p.y), acc.y)};
+}
+
+// band stage over the tile's 16 frames: 8 waves x 8 slots x 8 frame pairs along the host-built schedule (r32x16_layout.h's format with 8-byte
+// weights): a lane sums one band for two frames in ascending-bin order
+template <int AMP>
+__device__ __forceinline__ void mel_tile_sched_d(const StftArgs &a, const double *pw, const unsigned *sched, unsigned b, unsigned f0, unsigned nf,
+                                                 double eps, unsigned tid) {
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u, slot = lane >> 3, fp = lane & 7u;
+    constexpr unsigned kDrop = 0x80000000u;  // past the descriptor's range: the hardware drops the store
+    const unsigned obytes = (a.n_out * a.n_frames - f0) * 8u;
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc((const double *)a.out + (size_t)b * a.n_out * a.n_frames + f0, obytes);
+    const unsigned fo0 = 2u * fp < nf ? 16u * fp : kDrop, fo1 = 2u * fp + 1u < nf ? 16u * fp + 8u : kDrop;
+    const uint4 *info = (const uint4 *)(sched + 4) + wave * 8u + slot;
+    uint4 cur = info[0];
+#pragma unroll
+    for (unsigned seg = 0; seg < (unsigned)kDSegs; ++seg) {
+        const uint4 nxt = seg + 1u < (unsigned)kDSegs ? info[(seg + 1u) * 64u] : cur;
+        const unsigned L = __builtin_amdgcn_readfirstlane(cur.x);
+        const v2d *wr = (const v2d *)(sched + cur.y);
+        const v2d *pr = (const v2d *)(pw + (cur.z >> 1) * 32u + fp * 4u);  // kstart is even
+        v2d acc = {0.0, 0.0};
+        for (unsigned t = 0; t < L; t += 4u) {  // (bin t: frames 2 fp, 2 fp + 1), (bin t + 1: the same two frames), then bins t + 2, t + 3
+            const v2d w01 = wr[t >> 1], w23 = wr[(t >> 1) + 1u];
+            const v2d q0 = pr[(t >> 1) * 16u], q1 = pr[(t >> 1) * 16u + 1u], q2 = pr[(t >> 1) * 16u + 16u], q3 = pr[(t >> 1) * 16u + 17u];
+            acc = mul_add_unfused_d(w01.x, q0, acc);
+            acc = mul_add_unfused_d(w01.y, q1, acc);
+            acc = mul_add_unfused_d(w23.x, q2, acc);
+            acc = mul_add_unfused_d(w23.y, q3, acc);
+        }
+        const bool have = cur.w != 0xffffffffu;
+        const unsigned bo = cur.w * a.n_frames * 8u;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, amp_f64<AMP>(acc.x, eps)), ro, (int)((have && fo0 != kDrop) ? bo + fo0 : kDrop), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, amp_f64<AMP>(acc.y, eps)), ro, (int)((have && fo1 != kDrop) ? bo + fo1 : kDrop), 0, 0);
+        cur = nxt;
+    }
+}
+
 template <int MODE, int AMP, int ROUNDS>
 __global__ __launch_bounds__(512, 2) void k_d32x16(StftArgs a, unsigned per_xcd, unsigned total, unsigned slots) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -73,6 +111,9 @@ __global__ __launch_bounds__(512, 2) void k_d32x16(StftArgs a, unsigned per_xcd,
     unsigned char *tabs = smem + kDEx;
     ((v4f *)(tabs + kDWinOff))[tid] = ((const v4f *)a.window)[tid];  // 1024 doubles
     if (tid < 256u) ((v4f *)(tabs + kDTw2Off))[tid] = ((const v4f *)a.tw2)[tid];
+    unsigned *sched = (unsigned *)(tabs + kDSchOff);
+    if constexpr (MODE == OUT_MEL)
+        for (unsigned i = tid; i < a.mel_sched_words; i += 512u) sched[i] = a.mel_sched[i];
 
     // XCD x owns the contiguous run of tiles [x per_xcd, (x + 1) per_xcd); its `slots` resident workgroups walk it with that stride
     const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
@@ -87,6 +128,7 @@ __global__ __launch_bounds__(512, 2) void k_d32x16(StftArgs a, unsigned per_xcd,
     const unsigned kb = half ? (j0 ? 16u : 32u - r) : r;  // own H[u] = Z[kb + 32 u]
     const double eps = a.eps;
     constexpr unsigned ES = MODE == OUT_COMPLEX ? 16u : 8u;
+    double *pwd = (double *)(smem + kDPwOff);
     const unsigned step = 32u * a.n_frames * ES;  // uniform: 32 bins further
     const v2d *twj = (const v2d *)(tabs + kDTw2Off) + kb * 8u;
     v2d twa[4], twb[4];  // W_512^(k1 n2) = twa[k1 >> 2] * twb[k1 & 3]
@@ -165,8 +207,9 @@ __global__ __launch_bounds__(512, 2) void k_d32x16(StftArgs a, unsigned per_xcd,
             Fft<8, true, v2d>::run(o, wo);
             Comb<16, 0, v2d>::run(xr, e, o);
         }
-        // barrier 2: every wave has read its columns: pass 1 may write ex
-        if constexpr (ROUNDS > 0) __syncthreads();
+        // barrier 2: every wave has read its columns (and, filterbank outputs, finished the previous tile's band stage, whose |X|^2 tile the
+        // upper half of ex overlays): pass 1 may write ex
+        if constexpr (ROUNDS > 0 || MODE == OUT_MEL) __syncthreads();
         {
             unsigned char *dst = smem + p1f * kDFS + n2 * 16u;
 #pragma unroll
@@ -225,8 +268,16 @@ __global__ __launch_bounds__(512, 2) void k_d32x16(StftArgs a, unsigned per_xcd,
         const __amdgpu_buffer_rsrc_t ro = make_rsrc((unsigned char *)a.out + (size_t)b * 513u * a.n_frames * ES, 513u * a.n_frames * ES);
         // bins kb + 32 u upwards; the mirrored bins 512 - kb - 32 u count down: lane part 7 steps low, scalar part (7 - u) steps
         const unsigned oa = (kb * a.n_frames + p2ofs) * ES, ob = ((512u - 224u - kb) * a.n_frames + p2ofs) * ES;
-        auto emit = [&](unsigned voff, unsigned soff, v2d X, bool conj) {
-            if constexpr (MODE == OUT_COMPLEX) {
+        if constexpr (MODE == OUT_MEL) {  // bins 513..523 are read with zero weights
+            if (tid < 176u) pwd[pwd_index(513u + (tid >> 4), tid & 15u)] = 0.0;
+        }
+        double *pw_a = pwd + pwd_index(kb, p2f), *pw_b = pwd + pwd_index(512u - 224u - kb, p2f);
+        constexpr int PSTEP = 16 * 32;  // doubles between bins k and k + 32 in the |X|^2 tile
+        auto emit = [&](unsigned voff, unsigned soff, double *pwp, v2d X, bool conj) {
+            if constexpr (MODE == OUT_MEL) {
+                const double p = __builtin_fma(X.x, X.x, X.y * X.y);
+                *pwp = AMP == AMP_MAG_IN ? sqrt(p) : p;  // (a lane without a frame writes its mirror's values into its own slot: never stored)
+            } else if constexpr (MODE == OUT_COMPLEX) {
                 const v2d V = conj ? (v2d){X.x, -X.y} : X;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, V), ro, (int)voff, (int)soff, 0);
             } else {
@@ -241,10 +292,14 @@ __global__ __launch_bounds__(512, 2) void k_d32x16(StftArgs a, unsigned per_xcd,
             const v2d P = H[u], Q = swp(R[7 - u]);
             const v2d E = pfma(Q, (v2d){1.0, -1.0}, P), D = pfma(Q, (v2d){-1.0, 1.0}, P);
             const v2d T = cmulv(D, twj[u]);
-            emit(oa, u * step, E + T, false);
-            emit(ob, (7 - u) * step, E - T, true);
+            emit(oa, u * step, pw_a + u * PSTEP, E + T, false);
+            emit(ob, (7 - u) * step, pw_b + (7 - u) * PSTEP, E - T, true);
         }
-        if (j0 && half == 0u) emit((256u * a.n_frames + p2ofs) * ES, 0u, h8 * (v2d){2.0, -2.0}, false);  // X[256] = 2 conj(Z[256])
+        if (j0 && half == 0u) emit((256u * a.n_frames + p2ofs) * ES, 0u, pwd + pwd_index(256u, p2f), h8 * (v2d){2.0, -2.0}, false);  // X[256] = 2 conj(Z[256])
+        if constexpr (MODE == OUT_MEL) {
+            __syncthreads();  // |X|^2 tile complete
+            mel_tile_sched_d<AMP>(a, pwd, sched, b, f0, nf, eps, tid);
+        }
         wid = next;
     }
 }
@@ -256,10 +311,11 @@ hipError_t launch_variant_d(const StftArgs &a, hipStream_t s) {
     const unsigned cu_slots = std::max(1u, device_cu_count() / 8u);
     const unsigned nslots = per_xcd < cu_slots ? per_xcd : cu_slots;  // one 512-thread workgroup per CU
     const unsigned chunks = (15u * a.hop + 1024u + 1u) >> 1;         // 16-byte chunks of a tile's samples
+    const unsigned lds = (unsigned)kDLdsBase + (MODE == OUT_MEL ? ((a.mel_sched_words * 4u + 15u) & ~15u) + 64u : 0u);
     auto go = [&](auto kernel) -> hipError_t {
-        hipError_t e = set_max_dynamic_lds((const void *)kernel, kDLds);
+        hipError_t e = set_max_dynamic_lds((const void *)kernel, kDLdsMax);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kernel, dim3(nslots * 8), dim3(512), kDLds, s, a, per_xcd, total, nslots);
+        hipLaunchKernelGGL(kernel, dim3(nslots * 8), dim3(512), lds, s, a, per_xcd, total, nslots);
         return hipGetLastError();
     };
     if (chunks <= 5u * 512u) return go(k_d32x16<MODE, AMP, 5>);
@@ -269,7 +325,9 @@ hipError_t launch_variant_d(const StftArgs &a, hipStream_t s) {
 }  // namespace
 
 bool plan_geometry_d32x16_f64(StftArgs &a) {
-    if (a.n_fft != 1024 || (a.hop & 1u) || a.out_mode == OUT_MEL) return false;  // (filterbank outputs: k_reg_radix)
+    if (a.n_fft != 1024 || (a.hop & 1u)) return false;
+    // filterbank outputs need the band schedule (built on the host before this is asked; a bank without one takes the register-tiled kernel)
+    if (a.out_mode == OUT_MEL && (a.mel_sched_words == 0 || a.mel_sched_words > (unsigned)kDSchMaxWords)) return false;
     if (a.n_samples >= (1ull << 28)) return false;                                        // 32-bit byte offsets into a sample row
     if ((unsigned long long)a.n_frames * 513ull * 16ull >= 0x7fffffffull) return false;  // and into one output signal
     a.ft = 16;
@@ -280,7 +338,12 @@ hipError_t launch_d32x16_f64(const StftArgs &a, hipStream_t s) {
     const unsigned long long total64 = (unsigned long long)a.tiles * a.batch;
     if (total64 == 0 || total64 >= 0x7ffffff0ull) return hipErrorInvalidConfiguration;
     if (a.out_mode == OUT_COMPLEX) return launch_variant_d<OUT_COMPLEX, AMP_POWER>(a, s);
-    if (a.out_mode != OUT_LINEAR) return hipErrorInvalidConfiguration;
+    if (a.out_mode == OUT_MEL) {
+        if (a.amp == AMP_MAGNITUDE) return launch_variant_d<OUT_MEL, AMP_MAGNITUDE>(a, s);
+        if (a.amp == AMP_DB) return launch_variant_d<OUT_MEL, AMP_DB>(a, s);
+        if (a.amp == AMP_MAG_IN) return launch_variant_d<OUT_MEL, AMP_MAG_IN>(a, s);
+        return launch_variant_d<OUT_MEL, AMP_POWER>(a, s);
+    }
     if (a.amp == AMP_MAGNITUDE) return launch_variant_d<OUT_LINEAR, AMP_MAGNITUDE>(a, s);
     if (a.amp == AMP_DB) return launch_variant_d<OUT_LINEAR, AMP_DB>(a, s);
     return launch_variant_d<OUT_LINEAR, AMP_POWER>(a, s);

@@ -389,14 +389,15 @@ sgx_status grow(sgx_plan *pl, void **buf, size_t *have, size_t need);
 // (possible only with non-finite or > 1e19 samples, which poison the whole frame's spectrum anyway) within the padded cover
 // of a band — up to 11 bins past its last — makes that band NaN where the reference's CSR sum would not look at the bin.
 // (NW waves; `ahead` = 1: one more, empty, segment of records behind the last — k_r32x16 fetches a record ahead unconditionally)
-void build_band_schedule(sgx_plan *pl, unsigned NW = 4, unsigned kSegs = r32x16::kSchedSegs, unsigned max_words = r32x16::kMelMaxWords, unsigned ahead = 1) {
+void build_band_schedule(sgx_plan *pl, unsigned NW = 4, unsigned kSegs = r32x16::kSchedSegs, unsigned max_words = r32x16::kMelMaxWords, unsigned ahead = 1,
+                         unsigned wwords = 1 /* 32-bit words per weight: 1 = f32, 2 = f64 (k_d32x16) */) {
     pl->h_mel_sched.clear();
     pl->mel_sched_words = 0;
     if (pl->out_mode != OUT_MEL || pl->mel_ptr.size() != size_t(pl->p.n_mels) + 1) return;
     for (size_t m = 0; m < pl->p.n_mels; ++m)
         for (uint32_t i = pl->mel_ptr[m]; i + 1 < pl->mel_ptr[m + 1]; ++i)
             if (pl->mel_col[i + 1] != pl->mel_col[i] + 1) return;  // rows must be runs of consecutive bins
-    if (pl->p.n_fft == 1024 && pl->mel_val.size() >= size_t(48) * pl->p.n_mels) return;  // wide rows: matrix-core epilogue
+    if (wwords == 1 && pl->p.n_fft == 1024 && pl->mel_val.size() >= size_t(48) * pl->p.n_mels) return;  // f32, wide rows: matrix-core epilogue
     {
         const unsigned nm = pl->p.n_mels;
         std::vector<unsigned> order(nm);
@@ -448,7 +449,7 @@ void build_band_schedule(sgx_plan *pl, unsigned NW = 4, unsigned kSegs = r32x16:
                 const Group *G = have ? &groups[per_wave[w][seg]] : nullptr;
                 const unsigned L = have ? G->L : 0, lpad = L == 0 ? 0u : ((L / 4) & 1u) ? L : L + 4;  // lpad / 4 odd: the 8 slots' rows start on different banks (an empty segment reads no weights)
                 const unsigned woff = unsigned((words.size() + 3) & ~size_t(3));
-                words.resize(woff + 8 * size_t(lpad), 0);
+                words.resize(woff + 8 * size_t(lpad) * wwords, 0);
                 for (unsigned q = 0; q < 8; ++q) {
                     Slot S = have ? G->s[q] : Slot{0xffffffffu, q, 0};
                     if (S.band != 0xffffffffu && S.steps > 0) {
@@ -462,14 +463,18 @@ void build_band_schedule(sgx_plan *pl, unsigned NW = 4, unsigned kSegs = r32x16:
                         }
                         const uint32_t p0 = pl->mel_ptr[S.band], c0 = pl->mel_col[p0];
                         for (uint32_t i = p0; i < pl->mel_ptr[S.band + 1]; ++i) {
-                            const float wv = float(pl->mel_val[i]);
-                            uint32_t bits;
-                            std::memcpy(&bits, &wv, 4);
-                            words[woff + q * lpad + (c0 - S.ks) + (i - p0)] = bits;
+                            const size_t at = woff + (size_t(q) * lpad + (c0 - S.ks) + (i - p0)) * wwords;
+                            if (wwords == 2) {
+                                const double wv = double(pl->mel_val[i]);
+                                std::memcpy(&words[at], &wv, 8);
+                            } else {
+                                const float wv = float(pl->mel_val[i]);
+                                std::memcpy(&words[at], &wv, 4);
+                            }
                         }
                     }
                     uint32_t *r = &words[ro + 4 * q];
-                    r[0] = L; r[1] = woff + q * lpad; r[2] = S.ks; r[3] = S.band;
+                    r[0] = L; r[1] = woff + q * lpad * wwords; r[2] = S.ks; r[3] = S.band;
                 }
             }
         words.resize(words.size() + 4, 0);
@@ -577,7 +582,8 @@ sgx_status build_device_tables(sgx_plan *pl) {
             if ((st = upload<uint32_t>(pl, &pl->d_mm_blk, blk)) != SGX_OK) return st;
         }
         // Band schedule of the tuned kernel: built on the host at plan creation (build_band_schedule), uploaded here
-        if (std::is_same<T, float>::value && (pl->kind == K_R32X16_F32 || pl->kind == K_R32X32_F32) && !pl->h_mel_sched.empty() && !pl->d_mm_frag) {
+        if (((std::is_same<T, float>::value && (pl->kind == K_R32X16_F32 || pl->kind == K_R32X32_F32)) || (std::is_same<T, double>::value && pl->kind == K_D32X16_F64)) &&
+            !pl->h_mel_sched.empty() && !pl->d_mm_frag) {
             if ((st = upload<uint32_t>(pl, &pl->d_mel_sched, pl->h_mel_sched)) != SGX_OK) return st;
         }
     }
@@ -1202,6 +1208,7 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
     if (params->dtype == SGX_F64 && params->n_fft == 1024 && params->hop_size % 2 == 0) pl->kind = K_D32X16_F64;  // per-bin and complex outputs (filterbanks, odd hops: register-tiled kernel)
     if (pl->kind == K_R32X16_F32) build_band_schedule(pl);  // before the kind is resolved: plan_geometry_r32x16_f32 asks for it
     if (pl->kind == K_R32X32_F32) build_band_schedule(pl, 8, r32x32::kSegs2, r32x32::kSch2MaxWords, 0);
+    if (pl->kind == K_D32X16_F64) build_band_schedule(pl, 8, d32x16::kDSegs, d32x16::kDSchMaxWords, 0, 2);
     {
         StftArgs probe;
         fill_args(pl, probe, nullptr, nullptr, 1, params->n_fft, params->n_fft, 1);

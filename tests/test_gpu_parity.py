@@ -164,19 +164,22 @@ def test_tuned_2048(hop, amp, floor, n_mels):
 
 # ------------------------------------------------------------------ n_fft 1024, f64: the tuned kernel k_d32x16 (round 4)
 @pytest.mark.parametrize("hop", [256, 128, 512, 1024, 64, 272, 274, 600, 2])
-@pytest.mark.parametrize("amp,floor", [("complex", None), ("power", None), ("magnitude", None), ("db", -80.0)])
-def test_tuned_f64_1024(hop, amp, floor):
+@pytest.mark.parametrize("amp,floor,n_mels", [("complex", None, None), ("power", None, None), ("magnitude", None, None), ("db", -80.0, None),
+                                              ("power", None, 80), ("db", -80.0, 80), ("magnitude", None, 40), ("power", None, 128),
+                                              ("db", -80.0, 24)])
+def test_tuned_f64_1024(hop, amp, floor, n_mels):
     """BASELINE's shape in f64 on k_d32x16 (half rows in lane pairs traded with v_permlane32_swap): staged samples up to hop 272, per-lane
     columns above; per-bin and complex outputs; frame counts that are not multiples of the 16-frame tile; centre on and off; a signal's
-    bits independent of its batch.  Filterbank outputs and odd hops stay on the register-tiled kernel."""
+    bits independent of its batch; filterbank outputs through the scheduled band stage (8-byte weights).  Odd hops stay on the register-tiled kernel."""
     n = 23 * 512 + 77 if hop >= 64 else 3000
     kw = dict(n_fft=1024, hop=hop, amp=amp, floor=floor, dtype="float64")
+    if n_mels:
+        kw.update(n_mels=n_mels, fmin=0.0, fmax=8000.0)
     plan, got = run_case(n=n, batch=3, **kw)
     assert plan.kernel_name == "d32x16_f64"
     x = signals(3, n, np.float64, 0)
     assert np.array_equal(np.asarray(plan.compute_batch(x[2:3]))[0], np.asarray(got)[2])
     run_case(n=n, batch=2, centre=False, **kw)
-    assert run_case(n=n, batch=2, n_fft=1024, hop=hop, n_mels=40, fmin=0.0, fmax=8000.0, amp="power", dtype="float64")[0].kernel_name == "reg_radix"
 
 
 @pytest.mark.parametrize("n", [1, 5, 511, 512, 513, 1023, 1024, 1025, 1279, 1280, 1281, 4097, 5119, 5120, 5121])
@@ -186,6 +189,7 @@ def test_ragged_lengths_f64_1024(n, centre):
         n += 1024
     run_case(n=n, batch=2, n_fft=1024, hop=256, centre=centre, amp="complex", dtype="float64")
     run_case(n=n, batch=3, n_fft=1024, hop=256, centre=centre, amp="power", dtype="float64")
+    run_case(n=n, batch=2, n_fft=1024, hop=256, centre=centre, n_mels=80, fmin=0.0, fmax=8000.0, amp="db", floor=-80.0, dtype="float64")
 
 @pytest.mark.parametrize("n", [1, 5, 1023, 1024, 1025, 2047, 2048, 2049, 2559, 2560, 2561, 8193, 10239, 10240, 10241])
 @pytest.mark.parametrize("centre", [True, False])
@@ -595,7 +599,7 @@ def test_register_tiled_mel_in_parts_ragged_rounds(cfg2_x, n_fft, hop, dtype, ba
     plan, op = make(n_fft, hop, dtype=dtype, n_mels=80, fmin=0.0, fmax=8000.0, amp="db", floor=-80.0)
     x = cfg2_x[:batch] if dtype == "float32" else cfg2_x[:batch].astype(np.float64)
     got = plan.compute_batch(x)
-    assert plan.kernel_name == "reg_radix"
+    assert plan.kernel_name == ("d32x16_f64" if (n_fft, dtype) == (1024, "float64") else "reg_radix")  # (f64 1024: the tuned kernel, round 4)
     ref = orc.spectrogram_batch(op, x.astype(np.float64), nthreads=orc.max_threads())
     pop = orc.Params(**{**op.__dict__, "amp": "power", "floor_db": None, "_keep": []})
     check(got, ref, "db", dtype, -80.0, orc.spectrogram_batch(pop, x.astype(np.float64), nthreads=orc.max_threads()))
