@@ -12,7 +12,8 @@ signals that is already resident in HBM.  Workloads (BASELINE.json configs):
 The default run (what the driver records) carries, next to the headline line of `--workload` (default linear_power), a
 `workloads` object with short legs of the other BASELINE configurations — mel_power (north_star's target sentence), mel_db
 (configs[2]), config4's per-GPU shard (configs[3]), configs[4]: fft2d / convolve_fft over 512 x 1024 x 1024 images, and chirpz_1009
-(a prime frame length, 64 utterances: the reference plans every length) — each with its own ms_per_step, value and roofline; `cold_ms_per_step` (the W + K steps from idle clocks, measured before anything
+(a prime frame length, 64 utterances: the reference plans every length), the inverse STFT, and linear_power_f64 / mel_db_f64
+(configs[1] / configs[2] in the reference's other `Sample` type, the Python API's default dtype) — each with its own ms_per_step, value and roofline; `cold_ms_per_step` (the W + K steps from idle clocks, measured before anything
 else has run); `roofline.peak_measured` (sgx_membench: copy / read / write rates of this very device, in-process); and a
 NumPy / pocketfft datapoint inside `cpu_baseline`.  `--no-legs` switches the extra legs off.
 
@@ -39,7 +40,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak is ~6290 GB/s
 VALU_PEAK_TFLOPS = 157.3   # FP32 vector peak (same guide)
 FLOPS_PER_FRAME = {"linear_power": 28.1e3, "stft": 26.6e3, "mel_power": 30.1e3, "mel_db": 30.1e3}  # FFT 25.6 k + window 1 k (+ |.|^2 1.5 k, Mel 2 k)
-LEGS = ("mel_power", "mel_db", "config4", "istft", "fft2d", "convolve_fft", "chirpz_1009")  # the default run's extra legs (besides the headline workload)
+LEGS = ("mel_power", "mel_db", "config4", "istft", "fft2d", "convolve_fft", "chirpz_1009", "linear_power_f64", "mel_db_f64")  # the default run's extra legs (besides the headline workload)
 IMG_SIDE, IMG_BATCH = 1024, 512  # BASELINE configs[4]
 SR, N_FFT, HOP, N_SAMPLES = 16000.0, 1024, 256, 160000
 WORKLOADS = {  # name -> (kernel workload, utterances per GPU, BASELINE config index)
@@ -403,6 +404,43 @@ def stft_leg(torch, sg, dev, name: str, xs256, args, peak):
             "kernel": plan.kernel_name, "steps": args.steps, "warmup": args.warmup, "preheat_steps": ph,
             "ms_per_step": dt / args.steps * 1e3, "value": frames * args.steps / dt, "unit": "frames/s",
             "roofline": stft_roofline(kernel_wl, batch, n_frames, kernel_ms, peak)}
+
+
+def f64_leg(torch, sg, dev, name: str, xs256, args, peak):
+    """BASELINE configs[1] / configs[2] in the reference's other `Sample` type (f64: the Python API's default dtype, src/sample.rs:23-86):
+    256 x 10 s, n_fft 1024 / hop 256 on the tuned f64 kernel k_d32x16.  Algorithmic bytes: 8-byte samples in, 8-byte outputs out."""
+    kernel_wl = {"linear_power_f64": "linear_power", "mel_db_f64": "mel_db"}[name]
+    params = sg.SpectrogramParams(sg.StftParams(N_FFT, HOP, sg.WindowType.hanning, True), SR)
+    planner = sg.SpectrogramPlanner()
+    plan = (planner.linear_power_plan(params, dtype="float64") if kernel_wl == "linear_power" else
+            planner.mel_db_plan(params, sg.MelParams(80, 0.0, 8000.0), sg.LogParams(-80.0), dtype="float64"))
+    n_bins, n_frames = plan.output_shape(N_SAMPLES)
+    xs = [x.double() for x in xs256]
+    outs = [torch.empty((256, n_bins, n_frames), dtype=torch.float64, device=dev) for _ in xs]
+    stream = torch.cuda.current_stream(dev)
+
+    def step(i):
+        plan.compute_batch(xs[i % len(xs)], out=outs[i % len(xs)])
+
+    def fence():
+        torch.cuda.synchronize(dev)
+
+    ph = preheat(step, fence, args.preheat_s)
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    dt, kernel_ms = timed_steps(torch, stream, step, args.steps, fence)
+    frames = 256 * n_frames
+    rd, wr = N_SAMPLES * 8.0 / n_frames, n_bins * 8.0
+    fps = frames / (kernel_ms * 1e-3)
+    roof = {"bound": "hbm", "achieved": (rd + wr) * fps / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (rd + wr) * fps / 1e9 / HBM_PEAK_GBS,
+            "traffic": None, "kernel_ms": kernel_ms, "kernel_ms_scope": "HIP events over the timed region", "algorithmic_bytes_per_frame": rd + wr,
+            "frames_per_launch": frames}
+    if peak and peak.get("copy"):
+        roof["frac_of_measured_copy"] = roof["achieved"] / peak["copy"]
+    return {"config": f"configs[{1 if kernel_wl == 'linear_power' else 2}] in f64: 256 x 10 s 16 kHz, {kernel_wl} n_fft=1024 hop=256 Hanning centre",
+            "dtype": "f64", "kernel": plan.kernel_name, "steps": args.steps, "warmup": args.warmup, "preheat_steps": ph,
+            "ms_per_step": dt / args.steps * 1e3, "value": frames * args.steps / dt, "unit": "frames/s", "roofline": roof}
 
 
 def istft_leg(torch, sg, dev, xs256, args, peak):
@@ -903,6 +941,8 @@ def main() -> int:
                 wl[name] = chirpz_leg(torch, sg, dev, xs256, args)
             elif name == "istft":
                 wl[name] = istft_leg(torch, sg, dev, xs256, args, peak)
+            elif name.endswith("_f64"):
+                wl[name] = f64_leg(torch, sg, dev, name, xs256, args, peak)
             else:
                 wl[name] = stft_leg(torch, sg, dev, name, xs256, args, peak)
             torch.cuda.empty_cache()

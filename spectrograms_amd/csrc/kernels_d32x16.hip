@@ -27,6 +27,7 @@
 
 #include "buffer_ops.h"
 #include "fft_inreg.h"
+#include "d32x16_layout.h"
 #include "r32x16_layout.h"
 #include "sgx_internal.h"
 
@@ -40,7 +41,9 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
-__host__ __device__ constexpr unsigned pwd_index(unsigned k, unsigned f) { return (k >> 1) * 32u + (f >> 1) * 4u + (k & 1u) * 2u + (f & 1u); }
+// a bin's 16 frames are 128 bytes = half of the LDS banks: a 16-lane read group is two slots, whose first bins the schedule makes even and
+// odd (build_band_schedule), so that the two read different halves at every step
+__host__ __device__ constexpr unsigned pwd_index(unsigned k, unsigned f) { return k * 16u + f; }
 
 template <int AMP>
 __device__ __forceinline__ double amp_f64(double p, double eps) {
@@ -86,20 +89,25 @@ __device__ __forceinline__ void mel_tile_sched_d(const StftArgs &a, const double
         const uint4 nxt = seg + 1u < (unsigned)kDSegs ? info[(seg + 1u) * 64u] : cur;
         const unsigned L = __builtin_amdgcn_readfirstlane(cur.x);
         const v2d *wr = (const v2d *)(sched + cur.y);
-        const v2d *pr = (const v2d *)(pw + (cur.z >> 1) * 32u + fp * 4u);  // kstart is even
+        const v2d *pr = (const v2d *)(pw + cur.z * 16u + fp * 2u);
         v2d acc = {0.0, 0.0};
-        for (unsigned t = 0; t < L; t += 4u) {  // (bin t: frames 2 fp, 2 fp + 1), (bin t + 1: the same two frames), then bins t + 2, t + 3
+        // bins t .. t + 3, frames 2 fp and 2 fp + 1 of each.  (Reading a step ahead of the sums measured the same: 64 x 10 s Mel-80 power 73-75 us
+        // both ways.)
+        for (unsigned t = 0; t < L; t += 4u) {
             const v2d w01 = wr[t >> 1], w23 = wr[(t >> 1) + 1u];
-            const v2d q0 = pr[(t >> 1) * 16u], q1 = pr[(t >> 1) * 16u + 1u], q2 = pr[(t >> 1) * 16u + 16u], q3 = pr[(t >> 1) * 16u + 17u];
+            const v2d q0 = pr[t * 8u], q1 = pr[t * 8u + 8u], q2 = pr[t * 8u + 16u], q3 = pr[t * 8u + 24u];
             acc = mul_add_unfused_d(w01.x, q0, acc);
             acc = mul_add_unfused_d(w01.y, q1, acc);
             acc = mul_add_unfused_d(w23.x, q2, acc);
             acc = mul_add_unfused_d(w23.y, q3, acc);
         }
         const bool have = cur.w != 0xffffffffu;
-        const unsigned bo = cur.w * a.n_frames * 8u;
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, amp_f64<AMP>(acc.x, eps)), ro, (int)((have && fo0 != kDrop) ? bo + fo0 : kDrop), 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, amp_f64<AMP>(acc.y, eps)), ro, (int)((have && fo1 != kDrop) ? bo + fo1 : kDrop), 0, 0);
+        // (a segment the wave has no band in is skipped whole: an f64 log10 is some hundred instructions — 64 x 10 s, Mel-80 dB: 87 -> 81 us)
+        if (__builtin_amdgcn_ballot_w64(have) != 0ull) {
+            const unsigned bo = cur.w * a.n_frames * 8u;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, amp_f64<AMP>(acc.x, eps)), ro, (int)((have && fo0 != kDrop) ? bo + fo0 : kDrop), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, amp_f64<AMP>(acc.y, eps)), ro, (int)((have && fo1 != kDrop) ? bo + fo1 : kDrop), 0, 0);
+        }
         cur = nxt;
     }
 }

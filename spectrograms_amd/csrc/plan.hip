@@ -11,6 +11,7 @@
 #include <new>
 #include <type_traits>
 
+#include "d32x16_layout.h"
 #include "r32x16_layout.h"
 #include "reg_radix.h"
 #include "sgx_internal.h"
@@ -418,9 +419,14 @@ void build_band_schedule(sgx_plan *pl, unsigned NW = 4, unsigned kSegs = r32x16:
                 S.band = order[8 * g + q];
                 if (len(S.band) == 0) continue;  // degenerate triangle: empty sum, still written
                 const unsigned c0 = pl->mel_col[pl->mel_ptr[S.band]], c1 = pl->mel_col[pl->mel_ptr[S.band + 1] - 1];
-                const unsigned want = (q & 2u) ? 2u : 0u;        // slots 0, 1 start at 0 mod 4, slots 2, 3 at 2 mod 4 (bank halves)
-                const unsigned back = (c0 + 4u - want) & 3u;      // (c0 - want) mod 4
-                S.ks = c0 >= back ? c0 - back : (c0 & ~1u);       // always even: the kernel reads bin pairs
+                if (wwords == 2) {  // k_d32x16: a bin row of the |X|^2 tile is half of the banks; neighbouring slots start on even / odd bins
+                    const unsigned back = (c0 + 2u - (q & 1u)) & 1u;
+                    S.ks = c0 >= back ? c0 - back : c0;
+                } else {
+                    const unsigned want = (q & 2u) ? 2u : 0u;    // slots 0, 1 start at 0 mod 4, slots 2, 3 at 2 mod 4 (bank halves)
+                    const unsigned back = (c0 + 4u - want) & 3u;  // (c0 - want) mod 4
+                    S.ks = c0 >= back ? c0 - back : (c0 & ~1u);   // always even: the kernel reads bin pairs
+                }
                 S.steps = c1 - S.ks + 1;
 #if SGX_BANDPF
                 G.L = std::max(G.L, (S.steps + 7u) & ~7u);  // the kernel takes 8 steps per group (software pipeline)

@@ -1,22 +1,17 @@
-import os, sys; sys.path.insert(0, os.getcwd())
-import numpy as np, torch
+import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, numpy as np
 import spectrograms_amd as sg
-from oracle import oracle as orc
 from tests import helpers as H
-B = 256
-x32 = H.cfg2_batch(B)
-for dtype, n_fft, hop in (("float64", 1024, 256), ("float64", 512, 128), ("float64", 2048, 512), ("float64", 256, 64)):
-    x = torch.from_numpy(x32).to(torch.float64).cuda()
-    params = sg.SpectrogramParams(sg.StftParams(n_fft, hop, sg.WindowType.hanning, True), 16000.0)
-    for name, plan in (("linear", sg.SpectrogramPlanner().linear_power_plan(params, dtype=dtype)),
-                       ("mel80db", sg.SpectrogramPlanner().mel_db_plan(params, sg.MelParams(80, 0.0, 8000.0), sg.LogParams(-80.0), dtype=dtype))):
-        nb, nf = plan.output_shape(x.shape[1])
-        out = torch.empty((B, nb, nf), dtype=torch.float64, device="cuda")
-        plan.time_batch_torch(x, out, 2)
-        ms = plan.time_batch_torch(x, out, 5)
-        err = ""
-        if name == "linear":
-            ref = orc.spectrogram_batch(orc.Params(n_fft=n_fft, hop=hop), x32[:2].astype(np.float64))
-            got = plan.compute_batch(x[:2]).cpu().numpy()
-            err = "relerr=%.2e" % (np.abs(got - ref).max() / ref.max())
-        print(f"{dtype} n_fft={n_fft:5d} {name:8s} {ms * 1e3:9.1f} us {err}", flush=True)
+B = int(os.environ.get("B", 64))
+x = torch.from_numpy(H.cfg2_batch(B)).double().cuda()
+params = sg.SpectrogramParams(sg.StftParams(1024, 256, sg.WindowType.hanning, True), 16000.0)
+P = sg.SpectrogramPlanner()
+mel = sg.MelParams(80, 0.0, 8000.0)
+for name, plan in (("linear_power", P.linear_power_plan(params, dtype="float64")), ("linear_db", P.linear_db_plan(params, sg.LogParams(-80.0), dtype="float64")),
+                   ("mel_power", P.mel_power_plan(params, mel, dtype="float64")), ("mel_db", P.mel_db_plan(params, mel, sg.LogParams(-80.0), dtype="float64")),
+                   ("mel128_db", P.mel_db_plan(params, sg.MelParams(128, 0.0, 8000.0), sg.LogParams(-80.0), dtype="float64")), ("stft", P.stft_plan(params, dtype="float64"))):
+    nb, nf = plan.output_shape(x.shape[1])
+    out = torch.empty((B, nb, nf) + ((2,) if name == "stft" else ()), dtype=torch.float64, device="cuda")
+    plan.time_batch_torch(x, out, 3)
+    ms = plan.time_batch_torch(x, out, 10)
+    print(f"f64 1024/256 B={B} {name:12s} {plan.kernel_name:11s} {ms*1e3:8.1f} us {B*nf/ms/1e3:8.1f} M frames/s", flush=True)
