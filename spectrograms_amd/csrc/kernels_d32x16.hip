@@ -287,7 +287,12 @@ __global__ __launch_bounds__(512, 2) void k_d32x16(StftArgs a, unsigned per_xcd,
                 *pwp = AMP == AMP_MAG_IN ? sqrt(p) : p;  // (a lane without a frame writes its mirror's values into its own slot: never stored)
             } else if constexpr (MODE == OUT_COMPLEX) {
                 const v2d V = conj ? (v2d){X.x, -X.y} : X;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, V), ro, (int)voff, (int)soff, 0);
+                // The whole offset in the lane register, soffset = 0.  With a scalar-register soffset the compiler assumes that a 16-byte store's
+                // data registers may be rewritten by the very next instruction (GCNHazardRecognizer: the ">8-byte store data" hazard "only exists
+                // without a register soffset") and did so — and on this device lanes 12..15 of every 16-lane row then stored the NEW contents now
+                // and then: 0.06 % of the complex STFT wrong at hop >= 274 (64 x 10 s; staged hops happened to schedule apart).  With an
+                // immediate soffset it keeps the wait states itself.
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, V), ro, (int)(voff + soff), 0, 0);
             } else {
                 const double p = __builtin_fma(X.x, X.x, X.y * X.y);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, amp_f64<AMP>(p, eps)), ro, (int)voff, (int)soff, 0);

@@ -965,7 +965,7 @@ sgx_status grow(sgx_plan *pl, void **buf, size_t *have, size_t need) {
 
 void free_device(sgx_plan *pl) {
     void **bufs[] = {&pl->d_window, &pl->d_tw, &pl->d_tw1, &pl->d_tw2, &pl->d_mel_ptr, &pl->d_mel_col,
-                     &pl->d_mel_val, &pl->d_dct, &pl->d_lifter, &pl->d_melbuf, &pl->d_pwbuf, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_mm_frag, &pl->d_mm_blk, &pl->d_mel_sched, &pl->d_itw, &pl->d_itwr, &pl->d_itw1, &pl->d_itwr2, &pl->d_itw12, &pl->d_frames, &pl->d_flag, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half, &pl->d_bs_chirp, &pl->d_bs_tw, &pl->d_bs_wc, &pl->d_bs_bhp, &pl->bs_half.chirp, &pl->bs_half.bhp, &pl->bs_half.tw};
+                     &pl->d_mel_val, &pl->d_dct, &pl->d_lifter, &pl->d_melbuf, &pl->d_pwbuf, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_mm_frag, &pl->d_mm_blk, &pl->d_mel_sched, &pl->d_itw, &pl->d_itwr, &pl->d_itw1, &pl->d_itwr2, &pl->d_itw12, &pl->d_itwrd, &pl->d_itw1d, &pl->d_frames, &pl->d_flag, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half, &pl->d_bs_chirp, &pl->d_bs_tw, &pl->d_bs_wc, &pl->d_bs_bhp, &pl->bs_half.chirp, &pl->bs_half.bhp, &pl->bs_half.tw};
     for (void **b : bufs)
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
@@ -1053,6 +1053,22 @@ sgx_status inverse_tables(sgx_plan *pl) {
         if ((st = upload<float>(pl, &pl->d_itwr2, tr)) != SGX_OK) return st;
         if ((st = upload<float>(pl, &pl->d_itw12, t1)) != SGX_OK) return st;
     }
+    if (std::is_same<T, double>::value && n == 1024 && pl->p.hop_size >= 64) {  // tables of the fused tuned f64 n_fft 1024 kernel (ov = 1023 / hop < 16)
+        std::vector<double> tr(2 * 512), t1(2 * 16 * 32);
+        for (unsigned k = 0; k < 512; ++k) {
+            const double a = 2.0 * kPi * double(k) / 1024.0;  // conj(W_1024^k)
+            tr[2 * k] = std::cos(a);
+            tr[2 * k + 1] = std::sin(a);
+        }
+        for (unsigned k1 = 0; k1 < 16; ++k1)
+            for (unsigned n2 = 0; n2 < 32; ++n2) {
+                const double b2 = -2.0 * kPi * double(k1 * n2) / 512.0;  // W_512^(k1 n2)
+                t1[2 * (k1 * 32 + n2)] = std::cos(b2);
+                t1[2 * (k1 * 32 + n2) + 1] = std::sin(b2);
+            }
+        if ((st = upload<double>(pl, &pl->d_itwrd, tr)) != SGX_OK) return st;
+        if ((st = upload<double>(pl, &pl->d_itw1d, t1)) != SGX_OK) return st;
+    }
     SGX_HIP(pl, hipMalloc(&pl->d_flag, sizeof(unsigned)));
     return SGX_OK;
 }
@@ -1111,6 +1127,11 @@ sgx_status run_istft(sgx_plan *pl, const void *spec, size_t batch, size_t n_fram
     if (pl->d_itwr2 && n_frames * 1025ull * 8ull < 0x7fffffffull) {  // fused tuned kernel at n_fft 2048 (kernels_istft2048.hip)
         SGX_HIP(pl, launch_istft2048(spec, out, pl->d_window, unsigned(n_frames), pl->p.hop_size, unsigned(batch), start, out_len, 1.0f / 2048.0f,
                                      (unsigned *)pl->d_flag, pl->d_itwr2, pl->d_itw12, s));
+        return SGX_OK;
+    }
+    if (pl->d_itwrd && n_frames * 513ull * 16ull < 0x7fffffffull) {  // fused tuned f64 kernel at n_fft 1024 (kernels_istft_d1024.hip)
+        SGX_HIP(pl, launch_istft_d1024(spec, out, pl->d_window, unsigned(n_frames), pl->p.hop_size, unsigned(batch), start, out_len, 1.0 / 1024.0,
+                                       (unsigned *)pl->d_flag, pl->d_itwrd, pl->d_itw1d, s));
         return SGX_OK;
     }
     // fused register-tiled kernel (every length with a pass split, hop <= n_fft, at most half a tile of halo frames): the windowed
@@ -1533,7 +1554,7 @@ sgx_status sgx_reserve(sgx_plan *plan, size_t batch, size_t n_samples, int32_t h
     if (inverse) {  // sgx_istft of `batch` spectra whose frame count is that of n_samples-long signals
         // the same tests run_istft applies: tuned n_fft = 1024 kernel, else the fused register-tiled kernel; only the unfused
         // fallback (rows + overlap-add) touches the frame scratch
-        const bool fused = (plan->d_itwr && nf * 513ull * 8ull < 0x7fffffffull) || (plan->d_itwr2 && nf * 1025ull * 8ull < 0x7fffffffull) ||
+        const bool fused = (plan->d_itwr && nf * 513ull * 8ull < 0x7fffffffull) || (plan->d_itwr2 && nf * 1025ull * 8ull < 0x7fffffffull) || (plan->d_itwrd && nf * 513ull * 16ull < 0x7fffffffull) ||
                            (nf <= 0xffffffffull && batch <= 0xffffffffull &&
                             istft_reg_fuses(plan->d_window, plan->p.n_fft, unsigned(nf), plan->p.hop_size, unsigned(batch), plan->dtype));
         if (!fused && (st = grow(plan, &plan->d_frames, &plan->d_frames_bytes, batch * nf * plan->p.n_fft * plan->elem)) != SGX_OK) return st;

@@ -337,3 +337,28 @@ def test_gpu_istft_fuzz_tuned_shapes():
             ref = orc.istft(S[b].astype(np.complex128), n_fft, hop, "hamming", centre)
             assert y[b].shape == ref.shape, (n_fft, hop, centre, batch, n)
             assert np.max(np.abs(y[b] - ref)) < 2e-5 * max(1.0, np.max(np.abs(ref))), (it, n_fft, hop, centre, batch, n, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hop,centre,n,batch", [(256, True, 100000, 5), (256, False, 33333, 3), (512, True, 70001, 2), (64, True, 20000, 2), (100, True, 20000, 2),
+                                               (1024, True, 50000, 4), (300, True, 1023, 2), (256, True, 1, 1), (128, False, 9000, 7), (256, True, 160000, 64)])
+def test_gpu_istft_f64_1024_tuned(hop, centre, n, batch):
+    """k_istft_d1024 (f64 n_fft 1024, hop >= 64): lane-pair fold and trade, carried overlap-add in f64 with the compile-time form at hops 256 / 512 /
+    1024, runs that start inside a signal, ragged frame counts, signals shorter than a frame; the oracle and bit-equality of a signal alone."""
+    rng = np.random.default_rng(17)
+    if not centre and n < 1024:
+        n = 1024 + n
+    x = rng.standard_normal((batch, n))
+    wname = "hanning" if centre and hop < 1024 else "hamming"  # (see test_gpu_istft_2048_long_signals)
+    params = sg.SpectrogramParams(sg.StftParams(1024, hop, getattr(sg.WindowType, wname), centre), 16000.0)
+    plan = sg.Plan(params, _ffi.AMP_COMPLEX, None, None, "float64")
+    S = np.ascontiguousarray(plan.compute_batch(x))
+    y = plan.istft_batch(S)
+    for b in sorted({0, batch - 1, batch // 2}):
+        ref = orc.istft(S[b], 1024, hop, wname, centre)
+        assert y[b].shape == ref.shape
+        assert np.max(np.abs(y[b] - ref)) < 1e-10 * max(1.0, np.max(np.abs(ref))), (hop, centre, n, batch, b)
+    m = min(y.shape[1], n)
+    assert np.max(np.abs(y[:, 600:m - 600] - x[:, 600:m - 600])) < 1e-9 if m > 1300 else True
+    one = plan.istft_batch(np.ascontiguousarray(S[batch - 1:]))
+    assert np.array_equal(one[0], y[batch - 1])
