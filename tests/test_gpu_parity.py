@@ -192,24 +192,34 @@ def test_ragged_lengths_f64_1024(n, centre):
     run_case(n=n, batch=2, n_fft=1024, hop=256, centre=centre, n_mels=80, fmin=0.0, fmax=8000.0, amp="db", floor=-80.0, dtype="float64")
 
 
-@pytest.mark.parametrize("dtype,n_fft,hop,amp", [("float64", 1024, 512, "complex"), ("float64", 1024, 1024, "complex"), ("float64", 1024, 600, "complex"),
-                                                  ("float64", 1024, 274, "complex"), ("float64", 1024, 256, "complex"), ("float64", 1024, 512, "power"),
-                                                  ("float32", 2048, 1024, "complex"), ("float32", 2048, 2048, "power"), ("float32", 2048, 600, "complex"),
-                                                  ("float32", 512, 128, "complex"), ("float32", 512, 256, "complex"), ("float32", 1024, 512, "complex")])
-def test_tuned_kernels_many_tiles_per_workgroup(dtype, n_fft, hop, amp):
-    """64 x 10 s through the tuned kernels' per-lane-column (unstaged) and complex variants: several tiles per workgroup, every element of
-    every row against the oracle.  Round 4 found 0.06 % of k_d32x16's complex STFT wrong at hop >= 274 ONLY at this size (a 16-byte store whose
-    data registers were rewritten by the next instruction, kernels_d32x16.hip: emit): the small-shape tests run one tile per workgroup."""
+@pytest.mark.parametrize("dtype,n_fft,hop,amp,n_mels", [
+    ("float64", 1024, 512, "complex", None), ("float64", 1024, 1024, "complex", None), ("float64", 1024, 600, "complex", None),
+    ("float64", 1024, 274, "complex", None), ("float64", 1024, 256, "complex", None), ("float64", 1024, 512, "power", None),
+    ("float64", 1024, 512, "power", 80), ("float64", 1024, 256, "power", 128),
+    ("float32", 2048, 1024, "complex", None), ("float32", 2048, 2048, "power", None), ("float32", 2048, 600, "complex", None),
+    ("float32", 2048, 1024, "power", 80), ("float32", 512, 128, "complex", None), ("float32", 512, 256, "complex", None),
+    ("float32", 1024, 512, "complex", None), ("float32", 1024, 600, "power", 80),
+    # the generic kernels at the same size: register-tiled (powers of two, composite), chirp-z, f64 complex (16-byte stores)
+    ("float32", 4096, 1024, "complex", None), ("float64", 2048, 512, "complex", None), ("float64", 400, 160, "complex", None),
+    ("float32", 400, 160, "complex", None), ("float32", 1009, 252, "complex", None), ("float64", 509, 128, "complex", None),
+    ("float64", 512, 128, "power", 40)])
+def test_tuned_kernels_many_tiles_per_workgroup(dtype, n_fft, hop, amp, n_mels):
+    """64 x 10 s through the tuned kernels' per-lane-column (unstaged), complex and filterbank variants and through the generic kernels: several
+    tiles per workgroup, every element of every row against the oracle.  Round 4 found 0.06 % of k_d32x16's complex STFT wrong at hop >= 274
+    ONLY at this size (a 16-byte store whose data registers were rewritten by the next instruction, kernels_d32x16.hip: emit): the small-shape
+    tests run one tile per workgroup."""
     x = H.cfg2_batch(64).astype(np.float64 if dtype == "float64" else np.float32)
-    params = sg.SpectrogramParams(sg.StftParams(n_fft, hop, sg.WindowType.hanning, True), 16000.0)
-    plan = sg.Plan(params, _ffi.AMP_COMPLEX if amp == "complex" else _ffi.AMP_POWER, None, None, dtype)
-    op = orc.Params(n_fft=n_fft, hop=hop)
+    kw = dict(n_fft=n_fft, hop=hop, dtype=dtype, amp=amp)
+    if n_mels:
+        kw.update(n_mels=n_mels, fmin=0.0, fmax=8000.0)
+    plan, op = make(**kw)
     x64 = x.astype(np.float64)
     ref = orc.stft_batch(op, x64, nthreads=orc.max_threads()) if amp == "complex" else orc.spectrogram_batch(op, x64, nthreads=orc.max_threads())
     for rep in range(2):
         got = np.asarray(plan.compute_batch(x))
         err = np.max(np.abs(got - ref))
         assert err <= (1e-10 if dtype == "float64" else 2e-4) * max(1.0, float(np.max(np.abs(ref)))), (rep, err)
+
 
 @pytest.mark.parametrize("n", [1, 5, 1023, 1024, 1025, 2047, 2048, 2049, 2559, 2560, 2561, 8193, 10239, 10240, 10241])
 @pytest.mark.parametrize("centre", [True, False])
