@@ -513,7 +513,7 @@ def test_dimension_mismatch_and_r2c():
         plan.compute_batch(x, out=np.empty((2, 513, 5), np.float32))
     # conforming R2cPlan::process: DC of ones = N (fft_backend.rs:1880-1907), [1,1,1] padded -> 3 (fft_padding_tests.rs:149-158)
     for dtype, tol in (("float32", 1e-5), ("float64", 1e-12)):
-        for n in (8, 1024, 400):
+        for n in (8, 1024, 2048, 400):  # (1024: the tuned f32 and f64 kernels, 2048: the tuned f32 kernel — with a window of ones)
             p, _ = make(n, max(1, n // 4), dtype=dtype)
             X = p.r2c(np.ones(n))
             assert abs(X[0] - n) < tol * n and np.max(np.abs(X[1:])) < tol * n
