@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Repeat-run parity at full size: BATCH x 10 s through the tuned kernels, every element against the oracle, REPS launches each (an intermittent
+fault — e.g. the 16-byte store hazard of DESIGN.md §3.5 — shows as a non-zero count of bad elements in some launch)."""
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import spectrograms_amd as sg
+from spectrograms_amd import _ffi
+from oracle import oracle as orc
+from tests import helpers as H
+
+B = int(os.environ.get("BATCH", 256)); REPS = int(os.environ.get("REPS", 6))
+base = H.cfg2_batch(B)
+CASES = [("float32", 1024, 256, "complex", 0), ("float32", 1024, 256, "power", 0), ("float32", 1024, 256, "power", 80), ("float32", 1024, 512, "complex", 0),
+         ("float32", 2048, 512, "complex", 0), ("float32", 2048, 512, "power", 80), ("float32", 512, 128, "complex", 0), ("float32", 512, 160, "power", 80),
+         ("float64", 1024, 256, "complex", 0), ("float64", 1024, 256, "power", 0), ("float64", 1024, 256, "power", 80), ("float64", 1024, 512, "complex", 0),
+         ("float64", 512, 128, "complex", 0), ("float32", 400, 160, "power", 80)]
+bad_total = 0
+for dtype, n_fft, hop, amp, nm in CASES:
+    x = base.astype(np.float64 if dtype == "float64" else np.float32)
+    params = sg.SpectrogramParams(sg.StftParams(n_fft, hop, sg.WindowType.hanning, True), 16000.0)
+    mel = sg.MelParams(nm, 0.0, 8000.0) if nm else None
+    plan = sg.Plan(params, _ffi.AMP_COMPLEX if amp == "complex" else _ffi.AMP_POWER, mel, None, dtype)
+    op = orc.Params(n_fft=n_fft, hop=hop, n_mels=nm, f_min=0.0, f_max=8000.0)
+    x64 = base.astype(np.float64)
+    ref = orc.stft_batch(op, x64, nthreads=orc.max_threads()) if amp == "complex" else orc.spectrogram_batch(op, x64, nthreads=orc.max_threads())
+    tol = (1e-10 if dtype == "float64" else 2e-4) * max(1.0, float(np.abs(ref).max()))
+    xd = torch.from_numpy(x).cuda()
+    counts = []
+    for r in range(REPS):
+        got = plan.compute_batch(xd).cpu().numpy()
+        if amp == "complex" and not np.iscomplexobj(got):
+            got = got[..., 0] + 1j * got[..., 1]
+        counts.append(int((np.abs(got - ref) > tol).sum()))
+    bad_total += sum(counts)
+    print(f"{dtype} {n_fft}/{hop} {amp}{'-mel%d' % nm if nm else ''} {plan.kernel_name}: bad elements per launch {counts}", flush=True)
+print("TOTAL BAD", bad_total)
+sys.exit(1 if bad_total else 0)
