@@ -758,8 +758,10 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     const unsigned half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
     const unsigned tid = threadIdx.x & 255u;
-    unsigned char *smem = smem_all + half * kExBytes;  // this half's ex / xs / pw buffer
-    unsigned char *tabs = smem_all + 2 * kExBytes;     // tables sit behind the two ex buffers
+    constexpr bool H256M = HOP512 == 256 && MODE == OUT_MEL && !PACK;  // larger halves: r32x16_layout.h
+    constexpr unsigned EXB = H256M ? (unsigned)kExBytesH256 : (unsigned)kExBytes, POFF = H256M ? (unsigned)kOutOffH256 : (unsigned)kOutOff;
+    unsigned char *smem = smem_all + half * EXB;  // this half's ex / xs / pw buffer
+    unsigned char *tabs = smem_all + 2 * EXB;     // tables sit behind the two ex buffers
     if (threadIdx.x < 256u) ((v4f *)(tabs + kWinOff))[threadIdx.x] = ((const v4f *)a.window)[threadIdx.x];
     for (unsigned i = threadIdx.x; i < 16u * 17u; i += 512u) ((v4f *)(tabs + kTw2Off))[i] = ((const v4f *)a.tw2)[i];
     unsigned *sched = (unsigned *)(tabs + kMelOff);
@@ -1070,7 +1072,7 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
         // and the band stage (~5 k cycles: more than an HBM round trip)
         if constexpr (DMA)
             if (lead + slots * 2u < hi) load_tile(next);
-        float *pwf = (float *)(smem + (PWT ? kOutOff : 0));  // PWT: above the staged samples, so the next staging does not wait for it
+        float *pwf = (float *)(smem + (PWT ? POFF : 0u));  // PWT: above the staged samples, so the next staging does not wait for it
         if constexpr (MODE == OUT_MEL) {
             if constexpr (P512) {  // bins 257..267 are read with zero weights
                 for (unsigned i = tid; i < 11u * 32u; i += 256u) pwf[pwt512_index(257u + (i >> 5), i & 31u)] = 0.0f;
@@ -1176,10 +1178,10 @@ hipError_t launch_variant(const StftArgs &a0, hipStream_t s) {
     const unsigned cu_slots = SGX_SLOTS ? SGX_SLOTS : std::max(1u, device_cu_count() / 8u);
     const unsigned nslots = pairs < cu_slots ? pairs : cu_slots;  // one 512-thread workgroup per CU
     const bool pwt = MODE == OUT_MEL && a.mel_sched != nullptr;
-    auto go = [&](auto kernel) -> hipError_t {
-        hipError_t e = set_max_dynamic_lds((const void *)kernel, kLdsBytes);
+    auto go = [&](auto kernel, unsigned lds = (unsigned)kLdsBytes) -> hipError_t {
+        hipError_t e = set_max_dynamic_lds((const void *)kernel, 163840);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kernel, dim3(nslots * 8), dim3(512), kLdsBytes, s, a, per_xcd, total, nslots);
+        hipLaunchKernelGGL(kernel, dim3(nslots * 8), dim3(512), lds, s, a, per_xcd, total, nslots);
         return hipGetLastError();
     };
     constexpr bool W = MODE != OUT_MEL;
@@ -1192,6 +1194,8 @@ hipError_t launch_variant(const StftArgs &a0, hipStream_t s) {
                 if (a.hop == 64u) return go(k_r32x16<MODE, AMP, 3, false, false, true, 64>);
                 if (a.hop == 128u) return go(k_r32x16<MODE, AMP, 5, false, false, true, 128>);
                 if (a.hop == 160u) return go(k_r32x16<MODE, AMP, 6, false, false, true, 160>);
+                if (a.hop == 256u)  // the reference's Mel benchmark shape, benches/spectrogram_benchmarks.rs:105-141 (larger halves: r32x16_layout.h)
+                    return go(k_r32x16<MODE, AMP, 9, false, false, true, 256>, 2u * kExBytesH256 + kMelOff + ((a.mel_sched_words * 4u + 15u) & ~15u) + 64u);
                 return hipErrorInvalidConfiguration;
             }
             if (a.hop == 256u) return go(k_r32x16<MODE, AMP, 5, false, true, true>);
@@ -1230,7 +1234,7 @@ extern "C" int sgx_debug_read_stamps(unsigned long long *out, int reset) {
 bool plan_geometry_r32x16_f32(StftArgs &a) {
     // P512: two frames per transform, 32-frame tiles; filterbank outputs need the band schedule (built on the host at plan creation,
     // before this is asked: a bank without one resolves to the register-tiled kernel)
-    if (a.n_fft == 512 && a.hop == 256 && a.out_mode == OUT_MEL) return false;  // (the staged tile would reach into the |X|^2 tile)
+    if (a.n_fft == 512 && a.hop == 256 && a.out_mode == OUT_MEL && a.mel_sched_words > (unsigned)kMelMaxWordsH256) return false;  // (larger halves, shorter schedule)
     if (a.n_fft == 512 && a.out_mode == OUT_MEL && a.mel_sched_words == 0) return false;
     if (a.n_fft == 512 && (a.hop == 64 || a.hop == 128 || a.hop == 160 || a.hop == 256)) {
         if (a.n_samples >= (1ull << 29) || (unsigned long long)a.n_frames * 257ull * 8ull >= 0x7fffffffull) return false;

@@ -18,6 +18,11 @@ constexpr int kTw2Bytes = 16 * 17 * 16;         // row stride 272 B: jobs j and 
 constexpr int kMelOff = kTw2Off + kTw2Bytes;    // filterbank schedule (below)
 constexpr int kMelMaxWords = 4096;
 constexpr int kLdsBytes = 2 * kExBytes + kMelOff + kMelMaxWords * 4;  // 156416 of the CU's 163840
+// n_fft 512 at hop 256 with filterbank outputs: the tile's staged samples (36 864 B + 64 B of padding per 2 KiB = 38 016 B) and the |X|^2 tile
+// (34 816 B) do not fit one 65 792-byte half, so this variant's halves are larger and its schedule shorter (a 257-bin bank needs ~1500 words)
+constexpr int kExBytesH256 = 72960;                       // 285 x 256
+constexpr int kOutOffH256 = kExBytesH256 - 16 * 17 * 128;  // 38144 >= 38016
+constexpr int kMelMaxWordsH256 = (163840 - 2 * kExBytesH256 - kMelOff) / 4 - 16;  // 2352
 
 // Filterbank schedule (32-bit words; floats where noted), for the 4 waves x 8 slots of a half:
 //   [0] nseg  [1] total words  [2..3] 0

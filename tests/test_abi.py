@@ -299,4 +299,5 @@ def test_kernel_kind_is_resolved_with_the_band_schedule_known():
     assert erb.kernel_name == "reg_radix"  # 64 dense rows of 257 bins: too many words for the LDS schedule
     lin = host_plan(512, 128, dtype="float32")
     assert lin.kernel_name == "r32x16_f32"
-    assert host_plan(512, 256, mel=sg.MelParams(40, 0.0, 8000.0), dtype="float32").kernel_name == "reg_radix"
+    assert host_plan(512, 256, mel=sg.MelParams(40, 0.0, 8000.0), dtype="float32").kernel_name == "r32x16_f32"  # (round 4: larger LDS halves at hop 256)
+    assert host_plan(512, 200, mel=sg.MelParams(40, 0.0, 8000.0), dtype="float32").kernel_name == "reg_radix"

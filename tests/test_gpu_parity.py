@@ -198,7 +198,7 @@ def test_ragged_lengths_f64_1024(n, centre):
     ("float64", 1024, 512, "power", 80), ("float64", 1024, 256, "power", 128),
     ("float32", 2048, 1024, "complex", None), ("float32", 2048, 2048, "power", None), ("float32", 2048, 600, "complex", None),
     ("float32", 2048, 1024, "power", 80), ("float32", 512, 128, "complex", None), ("float32", 512, 256, "complex", None),
-    ("float32", 1024, 512, "complex", None), ("float32", 1024, 600, "power", 80),
+    ("float32", 1024, 512, "complex", None), ("float32", 1024, 600, "power", 80), ("float32", 512, 256, "power", 80), ("float32", 512, 256, "power", 128),
     # the generic kernels at the same size: register-tiled (powers of two, composite), chirp-z, f64 complex (16-byte stores)
     ("float32", 4096, 1024, "complex", None), ("float64", 2048, 512, "complex", None), ("float64", 400, 160, "complex", None),
     ("float32", 400, 160, "complex", None), ("float32", 1009, 252, "complex", None), ("float64", 509, 128, "complex", None),
@@ -358,6 +358,21 @@ def test_linear_amp_scales(n_fft, hop, amp, floor, dtype):
 def test_mel(n_fft, hop, n_mels, fmin, fmax, norm, amp, floor, dtype):
     run_case(n=9000, n_fft=n_fft, hop=hop, n_mels=n_mels, fmin=fmin, fmax=fmax, norm=norm, amp=amp, floor=floor,
              dtype=dtype)
+
+
+@pytest.mark.parametrize("amp,floor", [("power", None), ("magnitude", None), ("db", -80.0)])
+@pytest.mark.parametrize("n_mels,norm", [(40, None), (80, None), (128, "slaney"), (24, "l1")])
+def test_mel_512_hop256_tuned(n_mels, norm, amp, floor):
+    """The reference's Mel benchmark shape n_fft 512 / hop 256 x {40, 80, 128} bands (benches/spectrogram_benchmarks.rs:105-141) on k_r32x16's
+    two-frames-per-transform mode with the larger LDS halves of r32x16_layout.h: odd and even frame counts, ragged batch, centre off,
+    a signal's bits independent of its batch."""
+    kw = dict(n_fft=512, hop=256, n_mels=n_mels, fmin=0.0, fmax=8000.0, norm=norm, amp=amp, floor=floor, dtype="float32")
+    plan, got = run_case(n=9000, batch=3, **kw)
+    assert plan.kernel_name == "r32x16_f32"
+    x = signals(3, 9000, np.float32, 0)
+    assert np.array_equal(np.asarray(plan.compute_batch(x[2:3]))[0], np.asarray(got)[2])
+    run_case(n=9100, batch=2, centre=False, **kw)
+    run_case(n=300, batch=5, **kw)
 
 
 # ------------------------------------------------------------------ golden vectors (reference numpy_impls) through the C ABI
