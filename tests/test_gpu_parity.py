@@ -375,6 +375,20 @@ def test_mel_512_hop256_tuned(n_mels, norm, amp, floor):
     run_case(n=300, batch=5, **kw)
 
 
+@pytest.mark.parametrize("dtype,n_fft,hop,n", [("float64", 1024, 256, 1024), ("float64", 1024, 256, 2000), ("float32", 2048, 512, 1500), ("float32", 2048, 512, 3000)])
+def test_short_signal_batches_leave_the_one_signal_tiles(dtype, n_fft, hop, n):
+    """Batches of signals of a few frames: the 16-frame tiles of k_d32x16 / k_r32x32 hold ONE signal, so below 8 (5) frames per signal the call
+    runs on the register-tiled kernel (same plan, decided per call); results do not depend on which."""
+    plan, got = run_case(n=n, batch=33, n_fft=n_fft, hop=hop, amp="power", dtype=dtype)
+    x = signals(33, n, np.float32 if dtype == "float32" else np.float64, 0)
+    one = np.asarray(plan.compute_batch(x[5:6]))[0]  # batch 1: the tuned kernel
+    ref = np.asarray(got)[5]
+    assert np.max(np.abs(one - ref)) <= (1e-10 if dtype == "float64" else 2e-4) * max(1.0, float(np.max(np.abs(ref))))
+    run_case(n=n, batch=7, n_fft=n_fft, hop=hop, amp="complex", dtype=dtype)
+    if dtype == "float64":
+        run_case(n=n, batch=7, n_fft=n_fft, hop=hop, n_mels=40, fmin=0.0, fmax=8000.0, amp="db", floor=-80.0, dtype=dtype)
+
+
 # ------------------------------------------------------------------ golden vectors (reference numpy_impls) through the C ABI
 def test_golden_config1_f64(golden_dir):
     g = np.load(os.path.join(golden_dir, "config1_ref.npz"))
