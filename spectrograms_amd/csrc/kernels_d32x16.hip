@@ -335,6 +335,247 @@ hipError_t launch_variant_d(const StftArgs &a, hipStream_t s) {
     return go(k_d32x16<MODE, AMP, 0>);
 }
 
+// ====================================================================================================================================
+// k_d512: f64 n_fft = 512 at even hops up to 260 (the reference's Mel benchmark shape 512 / 256, benches/spectrogram_benchmarks.rs:105-141, in
+// its default type).  TWO consecutive frames per 512-point complex transform — z[n] = a[n] + i b[n], a = frame 2 p, b = frame 2 p + 1, both
+// times w[n] / 2 — so a tile is 32 frames in 16 slots and passes 1 and 2 are k_d32x16's; the real split becomes the two-sequence split
+// (no twiddles): with (P, Q) = (Z[k], Z[512 - k]):  A[k] = P + conj Q,  B[k] = -i (P - conj Q), k = 0 .. 256.  A lane's 8 pairs give 8 bins
+// of two neighbouring frames: 16 lanes x 16 bytes = 256-byte runs.
+__host__ __device__ constexpr unsigned pwd512_index(unsigned k, unsigned f) { return k * 32u + f; }
+
+template <int AMP>
+__device__ __forceinline__ void mel_tile_sched_d512(const StftArgs &a, const double *pw, const unsigned *sched, unsigned b, unsigned f0, unsigned nf,
+                                                    double eps, unsigned tid) {
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u, slot = lane >> 3, fp = lane & 7u;
+    constexpr unsigned kDrop = 0x80000000u;
+    const unsigned obytes = (a.n_out * a.n_frames - f0) * 8u;
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc((const double *)a.out + (size_t)b * a.n_out * a.n_frames + f0, obytes);
+    const uint4 *info = (const uint4 *)(sched + 4) + wave * 8u + slot;
+    uint4 cur = info[0];
+#pragma unroll
+    for (unsigned seg = 0; seg < (unsigned)d512::kSegs; ++seg) {
+        const uint4 nxt = seg + 1u < (unsigned)d512::kSegs ? info[(seg + 1u) * 64u] : cur;
+        const unsigned L = __builtin_amdgcn_readfirstlane(cur.x);
+        const bool have = cur.w != 0xffffffffu;
+        if (__builtin_amdgcn_ballot_w64(have) != 0ull) {
+            const v2d *wr = (const v2d *)(sched + cur.y);
+            const unsigned bo = cur.w * a.n_frames * 8u;
+#pragma unroll
+            for (unsigned h = 0; h < 2u; ++h) {  // the tile's two halves of 16 frames; neighbouring slots take them in opposite order (a bin row is
+                                                 // 256 bytes = all banks: the two slots of a 16-lane read group then read different halves of it)
+                const unsigned fpair = fp + 8u * ((h + slot) & 1u);
+                const v2d *pr = (const v2d *)(pw + cur.z * 32u + fpair * 2u);
+                v2d acc = {0.0, 0.0};
+                for (unsigned t = 0; t < L; t += 4u) {
+                    const v2d w01 = wr[t >> 1], w23 = wr[(t >> 1) + 1u];
+                    const v2d q0 = pr[t * 16u], q1 = pr[t * 16u + 16u], q2 = pr[t * 16u + 32u], q3 = pr[t * 16u + 48u];
+                    acc = mul_add_unfused_d(w01.x, q0, acc);
+                    acc = mul_add_unfused_d(w01.y, q1, acc);
+                    acc = mul_add_unfused_d(w23.x, q2, acc);
+                    acc = mul_add_unfused_d(w23.y, q3, acc);
+                }
+                const unsigned fo0 = 2u * fpair < nf ? 16u * fpair : kDrop, fo1 = 2u * fpair + 1u < nf ? 16u * fpair + 8u : kDrop;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, amp_f64<AMP>(acc.x, eps)), ro, (int)((have && fo0 != kDrop) ? bo + fo0 : kDrop), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, amp_f64<AMP>(acc.y, eps)), ro, (int)((have && fo1 != kDrop) ? bo + fo1 : kDrop), 0, 0);
+            }
+        }
+        cur = nxt;
+    }
+}
+
+template <int MODE, int AMP, int ROUNDS>
+__global__ __launch_bounds__(512, 2) void k_d512(StftArgs a, unsigned per_xcd, unsigned total, unsigned slots) {
+    constexpr bool BIG = MODE == OUT_MEL && ROUNDS == 9;  // the |X|^2 tile sits behind 72 KiB of staged samples: a longer buffer
+    constexpr unsigned BUF = BIG ? (unsigned)d512::kBuf9 : (unsigned)d512::kEx, PWOFF = BIG ? (unsigned)d512::kPwOff9 : (unsigned)d512::kPwOff5;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned tid = threadIdx.x;
+    unsigned char *tabs = smem + BUF;
+    if (tid < 256u) ((v4f *)tabs)[tid] = ((const v4f *)a.window)[tid];  // 512 doubles w[n] / 2
+    unsigned *sched = (unsigned *)(tabs + d512::kWinBytes);
+    if constexpr (MODE == OUT_MEL)
+        for (unsigned i = tid; i < a.mel_sched_words; i += 512u) sched[i] = a.mel_sched[i];
+
+    const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const unsigned lo = xcd * per_xcd, hi = min(lo + per_xcd, total);
+    unsigned wid = lo + slot;
+
+    const unsigned p1s = tid >> 5, n2 = tid & 31u;  // pass-1 identity: slot (frame pair) and column
+    const unsigned wave = tid >> 6, lane = tid & 63u, half = lane >> 5, p2s = lane & 15u;
+    const unsigned r = wave + 8u * ((lane >> 4) & 1u);
+    const unsigned row = half ? ((16u - r) & 15u) : r;
+    const bool j0 = r == 0u;
+    const unsigned kb = half ? (j0 ? 16u : 32u - r) : r;  // own H[u] = Z[kb + 32 u]: bins kb + 32 u of the slot's two frames
+    const double eps = a.eps;
+    constexpr unsigned ES = MODE == OUT_COMPLEX ? 16u : 8u;
+    const unsigned step = 32u * a.n_frames * ES;
+    double *pwd = (double *)(smem + PWOFF);
+    v2d twa[4], twb[4];  // W_512^(k1 n2) = twa[k1 >> 2] * twb[k1 & 3]
+    {
+        const v2d *t1 = (const v2d *)a.tw1 + n2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            twa[q] = t1[32 * 4 * q];
+            twb[q] = t1[32 * q];
+        }
+    }
+    const double sg = half ? -1.0 : 1.0, hb = half ? 1.0 : 0.0;
+
+    v4f creg[ROUNDS];
+    const unsigned hop = a.hop;
+    const unsigned row_bytes = (unsigned)a.n_samples * 8u;
+    auto load_tile = [&](unsigned w) {
+        const unsigned b = w / a.tiles, f0 = (w - b * a.tiles) * 32u;
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc((const double *)a.x + (size_t)b * a.sample_stride, row_bytes);
+        const int tile_lo = (int)(f0 * hop) - (int)a.pad;  // (negative in the left padding: out of range as an unsigned offset, reads 0 — S1)
+        const int vo = (tile_lo + 2 * (int)tid) * 8;
+#pragma unroll
+        for (int q = 0; q < ROUNDS; ++q) creg[q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rx, vo + q * 8192, 0, 0));
+    };
+    if (wid < hi) load_tile(wid);
+    __syncthreads();  // tables visible
+
+    const unsigned char *xa = smem + (2u * p1s * hop + n2) * 8u;  // a[n2] of this slot; b[n] is hop samples further
+    const unsigned hop8 = hop * 8u;
+    const double *w1 = (const double *)tabs + n2;
+
+    while (wid < hi) {
+        const unsigned b = wid / a.tiles, f0 = (wid - b * a.tiles) * 32u;
+        const unsigned nf = min(32u, a.n_frames - f0);
+        v2d xr[16];
+        {
+            v2d e[8], we[8], o[8], wo[8];
+#pragma unroll
+            for (int q = 0; q < ROUNDS; ++q) *(v4f *)(smem + (q * 512u + tid) * 16u) = creg[q];
+            __syncthreads();  // barrier 1: the staged samples are complete
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {  // n = 32 n1 + n2, n1 = 2 k
+                const double w = w1[64 * k];
+                e[k] = (v2d){*(const double *)(xa + k * 512), *(const double *)(xa + hop8 + k * 512)};
+                we[k] = (v2d){w, w};
+            }
+            Fft<8, true, v2d>::run(e, we);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {  // n1 = 2 k + 1
+                const double w = w1[64 * k + 32];
+                o[k] = (v2d){*(const double *)(xa + k * 512 + 256), *(const double *)(xa + hop8 + k * 512 + 256)};
+                wo[k] = (v2d){w, w};
+            }
+            Fft<8, true, v2d>::run(o, wo);
+            Comb<16, 0, v2d>::run(xr, e, o);
+        }
+        __syncthreads();  // barrier 2: the columns are read (and the previous tile's band stage is done): pass 1 may write ex
+        {
+            unsigned char *dst = smem + p1s * kDFS + n2 * 16u;
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) {
+                const int qa = k1 >> 2, qb = k1 & 3;
+                v2d v = xr[k1];
+                if (qb) v = cmulv(v, twb[qb]);
+                if (qa) v = cmulv(v, twa[qa]);
+                *(v2d *)(dst + k1 * 512) = v;
+            }
+        }
+        const unsigned next = wid + slots;
+        if (next < hi) load_tile(next);  // in flight during pass 2
+        __syncthreads();  // barrier 3: ex complete
+        // a slot without frames (last tile of a signal) mirrors the tile's last slot: same values to the same addresses
+        const unsigned se = min(p2s, (nf - 1u) >> 1);
+        v2d H[16];
+        {
+            const unsigned char *rp = smem + se * kDFS + row * 512u;
+            double hbl = hb;
+            asm volatile("" : "+v"(hbl));
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                const v2d x0 = *(const v2d *)(rp + n * 16), x1 = *(const v2d *)(rp + n * 16 + 256);
+                v2d d = pfma(x1, (v2d){sg, sg}, x0);
+                if (n > 0) {
+                    const double c = kCos64[2 * n], s = -kSin64[2 * n];
+                    const v2d t = {__builtin_fma(hbl, c - 1.0, 1.0), hbl * s};
+                    d = cmulv(d, t);
+                }
+                H[n] = d;
+                if ((n & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();  // barrier 4: ex consumed
+        Fft<16, false, v2d>::run(H, H);
+        const v2d h8 = H[8];
+        v2d R[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            R[j] = H[8 + j];
+            trade32(R[j]);
+        }
+        if (j0) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) R[j] = swp(half ? H[8 + j] : H[9 + j]);
+            R[7] = swp(half ? H[15] : H[0]);
+            asm volatile("" ::: "memory");
+        }
+        constexpr unsigned kDrop = 0x80000000u;
+        const unsigned fa = 2u * se;  // the slot's frames fa, fa + 1 of the tile
+        const bool vb = fa + 1u < nf;
+        const __amdgpu_buffer_rsrc_t ro = make_rsrc((unsigned char *)a.out + (size_t)b * 257u * a.n_frames * ES, 257u * a.n_frames * ES);
+        const unsigned oa = (kb * a.n_frames + f0 + fa) * ES;
+        if constexpr (MODE == OUT_MEL) {  // bins 257..267 are read with zero weights
+            if (tid < 352u) pwd[pwd512_index(257u + (tid >> 5), tid & 31u)] = 0.0;
+        }
+        double *pw_a = pwd + pwd512_index(kb, fa);
+        constexpr int PSTEP = 32 * 32;  // doubles between bins k and k + 32
+        auto emit = [&](unsigned voff, unsigned soff, double *pwp, v2d Xa, v2d Xb) {
+            if constexpr (MODE == OUT_MEL) {
+                const double pa = __builtin_fma(Xa.x, Xa.x, Xa.y * Xa.y), pb = __builtin_fma(Xb.x, Xb.x, Xb.y * Xb.y);
+                *(v2d *)pwp = AMP == AMP_MAG_IN ? (v2d){sqrt(pa), sqrt(pb)} : (v2d){pa, pb};
+            } else if constexpr (MODE == OUT_COMPLEX) {  // (16-byte stores: the whole offset in the lane register, see k_d32x16)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, Xa), ro, (int)(voff + soff), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, Xb), ro, (int)(vb ? voff + soff + 16u : kDrop), 0, 0);
+            } else {
+                const double pa = __builtin_fma(Xa.x, Xa.x, Xa.y * Xa.y), pb = __builtin_fma(Xb.x, Xb.x, Xb.y * Xb.y);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, amp_f64<AMP>(pa, eps)), ro, (int)voff, (int)soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, amp_f64<AMP>(pb, eps)), ro, (int)(vb ? voff + 8u : kDrop), (int)soff, 0);
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            // (P, Q) = (Z[k], Z[512 - k]): A[k] = P + conj Q = (P.x + Q.x, P.y - Q.y); B[k] = -i (P - conj Q) = (P.y + Q.y, Q.x - P.x)
+            const v2d P = H[u], Q = swp(R[7 - u]);
+            const v2d Xa = pfma(Q, (v2d){1.0, -1.0}, P);
+            const v2d D = pfma(Q, (v2d){-1.0, 1.0}, P);
+            const v2d Xb = (v2d){D.y, -D.x};
+            emit(oa, u * step, pw_a + u * PSTEP, Xa, Xb);
+        }
+        if (j0 && half == 0u)  // bin 256: Z[256] pairs with itself
+            emit((256u * a.n_frames + f0 + fa) * ES, 0u, pwd + pwd512_index(256u, fa), (v2d){2.0 * h8.x, 0.0}, (v2d){2.0 * h8.y, 0.0});
+        if constexpr (MODE == OUT_MEL) {
+            __syncthreads();  // |X|^2 tile complete
+            mel_tile_sched_d512<AMP>(a, pwd, sched, b, f0, nf, eps, tid);
+        }
+        wid = next;
+    }
+}
+
+template <int MODE, int AMP>
+hipError_t launch_variant_d512(const StftArgs &a, hipStream_t s) {
+    const unsigned total = a.tiles * a.batch;
+    const unsigned per_xcd = (total + 7u) / 8u;
+    const unsigned cu_slots = std::max(1u, device_cu_count() / 8u);
+    const unsigned nslots = per_xcd < cu_slots ? per_xcd : cu_slots;
+    const bool r5 = (31u * a.hop + 512u) * 8u <= 5u * 8192u;  // hop <= 148
+    const bool big = MODE == OUT_MEL && !r5;
+    const unsigned lds = (big ? (unsigned)d512::kBuf9 : (unsigned)d512::kEx) + (unsigned)d512::kWinBytes +
+                         (MODE == OUT_MEL ? ((a.mel_sched_words * 4u + 15u) & ~15u) + 64u : 0u);
+    auto go = [&](auto kernel) -> hipError_t {
+        hipError_t e = set_max_dynamic_lds((const void *)kernel, 163840);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kernel, dim3(nslots * 8), dim3(512), lds, s, a, per_xcd, total, nslots);
+        return hipGetLastError();
+    };
+    if (r5) return go(k_d512<MODE, AMP, 5>);
+    return go(k_d512<MODE, AMP, 9>);
+}
+
 }  // namespace
 
 bool plan_geometry_d32x16_f64(StftArgs &a) {
@@ -363,6 +604,32 @@ hipError_t launch_d32x16_f64(const StftArgs &a, hipStream_t s) {
     if (a.amp == AMP_MAGNITUDE) return launch_variant_d<OUT_LINEAR, AMP_MAGNITUDE>(a, s);
     if (a.amp == AMP_DB) return launch_variant_d<OUT_LINEAR, AMP_DB>(a, s);
     return launch_variant_d<OUT_LINEAR, AMP_POWER>(a, s);
+}
+
+
+bool plan_geometry_d512_f64(StftArgs &a) {
+    if (a.n_fft != 512 || (a.hop & 1u) || a.hop > 260u) return false;  // (the whole 32-frame tile is staged: (31 hop + 512) * 8 <= 9 * 8192)
+    if (a.batch > 1u && a.n_frames < 16u) return false;  // batches of short signals: mostly empty 32-frame tiles (see plan_geometry_d32x16_f64)
+    if (a.out_mode == OUT_MEL && (a.mel_sched_words == 0 || a.mel_sched_words > (unsigned)d512::kSchMaxWords)) return false;
+    if (a.n_samples >= (1ull << 28)) return false;
+    if ((unsigned long long)a.n_frames * 257ull * 16ull >= 0x7fffffffull) return false;
+    a.ft = 32;
+    return true;
+}
+
+hipError_t launch_d512_f64(const StftArgs &a, hipStream_t s) {
+    const unsigned long long total64 = (unsigned long long)a.tiles * a.batch;
+    if (total64 == 0 || total64 >= 0x7ffffff0ull) return hipErrorInvalidConfiguration;
+    if (a.out_mode == OUT_COMPLEX) return launch_variant_d512<OUT_COMPLEX, AMP_POWER>(a, s);
+    if (a.out_mode == OUT_MEL) {
+        if (a.amp == AMP_MAGNITUDE) return launch_variant_d512<OUT_MEL, AMP_MAGNITUDE>(a, s);
+        if (a.amp == AMP_DB) return launch_variant_d512<OUT_MEL, AMP_DB>(a, s);
+        if (a.amp == AMP_MAG_IN) return launch_variant_d512<OUT_MEL, AMP_MAG_IN>(a, s);
+        return launch_variant_d512<OUT_MEL, AMP_POWER>(a, s);
+    }
+    if (a.amp == AMP_MAGNITUDE) return launch_variant_d512<OUT_LINEAR, AMP_MAGNITUDE>(a, s);
+    if (a.amp == AMP_DB) return launch_variant_d512<OUT_LINEAR, AMP_DB>(a, s);
+    return launch_variant_d512<OUT_LINEAR, AMP_POWER>(a, s);
 }
 
 }  // namespace sgx

@@ -134,9 +134,9 @@ def test_pow2_sizes(n_fft, hop, amp, dtype):
     plan, _ = run_case(n=max(6000, 3 * n_fft), n_fft=n_fft, hop=hop, amp=amp, dtype=dtype)
     fits = n_fft <= (4096 if dtype == "float64" else 8192)  # an 8192-point f64 tile (164 KB with its tables) exceeds the CU's LDS
     tuned = dtype == "float32" and (n_fft == 1024 or (n_fft == 512 and hop in (64, 128, 160, 256)) or (n_fft == 2048 and hop % 2 == 0))
-    tuned64 = dtype == "float64" and n_fft == 1024 and hop % 2 == 0
+    tuned64 = dtype == "float64" and hop % 2 == 0 and (n_fft == 1024 or (n_fft == 512 and hop <= 260))
     if tuned64:
-        assert plan.kernel_name == "d32x16_f64"
+        assert plan.kernel_name == ("d32x16_f64" if n_fft == 1024 else "d512_f64")
     elif 32 <= n_fft and fits and not tuned:
         assert plan.kernel_name == "reg_radix"
 
@@ -182,6 +182,36 @@ def test_tuned_f64_1024(hop, amp, floor, n_mels):
     run_case(n=n, batch=2, centre=False, **kw)
 
 
+
+# ------------------------------------------------------------------ n_fft 512, f64: two frames per transform on k_d512 (round 4)
+@pytest.mark.parametrize("hop", [256, 128, 64, 160, 148, 150, 260, 2])
+@pytest.mark.parametrize("amp,floor,n_mels", [("complex", None, None), ("power", None, None), ("magnitude", None, None), ("db", -80.0, None),
+                                              ("power", None, 80), ("db", -80.0, 40), ("magnitude", None, 128)])
+def test_tuned_f64_512(hop, amp, floor, n_mels):
+    """f64 n_fft 512 (the reference's Mel benchmark shape 512 / 256 in its default type) on k_d512: both staging depths (hop <= 148 / <= 260),
+    odd and even frame counts (a slot's second frame may not exist), centre on and off, a signal's bits independent of its batch; hops
+    above 260 and odd hops stay on the register-tiled kernel."""
+    n = 37 * 256 + 77 if hop >= 64 else 2500
+    kw = dict(n_fft=512, hop=hop, amp=amp, floor=floor, dtype="float64")
+    if n_mels:
+        kw.update(n_mels=n_mels, fmin=0.0, fmax=8000.0)
+    plan, got = run_case(n=n, batch=3, **kw)
+    assert plan.kernel_name == "d512_f64"
+    x = signals(3, n, np.float64, 0)
+    assert np.array_equal(np.asarray(plan.compute_batch(x[2:3]))[0], np.asarray(got)[2])
+    run_case(n=n + hop, batch=2, centre=False, **kw)
+    assert make(512, 262, dtype="float64")[0].kernel_name == "reg_radix"
+
+
+@pytest.mark.parametrize("n", [1, 5, 255, 256, 257, 511, 512, 513, 767, 768, 769, 8191, 8192, 8193, 8447, 8448, 8449])
+@pytest.mark.parametrize("centre", [True, False])
+def test_ragged_lengths_f64_512(n, centre):
+    if not centre and n < 512:
+        n += 512
+    run_case(n=n, batch=2, n_fft=512, hop=256, centre=centre, amp="complex", dtype="float64")
+    run_case(n=n, batch=3, n_fft=512, hop=128, centre=centre, amp="power", dtype="float64")
+    run_case(n=n, batch=2, n_fft=512, hop=256, centre=centre, n_mels=80, fmin=0.0, fmax=8000.0, amp="db", floor=-80.0, dtype="float64")
+
 @pytest.mark.parametrize("n", [1, 5, 511, 512, 513, 1023, 1024, 1025, 1279, 1280, 1281, 4097, 5119, 5120, 5121])
 @pytest.mark.parametrize("centre", [True, False])
 def test_ragged_lengths_f64_1024(n, centre):
@@ -202,7 +232,8 @@ def test_ragged_lengths_f64_1024(n, centre):
     # the generic kernels at the same size: register-tiled (powers of two, composite), chirp-z, f64 complex (16-byte stores)
     ("float32", 4096, 1024, "complex", None), ("float64", 2048, 512, "complex", None), ("float64", 400, 160, "complex", None),
     ("float32", 400, 160, "complex", None), ("float32", 1009, 252, "complex", None), ("float64", 509, 128, "complex", None),
-    ("float64", 512, 128, "power", 40)])
+    ("float64", 512, 128, "power", 40), ("float64", 512, 256, "complex", None), ("float64", 512, 128, "complex", None), ("float64", 512, 256, "power", 80),
+    ("float64", 512, 64, "power", None), ("float64", 512, 260, "power", 128)])
 def test_tuned_kernels_many_tiles_per_workgroup(dtype, n_fft, hop, amp, n_mels):
     """64 x 10 s through the tuned kernels' per-lane-column (unstaged), complex and filterbank variants and through the generic kernels: several
     tiles per workgroup, every element of every row against the oracle.  Round 4 found 0.06 % of k_d32x16's complex STFT wrong at hop >= 274
@@ -636,7 +667,7 @@ def test_full_size_register_tiled_kernel(cfg2_x, n_fft, hop, dtype):
     x = cfg2_x if dtype == "float32" else cfg2_x.astype(np.float64)
     got = plan.compute_batch(x)
     # (f32 512 at hops 64 / 128 / 160 takes the tuned kernel's two-frames-per-transform mode)
-    assert plan.kernel_name == {(512, "float32"): "r32x16_f32", (2048, "float32"): "r32x32_f32", (1024, "float64"): "d32x16_f64"}.get((n_fft, dtype), "reg_radix")
+    assert plan.kernel_name == {(512, "float32"): "r32x16_f32", (2048, "float32"): "r32x32_f32", (1024, "float64"): "d32x16_f64", (512, "float64"): "d512_f64"}.get((n_fft, dtype), "reg_radix")
     nf = (160000 + 2 * (n_fft // 2) - n_fft) // hop + 1
     assert got.shape == (256, n_fft // 2 + 1, nf)
     ref = orc.spectrogram_batch(op, x, nthreads=orc.max_threads())
@@ -658,7 +689,7 @@ def test_register_tiled_mel_in_parts_ragged_rounds(cfg2_x, n_fft, hop, dtype, ba
     plan, op = make(n_fft, hop, dtype=dtype, n_mels=80, fmin=0.0, fmax=8000.0, amp="db", floor=-80.0)
     x = cfg2_x[:batch] if dtype == "float32" else cfg2_x[:batch].astype(np.float64)
     got = plan.compute_batch(x)
-    assert plan.kernel_name == ("d32x16_f64" if (n_fft, dtype) == (1024, "float64") else "reg_radix")  # (f64 1024: the tuned kernel, round 4)
+    assert plan.kernel_name == {(1024, "float64"): "d32x16_f64", (512, "float64"): "d512_f64"}.get((n_fft, dtype), "reg_radix")  # (f64 1024 / 512: the tuned kernels, round 4)
     ref = orc.spectrogram_batch(op, x.astype(np.float64), nthreads=orc.max_threads())
     pop = orc.Params(**{**op.__dict__, "amp": "power", "floor_db": None, "_keep": []})
     check(got, ref, "db", dtype, -80.0, orc.spectrogram_batch(pop, x.astype(np.float64), nthreads=orc.max_threads()))
