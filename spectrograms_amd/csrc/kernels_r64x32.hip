@@ -1,0 +1,270 @@
+// kernels_r64x32.hip — tuned f32, n_fft = 4096 STFT kernel for gfx950 (round 4): per-bin and complex outputs (filterbank outputs take the split
+// path: this kernel's per-bin power, then k_bank_rows).  k_d32x16's construction (kernels_d32x16.hip) at 2048 complex f32 points: a tile = 8
+// consecutive frames of one signal, one persistent 512-thread workgroup per CU, a 128 KiB exchange buffer ex[f][k1][n2] of 8-byte elements.
+//
+//   pass 1  lane (f = 0..7, n2 = 0..63) owns z[64 n1 + n2], n1 = 0..31, of frame f, z[n] = w[2n] x[2n] + i w[2n+1] x[2n+1] (window pre-scaled
+//           by 1/2 on the host — exact); one 32-point FFT in registers; twiddle W_2048^(k1 n2); one ds_write_b64 per value.
+//   pass 2  32 rows of 64 points.  The real split pairs Z[k] with Z[2048 - k] = row 32 - k1, element 63 - k2: the even-indexed outputs of
+//           row r pair with the odd-indexed outputs of row 32 - r.  A half row (one decimation-in-frequency step as the row is read, then a
+//           32-point FFT: 64 data registers) is one lane's work; the partner halves sit in lanes l and l + 32 of one wave and trade the
+//           upper 16 values with v_permlane32_swap_b32 (32 instructions).  Each lane then splits 16 pairs = 32 bins: own H[u] = Z[kb + 64 u]
+//           with the partner's Z[2048 - kb - 64 u], kb = r (half 0) or 64 - r (half 1).  Row 0's halves pair inside themselves (kb = 0, 32).
+//           32 rows x 2 halves x 8 frames = the 512 lanes.
+//   store   the 8 lanes of a (row, half) hold one bin of 8 consecutive frames: 32-byte runs (64 for the complex STFT).
+//
+// Samples: the tile's 7 hop + 4096 samples once, 16-byte buffer loads one tile ahead, staged in LDS over the idle exchange buffer (hop <= 2048);
+// longer hops load their columns per lane.  Reference semantics: spectrogram.rs:1301-1334, :2068-2080.
+#include <type_traits>
+#include <utility>
+
+#include "buffer_ops.h"
+#include "fft_inreg.h"
+#include "sgx_internal.h"
+
+namespace sgx {
+namespace {
+
+using namespace inreg;
+
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+
+constexpr int kQFS = 16384 + 16;           // LDS bytes per frame of ex[f][32][64] (16 B more: the 8 frames of a read group on distinct banks)
+constexpr int kQEx = 8 * kQFS;             // 131200: exchange buffer; also holds the staged samples (<= 73728 B)
+constexpr int kQWinOff = 0;                // tables behind it: v2f win[2048] = (w[2n], w[2n+1]) / 2
+constexpr int kQTw2Off = 16384;            // v2f tw2[64][16]: entry u of lane kind kb = W' = -i W_4096^(kb + 64 u)
+constexpr int kQLds = kQEx + kQTw2Off + 64 * 16 * 8;  // 155776
+
+template <int AMP>
+__device__ __forceinline__ float amp_q(float p, float eps) {
+    if constexpr (AMP == AMP_MAGNITUDE) return sqrtf(p);
+    else if constexpr (AMP == AMP_DB) return __builtin_log2f(fmaxf(p, eps)) * 3.01029995663981195f;  // as kernels_r32x16.hip
+    else return p;
+}
+
+// lanes l and l ^ 32 trade a complex value; each receives the other's as (im, re)
+__device__ __forceinline__ void trade32f(v2f &v) {
+    const float vx = v.x, vy = v.y;  // (scalars first: __builtin_bit_cast of a vector-element lvalue other than .x reads element 0 with this clang)
+    const unsigned re = __builtin_bit_cast(unsigned, vx), im = __builtin_bit_cast(unsigned, vy);
+    const v2u s1 = __builtin_amdgcn_permlane32_swap(re, im, false, false);     // re = {a.re | a.im}, im = {b.re | b.im}
+    const v2u s2 = __builtin_amdgcn_permlane32_swap(s1.y, s1.x, false, false);  // im = {b.re | a.re}, re = {b.im | a.im}
+    const unsigned nim = s2.x, nre = s2.y;
+    v.x = __builtin_bit_cast(float, nre);
+    v.y = __builtin_bit_cast(float, nim);
+}
+
+template <int MODE, int AMP, int ROUNDS>
+__global__ __launch_bounds__(512, 2) void k_r64x32(StftArgs a, unsigned per_xcd, unsigned total, unsigned slots) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned tid = threadIdx.x;
+    unsigned char *tabs = smem + kQEx;
+    ((v4f *)(tabs + kQWinOff))[tid] = ((const v4f *)a.window)[tid];                 // 4096 floats, 1024 x 16 B
+    ((v4f *)(tabs + kQWinOff))[tid + 512u] = ((const v4f *)a.window)[tid + 512u];
+    ((v4f *)(tabs + kQTw2Off))[tid] = ((const v4f *)a.tw2)[tid];                    // 8192 B
+
+    const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const unsigned lo = xcd * per_xcd, hi = min(lo + per_xcd, total);
+    unsigned wid = lo + slot;
+
+    const unsigned p1f = tid >> 6, n2 = tid & 63u;  // pass-1 identity
+    const unsigned wave = tid >> 6, lane = tid & 63u, half = lane >> 5, p2f = lane & 7u;
+    const unsigned r = wave + 8u * ((lane >> 3) & 3u);  // pass-2 job: row r (half 0: its even outputs) with row 32 - r (half 1: its odd outputs)
+    const unsigned row = half ? ((32u - r) & 31u) : r;
+    const bool j0 = r == 0u;
+    const unsigned kb = half ? (j0 ? 32u : 64u - r) : r;  // own H[u] = Z[kb + 64 u]
+    const float eps = (float)a.eps;
+    constexpr unsigned ES = MODE == OUT_COMPLEX ? 8u : 4u;
+    const unsigned step = 64u * a.n_frames * ES;  // uniform: 64 bins further
+    const v2f *twj = (const v2f *)(tabs + kQTw2Off) + kb * 16u;
+    v2f twa[4], twb[8];  // W_2048^(k1 n2) = twa[k1 >> 3] * twb[k1 & 7]
+    {
+        const v2f *t1 = (const v2f *)a.tw1 + n2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) twa[q] = t1[64 * 8 * q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) twb[q] = t1[64 * q];
+    }
+    const float sg = half ? -1.f : 1.f, hb = half ? 1.f : 0.f;
+
+    constexpr int NCR = ROUNDS > 0 ? ROUNDS : 1;
+    v4f creg[NCR];
+    v2f xd[ROUNDS > 0 ? 1 : 32];
+    const unsigned hop = a.hop;
+    const unsigned row_bytes = (unsigned)a.n_samples * 4u;  // host: n_samples < 2^29
+    auto load_tile = [&](unsigned w) {
+        const unsigned b = w / a.tiles, f0 = (w - b * a.tiles) * 8u;
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc((const float *)a.x + (size_t)b * a.sample_stride, row_bytes);
+        const int tile_lo = (int)(f0 * hop) - (int)a.pad;  // (negative in the left padding: out of range as an unsigned offset, reads 0 — S1)
+        if constexpr (ROUNDS > 0) {
+            const int vo = (tile_lo + 4 * (int)tid) * 4;
+#pragma unroll
+            for (int q = 0; q < ROUNDS; ++q) creg[q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rx, vo + q * 8192, 0, 0));
+        } else {
+            const int vo = ((int)(p1f * hop) + tile_lo + 2 * (int)n2) * 4;  // (even hop: a pair never straddles the row start)
+#pragma unroll
+            for (int n1 = 0; n1 < 32; ++n1) {
+                int o = vo + n1 * 512;
+                asm("" : "+v"(o));  // the whole offset in the lane register: an immediate part is added without wrapping (buffer_ops.h)
+                xd[n1] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rx, o, 0, 0));
+            }
+        }
+    };
+    if (wid < hi) load_tile(wid);
+    __syncthreads();  // tables visible
+
+    const unsigned char *xs = smem + p1f * hop * 4u + n2 * 8u;
+    const v2f *w2 = (const v2f *)(tabs + kQWinOff) + n2;
+
+    while (wid < hi) {
+        const unsigned b = wid / a.tiles, f0 = (wid - b * a.tiles) * 8u;
+        const unsigned nf = min(8u, a.n_frames - f0);
+        v2f xr[32];
+        {
+            v2f e[16], we[16], o[16], wo[16];
+            if constexpr (ROUNDS > 0) {
+#pragma unroll
+                for (int q = 0; q < ROUNDS; ++q) *(v4f *)(smem + (q * 512u + tid) * 16u) = creg[q];
+                __syncthreads();  // barrier 1: the staged samples are complete
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {  // n1 = 2 k
+                if constexpr (ROUNDS > 0) e[k] = *(const v2f *)(xs + k * 1024);
+                else e[k] = xd[2 * k];
+                we[k] = w2[128 * k];
+            }
+            Fft<16, true>::run(e, we);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {  // n1 = 2 k + 1
+                if constexpr (ROUNDS > 0) o[k] = *(const v2f *)(xs + k * 1024 + 512);
+                else o[k] = xd[2 * k + 1];
+                wo[k] = w2[128 * k + 64];
+            }
+            Fft<16, true>::run(o, wo);
+            Comb<32, 0, v2f>::run(xr, e, o);
+        }
+        if constexpr (ROUNDS > 0) __syncthreads();  // barrier 2: every wave has read its columns: pass 1 may write ex
+        {
+            unsigned char *dst = smem + p1f * kQFS + n2 * 8u;
+#pragma unroll
+            for (int k1 = 0; k1 < 32; ++k1) {  // twiddle by W_2048^(k1 n2), write row k1 of this lane's column
+                const int qa = k1 >> 3, qb = k1 & 7;
+                v2f v = xr[k1];
+                if (qb) v = cmulv(v, twb[qb]);
+                if (qa) v = cmulv(v, twa[qa]);
+                *(v2f *)(dst + k1 * 512) = v;
+            }
+        }
+        const unsigned next = wid + slots;
+        if (next < hi) load_tile(next);  // in flight during pass 2
+        __syncthreads();  // barrier 3: ex complete
+        // pass 2.  A lane whose frame does not exist (last tile of a signal) mirrors the tile's last frame: same values to the same addresses.
+        const unsigned fe = min(p2f, nf - 1u);
+        v2f H[32];
+        {
+            const unsigned char *rp = smem + fe * kQFS + row * 512u;
+            float hbl = hb;
+            asm volatile("" : "+v"(hbl));  // (not loop-invariant: the 31 lane twiddles below would otherwise be kept in registers across tiles)
+            // one decimation-in-frequency step: even outputs x[n] + x[n + 32]; odd: (x[n] - x[n + 32]) W_64^n
+#pragma unroll
+            for (int n = 0; n < 32; n += 2) {
+                const v4f a0 = *(const v4f *)(rp + n * 8), a1 = *(const v4f *)(rp + n * 8 + 256);
+                v2f d0 = pfma((v2f){a1.x, a1.y}, (v2f){sg, sg}, (v2f){a0.x, a0.y});
+                v2f d1 = pfma((v2f){a1.z, a1.w}, (v2f){sg, sg}, (v2f){a0.z, a0.w});
+                if (n > 0) {
+                    const float c = (float)kCos64[n], s = (float)-kSin64[n];  // W_64^n
+                    d0 = cmulv(d0, (v2f){__builtin_fmaf(hbl, c - 1.f, 1.f), hbl * s});  // half 0: 1; half 1: W_64^n
+                }
+                {
+                    const float c = (float)kCos64[n + 1], s = (float)-kSin64[n + 1];
+                    d1 = cmulv(d1, (v2f){__builtin_fmaf(hbl, c - 1.f, 1.f), hbl * s});
+                }
+                H[n] = d0;
+                H[n + 1] = d1;
+                if ((n & 7) == 6) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();  // barrier 4: ex consumed: the next staging may overwrite it
+        Fft<32, false>::run(H, H);
+        const v2f h16 = H[16];
+        v2f R[16];  // R[j] = the partner's H[16 + j] as (im, re)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            R[j] = H[16 + j];
+            trade32f(R[j]);
+        }
+        if (j0) {
+            // row 0: both halves pair inside themselves.  Half 0 (E[m] = Z[64 m]): E[u] with E[32 - u] (u = 0: Z[0] with itself gives bins 0 and
+            // 2048; E[16] = Z[1024] pairs with itself, below).  Half 1 (O[m] = Z[32 + 64 m]): O[u] with O[31 - u].
+#pragma unroll
+            for (int j = 0; j < 15; ++j) R[j] = swp(half ? H[16 + j] : H[17 + j]);
+            R[15] = swp(half ? H[31] : H[0]);
+            asm volatile("" ::: "memory");  // keeps this a branch
+        }
+        const unsigned p2ofs = f0 + fe;
+        const __amdgpu_buffer_rsrc_t ro = make_rsrc((unsigned char *)a.out + (size_t)b * 2049u * a.n_frames * ES, 2049u * a.n_frames * ES);
+        // bins kb + 64 u upwards; the mirrored bins 2048 - kb - 64 u count down: lane part 15 steps low, scalar part (15 - u) steps
+        const unsigned oa = (kb * a.n_frames + p2ofs) * ES, ob = ((2048u - 960u - kb) * a.n_frames + p2ofs) * ES;
+        auto emit = [&](unsigned voff, unsigned soff, v2f X, bool conj) {
+            if constexpr (MODE == OUT_COMPLEX) {
+                const v2f V = conj ? (v2f){X.x, -X.y} : X;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, V), ro, (int)voff, (int)soff, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, amp_q<AMP>(__builtin_fmaf(X.x, X.x, X.y * X.y), eps)), ro, (int)voff, (int)soff, 0);
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            // pair (P, Q) = (Z[k], Z[2048 - k]): E = (P.x + Q.x, P.y - Q.y), D = (P.x - Q.x, P.y + Q.y), T = W' D with W' = -i W_4096^k:
+            //   X[k] = E + T, X[2048 - k] = conj(E - T)   (window pre-halved: no 1/2)
+            const v2f P = H[u], Q = swp(R[15 - u]);
+            const v2f E = pfma(Q, (v2f){1.f, -1.f}, P), D = pfma(Q, (v2f){-1.f, 1.f}, P);
+            const v2f T = cmulv(D, twj[u]);
+            emit(oa, u * step, E + T, false);
+            emit(ob, (15 - u) * step, E - T, true);
+        }
+        if (j0 && half == 0u) emit((1024u * a.n_frames + p2ofs) * ES, 0u, h16 * (v2f){2.f, -2.f}, false);  // X[1024] = 2 conj(Z[1024])
+        wid = next;
+    }
+}
+
+template <int MODE, int AMP>
+hipError_t launch_variant_q(const StftArgs &a, hipStream_t s) {
+    const unsigned total = a.tiles * a.batch;
+    const unsigned per_xcd = (total + 7u) / 8u;
+    const unsigned cu_slots = std::max(1u, device_cu_count() / 8u);
+    const unsigned nslots = per_xcd < cu_slots ? per_xcd : cu_slots;  // one 512-thread workgroup per CU
+    const unsigned bytes = (7u * a.hop + 4096u) * 4u;                 // a tile's samples
+    auto go = [&](auto kernel) -> hipError_t {
+        hipError_t e = set_max_dynamic_lds((const void *)kernel, kQLds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kernel, dim3(nslots * 8), dim3(512), kQLds, s, a, per_xcd, total, nslots);
+        return hipGetLastError();
+    };
+    if (bytes <= 6u * 8192u) return go(k_r64x32<MODE, AMP, 6>);
+    if (bytes <= 9u * 8192u) return go(k_r64x32<MODE, AMP, 9>);
+    return go(k_r64x32<MODE, AMP, 0>);
+}
+
+}  // namespace
+
+bool plan_geometry_r64x32_f32(StftArgs &a) {
+    if (a.n_fft != 4096 || (a.hop & 1u) || a.out_mode == OUT_MEL) return false;  // (filterbank outputs: per-bin power here, then k_bank_rows)
+    if (a.batch > 1u && a.n_frames < 4u) return false;                                      // batches of very short signals: mostly empty tiles
+    if (a.n_samples >= (1ull << 29)) return false;                                        // 32-bit byte offsets into a sample row
+    if ((unsigned long long)a.n_frames * 2049ull * 8ull >= 0x7fffffffull) return false;  // and into one output signal
+    a.ft = 8;
+    return true;
+}
+
+hipError_t launch_r64x32_f32(const StftArgs &a, hipStream_t s) {
+    const unsigned long long total64 = (unsigned long long)a.tiles * a.batch;
+    if (total64 == 0 || total64 >= 0x7ffffff0ull) return hipErrorInvalidConfiguration;
+    if (a.out_mode == OUT_COMPLEX) return launch_variant_q<OUT_COMPLEX, AMP_POWER>(a, s);
+    if (a.out_mode != OUT_LINEAR) return hipErrorInvalidConfiguration;
+    if (a.amp == AMP_MAGNITUDE) return launch_variant_q<OUT_LINEAR, AMP_MAGNITUDE>(a, s);
+    if (a.amp == AMP_DB) return launch_variant_q<OUT_LINEAR, AMP_DB>(a, s);
+    return launch_variant_q<OUT_LINEAR, AMP_POWER>(a, s);
+}
+
+}  // namespace sgx
