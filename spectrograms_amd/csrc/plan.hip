@@ -708,6 +708,28 @@ sgx_status build_device_tables(sgx_plan *pl) {
         if ((st = upload<float>(pl, &pl->d_window_half, wh)) != SGX_OK) return st;
         if ((st = upload<float>(pl, &pl->d_ones_half, oh)) != SGX_OK) return st;
     }
+    if (pl->kind == K_D32X32_F64) {
+        // tw1[k1][n2] = W_1024^(k1 n2), 32 x 32 (pass-1 twiddles); tw2[kb][u] = W' = -i W_2048^(kb + 64 u) (kernels_d32x32.hip); window w / 2
+        std::vector<double> t1(2 * 32 * 32), t2(2 * 64 * 8);
+        for (unsigned k1 = 0; k1 < 32; ++k1)
+            for (unsigned n2 = 0; n2 < 32; ++n2) {
+                const double a = -2.0 * kPi * double(k1 * n2) / 1024.0;
+                t1[2 * (k1 * 32 + n2)] = std::cos(a);
+                t1[2 * (k1 * 32 + n2) + 1] = std::sin(a);
+            }
+        for (unsigned kb = 0; kb < 64; ++kb)
+            for (unsigned u = 0; u < 8; ++u) {
+                const double a = -2.0 * kPi * double(kb + 64 * u) / 2048.0;
+                t2[2 * (kb * 8 + u)] = std::sin(a);       // W' = -i (wr + i wi) = (wi, -wr)
+                t2[2 * (kb * 8 + u) + 1] = -std::cos(a);
+            }
+        if ((st = upload<double>(pl, &pl->d_tw1, t1)) != SGX_OK) return st;
+        if ((st = upload<double>(pl, &pl->d_tw2, t2)) != SGX_OK) return st;
+        std::vector<double> wh(2048), oh(2048, 0.5);
+        for (unsigned i = 0; i < 2048; ++i) wh[i] = 0.5 * double(pl->window[i]);
+        if ((st = upload<double>(pl, &pl->d_window_half, wh)) != SGX_OK) return st;
+        if ((st = upload<double>(pl, &pl->d_ones_half, oh)) != SGX_OK) return st;
+    }
     if (pl->kind == K_D512_F64) {
         // tw1[k1][n2] = W_512^(k1 n2), 16 x 32 (the 512-point complex transform of a frame pair: kernels_d32x16.hip k_d512); window w[n] / 2
         std::vector<double> t1(2 * 16 * 32);
@@ -850,6 +872,7 @@ bool set_geometry(const sgx_plan *pl, StftArgs &a, KernelKind kind) {
     case K_D32X16_F64: ok = plan_geometry_d32x16_f64(a); break;
     case K_D512_F64: ok = plan_geometry_d512_f64(a); break;
     case K_R64X32_F32: ok = plan_geometry_r64x32_f32(a); break;
+    case K_D32X32_F64: ok = plan_geometry_d32x32_f64(a); break;
     case K_LDS_RADIX2: ok = plan_geometry_lds_radix2(a, pl->dtype); break;
     case K_DIRECT_DFT: ok = plan_geometry_direct_dft(a, pl->dtype); break;
     case K_TWO_FACTOR: ok = plan_geometry_two_factor(a, pl->dtype); break;
@@ -888,6 +911,7 @@ hipError_t launch(sgx_plan *pl, const StftArgs &a, KernelKind kind, hipStream_t 
     case K_D32X16_F64: return launch_d32x16_f64(a, s);
     case K_D512_F64: return launch_d512_f64(a, s);
     case K_R64X32_F32: return launch_r64x32_f32(a, s);
+    case K_D32X32_F64: return launch_d32x32_f64(a, s);
     case K_LDS_RADIX2: return launch_lds_radix2(a, pl->dtype, s);
     case K_TWO_FACTOR: return launch_two_factor(a, pl->dtype, s);
     case K_REG_RADIX: return launch_reg_radix(a, pl->dtype, s);
@@ -1223,6 +1247,7 @@ const char *sgx_kernel_name(const sgx_plan *plan) {
     case K_D32X16_F64: return "d32x16_f64";
     case K_D512_F64: return "d512_f64";
     case K_R64X32_F32: return "r64x32_f32";
+    case K_D32X32_F64: return "d32x32_f64";
     case K_LDS_RADIX2: return "lds_radix2";
     case K_TWO_FACTOR: return "two_factor_dft";
     case K_REG_RADIX: return "reg_radix";
@@ -1278,6 +1303,7 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
     if (params->dtype == SGX_F64 && params->n_fft == 1024 && params->hop_size % 2 == 0) pl->kind = K_D32X16_F64;  // per-bin and complex outputs (filterbanks, odd hops: register-tiled kernel)
     if (params->dtype == SGX_F64 && params->n_fft == 512 && params->hop_size % 2 == 0 && params->hop_size <= 260) pl->kind = K_D512_F64;  // two frames per transform
     if (params->dtype == SGX_F32 && params->n_fft == 4096 && params->hop_size % 2 == 0) pl->kind = K_R64X32_F32;  // per-bin and complex outputs; filterbanks: split path
+    if (params->dtype == SGX_F64 && params->n_fft == 2048 && params->hop_size % 2 == 0) pl->kind = K_D32X32_F64;  // per-bin and complex outputs
     if (pl->kind == K_R32X16_F32) build_band_schedule(pl);  // before the kind is resolved: plan_geometry_r32x16_f32 asks for it
     if (pl->kind == K_R32X32_F32) build_band_schedule(pl, 8, r32x32::kSegs2, r32x32::kSch2MaxWords, 0);
     if (pl->kind == K_D32X16_F64) build_band_schedule(pl, 8, d32x16::kDSegs, d32x16::kDSchMaxWords, 0, 2);

@@ -19,8 +19,8 @@ namespace sgx {
 enum OutMode : int { OUT_LINEAR = 0, OUT_MEL = 1, OUT_COMPLEX = 2 };
 // AMP_MAG_IN: the mapping consumes sqrt(power) and its output is final (chromagram: bank applied to magnitudes)
 enum AmpMode : int { AMP_POWER = 0, AMP_MAGNITUDE = 1, AMP_DB = 2, AMP_MAG_IN = 3 };
-enum KernelKind : int { K_DIRECT_DFT = 0, K_LDS_RADIX2 = 1, K_R32X16_F32 = 2, K_TWO_FACTOR = 3, K_REG_RADIX = 4, K_BLUESTEIN = 5, K_R32X32_F32 = 6, K_D32X16_F64 = 7, K_D512_F64 = 8, K_R64X32_F32 = 9 };
-inline bool kind_is_tuned(KernelKind k) { return k == K_R32X16_F32 || k == K_R32X32_F32 || k == K_D32X16_F64 || k == K_D512_F64 || k == K_R64X32_F32; }  // the shape-specific kernels at the head of the chain
+enum KernelKind : int { K_DIRECT_DFT = 0, K_LDS_RADIX2 = 1, K_R32X16_F32 = 2, K_TWO_FACTOR = 3, K_REG_RADIX = 4, K_BLUESTEIN = 5, K_R32X32_F32 = 6, K_D32X16_F64 = 7, K_D512_F64 = 8, K_R64X32_F32 = 9, K_D32X32_F64 = 10 };
+inline bool kind_is_tuned(KernelKind k) { return k == K_R32X16_F32 || k == K_R32X32_F32 || k == K_D32X16_F64 || k == K_D512_F64 || k == K_R64X32_F32 || k == K_D32X32_F64; }  // the shape-specific kernels at the head of the chain
 
 // Kernel arguments (POD, passed by value).  Layouts in HBM:
 //   x      : [batch][sample_stride] T, row b valid for n_samples elements
@@ -87,6 +87,8 @@ hipError_t launch_d512_f64(const StftArgs &a, hipStream_t s);  // f64 n_fft 512,
 bool plan_geometry_d512_f64(StftArgs &a);
 hipError_t launch_r64x32_f32(const StftArgs &a, hipStream_t s);  // f32 n_fft 4096, per-bin and complex outputs (kernels_r64x32.hip)
 bool plan_geometry_r64x32_f32(StftArgs &a);
+hipError_t launch_d32x32_f64(const StftArgs &a, hipStream_t s);  // f64 n_fft 2048, per-bin and complex outputs (kernels_d32x32.hip)
+bool plan_geometry_d32x32_f64(StftArgs &a);
 // MFCC epilogue over a Mel-dB tensor [batch][n_mels][n_frames] -> [batch][n_out][n_frames]; basis [n_mfcc][n_mels], lifter [n_mfcc]
 hipError_t launch_mfcc(const void *mel, void *out, const void *basis, const void *lifter, unsigned batch, unsigned n_mels,
                        unsigned n_frames, unsigned n_mfcc, unsigned skip, int has_lifter, int dtype, hipStream_t s);

@@ -134,9 +134,9 @@ def test_pow2_sizes(n_fft, hop, amp, dtype):
     plan, _ = run_case(n=max(6000, 3 * n_fft), n_fft=n_fft, hop=hop, amp=amp, dtype=dtype)
     fits = n_fft <= (4096 if dtype == "float64" else 8192)  # an 8192-point f64 tile (164 KB with its tables) exceeds the CU's LDS
     tuned = dtype == "float32" and (n_fft == 1024 or (n_fft == 512 and hop in (64, 128, 160, 256)) or (n_fft in (2048, 4096) and hop % 2 == 0))
-    tuned64 = dtype == "float64" and hop % 2 == 0 and (n_fft == 1024 or (n_fft == 512 and hop <= 260))
+    tuned64 = dtype == "float64" and hop % 2 == 0 and (n_fft in (1024, 2048) or (n_fft == 512 and hop <= 260))
     if tuned64:
-        assert plan.kernel_name == ("d32x16_f64" if n_fft == 1024 else "d512_f64")
+        assert plan.kernel_name == {1024: "d32x16_f64", 512: "d512_f64", 2048: "d32x32_f64"}[n_fft]
     elif 32 <= n_fft and fits and not tuned:
         assert plan.kernel_name == "reg_radix"
 
@@ -231,7 +231,8 @@ def test_ragged_lengths_f64_1024(n, centre):
     ("float32", 1024, 512, "complex", None), ("float32", 1024, 600, "power", 80), ("float32", 512, 256, "power", 80), ("float32", 512, 256, "power", 128),
     # the generic kernels at the same size: register-tiled (powers of two, composite), chirp-z, f64 complex (16-byte stores)
     ("float32", 4096, 1024, "complex", None), ("float32", 4096, 1024, "power", None), ("float32", 4096, 2048, "power", None), ("float32", 4096, 4096, "complex", None),
-    ("float32", 4096, 1024, "power", 80), ("float64", 2048, 512, "complex", None), ("float64", 400, 160, "complex", None),
+    ("float32", 4096, 1024, "power", 80), ("float64", 2048, 512, "complex", None), ("float64", 2048, 1024, "power", None), ("float64", 2048, 2048, "complex", None),
+    ("float64", 2048, 512, "power", 80), ("float64", 400, 160, "complex", None),
     ("float32", 400, 160, "complex", None), ("float32", 1009, 252, "complex", None), ("float64", 509, 128, "complex", None),
     ("float64", 512, 128, "power", 40), ("float64", 512, 256, "complex", None), ("float64", 512, 128, "complex", None), ("float64", 512, 256, "power", 80),
     ("float64", 512, 64, "power", None), ("float64", 512, 260, "power", 128)])
@@ -276,6 +277,30 @@ def test_ragged_lengths_4096(n, centre):
         n += 4096
     run_case(n=n, batch=2, n_fft=4096, hop=1024, centre=centre, amp="complex")
     run_case(n=n, batch=3, n_fft=4096, hop=512, centre=centre, amp="power")
+
+
+# ------------------------------------------------------------------ n_fft 2048, f64: the tuned kernel k_d32x32 (round 4)
+@pytest.mark.parametrize("hop", [1024, 512, 256, 2048, 100, 584, 586, 1026, 2])
+@pytest.mark.parametrize("amp,floor", [("complex", None), ("power", None), ("magnitude", None), ("db", -80.0)])
+def test_tuned_f64_2048(hop, amp, floor):
+    """f64 n_fft 2048 (the reference's Criterion shape 2048 / 1024 in its type) on k_d32x32: two lanes per column in pass 1, half rows in lane
+    pairs in pass 2; both staging depths and the per-lane columns above hop 1024; frame counts that are not multiples of 8; centre on and off."""
+    n = 27 * 512 + 77 if hop >= 100 else 5000
+    kw = dict(n_fft=2048, hop=hop, amp=amp, floor=floor, dtype="float64")
+    plan, got = run_case(n=n, batch=3, **kw)
+    assert plan.kernel_name == "d32x32_f64"
+    x = signals(3, n, np.float64, 0)
+    assert np.array_equal(np.asarray(plan.compute_batch(x[2:3]))[0], np.asarray(got)[2])
+    run_case(n=n, batch=2, centre=False, **kw)
+
+
+@pytest.mark.parametrize("n", [1, 5, 1023, 1024, 1025, 2047, 2048, 2049, 2559, 2560, 2561, 6143, 6144, 6145])
+@pytest.mark.parametrize("centre", [True, False])
+def test_ragged_lengths_f64_2048(n, centre):
+    if not centre and n < 2048:
+        n += 2048
+    run_case(n=n, batch=2, n_fft=2048, hop=512, centre=centre, amp="complex", dtype="float64")
+    run_case(n=n, batch=3, n_fft=2048, hop=1024, centre=centre, amp="power", dtype="float64")
 
 @pytest.mark.parametrize("n", [1, 5, 1023, 1024, 1025, 2047, 2048, 2049, 2559, 2560, 2561, 8193, 10239, 10240, 10241])
 @pytest.mark.parametrize("centre", [True, False])
@@ -328,7 +353,7 @@ def test_long_frames_filterbank_in_a_second_launch(n_fft, hop, dtype, n_mels, no
     multiples of 64, one signal vs the batch, and a second call on the same plan (the tensor is reused)."""
     plan, got = run_case(n=5 * n_fft + 123, batch=3, n_fft=n_fft, hop=hop, n_mels=n_mels, norm=norm, amp=amp, floor=floor, dtype=dtype)
     assert plan.kernel_name == {(16384, "float32"): "lds_radix2", (8192, "float64"): "lds_radix2", (3000, "float32"): "bluestein",
-                                (6000, "float32"): "bluestein", (4096, "float32"): "r64x32_f32"}.get((n_fft, dtype), "reg_radix")  # (4096 f32: per-bin power on the tuned kernel)
+                                (6000, "float32"): "bluestein", (4096, "float32"): "r64x32_f32", (2048, "float64"): "d32x32_f64"}.get((n_fft, dtype), "reg_radix")  # (4096 f32, 2048 f64: per-bin power on the tuned kernels)
     x = signals(3, 5 * n_fft + 123, np.float32 if dtype == "float32" else np.float64, 0)
     assert np.array_equal(np.asarray(plan.compute_batch(x[1:2]))[0], np.asarray(got)[1])
     assert np.array_equal(np.asarray(plan.compute_batch(x)), np.asarray(got))

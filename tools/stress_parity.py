@@ -15,7 +15,7 @@ CASES = [("float32", 1024, 256, "complex", 0), ("float32", 1024, 256, "power", 0
          ("float32", 2048, 512, "complex", 0), ("float32", 2048, 512, "power", 80), ("float32", 512, 128, "complex", 0), ("float32", 512, 160, "power", 80),
          ("float64", 1024, 256, "complex", 0), ("float64", 1024, 256, "power", 0), ("float64", 1024, 256, "power", 80), ("float64", 1024, 512, "complex", 0),
          ("float64", 512, 128, "complex", 0), ("float64", 512, 256, "power", 80), ("float64", 512, 256, "power", 0), ("float32", 512, 256, "power", 80),
-         ("float32", 4096, 1024, "complex", 0), ("float32", 4096, 1024, "power", 0), ("float32", 400, 160, "power", 80)]
+         ("float32", 4096, 1024, "complex", 0), ("float64", 2048, 512, "complex", 0), ("float64", 2048, 1024, "power", 0), ("float32", 4096, 1024, "power", 0), ("float32", 400, 160, "power", 80)]
 bad_total = 0
 for dtype, n_fft, hop, amp, nm in CASES:
     x = base.astype(np.float64 if dtype == "float64" else np.float32)
