@@ -582,7 +582,7 @@ bool plan_geometry_d32x16_f64(StftArgs &a) {
     if (a.n_fft != 1024 || (a.hop & 1u)) return false;
     // batches of short signals: a tile is 16 frames of ONE signal, so 5-frame signals leave 11/16 of every tile idle and the register-tiled
     // kernel (tiles of 1-2 frames at this length) is faster: 16 384 x 5 frames 351 us here against 254 us (17 frames: 175 against 227)
-    if (a.batch > 1u && a.n_frames < 8u) return false;
+    if (a.x != nullptr && a.n_frames < 8u) return false;
     // filterbank outputs need the band schedule (built on the host before this is asked; a bank without one takes the register-tiled kernel)
     if (a.out_mode == OUT_MEL && (a.mel_sched_words == 0 || a.mel_sched_words > (unsigned)kDSchMaxWords)) return false;
     if (a.n_samples >= (1ull << 28)) return false;                                        // 32-bit byte offsets into a sample row
@@ -609,7 +609,7 @@ hipError_t launch_d32x16_f64(const StftArgs &a, hipStream_t s) {
 
 bool plan_geometry_d512_f64(StftArgs &a) {
     if (a.n_fft != 512 || (a.hop & 1u) || a.hop > 260u) return false;  // (the whole 32-frame tile is staged: (31 hop + 512) * 8 <= 9 * 8192)
-    if (a.batch > 1u && a.n_frames < 16u) return false;  // batches of short signals: mostly empty 32-frame tiles (see plan_geometry_d32x16_f64)
+    if (a.x != nullptr && a.n_frames < 16u) return false;  // batches of short signals: mostly empty 32-frame tiles (see plan_geometry_d32x16_f64)
     if (a.out_mode == OUT_MEL && (a.mel_sched_words == 0 || a.mel_sched_words > (unsigned)d512::kSchMaxWords)) return false;
     if (a.n_samples >= (1ull << 28)) return false;
     if ((unsigned long long)a.n_frames * 257ull * 16ull >= 0x7fffffffull) return false;

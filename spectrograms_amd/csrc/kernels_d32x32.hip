@@ -256,7 +256,7 @@ hipError_t launch_variant_e(const StftArgs &a, hipStream_t s) {
 
 bool plan_geometry_d32x32_f64(StftArgs &a) {
     if (a.n_fft != 2048 || (a.hop & 1u) || a.out_mode == OUT_MEL) return false;  // (filterbank outputs: the register-tiled kernel)
-    if (a.batch > 1u && a.n_frames < 4u) return false;                                      // batches of very short signals: mostly empty tiles
+    if (a.x != nullptr && a.n_frames < 4u) return false;                                      // batches of very short signals: mostly empty tiles
     if (a.n_samples >= (1ull << 28)) return false;                                        // 32-bit byte offsets into a sample row
     if ((unsigned long long)a.n_frames * 1025ull * 16ull >= 0x7fffffffull) return false;  // and into one output signal
     a.ft = 8;

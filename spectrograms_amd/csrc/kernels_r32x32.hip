@@ -355,7 +355,7 @@ hipError_t launch_variant2(const StftArgs &a, hipStream_t s) {
 
 bool plan_geometry_r32x32_f32(StftArgs &a) {
     if (a.n_fft != 2048 || (a.hop & 1u)) return false;
-    if (a.batch > 1u && a.n_frames < 5u) return false;  // batches of very short signals: mostly empty 16-frame tiles (16 384 x 5 frames: even with k_reg_radix)
+    if (a.x != nullptr && a.n_frames < 5u) return false;  // batches of very short signals: mostly empty 16-frame tiles (16 384 x 5 frames: even with k_reg_radix)
     if (a.n_samples >= (1ull << 29)) return false;                                        // 32-bit byte offsets into a sample row
     if ((unsigned long long)a.n_frames * 1025ull * 8ull >= 0x7fffffffull) return false;  // and into one output signal
     // filterbank outputs need the band schedule (built on the host before this is asked; a bank without one takes the register-tiled kernel)

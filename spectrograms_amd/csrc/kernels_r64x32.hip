@@ -250,7 +250,7 @@ hipError_t launch_variant_q(const StftArgs &a, hipStream_t s) {
 
 bool plan_geometry_r64x32_f32(StftArgs &a) {
     if (a.n_fft != 4096 || (a.hop & 1u) || a.out_mode == OUT_MEL) return false;  // (filterbank outputs: per-bin power here, then k_bank_rows)
-    if (a.batch > 1u && a.n_frames < 4u) return false;                                      // batches of very short signals: mostly empty tiles
+    if (a.x != nullptr && a.n_frames < 4u) return false;                                      // batches of very short signals: mostly empty tiles
     if (a.n_samples >= (1ull << 29)) return false;                                        // 32-bit byte offsets into a sample row
     if ((unsigned long long)a.n_frames * 2049ull * 8ull >= 0x7fffffffull) return false;  // and into one output signal
     a.ft = 8;

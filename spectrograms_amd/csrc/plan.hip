@@ -1532,10 +1532,8 @@ sgx_status sgx_r2c(sgx_plan *plan, const void *in, size_t in_len, void *out, siz
     a.n_out = plan->nb_fft;
     a.amp = AMP_POWER;
     KernelKind kind = plan->kind;
-    if (!set_geometry(plan, a, kind)) {
-        kind = K_DIRECT_DFT;
-        if (!set_geometry(plan, a, kind)) return set_err(plan, SGX_BACKEND, "hip -- FFT backend error: n_fft too large");
-    }
+    if (!resolve_geometry(plan, a, kind))  // (down the chain: a single frame leaves the tuned kernels' multi-frame tiles for the register-tiled kernel)
+        return set_err(plan, SGX_BACKEND, "hip -- FFT backend error: n_fft too large");
     if (kind_is_tuned(kind)) a.window = plan->d_ones_half;
     SGX_HIP(plan, launch(plan, a, kind, nullptr));
     SGX_HIP(plan, hipMemcpy(out, plan->d_out, 2 * nb * plan->elem, hipMemcpyDeviceToHost));

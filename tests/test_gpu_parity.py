@@ -781,6 +781,42 @@ def test_fuzz_shapes():
     assert {"reg_radix", "direct_dft", "lds_radix2", "bluestein"} <= seen, seen  # (two-factor: its own tests above)
 
 
+def test_fuzz_tuned_kernels():
+    """Seeded random sweep over the shape-specific kernels only (even hops): every staging depth and the per-lane-column variants, windows,
+    centre on / off, signals from shorter than a frame to dozens of tiles, batches up to several tiles per workgroup, every output mode —
+    against the oracle; the batch's last signal against its own launch, bit for bit."""
+    rng = np.random.default_rng(424242)
+    shapes = [("float32", 512), ("float32", 1024), ("float32", 2048), ("float32", 4096), ("float64", 512), ("float64", 1024), ("float64", 2048)]
+    seen = set()
+    for case in range(70):
+        dtype, n_fft = shapes[case % len(shapes)]
+        if n_fft == 512:
+            hop = int(rng.choice([64, 128, 160, 256])) if dtype == "float32" else 2 * int(rng.integers(1, 131))
+        else:
+            hop = 2 * int(rng.integers(1, n_fft // 2 + 1))
+        centre = bool(rng.integers(2))
+        window = sorted(WINDOWS)[rng.integers(len(WINDOWS))]
+        n = int(rng.integers(1, 60 * n_fft)) if rng.integers(3) else int(rng.integers(1, 3 * n_fft))
+        if not centre and n < n_fft:
+            n = n_fft + int(rng.integers(0, 3 * n_fft))
+        batch = int(rng.choice([1, 2, 3, 9, 40]))
+        kind = rng.integers(4)
+        kw = dict(n_fft=n_fft, hop=hop, centre=centre, window=window, dtype=dtype)
+        if kind == 0:
+            kw["amp"] = "complex"
+        elif kind == 1:
+            kw["amp"] = "power"
+        elif kind == 2:
+            kw.update(amp="db", floor=-80.0)
+        else:
+            kw.update(n_mels=int(rng.choice([24, 40, 80, 128])), fmin=0.0, fmax=8000.0, amp=str(rng.choice(["power", "magnitude"])))
+        plan, got = run_case(n=n, batch=batch, seed=1000 + case, **kw)
+        seen.add(plan.kernel_name)
+        x = signals(batch, n, np.float32 if dtype == "float32" else np.float64, 1000 + case)
+        assert np.array_equal(np.asarray(plan.compute_batch(x[batch - 1:]))[0], np.asarray(got)[batch - 1]), (case, kw, n, batch)
+    assert {"r32x16_f32", "r32x32_f32", "r64x32_f32", "d512_f64", "d32x16_f64", "d32x32_f64"} <= seen, seen
+
+
 def test_fuzz_chirpz_lengths():
     """Seeded sweep over frame lengths that take the chirp-z kernel (primes, 2 x prime, odd composites, unlisted even sizes; every
     convolution length from 64 to 16384): random hop, centre, window, signal length (shorter than a frame included), batch, output
