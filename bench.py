@@ -69,8 +69,10 @@ STAMP_FILES = {
     "stft": ("kernels_r32x16.hip", "fft_inreg.h", "r32x16_layout.h"),
     "2d": ("kernels_r32x16.hip", "kernels_c2c1024.hip", "fft2d.hip", "fft_inreg.h", "r32x16_layout.h"),
     "istft": ("kernels_c2c1024.hip", "fft_inreg.h"),
+    "f64": ("kernels_d32x16.hip", "d32x16_layout.h", "fft_inreg.h"),
 }
-STAMP_FAMILY = {"linear_power": "stft", "mel_power": "stft", "mel_db": "stft", "stft": "stft", "fft2d": "2d", "convolve_fft": "2d", "istft": "istft"}
+STAMP_FAMILY = {"linear_power": "stft", "mel_power": "stft", "mel_db": "stft", "stft": "stft", "fft2d": "2d", "convolve_fft": "2d", "istft": "istft",
+                "linear_power_f64": "f64", "mel_db_f64": "f64"}
 
 
 def kernel_source_stamp(family: str = "stft") -> str:
@@ -434,7 +436,7 @@ def f64_leg(torch, sg, dev, name: str, xs256, args, peak):
     rd, wr = N_SAMPLES * 8.0 / n_frames, n_bins * 8.0
     fps = frames / (kernel_ms * 1e-3)
     roof = {"bound": "hbm", "achieved": (rd + wr) * fps / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (rd + wr) * fps / 1e9 / HBM_PEAK_GBS,
-            "traffic": None, "kernel_ms": kernel_ms, "kernel_ms_scope": "HIP events over the timed region", "algorithmic_bytes_per_frame": rd + wr,
+            "traffic": measured_traffic(name), "kernel_ms": kernel_ms, "kernel_ms_scope": "HIP events over the timed region", "algorithmic_bytes_per_frame": rd + wr,
             "frames_per_launch": frames}
     if peak and peak.get("copy"):
         roof["frac_of_measured_copy"] = roof["achieved"] / peak["copy"]
