@@ -35,5 +35,20 @@ for dtype, n_fft, hop, amp, nm in CASES:
         counts.append(int((np.abs(got - ref) > tol).sum()))
     bad_total += sum(counts)
     print(f"{dtype} {n_fft}/{hop} {amp}{'-mel%d' % nm if nm else ''} {plan.kernel_name}: bad elements per launch {counts}", flush=True)
+# inverse STFT: the fused kernels (f32 1024 / 2048, f64 1024) and the register-tiled path, 64 signals, every sample against the oracle
+for dtype, n_fft, hop in (("float32", 1024, 256), ("float32", 2048, 512), ("float64", 1024, 256), ("float32", 1024, 100), ("float64", 1024, 512), ("float32", 512, 128)):
+    x = base[:64].astype(np.float64 if dtype == "float64" else np.float32)
+    params = sg.SpectrogramParams(sg.StftParams(n_fft, hop, sg.WindowType.hamming, True), 16000.0)
+    plan = sg.Plan(params, _ffi.AMP_COMPLEX, None, None, dtype)
+    S = np.ascontiguousarray(plan.compute_batch(x))
+    ref = np.stack([orc.istft(S[b].astype(np.complex128), n_fft, hop, "hamming", True) for b in range(64)])
+    tol = (1e-10 if dtype == "float64" else 2e-5) * max(1.0, float(np.abs(ref).max()))
+    Sd = torch.from_numpy(S).cuda()
+    counts = []
+    for r in range(REPS):
+        y = plan.istft_batch(Sd).cpu().numpy()
+        counts.append(int((np.abs(y - ref) > tol).sum()))
+    bad_total += sum(counts)
+    print(f"istft {dtype} {n_fft}/{hop}: bad samples per launch {counts}", flush=True)
 print("TOTAL BAD", bad_total)
 sys.exit(1 if bad_total else 0)
