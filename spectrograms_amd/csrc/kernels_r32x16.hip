@@ -365,7 +365,9 @@ __device__ __forceinline__ void pass2_pair512(v2f (&A)[16], v2f (&B)[16], bool j
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, (v2f){V.x, V.y}), ro, (int)vfull, soff, 0);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, (v2f){V.z, V.w}), ro, (int)vhalf, soff, 0);
             } else {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, V), ro, (int)vfull, soff, 0);
+                // (16-byte store: the whole offset in the lane register — with a scalar-register soffset the compiler lets the next instructions
+                // rewrite the data registers at once, which cost k_d32x16 0.06 % of its complex outputs: kernels_d32x16.hip emit)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, V), ro, (int)vfull + soff, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, (v2f){V.x, V.y}), ro, (int)vhalf, soff, 0);
             }
         } else {
