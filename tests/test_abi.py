@@ -301,3 +301,20 @@ def test_kernel_kind_is_resolved_with_the_band_schedule_known():
     assert lin.kernel_name == "r32x16_f32"
     assert host_plan(512, 256, mel=sg.MelParams(40, 0.0, 8000.0), dtype="float32").kernel_name == "r32x16_f32"  # (round 4: larger LDS halves at hop 256)
     assert host_plan(512, 200, mel=sg.MelParams(40, 0.0, 8000.0), dtype="float32").kernel_name == "reg_radix"
+
+
+def test_host_plans_over_the_tuned_shapes_and_banks():
+    """Plan creation (host tables, band schedules with 4- and 8-byte weights, split-path decisions) for every shape-specific kernel with every kind
+    of bank, without a device: no crash, and the kinds a plan asks for."""
+    want = {("float32", 512, 160): "r32x16_f32", ("float32", 1024, 256): "r32x16_f32", ("float32", 2048, 512): "r32x32_f32", ("float32", 4096, 1024): "r64x32_f32",
+            ("float64", 512, 160): "d512_f64", ("float64", 1024, 256): "d32x16_f64", ("float64", 2048, 512): "d32x32_f64", ("float64", 4096, 1024): "reg_radix",
+            ("float64", 512, 262): "reg_radix", ("float32", 8192, 2048): "reg_radix"}
+    for (dtype, n_fft, hop), kernel in want.items():
+        p = sg.SpectrogramParams(sg.StftParams(n_fft, hop, sg.WindowType.hanning, True), 16000.0)
+        assert sg.Plan(p, _ffi.AMP_POWER, None, None, dtype, device=HOST).kernel_name == kernel
+        assert sg.Plan(p, _ffi.AMP_COMPLEX, None, None, dtype, device=HOST).kernel_name == kernel
+        for mel in (sg.MelParams(80, 0.0, 8000.0), sg.MelParams(128, 0.0, 8000.0), sg.MelParams(400, 0.0, 8000.0), sg.MelParams(3, 0.0, 100.0)):
+            for amp, db in ((_ffi.AMP_POWER, None), (_ffi.AMP_MAGNITUDE, None), (_ffi.AMP_DECIBELS, sg.LogParams(-80.0))):
+                assert sg.Plan(p, amp, mel, db, dtype, device=HOST).output_shape(16000)[0] == mel.n_mels
+        for bank in (sg.ErbParams(64, 50.0, 8000.0), sg.LogHzParams(64, 50.0, 8000.0)):
+            assert sg.Plan(p, _ffi.AMP_POWER, bank, None, dtype, device=HOST).output_shape(16000)[0] == 64
