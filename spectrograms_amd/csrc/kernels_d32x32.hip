@@ -1,5 +1,5 @@
-// kernels_d32x32.hip — tuned f64, n_fft = 2048 STFT kernel for gfx950 (round 4): per-bin and complex outputs (filterbank outputs: the
-// register-tiled kernel).  The reference's Criterion suite times this shape in this type (benches/stft_benchmarks.rs:11-50: f64, 2048 / 1024).
+// kernels_d32x32.hip — tuned f64, n_fft = 2048 STFT kernel for gfx950 (round 4): per-bin, complex and (up to hop 585) filterbank
+// outputs.  The reference's Criterion suite times this shape in this type (benches/stft_benchmarks.rs:11-50: f64, 2048 / 1024).
 // k_r64x32's tile at 1024 complex f64 points — 8 consecutive frames of one signal, one persistent 512-thread workgroup per CU, a 128 KiB
 // exchange buffer ex[f][k1][n2] of 16-byte elements — with 32 rows of 32 points:
 //
@@ -37,6 +37,12 @@ constexpr int kEEx = 8 * kEFS;             // 131200: exchange buffer; also hold
 constexpr int kEWinOff = 0;                // tables behind it: v2d win[1024] = (w[2n], w[2n+1]) / 2
 constexpr int kETw2Off = 16384;            // v2d tw2[64][8]: entry u of lane kind kb = W' = -i W_2048^(kb + 64 u)
 constexpr int kELds = kEEx + kETw2Off + 64 * 8 * 16;  // 155776
+// filterbank outputs (hop <= 585: 6 staging rounds): the |X|^2 tile (1036 bins x 8 frames of f64: bin k, frame f at k * 8 + f) sits in the upper
+// half of the exchange buffer, above the staged samples; the band schedule (plan.hip build_band_schedule: 16 half-waves x 8 slots, 8-byte
+// weights) stays in GLOBAL memory — its 20 KB do not fit beside the tables, and every half-wave reads its own rows through L1
+constexpr int kEPwOff = kEEx - 1036 * 64;  // 64896 >= 6 * 8192
+constexpr int kESegs = 2;
+__host__ __device__ constexpr unsigned pwd8_index(unsigned k, unsigned f) { return k * 8u + f; }
 
 template <int AMP>
 __device__ __forceinline__ double amp_e(double p, double eps) {
@@ -58,6 +64,43 @@ __device__ __forceinline__ void trade32(v2d &v) {
     }
     v.x = __builtin_bit_cast(double, re);
     v.y = __builtin_bit_cast(double, im);
+}
+
+__device__ __forceinline__ v2d mul_add_unfused_e(double w, v2d p, v2d acc) {  // the reference's `acc += w * x`: two roundings (spectrogram.rs:102-117)
+    return (v2d){__dadd_rn(__dmul_rn(w, p.x), acc.x), __dadd_rn(__dmul_rn(w, p.y), acc.y)};
+}
+
+// band stage over the tile's 8 frames: 16 half-waves x 8 slots x 4 frame pairs; a lane sums one band for two frames in ascending-bin order
+template <int AMP>
+__device__ __forceinline__ void mel_tile_sched_e(const StftArgs &a, const double *pw, const unsigned *sched, unsigned b, unsigned f0, unsigned nf,
+                                                 double eps, unsigned tid) {
+    const unsigned vw = tid >> 5, slot = (tid >> 2) & 7u, fp = tid & 3u;
+    constexpr unsigned kDrop = 0x80000000u;  // past the descriptor's range: the hardware drops the store
+    const unsigned obytes = (a.n_out * a.n_frames - f0) * 8u;
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc((const double *)a.out + (size_t)b * a.n_out * a.n_frames + f0, obytes);
+    const unsigned fo0 = 2u * fp < nf ? 16u * fp : kDrop, fo1 = 2u * fp + 1u < nf ? 16u * fp + 8u : kDrop;
+    const uint4 *info = (const uint4 *)(sched + 4) + vw * 8u + slot;
+#pragma unroll
+    for (unsigned seg = 0; seg < (unsigned)kESegs; ++seg) {
+        const uint4 cur = info[seg * 128u];
+        const unsigned L = cur.x;  // (per half-wave: the two halves of a wave run to the longer one)
+        const bool have = cur.w != 0xffffffffu;
+        if (!have) continue;
+        const v2d *wr = (const v2d *)(sched + cur.y);
+        const v2d *pr = (const v2d *)(pw + cur.z * 8u + fp * 2u);
+        v2d acc = {0.0, 0.0};
+        for (unsigned t = 0; t < L; t += 4u) {  // bins t .. t + 3, frames 2 fp and 2 fp + 1 of each
+            const v2d w01 = wr[t >> 1], w23 = wr[(t >> 1) + 1u];
+            const v2d q0 = pr[t * 4u], q1 = pr[t * 4u + 4u], q2 = pr[t * 4u + 8u], q3 = pr[t * 4u + 12u];
+            acc = mul_add_unfused_e(w01.x, q0, acc);
+            acc = mul_add_unfused_e(w01.y, q1, acc);
+            acc = mul_add_unfused_e(w23.x, q2, acc);
+            acc = mul_add_unfused_e(w23.y, q3, acc);
+        }
+        const unsigned bo = cur.w * a.n_frames * 8u;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, amp_e<AMP>(acc.x, eps)), ro, (int)(fo0 != kDrop ? bo + fo0 : kDrop), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, amp_e<AMP>(acc.y, eps)), ro, (int)(fo1 != kDrop ? bo + fo1 : kDrop), 0, 0);
+    }
 }
 
 template <int MODE, int AMP, int ROUNDS>
@@ -83,6 +126,7 @@ __global__ __launch_bounds__(512, 2) void k_d32x32(StftArgs a, unsigned per_xcd,
     const double eps = a.eps;
     constexpr unsigned ES = MODE == OUT_COMPLEX ? 16u : 8u;
     const unsigned step = 64u * a.n_frames * ES;  // uniform: 64 bins further
+    double *pwd = (double *)(smem + kEPwOff);
     const v2d *twj = (const v2d *)(tabs + kETw2Off) + kb * 8u;
     // pass-1 twiddles W_1024^(k1 n2), k1 = 2 m + par: twm[m >> 2] * twl[m & 3] with twm[q] = W^(8 q n2), twl[j] = W^((2 j + par) n2)
     v2d twm[4], twl[4];
@@ -153,7 +197,8 @@ __global__ __launch_bounds__(512, 2) void k_d32x32(StftArgs a, unsigned per_xcd,
             }
             Fft<16, false, v2d>::run(xr, xr);
         }
-        if constexpr (ROUNDS > 0) __syncthreads();  // barrier 2: every wave has read its columns: pass 1 may write ex
+        // barrier 2: every wave has read its columns (and, filterbank outputs, finished the previous tile's band stage): pass 1 may write ex
+        if constexpr (ROUNDS > 0 || MODE == OUT_MEL) __syncthreads();
         {
             unsigned char *dst = smem + p1f * kEFS + par * 512u + n2 * 16u;  // rows k1 = 2 m + par
 #pragma unroll
@@ -209,8 +254,16 @@ __global__ __launch_bounds__(512, 2) void k_d32x32(StftArgs a, unsigned per_xcd,
         const __amdgpu_buffer_rsrc_t ro = make_rsrc((unsigned char *)a.out + (size_t)b * 1025u * a.n_frames * ES, 1025u * a.n_frames * ES);
         // bins kb + 64 u upwards; the mirrored bins 1024 - kb - 64 u count down: lane part 7 steps low, scalar part (7 - u) steps
         const unsigned oa = (kb * a.n_frames + p2ofs) * ES, ob = ((1024u - 448u - kb) * a.n_frames + p2ofs) * ES;
-        auto emit = [&](unsigned voff, unsigned soff, v2d X, bool conj) {
-            if constexpr (MODE == OUT_COMPLEX) {
+        if constexpr (MODE == OUT_MEL) {  // bins 1025..1035 are read with zero weights
+            if (tid < 88u) pwd[pwd8_index(1025u + (tid >> 3), tid & 7u)] = 0.0;
+        }
+        double *pw_a = pwd + pwd8_index(kb, p2f), *pw_b = pwd + pwd8_index(1024u - 448u - kb, p2f);
+        constexpr int PSTEP = 64 * 8;  // doubles between bins k and k + 64 in the |X|^2 tile
+        auto emit = [&](unsigned voff, unsigned soff, double *pwp, v2d X, bool conj) {
+            if constexpr (MODE == OUT_MEL) {
+                const double p = __builtin_fma(X.x, X.x, X.y * X.y);
+                *pwp = AMP == AMP_MAG_IN ? sqrt(p) : p;  // (a lane without a frame writes its mirror's values into its own slot: never stored)
+            } else if constexpr (MODE == OUT_COMPLEX) {
                 const v2d V = conj ? (v2d){X.x, -X.y} : X;
                 // (16-byte stores: the whole offset in the lane register, soffset = 0 — kernels_d32x16.hip: emit)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, V), ro, (int)(voff + soff), 0, 0);
@@ -226,10 +279,14 @@ __global__ __launch_bounds__(512, 2) void k_d32x32(StftArgs a, unsigned per_xcd,
             const v2d P = H[u], Q = swp(R[7 - u]);
             const v2d E = pfma(Q, (v2d){1.0, -1.0}, P), D = pfma(Q, (v2d){-1.0, 1.0}, P);
             const v2d T = cmulv(D, twj[u]);
-            emit(oa, u * step, E + T, false);
-            emit(ob, (7 - u) * step, E - T, true);
+            emit(oa, u * step, pw_a + u * PSTEP, E + T, false);
+            emit(ob, (7 - u) * step, pw_b + (7 - u) * PSTEP, E - T, true);
         }
-        if (j0 && half == 0u) emit((512u * a.n_frames + p2ofs) * ES, 0u, h8 * (v2d){2.0, -2.0}, false);  // X[512] = 2 conj(Z[512])
+        if (j0 && half == 0u) emit((512u * a.n_frames + p2ofs) * ES, 0u, pwd + pwd8_index(512u, p2f), h8 * (v2d){2.0, -2.0}, false);  // X[512] = 2 conj(Z[512])
+        if constexpr (MODE == OUT_MEL) {
+            __syncthreads();  // |X|^2 tile complete
+            mel_tile_sched_e<AMP>(a, pwd, a.mel_sched, b, f0, nf, eps, tid);
+        }
         wid = next;
     }
 }
@@ -248,14 +305,20 @@ hipError_t launch_variant_e(const StftArgs &a, hipStream_t s) {
         return hipGetLastError();
     };
     if (bytes <= 6u * 8192u) return go(k_d32x32<MODE, AMP, 6>);
-    if (bytes <= 9u * 8192u) return go(k_d32x32<MODE, AMP, 9>);
-    return go(k_d32x32<MODE, AMP, 0>);
+    if constexpr (MODE == OUT_MEL) {
+        return hipErrorInvalidConfiguration;  // (plan_geometry_d32x32_f64 keeps such hops away)
+    } else {
+        if (bytes <= 9u * 8192u) return go(k_d32x32<MODE, AMP, 9>);
+        return go(k_d32x32<MODE, AMP, 0>);
+    }
 }
 
 }  // namespace
 
 bool plan_geometry_d32x32_f64(StftArgs &a) {
-    if (a.n_fft != 2048 || (a.hop & 1u) || a.out_mode == OUT_MEL) return false;  // (filterbank outputs: the register-tiled kernel)
+    if (a.n_fft != 2048 || (a.hop & 1u)) return false;
+    // filterbank outputs: fused up to hop 585 (6 staging rounds below the |X|^2 tile) where the bank has a band schedule; else per-bin power + k_bank_rows
+    if (a.out_mode == OUT_MEL && (a.mel_sched_words == 0 || (7u * a.hop + 2048u) * 8u > 6u * 8192u)) return false;
     if (a.x != nullptr && a.n_frames < 4u) return false;                                      // batches of very short signals: mostly empty tiles
     if (a.n_samples >= (1ull << 28)) return false;                                        // 32-bit byte offsets into a sample row
     if ((unsigned long long)a.n_frames * 1025ull * 16ull >= 0x7fffffffull) return false;  // and into one output signal
@@ -267,7 +330,12 @@ hipError_t launch_d32x32_f64(const StftArgs &a, hipStream_t s) {
     const unsigned long long total64 = (unsigned long long)a.tiles * a.batch;
     if (total64 == 0 || total64 >= 0x7ffffff0ull) return hipErrorInvalidConfiguration;
     if (a.out_mode == OUT_COMPLEX) return launch_variant_e<OUT_COMPLEX, AMP_POWER>(a, s);
-    if (a.out_mode != OUT_LINEAR) return hipErrorInvalidConfiguration;
+    if (a.out_mode == OUT_MEL) {
+        if (a.amp == AMP_MAGNITUDE) return launch_variant_e<OUT_MEL, AMP_MAGNITUDE>(a, s);
+        if (a.amp == AMP_DB) return launch_variant_e<OUT_MEL, AMP_DB>(a, s);
+        if (a.amp == AMP_MAG_IN) return launch_variant_e<OUT_MEL, AMP_MAG_IN>(a, s);
+        return launch_variant_e<OUT_MEL, AMP_POWER>(a, s);
+    }
     if (a.amp == AMP_MAGNITUDE) return launch_variant_e<OUT_LINEAR, AMP_MAGNITUDE>(a, s);
     if (a.amp == AMP_DB) return launch_variant_e<OUT_LINEAR, AMP_DB>(a, s);
     return launch_variant_e<OUT_LINEAR, AMP_POWER>(a, s);

@@ -281,12 +281,15 @@ def test_ragged_lengths_4096(n, centre):
 
 # ------------------------------------------------------------------ n_fft 2048, f64: the tuned kernel k_d32x32 (round 4)
 @pytest.mark.parametrize("hop", [1024, 512, 256, 2048, 100, 584, 586, 1026, 2])
-@pytest.mark.parametrize("amp,floor", [("complex", None), ("power", None), ("magnitude", None), ("db", -80.0)])
-def test_tuned_f64_2048(hop, amp, floor):
+@pytest.mark.parametrize("amp,floor,n_mels", [("complex", None, None), ("power", None, None), ("magnitude", None, None), ("db", -80.0, None),
+                                              ("power", None, 80), ("db", -80.0, 128), ("magnitude", None, 40), ("power", None, 20)])
+def test_tuned_f64_2048(hop, amp, floor, n_mels):
     """f64 n_fft 2048 (the reference's Criterion shape 2048 / 1024 in its type) on k_d32x32: two lanes per column in pass 1, half rows in lane
     pairs in pass 2; both staging depths and the per-lane columns above hop 1024; frame counts that are not multiples of 8; centre on and off."""
     n = 27 * 512 + 77 if hop >= 100 else 5000
     kw = dict(n_fft=2048, hop=hop, amp=amp, floor=floor, dtype="float64")
+    if n_mels:  # fused band stage up to hop 585, per-bin power + bank rows above
+        kw.update(n_mels=n_mels, fmin=0.0, fmax=8000.0)
     plan, got = run_case(n=n, batch=3, **kw)
     assert plan.kernel_name == "d32x32_f64"
     x = signals(3, n, np.float64, 0)
@@ -301,6 +304,7 @@ def test_ragged_lengths_f64_2048(n, centre):
         n += 2048
     run_case(n=n, batch=2, n_fft=2048, hop=512, centre=centre, amp="complex", dtype="float64")
     run_case(n=n, batch=3, n_fft=2048, hop=1024, centre=centre, amp="power", dtype="float64")
+    run_case(n=n, batch=2, n_fft=2048, hop=512, centre=centre, n_mels=80, fmin=0.0, fmax=8000.0, amp="db", floor=-80.0, dtype="float64")
 
 @pytest.mark.parametrize("n", [1, 5, 1023, 1024, 1025, 2047, 2048, 2049, 2559, 2560, 2561, 8193, 10239, 10240, 10241])
 @pytest.mark.parametrize("centre", [True, False])
