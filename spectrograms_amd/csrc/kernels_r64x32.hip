@@ -1,5 +1,5 @@
-// kernels_r64x32.hip — tuned f32, n_fft = 4096 STFT kernel for gfx950 (round 4): per-bin and complex outputs (filterbank outputs take the split
-// path: this kernel's per-bin power, then k_bank_rows).  k_d32x16's construction (kernels_d32x16.hip) at 2048 complex f32 points: a tile = 8
+// kernels_r64x32.hip — tuned f32, n_fft = 4096 STFT kernel for gfx950 (round 4): per-bin, complex and (up to hop 1170) filterbank outputs
+// (longer hops: this kernel's per-bin power, then k_bank_rows).  k_d32x16's construction (kernels_d32x16.hip) at 2048 complex f32 points: a tile = 8
 // consecutive frames of one signal, one persistent 512-thread workgroup per CU, a 128 KiB exchange buffer ex[f][k1][n2] of 8-byte elements.
 //
 //   pass 1  lane (f = 0..7, n2 = 0..63) owns z[64 n1 + n2], n1 = 0..31, of frame f, z[n] = w[2n] x[2n] + i w[2n+1] x[2n+1] (window pre-scaled
@@ -34,6 +34,12 @@ constexpr int kQEx = 8 * kQFS;             // 131200: exchange buffer; also hold
 constexpr int kQWinOff = 0;                // tables behind it: v2f win[2048] = (w[2n], w[2n+1]) / 2
 constexpr int kQTw2Off = 16384;            // v2f tw2[64][16]: entry u of lane kind kb = W' = -i W_4096^(kb + 64 u)
 constexpr int kQLds = kQEx + kQTw2Off + 64 * 16 * 8;  // 155776
+// filterbank outputs (hop <= 1170: 6 staging rounds): the |X|^2 tile (2060 bins x 8 frames of f32: bin k, frame f at k * 8 + f) sits in the upper
+// half of the exchange buffer, above the staged samples; the band schedule (plan.hip build_band_schedule: 16 half-waves x 8 slots) stays in GLOBAL
+// memory (kernels_d32x32.hip)
+constexpr int kQPwOff = kQEx - 2060 * 32;  // 65280 >= 6 * 8192
+constexpr int kQSegs = 2;
+__host__ __device__ constexpr unsigned pwq_index(unsigned k, unsigned f) { return k * 8u + f; }
 
 template <int AMP>
 __device__ __forceinline__ float amp_q(float p, float eps) {
@@ -51,6 +57,45 @@ __device__ __forceinline__ void trade32f(v2f &v) {
     const unsigned nim = s2.x, nre = s2.y;
     v.x = __builtin_bit_cast(float, nre);
     v.y = __builtin_bit_cast(float, nim);
+}
+
+__device__ __forceinline__ v2f mul_add_unfused_q(float w, v2f p, v2f acc) {  // the reference's `acc += w * x`: two roundings (spectrogram.rs:102-117)
+#pragma clang fp contract(off)
+    const v2f m = (v2f){w, w} * p;
+    return m + acc;
+}
+
+// band stage over the tile's 8 frames: 16 half-waves x 8 slots x 4 frame pairs; a lane sums one band for two frames in ascending-bin order
+template <int AMP>
+__device__ __forceinline__ void mel_tile_sched_q(const StftArgs &a, const float *pw, const unsigned *sched, unsigned b, unsigned f0, unsigned nf,
+                                                 float eps, unsigned tid) {
+    const unsigned vw = tid >> 5, slot = (tid >> 2) & 7u, fp = tid & 3u;
+    constexpr unsigned kDrop = 0x80000000u;  // past the descriptor's range: the hardware drops the store
+    const unsigned obytes = (a.n_out * a.n_frames - f0) * 4u;
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc((const float *)a.out + (size_t)b * a.n_out * a.n_frames + f0, obytes);
+    const unsigned fo0 = 2u * fp < nf ? 8u * fp : kDrop, fo1 = 2u * fp + 1u < nf ? 8u * fp + 4u : kDrop;
+    const uint4 *info = (const uint4 *)(sched + 4) + vw * 8u + slot;
+#pragma unroll
+    for (unsigned seg = 0; seg < (unsigned)kQSegs; ++seg) {
+        const uint4 cur = info[seg * 128u];
+        const unsigned L = cur.x;  // (per half-wave: the two halves of a wave run to the longer one)
+        const bool have = cur.w != 0xffffffffu;
+        if (!have) continue;
+        const v4f *wr = (const v4f *)((const float *)sched + cur.y);
+        const v2f *pr = (const v2f *)(pw + cur.z * 8u + fp * 2u);
+        v2f acc = {0.f, 0.f};
+        for (unsigned t = 0; t < L; t += 4u) {  // bins t .. t + 3, frames 2 fp and 2 fp + 1 of each
+            const v4f w4 = wr[t >> 2];
+            const v2f q0 = pr[t * 4u], q1 = pr[t * 4u + 4u], q2 = pr[t * 4u + 8u], q3 = pr[t * 4u + 12u];
+            acc = mul_add_unfused_q(w4.x, q0, acc);
+            acc = mul_add_unfused_q(w4.y, q1, acc);
+            acc = mul_add_unfused_q(w4.z, q2, acc);
+            acc = mul_add_unfused_q(w4.w, q3, acc);
+        }
+        const unsigned bo = cur.w * a.n_frames * 4u;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, amp_q<AMP>(acc.x, eps)), ro, (int)(fo0 != kDrop ? bo + fo0 : kDrop), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, amp_q<AMP>(acc.y, eps)), ro, (int)(fo1 != kDrop ? bo + fo1 : kDrop), 0, 0);
+    }
 }
 
 template <int MODE, int AMP, int ROUNDS>
@@ -75,6 +120,7 @@ __global__ __launch_bounds__(512, 2) void k_r64x32(StftArgs a, unsigned per_xcd,
     const float eps = (float)a.eps;
     constexpr unsigned ES = MODE == OUT_COMPLEX ? 8u : 4u;
     const unsigned step = 64u * a.n_frames * ES;  // uniform: 64 bins further
+    float *pwq = (float *)(smem + kQPwOff);
     const v2f *twj = (const v2f *)(tabs + kQTw2Off) + kb * 16u;
     v2f twa[4], twb[8];  // W_2048^(k1 n2) = twa[k1 >> 3] * twb[k1 & 7]
     {
@@ -143,7 +189,8 @@ __global__ __launch_bounds__(512, 2) void k_r64x32(StftArgs a, unsigned per_xcd,
             Fft<16, true>::run(o, wo);
             Comb<32, 0, v2f>::run(xr, e, o);
         }
-        if constexpr (ROUNDS > 0) __syncthreads();  // barrier 2: every wave has read its columns: pass 1 may write ex
+        // barrier 2: every wave has read its columns (and, filterbank outputs, finished the previous tile's band stage): pass 1 may write ex
+        if constexpr (ROUNDS > 0 || MODE == OUT_MEL) __syncthreads();
         {
             unsigned char *dst = smem + p1f * kQFS + n2 * 8u;
 #pragma unroll
@@ -205,8 +252,16 @@ __global__ __launch_bounds__(512, 2) void k_r64x32(StftArgs a, unsigned per_xcd,
         const __amdgpu_buffer_rsrc_t ro = make_rsrc((unsigned char *)a.out + (size_t)b * 2049u * a.n_frames * ES, 2049u * a.n_frames * ES);
         // bins kb + 64 u upwards; the mirrored bins 2048 - kb - 64 u count down: lane part 15 steps low, scalar part (15 - u) steps
         const unsigned oa = (kb * a.n_frames + p2ofs) * ES, ob = ((2048u - 960u - kb) * a.n_frames + p2ofs) * ES;
-        auto emit = [&](unsigned voff, unsigned soff, v2f X, bool conj) {
-            if constexpr (MODE == OUT_COMPLEX) {
+        if constexpr (MODE == OUT_MEL) {  // bins 2049..2059 are read with zero weights
+            if (tid < 88u) pwq[pwq_index(2049u + (tid >> 3), tid & 7u)] = 0.f;
+        }
+        float *pw_a = pwq + pwq_index(kb, p2f), *pw_b = pwq + pwq_index(2048u - 960u - kb, p2f);
+        constexpr int PSTEP = 64 * 8;  // floats between bins k and k + 64 in the |X|^2 tile
+        auto emit = [&](unsigned voff, unsigned soff, float *pwp, v2f X, bool conj) {
+            if constexpr (MODE == OUT_MEL) {
+                const float p = __builtin_fmaf(X.x, X.x, X.y * X.y);
+                *pwp = AMP == AMP_MAG_IN ? sqrtf(p) : p;  // (a lane without a frame writes its mirror's values into its own slot: never stored)
+            } else if constexpr (MODE == OUT_COMPLEX) {
                 const v2f V = conj ? (v2f){X.x, -X.y} : X;
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, V), ro, (int)voff, (int)soff, 0);
             } else {
@@ -220,10 +275,14 @@ __global__ __launch_bounds__(512, 2) void k_r64x32(StftArgs a, unsigned per_xcd,
             const v2f P = H[u], Q = swp(R[15 - u]);
             const v2f E = pfma(Q, (v2f){1.f, -1.f}, P), D = pfma(Q, (v2f){-1.f, 1.f}, P);
             const v2f T = cmulv(D, twj[u]);
-            emit(oa, u * step, E + T, false);
-            emit(ob, (15 - u) * step, E - T, true);
+            emit(oa, u * step, pw_a + u * PSTEP, E + T, false);
+            emit(ob, (15 - u) * step, pw_b + (15 - u) * PSTEP, E - T, true);
         }
-        if (j0 && half == 0u) emit((1024u * a.n_frames + p2ofs) * ES, 0u, h16 * (v2f){2.f, -2.f}, false);  // X[1024] = 2 conj(Z[1024])
+        if (j0 && half == 0u) emit((1024u * a.n_frames + p2ofs) * ES, 0u, pwq + pwq_index(1024u, p2f), h16 * (v2f){2.f, -2.f}, false);  // X[1024] = 2 conj(Z[1024])
+        if constexpr (MODE == OUT_MEL) {
+            __syncthreads();  // |X|^2 tile complete
+            mel_tile_sched_q<AMP>(a, pwq, a.mel_sched, b, f0, nf, eps, tid);
+        }
         wid = next;
     }
 }
@@ -242,14 +301,20 @@ hipError_t launch_variant_q(const StftArgs &a, hipStream_t s) {
         return hipGetLastError();
     };
     if (bytes <= 6u * 8192u) return go(k_r64x32<MODE, AMP, 6>);
-    if (bytes <= 9u * 8192u) return go(k_r64x32<MODE, AMP, 9>);
-    return go(k_r64x32<MODE, AMP, 0>);
+    if constexpr (MODE == OUT_MEL) {
+        return hipErrorInvalidConfiguration;  // (plan_geometry_r64x32_f32 keeps such hops away)
+    } else {
+        if (bytes <= 9u * 8192u) return go(k_r64x32<MODE, AMP, 9>);
+        return go(k_r64x32<MODE, AMP, 0>);
+    }
 }
 
 }  // namespace
 
 bool plan_geometry_r64x32_f32(StftArgs &a) {
-    if (a.n_fft != 4096 || (a.hop & 1u) || a.out_mode == OUT_MEL) return false;  // (filterbank outputs: per-bin power here, then k_bank_rows)
+    if (a.n_fft != 4096 || (a.hop & 1u)) return false;
+    // filterbank outputs: fused up to hop 1170 (6 staging rounds below the |X|^2 tile) where the bank has a band schedule; else per-bin power + k_bank_rows
+    if (a.out_mode == OUT_MEL && (a.mel_sched_words == 0 || (7u * a.hop + 4096u) * 4u > 6u * 8192u)) return false;
     if (a.x != nullptr && a.n_frames < 4u) return false;                                      // batches of very short signals: mostly empty tiles
     if (a.n_samples >= (1ull << 29)) return false;                                        // 32-bit byte offsets into a sample row
     if ((unsigned long long)a.n_frames * 2049ull * 8ull >= 0x7fffffffull) return false;  // and into one output signal
@@ -261,7 +326,12 @@ hipError_t launch_r64x32_f32(const StftArgs &a, hipStream_t s) {
     const unsigned long long total64 = (unsigned long long)a.tiles * a.batch;
     if (total64 == 0 || total64 >= 0x7ffffff0ull) return hipErrorInvalidConfiguration;
     if (a.out_mode == OUT_COMPLEX) return launch_variant_q<OUT_COMPLEX, AMP_POWER>(a, s);
-    if (a.out_mode != OUT_LINEAR) return hipErrorInvalidConfiguration;
+    if (a.out_mode == OUT_MEL) {
+        if (a.amp == AMP_MAGNITUDE) return launch_variant_q<OUT_MEL, AMP_MAGNITUDE>(a, s);
+        if (a.amp == AMP_DB) return launch_variant_q<OUT_MEL, AMP_DB>(a, s);
+        if (a.amp == AMP_MAG_IN) return launch_variant_q<OUT_MEL, AMP_MAG_IN>(a, s);
+        return launch_variant_q<OUT_MEL, AMP_POWER>(a, s);
+    }
     if (a.amp == AMP_MAGNITUDE) return launch_variant_q<OUT_LINEAR, AMP_MAGNITUDE>(a, s);
     if (a.amp == AMP_DB) return launch_variant_q<OUT_LINEAR, AMP_DB>(a, s);
     return launch_variant_q<OUT_LINEAR, AMP_POWER>(a, s);

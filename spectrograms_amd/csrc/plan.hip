@@ -588,7 +588,7 @@ sgx_status build_device_tables(sgx_plan *pl) {
             if ((st = upload<uint32_t>(pl, &pl->d_mm_blk, blk)) != SGX_OK) return st;
         }
         // Band schedule of the tuned kernel: built on the host at plan creation (build_band_schedule), uploaded here
-        if (((std::is_same<T, float>::value && (pl->kind == K_R32X16_F32 || pl->kind == K_R32X32_F32)) || (std::is_same<T, double>::value && (pl->kind == K_D32X16_F64 || pl->kind == K_D512_F64 || pl->kind == K_D32X32_F64))) &&
+        if (((std::is_same<T, float>::value && (pl->kind == K_R32X16_F32 || pl->kind == K_R32X32_F32 || pl->kind == K_R64X32_F32)) || (std::is_same<T, double>::value && (pl->kind == K_D32X16_F64 || pl->kind == K_D512_F64 || pl->kind == K_D32X32_F64))) &&
             !pl->h_mel_sched.empty() && !pl->d_mm_frag) {
             if ((st = upload<uint32_t>(pl, &pl->d_mel_sched, pl->h_mel_sched)) != SGX_OK) return st;
         }
@@ -1308,6 +1308,7 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
     if (pl->kind == K_R32X32_F32) build_band_schedule(pl, 8, r32x32::kSegs2, r32x32::kSch2MaxWords, 0);
     if (pl->kind == K_D32X16_F64) build_band_schedule(pl, 8, d32x16::kDSegs, d32x16::kDSchMaxWords, 0, 2);
     if (pl->kind == K_D512_F64) build_band_schedule(pl, 8, d512::kSegs, d512::kSchMaxWords, 0, 2);
+    if (pl->kind == K_R64X32_F32) build_band_schedule(pl, 16, 2, 1u << 20, 0, 1);  // (as k_d32x32's, 4-byte weights)
     if (pl->kind == K_D32X32_F64) build_band_schedule(pl, 16, 2, 1u << 20, 0, 2);  // 16 half-waves x 8 slots; the table stays in global memory (kernels_d32x32.hip)
     {
         StftArgs probe;

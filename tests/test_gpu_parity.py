@@ -257,12 +257,15 @@ def test_tuned_kernels_many_tiles_per_workgroup(dtype, n_fft, hop, amp, n_mels):
 
 # ------------------------------------------------------------------ n_fft 4096, f32: the tuned kernel k_r64x32 (round 4)
 @pytest.mark.parametrize("hop", [1024, 512, 2048, 4096, 100, 1170, 1172, 2050, 2])
-@pytest.mark.parametrize("amp,floor", [("complex", None), ("power", None), ("magnitude", None), ("db", -80.0)])
-def test_tuned_4096(hop, amp, floor):
+@pytest.mark.parametrize("amp,floor,n_mels", [("complex", None, None), ("power", None, None), ("magnitude", None, None), ("db", -80.0, None),
+                                              ("power", None, 80), ("db", -80.0, 128), ("magnitude", None, 40), ("power", None, 20)])
+def test_tuned_4096(hop, amp, floor, n_mels):
     """f32 n_fft 4096 on k_r64x32 (8-frame tiles, half rows of 32 points in lane pairs): both staging depths and the per-lane columns above hop
     2048; per-bin and complex outputs; frame counts that are not multiples of 8; centre on and off; a signal's bits independent of its batch."""
     n = 27 * 1024 + 77 if hop >= 100 else 9000
     kw = dict(n_fft=4096, hop=hop, amp=amp, floor=floor, dtype="float32")
+    if n_mels:  # fused band stage up to hop 1170, per-bin power + bank rows above
+        kw.update(n_mels=n_mels, fmin=0.0, fmax=8000.0)
     plan, got = run_case(n=n, batch=3, **kw)
     assert plan.kernel_name == "r64x32_f32"
     x = signals(3, n, np.float32, 0)
@@ -277,6 +280,7 @@ def test_ragged_lengths_4096(n, centre):
         n += 4096
     run_case(n=n, batch=2, n_fft=4096, hop=1024, centre=centre, amp="complex")
     run_case(n=n, batch=3, n_fft=4096, hop=512, centre=centre, amp="power")
+    run_case(n=n, batch=2, n_fft=4096, hop=1024, centre=centre, n_mels=80, fmin=0.0, fmax=8000.0, amp="db", floor=-80.0)
 
 
 # ------------------------------------------------------------------ n_fft 2048, f64: the tuned kernel k_d32x32 (round 4)
