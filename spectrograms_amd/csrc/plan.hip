@@ -1118,6 +1118,17 @@ sgx_status inverse_tables(sgx_plan *pl) {
         if ((st = upload<float>(pl, &pl->d_itwr2, tr)) != SGX_OK) return st;
         if ((st = upload<float>(pl, &pl->d_itw12, t1)) != SGX_OK) return st;
     }
+    if (std::is_same<T, double>::value && n == 512 && pl->p.hop_size >= 32) {  // table of the fused f64 n_fft 512 kernel (two frames per transform): W_512^(k1 n2)
+        std::vector<double> t1(2 * 16 * 32);
+        for (unsigned k1 = 0; k1 < 16; ++k1)
+            for (unsigned n2 = 0; n2 < 32; ++n2) {
+                const double b2 = -2.0 * kPi * double(k1 * n2) / 512.0;
+                t1[2 * (k1 * 32 + n2)] = std::cos(b2);
+                t1[2 * (k1 * 32 + n2) + 1] = std::sin(b2);
+            }
+        if ((st = upload<double>(pl, &pl->d_itw1d, t1)) != SGX_OK) return st;
+        pl->istft_d512 = true;
+    }
     if (std::is_same<T, double>::value && n == 1024 && pl->p.hop_size >= 64) {  // tables of the fused tuned f64 n_fft 1024 kernel (ov = 1023 / hop < 16)
         std::vector<double> tr(2 * 512), t1(2 * 16 * 32);
         for (unsigned k = 0; k < 512; ++k) {
@@ -1192,6 +1203,11 @@ sgx_status run_istft(sgx_plan *pl, const void *spec, size_t batch, size_t n_fram
     if (pl->d_itwr2 && n_frames * 1025ull * 8ull < 0x7fffffffull) {  // fused tuned kernel at n_fft 2048 (kernels_istft2048.hip)
         SGX_HIP(pl, launch_istft2048(spec, out, pl->d_window, unsigned(n_frames), pl->p.hop_size, unsigned(batch), start, out_len, 1.0f / 2048.0f,
                                      (unsigned *)pl->d_flag, pl->d_itwr2, pl->d_itw12, s));
+        return SGX_OK;
+    }
+    if (pl->istft_d512 && n_frames * 257ull * 16ull < 0x7fffffffull) {  // fused f64 kernel at n_fft 512 (kernels_istft_d1024.hip: k_istft_d512)
+        SGX_HIP(pl, launch_istft_d512(spec, out, pl->d_window, unsigned(n_frames), pl->p.hop_size, unsigned(batch), start, out_len, 1.0 / 512.0,
+                                      (unsigned *)pl->d_flag, pl->d_itw1d, s));
         return SGX_OK;
     }
     if (pl->d_itwrd && n_frames * 513ull * 16ull < 0x7fffffffull) {  // fused tuned f64 kernel at n_fft 1024 (kernels_istft_d1024.hip)
@@ -1626,7 +1642,7 @@ sgx_status sgx_reserve(sgx_plan *plan, size_t batch, size_t n_samples, int32_t h
     if (inverse) {  // sgx_istft of `batch` spectra whose frame count is that of n_samples-long signals
         // the same tests run_istft applies: tuned n_fft = 1024 kernel, else the fused register-tiled kernel; only the unfused
         // fallback (rows + overlap-add) touches the frame scratch
-        const bool fused = (plan->d_itwr && nf * 513ull * 8ull < 0x7fffffffull) || (plan->d_itwr2 && nf * 1025ull * 8ull < 0x7fffffffull) || (plan->d_itwrd && nf * 513ull * 16ull < 0x7fffffffull) ||
+        const bool fused = (plan->d_itwr && nf * 513ull * 8ull < 0x7fffffffull) || (plan->d_itwr2 && nf * 1025ull * 8ull < 0x7fffffffull) || (plan->d_itwrd && nf * 513ull * 16ull < 0x7fffffffull) || (plan->istft_d512 && nf * 257ull * 16ull < 0x7fffffffull) ||
                            (nf <= 0xffffffffull && batch <= 0xffffffffull &&
                             istft_reg_fuses(plan->d_window, plan->p.n_fft, unsigned(nf), plan->p.hop_size, unsigned(batch), plan->dtype));
         if (!fused && (st = grow(plan, &plan->d_frames, &plan->d_frames_bytes, batch * nf * plan->p.n_fft * plan->elem)) != SGX_OK) return st;

@@ -220,6 +220,9 @@ hipError_t launch_c2r1024(const C2rArgs &a, const void *twr, const void *tw1, hi
 hipError_t launch_istft_d1024(const void *spec, void *out, const void *win, unsigned n_frames, unsigned hop, unsigned batch, unsigned long long start,
                               unsigned long long out_len, double scale, unsigned *bad_flag, const void *twr, const void *tw1,
                               hipStream_t s);  // fused tuned f64 n_fft 1024 inverse, hop >= 64 (kernels_istft_d1024.hip)
+hipError_t launch_istft_d512(const void *spec, void *out, const void *win, unsigned n_frames, unsigned hop, unsigned batch, unsigned long long start,
+                             unsigned long long out_len, double scale, unsigned *bad_flag, const void *tw1,
+                             hipStream_t s);  // fused f64 n_fft 512 inverse, two frames per transform, hop >= 32 (kernels_istft_d1024.hip)
 hipError_t launch_istft2048(const void *spec, void *out, const void *win, unsigned n_frames, unsigned hop, unsigned batch, unsigned long long start,
                             unsigned long long out_len, float scale, unsigned *bad_flag, const void *twr, const void *tw1, hipStream_t s);  // kernels_istft2048.hip
 hipError_t launch_istft1024(const void *spec, void *out, const void *win, unsigned n_frames, unsigned hop, unsigned batch,
@@ -342,6 +345,7 @@ struct sgx_plan {
     void *d_itw = nullptr, *d_frames = nullptr, *d_flag = nullptr;
     void *d_itwr = nullptr, *d_itw1 = nullptr;  // tuned f32 n_fft = 1024 inverse: conj(W_1024^k) [32][16], W_512^(k1 n2) [32][16]
     void *d_itwr2 = nullptr, *d_itw12 = nullptr;  // tuned f32 n_fft = 2048 inverse: conj(W_2048^k) [1024], W_1024^(k1 n2) [32][32]
+    bool istft_d512 = false;  // f64 n_fft 512, hop >= 32: the fused two-frames-per-transform inverse (d_itw1d holds its W_512^(k1 n2))
     void *d_itwrd = nullptr, *d_itw1d = nullptr;  // tuned f64 n_fft = 1024 inverse: conj(W_1024^k) [512], W_512^(k1 n2) [16][32] (f64)
     // K_BLUESTEIN: chirp, transformed chirp, length-M twiddles (the sequences themselves never leave LDS: no frame scratch)
     void *d_bs_chirp = nullptr, *d_bs_tw = nullptr, *d_bs_wc = nullptr, *d_bs_bhp = nullptr;

@@ -362,3 +362,32 @@ def test_gpu_istft_f64_1024_tuned(hop, centre, n, batch):
     assert np.max(np.abs(y[:, 600:m - 600] - x[:, 600:m - 600])) < 1e-9 if m > 1300 else True
     one = plan.istft_batch(np.ascontiguousarray(S[batch - 1:]))
     assert np.array_equal(one[0], y[batch - 1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hop,centre,n,batch", [(160, True, 100000, 5), (128, False, 33333, 3), (256, True, 70001, 2), (32, True, 9000, 2), (100, True, 20000, 2),
+                                               (512, True, 50000, 4), (300, True, 511, 2), (160, True, 1, 1), (64, False, 9000, 7), (160, True, 160000, 64),
+                                               (128, True, 160000, 64), (256, True, 40000, 130)])
+def test_gpu_istft_f64_512_tuned(hop, centre, n, batch):
+    """k_istft_d512 (f64 n_fft 512 — the reference's speech default 512 / 160 in its default type —, two frames per transform, hop >= 32): odd and even
+    frame counts (a slot's second frame may not exist), the compile-time overlap-add at hops 128 / 256 / 512 and the general walk, runs that start
+    inside a signal; the oracle and bit-equality of a signal alone."""
+    rng = np.random.default_rng(23)
+    if not centre and n < 512:
+        n = 512 + n
+    x = rng.standard_normal((batch, n))
+    wname = "hanning" if centre and hop < 512 else "hamming"  # (see test_gpu_istft_2048_long_signals)
+    params = sg.SpectrogramParams(sg.StftParams(512, hop, getattr(sg.WindowType, wname), centre), 16000.0)
+    plan = sg.Plan(params, _ffi.AMP_COMPLEX, None, None, "float64")
+    S = np.ascontiguousarray(plan.compute_batch(x))
+    y = plan.istft_batch(S)
+    for b in sorted({0, batch - 1, batch // 2}):
+        ref = orc.istft(S[b], 512, hop, wname, centre)
+        assert y[b].shape == ref.shape
+        assert np.max(np.abs(y[b] - ref)) < 1e-10 * max(1.0, np.max(np.abs(ref))), (hop, centre, n, batch, b)
+    one = plan.istft_batch(np.ascontiguousarray(S[batch - 1:]))
+    assert np.array_equal(one[0], y[batch - 1])
+    bad = S.copy()
+    bad[0, 0, 0] += 1e-3j  # an imaginary part in a DC bin: realfft's C2R reports it (fft_backend.rs:559-563)
+    with pytest.raises(Exception):
+        plan.istft_batch(bad)

@@ -36,7 +36,7 @@ for dtype, n_fft, hop, amp, nm in CASES:
     bad_total += sum(counts)
     print(f"{dtype} {n_fft}/{hop} {amp}{'-mel%d' % nm if nm else ''} {plan.kernel_name}: bad elements per launch {counts}", flush=True)
 # inverse STFT: the fused kernels (f32 1024 / 2048, f64 1024) and the register-tiled path, 64 signals, every sample against the oracle
-for dtype, n_fft, hop in (("float32", 1024, 256), ("float32", 2048, 512), ("float64", 1024, 256), ("float32", 1024, 100), ("float64", 1024, 512), ("float32", 512, 128)):
+for dtype, n_fft, hop in (("float32", 1024, 256), ("float32", 2048, 512), ("float64", 1024, 256), ("float32", 1024, 100), ("float64", 1024, 512), ("float32", 512, 128), ("float64", 512, 160), ("float64", 512, 128)):
     x = base[:64].astype(np.float64 if dtype == "float64" else np.float32)
     params = sg.SpectrogramParams(sg.StftParams(n_fft, hop, sg.WindowType.hamming, True), 16000.0)
     plan = sg.Plan(params, _ffi.AMP_COMPLEX, None, None, dtype)
