@@ -114,6 +114,41 @@ int main(void) {
     CHECK(strstr(sgx_last_error(plan), "Dimension mismatch") != NULL);
     sgx_plan_destroy(plan);
 
+    /* the other Sample type through the same entry points (src/sample.rs:23-86): f64, host pointers, the tuned f64 kernel */
+    {
+        sgx_params pd = p;
+        pd.dtype = SGX_F64;
+        sgx_plan *pl64 = NULL;
+        CHECK(sgx_plan_create(&pd, &pl64) == SGX_OK);
+        CHECK(strcmp(sgx_kernel_name(pl64), "d32x16_f64") == 0);
+        double *xd = (double *)malloc(B * N * sizeof(double)), *od = (double *)malloc(B * nb * nf * sizeof(double));
+        for (size_t i = 0; i < B * N; ++i) xd[i] = (double)x[i];
+        CHECK(sgx_execute(pl64, xd, B, N, N, od, B * nb * nf, SGX_MEM_HOST, NULL) == SGX_OK);
+        double w64 = 0.0, p64 = 0.0;
+        for (int q = 0; q < 3; ++q) {
+            const size_t f = q == 2 ? nf - 1 : frames[q], b = 2;
+            for (size_t k = 0; k < nb; k += 37) {
+                double re = 0.0, im = 0.0;
+                for (size_t i = 0; i < n_fft; ++i) {
+                    const long long si = (long long)(f * hop + i) - (long long)pad;
+                    const double v = (si < 0 || si >= (long long)N) ? 0.0 : xd[b * N + (size_t)si];
+                    const double w = 0.5 - 0.5 * cos(2.0 * kPi * (double)i / (double)(n_fft - 1));
+                    const double a = -2.0 * kPi * (double)((i * k) % n_fft) / (double)n_fft;
+                    re += v * w * cos(a);
+                    im += v * w * sin(a);
+                }
+                const double ref = re * re + im * im, got = od[(b * nb + k) * nf + f];
+                if (fabs(got - ref) > w64) w64 = fabs(got - ref);
+                if (ref > p64) p64 = ref;
+            }
+        }
+        printf("f64 linear power: max abs err %.3e (peak %.3e)\n", w64, p64);
+        CHECK(w64 <= 1e-10 * p64);
+        free(xd);
+        free(od);
+        sgx_plan_destroy(pl64);
+    }
+
     /* complex STFT -> inverse STFT round trip, all on the device */
     p.amp_scale = SGX_AMP_COMPLEX;
     CHECK(sgx_plan_create(&p, &plan) == SGX_OK);
