@@ -272,7 +272,9 @@ sgx_status sgx_clock_probe(int32_t device, void *hip_stream, double *mhz);
 
 const char *sgx_last_error(const sgx_plan *plan);
 const char *sgx_last_create_error(void);
-/* Name of the kernel variant the plan dispatches to ("r32x16_f32", "reg_radix", "lds_radix2", "two_factor_dft", "bluestein", "direct_dft"). */
+/* Name of the kernel variant the plan dispatches to: the shape-specific kernels "r32x16_f32", "r32x32_f32", "r64x32_f32", "d512_f64", "d32x16_f64",
+ * "d32x32_f64", or "reg_radix", "lds_radix2", "two_factor_dft", "bluestein", "direct_dft" (a diagnostic: a call may step down this chain for shapes the
+ * plan's kernel does not take). */
 const char *sgx_kernel_name(const sgx_plan *plan);
 int32_t sgx_abi_version(void);
 int32_t sgx_device_count(void);
