@@ -267,6 +267,9 @@ def parse_args(argv=None):
                     help="seconds of back-to-back headline launches for the `sustained` object (frames/s + shader clock); 0: none")
     ap.add_argument("--legs-timeout", type=float, default=240.0,
                     help="seconds the extra legs may take before the line is printed without the unfinished ones (0: no limit)")
+    ap.add_argument("--experimental-legs", default="",
+                    help="comma-separated opt-in legs of the N > 1 run: 'cabi' = configs[3] through the C ABI's own communicator "
+                         "(sgx_shard_execute_chunked) - not yet run on more than one real GPU, so not in the default line")
     ap.add_argument("--rehearse-multi-rank", action="store_true",
                     help="with --gpus 1: open a ONE-rank RCCL process group and run the N > 1 legs (config 4 compute / gather / C-ABI chunked) "
                          "instead of the single-GPU ones — every call the driver's 8-GPU run makes, against the real RCCL, on one GPU")
@@ -520,7 +523,7 @@ def sustained_leg(torch, lib, dev, step, fence, frames_per_step: int, seconds: f
             "how": f"blocks of {block} launches, sgx_clock_probe (one wave per CU, ~20 us) behind each block"}
 
 
-def multi_rank_legs(torch, dist, dev, world, plan, xs, steps, warm, reduce_max, sync, make_comm, label):
+def multi_rank_legs(torch, dist, dev, world, plan, xs, steps, warm, reduce_max, sync, make_comm, label, cabi=False, strong_total=0):
     """BASELINE configs[3] when the job has more than one rank: every rank's shard of utterances through
     the plan — compute only; with the all-gather of the output shards behind every launch (one all_gather on the launch stream); with
     the gather of step i overlapped with the compute of step i + 1 (OverlappedGather); and through the C ABI's own communicator
@@ -541,27 +544,42 @@ def multi_rank_legs(torch, dist, dev, world, plan, xs, steps, warm, reduce_max, 
         dist.barrier()
         sync()
 
-    def run(name, step, finish=None, extra=None):
+    def agree(err):
+        """Every rank learns whether ANY rank failed (max of a flag) before the next fence, so that a failure on one rank ends the leg
+        on all of them instead of leaving the others in a barrier."""
+        bad = reduce_max(0.0 if err is None else 1.0) > 0.0
+        if bad:
+            return {"error": repr(err)[:300] if err is not None else "failed on another rank"}
+        return None
+
+    def phase(n, step, finish):
         try:
-            for i in range(warm):
+            for i in range(n):
                 step(i)
             if finish:
                 finish()
-            fence()
-            t0 = time.perf_counter()
-            for i in range(steps):
-                step(i)
-            if finish:
-                finish()
-            fence()
-            dt = reduce_max(time.perf_counter() - t0)
-            ms = dt / steps * 1e3
-            r = {"config": label, "steps": steps, "warmup": warm, "ms_per_step": ms, "value": frames_all * steps / dt, "unit": "frames/s"}
-            if extra:
-                r.update(extra(ms))
-            res[name] = r
+            return None
         except Exception as e:  # the leg's error, not the whole line's
-            res[name] = {"error": repr(e)[:300]}
+            return e
+
+    def run(name, step, finish=None, extra=None, frames=frames_all):
+        bad = agree(phase(warm, step, finish))
+        if bad:
+            res[name] = bad
+            return
+        fence()
+        t0 = time.perf_counter()
+        bad = agree(phase(steps, step, finish))
+        if bad:
+            res[name] = bad
+            return
+        fence()
+        dt = reduce_max(time.perf_counter() - t0)
+        ms = dt / steps * 1e3
+        r = {"config": label, "steps": steps, "warmup": warm, "ms_per_step": ms, "value": frames * steps / dt, "unit": "frames/s"}
+        if extra:
+            r.update(extra(ms))
+        res[name] = r
 
     run("config4", lambda i: plan.compute_batch(xs[i % len(xs)], out=outs[i % len(xs)]))
     compute_ms = res["config4"].get("ms_per_step")
@@ -579,18 +597,21 @@ def multi_rank_legs(torch, dist, dev, world, plan, xs, steps, warm, reduce_max, 
         dist.all_gather_into_tensor(gathered, outs[i % len(xs)])
 
     run("config4_gather_sync", step_sync, extra=gather_extra)
-    try:  # the all-gather alone: achieved bytes per second per rank
-        fence()
-        t0 = time.perf_counter()
+    def gather_alone():
         for _ in range(5):
             dist.all_gather_into_tensor(gathered, outs[0])
+
+    fence()
+    t0 = time.perf_counter()
+    bad = agree(phase(1, lambda i: gather_alone(), None))
+    if bad:
+        res["config4_gather_alone"] = bad
+    else:
         fence()
         gms = reduce_max(time.perf_counter() - t0) / 5 * 1e3
         res["config4_gather_alone"] = {"ms": gms, "shard_MB": shard_bytes / 1e6, "GBps_per_rank": shard_bytes * (world - 1) / (gms * 1e-3) / 1e9,
                                        "GBps_per_link": shard_bytes / (gms * 1e-3) / 1e9,
                                        "note": "per link: one shard per peer over that peer's xGMI link (fully connected node); wall time of 5 back-to-back all-gathers between fences"}
-    except Exception as e:
-        res["config4_gather_alone"] = {"error": repr(e)[:300]}
     del gathered
     ov = OverlappedGather(oshape, torch.float32, dev, depth=len(xs))
 
@@ -601,14 +622,35 @@ def multi_rank_legs(torch, dist, dev, world, plan, xs, steps, warm, reduce_max, 
 
     run("config4_gather_overlap", step_ov, finish=ov.finish, extra=gather_extra)
     del ov
-    try:
-        comm = make_comm()
-        g2 = torch.empty((world * batch, n_bins, n_frames), dtype=torch.float32, device=dev)
-        run("config4_cabi_chunked4", lambda i: comm.execute(plan, xs[i % len(xs)], world * batch, g2, chunks=4), extra=gather_extra)
-        fence()
-        comm.close()
-    except Exception as e:
-        res["config4_cabi_chunked4"] = {"error": repr(e)[:300]}
+    # Strong scaling: ONE fixed job of `strong_total` utterances cut with sgx_shard_range — this rank computes only its
+    # block, so the step time should fall as 1 / world; `value` = the job's frames per second (north_star: ">= 6x at 8 GPUs").
+    if strong_total:
+        from spectrograms_amd.distributed import shard_range
+        _, cnt = shard_range(strong_total, world, dist.get_rank())
+        reps = -(-cnt // batch)
+        xsh = torch.cat([xs[0]] * reps)[:cnt].contiguous() if cnt else None
+        osh = torch.empty((cnt, n_bins, n_frames), dtype=torch.float32, device=dev) if cnt else None
+        run("config4_strong", (lambda i: plan.compute_batch(xsh, out=osh)) if cnt else (lambda i: None), frames=strong_total * n_frames,
+            extra=lambda ms: {"scaling": "strong", "utterances_total": strong_total, "utterances_this_rank": cnt})
+        del xsh, osh
+    if cabi:
+        # EXPERIMENTAL: sgx_shard_execute_chunked has run on a stand-in RCCL at 2-3 ranks and on the real RCCL at one rank only;
+        # its numbers are not part of the default line until it has run on >= 2 real GPUs (`--experimental-legs cabi`).
+        comm, err = None, None
+        try:
+            comm = make_comm()
+            g2 = torch.empty((world * batch, n_bins, n_frames), dtype=torch.float32, device=dev)
+        except Exception as e:
+            err = e
+        bad = agree(err)
+        if bad:
+            res["config4_cabi_chunked4"] = bad
+        else:
+            run("config4_cabi_chunked4", lambda i: comm.execute(plan, xs[i % len(xs)], world * batch, g2, chunks=4), extra=gather_extra)
+            res["config4_cabi_chunked4"]["experimental"] = True
+            fence()
+        if comm is not None:
+            comm.close()
     return res
 
 
@@ -925,7 +967,9 @@ def main() -> int:
             if rank == 0:
                 line["workloads_error"] = f"legs not finished after {args.legs_timeout:.0f} s: line printed without the rest"
             emit()
-            os._exit(0)
+            # non-zero: a hung leg is a failure the driver / CI must see; the line above still carries the headline and the
+            # finished legs.  No in-process restart, no exec: the process just leaves (a rank stuck in a collective cannot be joined).
+            os._exit(4)
 
         watchdog = threading.Timer(args.legs_timeout, bail)
         watchdog.daemon = True
@@ -961,7 +1005,8 @@ def main() -> int:
         wl4, b4, _ = WORKLOADS["config4"]
         mr = multi_rank_legs(torch, dist, dev, world, make_plan(sg, wl4), [torch.cat([x] * (b4 // 256)) for x in xs256],
                              max(3, min(args.steps, 20)), max(1, min(args.warmup, 3)), reduce_max, lambda: torch.cuda.synchronize(dev),
-                             lambda: ShardComm(dev), f"configs[3]: {b4} x 10 s per GPU x {world} GPUs, mel_power n_fft=1024 hop=256")
+                             lambda: ShardComm(dev), f"configs[3]: {b4} x 10 s per GPU x {world} GPUs, mel_power n_fft=1024 hop=256",
+                             cabi="cabi" in args.experimental_legs.split(","), strong_total=8192)
         if rank == 0:
             line["workloads"] = mr
     if watchdog is not None:
@@ -1024,7 +1069,7 @@ def dry_run(args, rank: int, world: int) -> int:
             return float(t.item())
 
         workloads = multi_rank_legs(torch, dist, "cpu", world, StandInPlan(), [torch.full((4, 64), float(rank + 1)) for _ in range(2)], 3, 1, rmax,
-                                    lambda: None, no_comm, "dry run: stand-in plan, gloo")
+                                    lambda: None, no_comm, "dry run: stand-in plan, gloo", cabi="cabi" in args.experimental_legs.split(","), strong_total=11)
     if rank == 0:
         print(json.dumps({"metric": "STFT frames/sec (f32, n_fft=1024 hop=256)", "value": 0.0, "unit": "frames/s", "n_gpus": world,
                           **({"workloads": workloads} if workloads else {}),

@@ -214,7 +214,11 @@ sgx_status sgx_shard_execute(sgx_plan *plan, sgx_comm *comm, const void *shard_s
  * travel on a second stream owned by the communicator (a group of ncclBroadcast per run, each into the piece's own place in
  * `gathered_out`), ordered by events only.  `hip_stream` waits for the last exchange before the call's work counts as complete,
  * so the call is asynchronous on `hip_stream` like sgx_shard_execute.  chunks == 1 or gathered_out == NULL: sgx_shard_execute.
- * The result equals sgx_shard_execute's bit for bit. */
+ * The result equals sgx_shard_execute's bit for bit.
+ * EXPERIMENTAL: exercised on a stand-in RCCL at 2-3 ranks (tests/c_abi/shard_ranks.c) and on the real RCCL at ONE rank only; no run
+ * on two or more real GPUs yet.  On any failure the two streams are re-joined before the call returns (the caller's stream waits
+ * for whatever was queued on the exchange stream), but collectives other ranks have already issued for later runs stay pending:
+ * after a non-OK status destroy the communicator (sgx_comm_destroy) on every rank. */
 sgx_status sgx_shard_execute_chunked(sgx_plan *plan, sgx_comm *comm, const void *shard_samples, size_t global_batch,
                                      size_t n_samples, size_t sample_stride, void *shard_out, void *gathered_out, int32_t chunks,
                                      void *hip_stream);

@@ -425,6 +425,105 @@ int orc_max_threads(void) {
 #endif
 }
 
+/* ---- long lengths that are not powers of two: chirp-z (Bluestein), f64 ------------------------------------------------
+ * The reference plans every length through rustfft (src/fft_backend.rs:372-389), which itself uses Bluestein / Rader for
+ * lengths with large prime factors; the oracle's direct O(n^2) sum is the definition (src/fft_backend.rs:16-18,128) but takes
+ * minutes at n = 100 003.  From ORC_CZT_MIN points on, non-power-of-two lengths use the published chirp-z identity
+ *   X[k] = conj(c_k) sum_j (x_j conj(c_j)) c_{k-j},  c_j = e^{i pi j^2 / n}  (forward; the inverse conjugates in and out),
+ * as a circular convolution of length M = 2^ceil(log2(2n-1)) on a plain f64 radix-2 FFT, angles reduced in integers
+ * (j^2 mod 2n).  Everything in f64 whatever the caller's type, like the direct sum's accumulation.  Pinned against numpy.fft
+ * in tests/test_oracle_golden.py. */
+#define ORC_CZT_MIN 2048
+typedef struct {
+    size_t n, M;
+    double *cr, *ci;   /* c_j, j < n */
+    double *br, *bi;   /* FFT_M of the wrapped chirp */
+    double *wr, *wi;   /* e^{-2 pi i j / M}, j < M/2 */
+    double *ar, *ai;   /* work, M */
+} orc_czt;
+
+static void orc_czt_free(orc_czt *z) {
+    free(z->cr); free(z->ci); free(z->br); free(z->bi); free(z->wr); free(z->wi); free(z->ar); free(z->ai);
+    memset(z, 0, sizeof(*z));
+}
+
+/* in-place radix-2 DIT on separate re / im arrays of length M (power of two), forward (e^{-}) */
+static void orc_czt_fft(const orc_czt *z, double *re, double *im) {
+    size_t M = z->M;
+    for (size_t i = 1, j = 0; i < M; i++) {
+        size_t bit = M >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { double t = re[i]; re[i] = re[j]; re[j] = t; t = im[i]; im[i] = im[j]; im[j] = t; }
+    }
+    for (size_t h = 1; h < M; h <<= 1) {
+        size_t step = M / (2 * h);
+        for (size_t b = 0; b < M; b += 2 * h)
+            for (size_t j = 0; j < h; j++) {
+                double wr = z->wr[j * step], wi = z->wi[j * step];
+                double xr = re[b + h + j], xi = im[b + h + j];
+                double tr = xr * wr - xi * wi, ti = xr * wi + xi * wr;
+                double ur = re[b + j], ui = im[b + j];
+                re[b + j] = ur + tr; im[b + j] = ui + ti;
+                re[b + h + j] = ur - tr; im[b + h + j] = ui - ti;
+            }
+    }
+}
+
+static int orc_czt_init(orc_czt *z, size_t n) {
+    memset(z, 0, sizeof(*z));
+    size_t M = 1;
+    while (M < 2 * n - 1) M <<= 1;
+    z->n = n; z->M = M;
+    z->cr = (double *)malloc(n * sizeof(double)); z->ci = (double *)malloc(n * sizeof(double));
+    z->br = (double *)calloc(M, sizeof(double)); z->bi = (double *)calloc(M, sizeof(double));
+    z->wr = (double *)malloc((M / 2 + 1) * sizeof(double)); z->wi = (double *)malloc((M / 2 + 1) * sizeof(double));
+    z->ar = (double *)malloc(M * sizeof(double)); z->ai = (double *)malloc(M * sizeof(double));
+    if (!z->cr || !z->ci || !z->br || !z->bi || !z->wr || !z->wi || !z->ar || !z->ai) { orc_czt_free(z); return ORC_INTERNAL; }
+    for (size_t j = 0; j < M / 2; j++) {
+        double a = -2.0 * M_PI * (double)j / (double)M;
+        z->wr[j] = cos(a); z->wi[j] = sin(a);
+    }
+    for (size_t j = 0; j < n; j++) {
+        unsigned long long q = ((unsigned long long)j * (unsigned long long)j) % (2ull * n); /* j < 2^31: no overflow */
+        double a = M_PI * (double)q / (double)n;
+        z->cr[j] = cos(a); z->ci[j] = sin(a);
+    }
+    z->br[0] = z->cr[0]; z->bi[0] = z->ci[0];
+    for (size_t j = 1; j < n; j++) {
+        z->br[j] = z->cr[j]; z->bi[j] = z->ci[j];
+        z->br[M - j] = z->cr[j]; z->bi[M - j] = z->ci[j];
+    }
+    orc_czt_fft(z, z->br, z->bi);
+    return ORC_OK;
+}
+
+/* (re, im)[0..n) -> its DFT (forward e^{-}, or inverse e^{+}, unnormalised) in place */
+static void orc_czt_run(orc_czt *z, double *re, double *im, int inverse) {
+    size_t n = z->n, M = z->M;
+    double sg = inverse ? -1.0 : 1.0;  /* inverse: conj in, conj out */
+    for (size_t j = 0; j < n; j++) {
+        double xr = re[j], xi = sg * im[j];
+        z->ar[j] = xr * z->cr[j] + xi * z->ci[j];   /* x conj(c) */
+        z->ai[j] = xi * z->cr[j] - xr * z->ci[j];
+    }
+    for (size_t j = n; j < M; j++) { z->ar[j] = 0.0; z->ai[j] = 0.0; }
+    orc_czt_fft(z, z->ar, z->ai);
+    for (size_t j = 0; j < M; j++) {  /* product, conjugated for the inverse transform by the conj-FFT-conj identity */
+        double pr = z->ar[j] * z->br[j] - z->ai[j] * z->bi[j];
+        double pi = z->ar[j] * z->bi[j] + z->ai[j] * z->br[j];
+        z->ar[j] = pr; z->ai[j] = -pi;
+    }
+    orc_czt_fft(z, z->ar, z->ai);
+    double inv = 1.0 / (double)M;
+    for (size_t k = 0; k < n; k++) {
+        double yr = z->ar[k] * inv, yi = -z->ai[k] * inv;
+        double Xr = yr * z->cr[k] + yi * z->ci[k];    /* y conj(c) */
+        double Xi = yi * z->cr[k] - yr * z->ci[k];
+        re[k] = Xr; im[k] = sg * Xi;
+    }
+}
+
 /* ---- typed part (T = f32 / f64), see oracle_typed.inc --------------------- */
 #define REAL float
 #define SUF(x) x##_f32

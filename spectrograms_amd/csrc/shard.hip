@@ -280,17 +280,30 @@ sgx_status sgx_shard_execute_chunked(sgx_plan *plan, sgx_comm *c, const void *sh
     // the exchange stream starts behind whatever the caller has queued (e.g. the last consumer of gathered_out)
     if (!hip_ok(hipEventRecord(c->gathered, s)) || !hip_ok(hipStreamWaitEvent(c->gstream, c->gathered, 0)))
         return comm_fail(c, SGX_BACKEND, "hip -- FFT backend error: stream ordering failed");
-    for (int k = 0; k < chunks; ++k) {
+    // A failure inside the loop (a launch that fails, an RCCL call that fails) must not leave the two streams half-joined: whatever
+    // happened, `gathered` is recorded on the exchange stream behind everything queued there and the caller's stream waits for it, so
+    // the next call — and the caller's own work on `s` — start from a defined order.  An RCCL group that was opened is
+    // always closed.  (What other ranks have already issued for later chunks cannot be withdrawn from here: a failed call means the
+    // communicator should be destroyed, which the header says.)
+    sgx_status result = SGX_OK;
+    std::string why;
+    auto fail = [&](sgx_status code, const std::string &msg) {
+        if (result == SGX_OK) { result = code; why = msg; }
+    };
+    for (int k = 0; k < chunks && result == SGX_OK; ++k) {
         size_t lo = 0, hi = 0;
         piece(count, k, &lo, &hi);
         if (hi > lo) {
             const char *xin = static_cast<const char *>(shard_samples) + lo * sample_stride * elem;
             st = sgx_execute(plan, xin, hi - lo, n_samples, sample_stride, own + lo * per_item * elem, (hi - lo) * per_item, SGX_MEM_DEVICE, hip_stream);
-            if (st != SGX_OK) return comm_fail(c, st, sgx_last_error(plan));
+            if (st != SGX_OK) { fail(st, sgx_last_error(plan)); break; }
         }
-        if (!hip_ok(hipEventRecord(c->chunk_done[k], s)) || !hip_ok(hipStreamWaitEvent(c->gstream, c->chunk_done[k], 0)))
-            return comm_fail(c, SGX_BACKEND, "hip -- FFT backend error: stream ordering failed");
-        SGX_NCCL(c, r.GroupStart());
+        if (!hip_ok(hipEventRecord(c->chunk_done[k], s)) || !hip_ok(hipStreamWaitEvent(c->gstream, c->chunk_done[k], 0))) {
+            fail(SGX_BACKEND, "hip -- FFT backend error: stream ordering failed");
+            break;
+        }
+        ncclResult_t ge = r.GroupStart();
+        if (ge != ncclSuccess) { fail(SGX_BACKEND, nccl_text(ge)); break; }
         for (int root = 0; root < c->world; ++root) {
             size_t rs = 0, rc = 0, plo = 0, phi = 0;
             (void)sgx_shard_range(global_batch, c->world, root, &rs, &rc);
@@ -299,12 +312,14 @@ sgx_status sgx_shard_execute_chunked(sgx_plan *plan, sgx_comm *c, const void *sh
             char *slice = gout + (rs + plo) * per_item * elem;
             const void *src = root == c->rank ? static_cast<const void *>(own + plo * per_item * elem) : static_cast<const void *>(slice);
             ncclResult_t e = r.Broadcast(src, slice, (phi - plo) * per_item, nt, root, c->comm, c->gstream);
-            if (e != ncclSuccess) { (void)r.GroupEnd(); return comm_fail(c, SGX_BACKEND, nccl_text(e)); }
+            if (e != ncclSuccess) { fail(SGX_BACKEND, nccl_text(e)); break; }
         }
-        SGX_NCCL(c, r.GroupEnd());
+        ge = r.GroupEnd();  // closes the group on the error path too
+        if (ge != ncclSuccess) fail(SGX_BACKEND, nccl_text(ge));
     }
-    if (!hip_ok(hipEventRecord(c->gathered, c->gstream)) || !hip_ok(hipStreamWaitEvent(s, c->gathered, 0)))
-        return comm_fail(c, SGX_BACKEND, "hip -- FFT backend error: stream ordering failed");
+    const bool joined = hip_ok(hipEventRecord(c->gathered, c->gstream)) && hip_ok(hipStreamWaitEvent(s, c->gathered, 0));
+    if (result != SGX_OK) return comm_fail(c, result, why);
+    if (!joined) return comm_fail(c, SGX_BACKEND, "hip -- FFT backend error: stream ordering failed");
     return SGX_OK;
 }
 

@@ -144,14 +144,44 @@ class ShardComm:
         if st != 0:
             raise _ffi.FFTBackendError((self._lib.sgx_comm_last_error(None) or b"").decode() or "sgx_comm_create failed")
 
-    def execute(self, plan, x_local, batch_total: int, gathered, chunks: int = 1, shard_out=None, stream: int = 0):
-        """x_local: this rank's [count, N] device tensor; gathered: [batch_total, n_bins, n_frames(, 2)] device tensor."""
+    def execute(self, plan, x_local, batch_total: int, gathered, chunks: int = 1, shard_out=None, stream: int = 0,
+                n_samples: Optional[int] = None):
+        """x_local: this rank's [count, N] device tensor (None, or zero rows, on a rank whose shard is empty — then `n_samples` says
+        N); gathered: contiguous [batch_total, n_bins, n_frames(, 2)] device tensor of the plan's dtype.  Everything the C side
+        writes through raw pointers is checked here first: row count against `sgx_shard_range`, dtype, device, contiguity."""
         import torch
 
+        tdt = torch.float32 if plan._dt == _ffi.F32 else torch.float64
+        _, count = shard_range(batch_total, self.world, self.rank)
+        rows = 0 if x_local is None else int(x_local.shape[0])
+        if rows != count:
+            raise ValueError(f"rank {self.rank} of {self.world}: local shard has {rows} rows, sgx_shard_range gives {count} of {batch_total}")
+        if rows:
+            if x_local.dim() != 2 or not x_local.is_cuda or x_local.dtype != tdt or x_local.stride(1) != 1:
+                raise ValueError("x_local must be a 2-D CUDA tensor of the plan's dtype with unit inner stride")
+            if n_samples is not None and n_samples != x_local.shape[1]:
+                raise ValueError(f"n_samples {n_samples} != x_local.shape[1] {x_local.shape[1]}")
+            n, stride, xp = int(x_local.shape[1]), int(x_local.stride(0)), x_local.data_ptr()
+            dev = x_local.device
+        else:
+            if n_samples is None and (x_local is None or x_local.dim() != 2):
+                raise ValueError("a rank with an empty shard passes n_samples (or a [0, N] tensor)")
+            n = int(n_samples if n_samples is not None else x_local.shape[1])
+            stride, xp, dev = n, None, gathered.device
+        for name, t in (("gathered", gathered), ("shard_out", shard_out)):
+            if t is None:
+                continue
+            if not t.is_cuda or t.device != dev or t.dtype != tdt or not t.is_contiguous():
+                raise ValueError(f"{name} must be a contiguous CUDA tensor of the plan's dtype on the samples' device")
+        nb, nf = plan.output_shape(n)
+        per = nb * nf * (2 if plan.is_complex else 1)
+        if gathered.numel() != batch_total * per:
+            raise _ffi.DimensionMismatchError(f"Dimension mismatch: expected {batch_total * per}, got {gathered.numel()}", batch_total * per, gathered.numel())
+        if shard_out is not None and shard_out.numel() != count * per:
+            raise _ffi.DimensionMismatchError(f"Dimension mismatch: expected {count * per}, got {shard_out.numel()}", count * per, shard_out.numel())
         s = stream or torch.cuda.current_stream(gathered.device).cuda_stream
-        n = x_local.shape[1] if x_local is not None and x_local.numel() else 0
-        st = self._lib.sgx_shard_execute_chunked(plan._h, self._h, x_local.data_ptr() if n else None, batch_total, x_local.shape[1],
-                                                 x_local.stride(0), shard_out.data_ptr() if shard_out is not None else None,
+        st = self._lib.sgx_shard_execute_chunked(plan._h, self._h, xp, batch_total, n, stride,
+                                                 shard_out.data_ptr() if shard_out is not None else None,
                                                  gathered.data_ptr(), int(chunks), C.c_void_p(s))
         if st != 0:
             msg = (self._lib.sgx_comm_last_error(self._h) or b"").decode() or f"sgx_shard_execute_chunked failed (status {st})"

@@ -17,7 +17,7 @@ def _run(args, env=None):
 
 
 def test_direct_multi_rank_run_spawns_its_ranks():
-    r = _run(["--gpus", "2", "--steps", "5", "--warmup", "1", "--workload", "config4", "--gather", "overlap", "--dry-run"])
+    r = _run(["--gpus", "2", "--steps", "5", "--warmup", "1", "--workload", "config4", "--gather", "overlap", "--dry-run", "--experimental-legs", "cabi"])
     assert r.returncode == 0, r.stderr
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]  # gloo may print a connection notice of its own
     assert len(lines) == 1, r.stdout
@@ -31,13 +31,21 @@ def test_direct_multi_rank_run_spawns_its_ranks():
     # only, all-gather behind every launch, gather overlapped with the next launch, the all-gather alone with its per-rank rate, and
     # the C ABI's chunked path — which has no device here and must report its error without taking the line down
     w = d["workloads"]
-    assert set(w) == {"config4", "config4_gather_sync", "config4_gather_alone", "config4_gather_overlap", "config4_cabi_chunked4"}
+    assert set(w) == {"config4", "config4_gather_sync", "config4_gather_alone", "config4_gather_overlap", "config4_strong", "config4_cabi_chunked4"}
+    # the strong-scaling leg: ONE fixed job (here 11 utterances) cut with sgx_shard_range — 6 + 5 rows over the two ranks
+    assert w["config4_strong"]["scaling"] == "strong" and w["config4_strong"]["utterances_total"] == 11 and w["config4_strong"]["utterances_this_rank"] == 6
+    assert w["config4_strong"]["value"] > 0
     for k in ("config4", "config4_gather_sync", "config4_gather_overlap"):
         assert w[k]["value"] > 0 and w[k]["ms_per_step"] > 0 and w[k]["steps"] == 3, w[k]
     for k in ("config4_gather_sync", "config4_gather_overlap"):
         assert w[k]["GBps_per_rank"] > 0 and w[k]["shard_MB"] == 4 * 8 * 5 * 4 / 1e6
     assert w["config4_gather_alone"]["GBps_per_rank"] > 0 and w["config4_gather_alone"]["GBps_per_link"] > 0
     assert "no HIP device" in w["config4_cabi_chunked4"]["error"]
+    # the C ABI's chunked leg is opt-in (experimental until it has run on more than one real GPU): the default line leaves it out
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"])
+    assert r.returncode == 0, r.stderr
+    w = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["workloads"]
+    assert "config4_cabi_chunked4" not in w and "config4_strong" in w
 
 
 def test_two_ranks_on_one_device_are_refused():

@@ -29,11 +29,12 @@ def test_bench_multi_rank_legs_rehearsal():
     """`bench.py --rehearse-multi-rank`: the legs the driver's `--gpus 8` run executes (config 4 compute, all-gather behind every launch,
     the all-gather alone, gather overlapped with the next launch, the C ABI's chunked path), here with a one-rank RCCL group."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--rehearse-multi-rank",
-                        "--no-cpu-baseline", "--preheat-s", "0.05"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=_env(29549), timeout=300)
+                        "--no-cpu-baseline", "--preheat-s", "0.05", "--experimental-legs", "cabi"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=_env(29549), timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     w = d["workloads"]
-    assert set(w) == {"config4", "config4_gather_sync", "config4_gather_alone", "config4_gather_overlap", "config4_cabi_chunked4"}
+    assert set(w) == {"config4", "config4_gather_sync", "config4_gather_alone", "config4_gather_overlap", "config4_strong", "config4_cabi_chunked4"}
+    assert w["config4_strong"]["utterances_this_rank"] == 8192 and w["config4_strong"]["value"] > 5e8
     for k, v in w.items():
         assert "error" not in v, (k, v)
     assert w["config4"]["value"] > 5e8 and w["config4_cabi_chunked4"]["value"] > 5e8
