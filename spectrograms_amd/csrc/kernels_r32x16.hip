@@ -682,71 +682,6 @@ __device__ __forceinline__ void mel_tile_sched(const StftArgs &a, const float *p
     }
 }
 
-// ---- filterbank stage on flat band streams (round 5; r32x16_layout.h) --------------------------------------------------------------
-// The same sums as mel_tile_sched — lane (slot, fp) of wave w adds weight * |X|^2 over its band's bins in ascending order, un-fused, two
-// frames packed — but a slot's bands are one stream of TRIPS trips of 4 bins, the same compile-time count for every lane: straight-line
-// code.  The segment form spent its time on control, not on sums or reads (profiles/experiments_r03/band_stage_ablations.txt: 13 of the
-// stage's 23 us with every LDS read removed): four serial segments of record -> readfirstlane -> pointers -> dynamic loop -> stores.
-// Here every trip's record, weights and |X|^2 reads are independent of the sums before them; a trip that completes a band stores the two
-// sums and clears them, any other trip "stores" to an offset past the descriptor (band code n_mels: dropped by the hardware), so the
-// store count is fixed (2 TRIPS: counted behind the next tile's loads like the segment form's).
-template <int AMP, int TRIPS>
-__device__ __forceinline__ void mel_tile_flat(const StftArgs &a, const float *pwT, const unsigned *tab, unsigned b, unsigned f0, unsigned nf,
-                                              float eps, unsigned tid) {
-    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u, slot = lane >> 3, fp = lane & 7u;
-    constexpr unsigned kDrop = 0x80000000u;
-    constexpr unsigned TG = (TRIPS + 3) / 4;
-    const unsigned obytes = (a.n_out * a.n_frames - f0) * 4u;
-    const __amdgpu_buffer_rsrc_t ro = make_rsrc((const float *)a.out + (size_t)b * a.n_out * a.n_frames + f0, obytes);
-    const unsigned fo0 = 2u * fp < nf ? 8u * fp : kDrop, fo1 = 2u * fp + 1u < nf ? 8u * fp + 4u : kDrop;
-    const unsigned nf4 = a.n_frames * 4u, none = a.n_mels;
-    const uint4 *rp = (const uint4 *)(tab + kFlatHdr) + wave * TG * 8u + slot;
-    const v4f *wp = (const v4f *)(tab + kFlatHdr + 4u * TG * 32u) + wave * (unsigned)TRIPS * 8u + slot;
-    const unsigned char *pwb = (const unsigned char *)pwT + fp * 16u;
-    unsigned rec[4 * TG];
-#pragma unroll
-    for (unsigned g = 0; g < TG; ++g) {
-        const uint4 r = rp[g * 8u];
-        rec[4 * g] = r.x; rec[4 * g + 1] = r.y; rec[4 * g + 2] = r.z; rec[4 * g + 3] = r.w;
-    }
-    // The reads of trip t + D are requested before trip t is summed (the scheduling barriers keep hipcc from sinking them next to their
-    // uses, which it does to save registers — and which exposes an LDS round trip per trip at two waves per SIMD).
-#ifndef SGX_FLATD
-#define SGX_FLATD 3
-#endif
-    constexpr int D = SGX_FLATD < TRIPS ? SGX_FLATD : TRIPS;
-    v4f w4[D], q0[D], q1[D];
-    auto request = [&](int t) {
-        const unsigned pofs = rec[t] & 0xffffu;
-        w4[t % D] = wp[t * 8];
-        q0[t % D] = *(const v4f *)(pwb + pofs);
-        q1[t % D] = *(const v4f *)(pwb + pofs + 128u);
-    };
-#pragma unroll
-    for (int t = 0; t < D; ++t) request(t);
-    __builtin_amdgcn_sched_barrier(0);
-    v2f acc = {0.0f, 0.0f};
-#pragma unroll
-    for (int t = 0; t < TRIPS; ++t) {
-        const unsigned band = rec[t] >> 16;
-        const v4f w = w4[t % D], a0 = q0[t % D], a1 = q1[t % D];
-        acc = mul_add_unfused(w.x, (v2f){a0.x, a0.y}, acc);
-        acc = mul_add_unfused(w.y, (v2f){a0.z, a0.w}, acc);
-        acc = mul_add_unfused(w.z, (v2f){a1.x, a1.y}, acc);
-        acc = mul_add_unfused(w.w, (v2f){a1.z, a1.w}, acc);
-        if (t + D < TRIPS) request(t + D);
-        // band * nf4 < 2^31 (plan_geometry_r32x16_f32; both factors < 2^24), so "no band" (n_mels rows in: past the descriptor) and "no frame" (kDrop)
-        // both land out of range
-        const unsigned bo = __umul24(band, nf4);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, amp_f32<AMP>(acc.x, eps)), ro, (int)(bo + fo0), 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, amp_f32<AMP>(acc.y, eps)), ro, (int)(bo + fo1), 0, 0);
-        const bool done = band != none;
-        acc.x = done ? 0.0f : acc.x;
-        acc.y = done ? 0.0f : acc.y;
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
 // P512: |X|^2 tile of 32 frames: bin pair x frame pair = four floats, 16 frame pairs per bin pair
 __host__ __device__ constexpr unsigned pwt512_index(unsigned k, unsigned f) { return (k >> 1) * 64u + (f >> 1) * 4u + (k & 1u) * 2u + (f & 1u); }
 // The same schedule (records per segment, wave, 8 slots) walked by lanes (4 slots x 16 frame pairs): a lane takes slots s and s + 4
@@ -815,9 +750,8 @@ __device__ __forceinline__ void mel_tile_sched512(const StftArgs &a, const float
 // direct path, ROUNDS = 0) through one descriptor over the whole batch, each pair range-checked against its own row in the lane;
 // outputs through one descriptor from the tile's first signal.  The reference's per-frame loop costs the same per frame whatever
 // the signal length (src/spectrogram.rs:240-294).
-template <int MODE, int AMP, int ROUNDS, bool WIDE, bool XSPAD, bool PWT, int HOP512 = 0, bool PACK = false, int FLAT = 0>
+template <int MODE, int AMP, int ROUNDS, bool WIDE, bool XSPAD, bool PWT, int HOP512 = 0, bool PACK = false>
 __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd, unsigned total, unsigned slots) {
-    static_assert(FLAT == 0 || (PWT && HOP512 == 0 && !PACK), "flat band streams: n_fft 1024, one-signal tiles");
     constexpr bool P512 = HOP512 != 0;           // n_fft 512 at hop HOP512
     static_assert(!PACK || (ROUNDS == 0 && !WIDE && !XSPAD && (HOP512 == 0 ? (MODE != OUT_MEL || PWT) : MODE != OUT_MEL)),
                   "PACK: direct loads, one-half tiles; n_fft 1024: scheduled band stage, n_fft 512: per-bin outputs");
@@ -839,11 +773,8 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
     if (threadIdx.x < 256u) ((v4f *)(tabs + kWinOff))[threadIdx.x] = ((const v4f *)a.window)[threadIdx.x];
     for (unsigned i = threadIdx.x; i < 16u * 17u; i += 512u) ((v4f *)(tabs + kTw2Off))[i] = ((const v4f *)a.tw2)[i];
     unsigned *sched = (unsigned *)(tabs + kMelOff);
-    if constexpr (FLAT != 0) {
-        for (unsigned i = threadIdx.x; i < a.mel_flat_words; i += 512u) sched[i] = a.mel_flat[i];
-    } else if constexpr (PWT) {
+    if constexpr (PWT)
         for (unsigned i = threadIdx.x; i < a.mel_sched_words; i += 512u) sched[i] = a.mel_sched[i];
-    }
 
     // XCD-aware work mapping: blocks g and g+8 share an XCD (round-robin dispatch).  XCD x owns the contiguous run of
     // work ids [x*per_xcd, (x+1)*per_xcd); its `slots` resident workgroups walk that run with stride `slots`, so tiles
@@ -1205,7 +1136,6 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
             if (a.n_mels == 12345u)
 #endif
             if constexpr (P512) mel_tile_sched512<AMP>(a, pwf, sched, b, f0, nf, eps, tid);
-            else if constexpr (FLAT != 0) mel_tile_flat<AMP, FLAT>(a, pwf, sched, b, f0, nf, eps, tid);
             else if constexpr (PWT) mel_tile_sched<AMP, PACK>(a, pwf, sched, b, f0, nf, eps, tid SGX_STAMP_ARGS);
             else if (a.mm_frag) map_tile_mfma<AMP>(a, pwf, b, f0, nf, eps, tid, 2u * half);
             else mel_tile_csr<AMP>(a, pwf, b, f0, nf, eps, tid, 256u);
@@ -1282,18 +1212,6 @@ hipError_t launch_variant(const StftArgs &a0, hipStream_t s) {
                     return go(k_r32x16<MODE, AMP, 9, false, false, true, 256>, 2u * kExBytesH256 + kMelOff + ((a.mel_sched_words * 4u + 15u) & ~15u) + 64u);
                 return hipErrorInvalidConfiguration;
             }
-#ifndef SGX_NOFLAT
-            // flat band streams (straight-line band stage), one kernel per menu length (r32x16_layout.h kFlatMenu)
-            auto flat = [&](auto trips) -> hipError_t {
-                constexpr int T = decltype(trips)::value;
-                if (a.hop == 256u) return go(k_r32x16<MODE, AMP, 5, false, true, true, 0, false, T>);
-                if (chunks <= 5u * 256u) return go(k_r32x16<MODE, AMP, 5, false, false, true, 0, false, T>);
-                return go(k_r32x16<MODE, AMP, 0, false, false, true, 0, false, T>);
-            };
-            if (a.mel_flat && a.mel_flat_trips == 10u) return flat(std::integral_constant<int, 10>{});
-            if (a.mel_flat && a.mel_flat_trips == 12u) return flat(std::integral_constant<int, 12>{});
-            if (a.mel_flat && a.mel_flat_trips == 16u) return flat(std::integral_constant<int, 16>{});
-#endif
             if (a.hop == 256u) return go(k_r32x16<MODE, AMP, 5, false, true, true>);
             if (chunks <= 5u * 256u) return go(k_r32x16<MODE, AMP, 5, false, false, true>);
             return go(k_r32x16<MODE, AMP, 0, false, false, true>);

@@ -492,75 +492,6 @@ void build_band_schedule(sgx_plan *pl, unsigned NW = 4, unsigned kSegs = r32x16:
     }
 }
 
-// Flat band streams of the tuned f32 kernel at n_fft 1024 (r32x16_layout.h): the same bank, the same sums in the same order
-// (ascending bins, un-fused: spectrogram.rs:102-117), dealt to the 32 (wave, slot) streams of a half longest-first.  A band's run starts at
-// the bin the slot's bank half asks for (0 or 2 mod 4) and covers whole trips of 4 bins; what is not the band's weighs +0 (exact for
-// finite |X|^2 — the same caveat as build_band_schedule's padding).  Built only when every stream fits the menu's longest kernel.
-void build_band_streams(sgx_plan *pl) {
-    pl->h_mel_flat.clear();
-    pl->mel_flat_trips = 0;
-    if (pl->h_mel_sched.empty() || pl->p.n_fft != 1024 || pl->out_mode != OUT_MEL) return;  // (same preconditions: rows are runs of bins, not the matrix-core bank)
-    const unsigned nm = pl->p.n_mels;
-    if (nm == 0 || nm >= 0xffffu) return;
-    struct Band { unsigned m, c0, c1; bool empty; };
-    std::vector<Band> bands(nm);
-    for (unsigned m = 0; m < nm; ++m) {
-        const uint32_t p0 = pl->mel_ptr[m], p1 = pl->mel_ptr[m + 1];
-        bands[m] = p1 > p0 ? Band{m, pl->mel_col[p0], pl->mel_col[p1 - 1], false} : Band{m, 0, 0, true};
-    }
-    auto start_of = [](const Band &b, unsigned cls) {  // first bin of the band's run in a slot of bank half `cls`
-        const unsigned want = cls ? 2u : 0u, back = (b.c0 + 4u - want) & 3u;
-        return b.c0 >= back ? b.c0 - back : (b.c0 & ~1u);  // (a band at bins 0 / 1 in an odd half: even start, a bank conflict, nothing else)
-    };
-    auto trips_of = [&](const Band &b, unsigned cls) { return b.empty ? 1u : (b.c1 - start_of(b, cls) + 4u) / 4u; };
-    std::vector<unsigned> order(nm);
-    for (unsigned m = 0; m < nm; ++m) order[m] = m;
-    std::stable_sort(order.begin(), order.end(), [&](unsigned x, unsigned y) { return trips_of(bands[x], 0) > trips_of(bands[y], 0); });
-    std::vector<std::vector<unsigned>> streams(32);  // stream = 8 wave + slot
-    unsigned load[32] = {0};
-    for (unsigned m : order) {
-        unsigned best = 0, best_t = ~0u;
-        for (unsigned st = 0; st < 32; ++st) {
-            const unsigned t = load[st] + trips_of(bands[m], ((st & 7u) >> 1) & 1u);
-            if (t < best_t) { best_t = t; best = st; }
-        }
-        streams[best].push_back(m);
-        load[best] = best_t;
-    }
-    unsigned need = 0;
-    for (unsigned st = 0; st < 32; ++st) need = std::max(need, load[st]);
-    unsigned trips = 0;
-    for (int t : r32x16::kFlatMenu)
-        if (unsigned(t) >= need) { trips = unsigned(t); break; }
-    if (trips == 0) return;  // longer than the longest kernel of the menu: the segment schedule runs it
-    const unsigned TG = (trips + 3u) / 4u;
-    std::vector<uint32_t> words(r32x16::flat_words(trips), 0);
-    words[0] = trips; words[1] = uint32_t(words.size()); words[2] = TG;
-    const size_t rec0 = r32x16::kFlatHdr, w0 = rec0 + size_t(4) * TG * 32;
-    for (unsigned st = 0; st < 32; ++st) {
-        const unsigned wave = st >> 3, slot = st & 7u, cls = (slot >> 1) & 1u;
-        unsigned t = 0;
-        auto rec_at = [&](unsigned tr) -> uint32_t & { return words[rec0 + ((size_t(wave) * TG + (tr >> 2)) * 8 + slot) * 4 + (tr & 3u)]; };
-        auto w_at = [&](unsigned tr, unsigned e) -> uint32_t & { return words[w0 + ((size_t(wave) * trips + tr) * 8 + slot) * 4 + e]; };
-        for (unsigned m : streams[st]) {
-            const Band &b = bands[m];
-            const unsigned ks = b.empty ? 0u : start_of(b, cls), nt = trips_of(b, cls);
-            for (unsigned q = 0; q < nt; ++q, ++t) {
-                rec_at(t) = ((ks + 4u * q) >> 1) * 128u | ((q + 1 == nt ? m : nm) << 16);
-                for (unsigned e = 0; e < 4; ++e) {
-                    const unsigned bin = ks + 4u * q + e;
-                    float wv = 0.0f;
-                    if (!b.empty && bin >= b.c0 && bin <= b.c1) wv = float(pl->mel_val[pl->mel_ptr[m] + (bin - b.c0)]);
-                    std::memcpy(&w_at(t, e), &wv, 4);
-                }
-            }
-        }
-        for (; t < 4u * TG; ++t) rec_at(t) = nm << 16;  // padding trips: bins 0..3 with weight +0, nothing stored
-    }
-    pl->mel_flat_trips = trips;
-    pl->h_mel_flat = std::move(words);
-}
-
 template <typename T>
 sgx_status build_device_tables(sgx_plan *pl) {
     const unsigned n = pl->p.n_fft;
@@ -660,7 +591,6 @@ sgx_status build_device_tables(sgx_plan *pl) {
         if (((std::is_same<T, float>::value && (pl->kind == K_R32X16_F32 || pl->kind == K_R32X32_F32 || pl->kind == K_R64X32_F32)) || (std::is_same<T, double>::value && (pl->kind == K_D32X16_F64 || pl->kind == K_D512_F64 || pl->kind == K_D32X32_F64))) &&
             !pl->h_mel_sched.empty() && !pl->d_mm_frag) {
             if ((st = upload<uint32_t>(pl, &pl->d_mel_sched, pl->h_mel_sched)) != SGX_OK) return st;
-            if (pl->kind == K_R32X16_F32 && !pl->h_mel_flat.empty() && (st = upload<uint32_t>(pl, &pl->d_mel_flat, pl->h_mel_flat)) != SGX_OK) return st;
         }
     }
     if (pl->p.n_mfcc > 0) {
@@ -927,9 +857,6 @@ void fill_args(const sgx_plan *pl, StftArgs &a, const void *x, void *out, size_t
     a.mm_nblk = pl->mm_nblk;
     a.mel_sched = (const unsigned *)pl->d_mel_sched;
     a.mel_sched_words = pl->mel_sched_words;
-    a.mel_flat = (const unsigned *)pl->d_mel_flat;
-    a.mel_flat_words = pl->d_mel_flat ? unsigned(pl->h_mel_flat.size()) : 0u;
-    a.mel_flat_trips = pl->d_mel_flat ? pl->mel_flat_trips : 0u;
     a.n_mels = p.n_mels;
     a.mel_nnz = unsigned(pl->mel_col.size());
     a.out_mode = pl->out_mode;
@@ -1103,7 +1030,7 @@ sgx_status grow(sgx_plan *pl, void **buf, size_t *have, size_t need) {
 
 void free_device(sgx_plan *pl) {
     void **bufs[] = {&pl->d_window, &pl->d_tw, &pl->d_tw1, &pl->d_tw2, &pl->d_mel_ptr, &pl->d_mel_col,
-                     &pl->d_mel_val, &pl->d_dct, &pl->d_lifter, &pl->d_melbuf, &pl->d_pwbuf, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_mm_frag, &pl->d_mm_blk, &pl->d_mel_sched, &pl->d_mel_flat, &pl->d_itw, &pl->d_itwr, &pl->d_itw1, &pl->d_itwr2, &pl->d_itw12, &pl->d_itwrd, &pl->d_itw1d, &pl->d_frames, &pl->d_flag, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half, &pl->d_bs_chirp, &pl->d_bs_tw, &pl->d_bs_wc, &pl->d_bs_bhp, &pl->bs_half.chirp, &pl->bs_half.bhp, &pl->bs_half.tw};
+                     &pl->d_mel_val, &pl->d_dct, &pl->d_lifter, &pl->d_melbuf, &pl->d_pwbuf, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_mm_frag, &pl->d_mm_blk, &pl->d_mel_sched, &pl->d_itw, &pl->d_itwr, &pl->d_itw1, &pl->d_itwr2, &pl->d_itw12, &pl->d_itwrd, &pl->d_itw1d, &pl->d_frames, &pl->d_flag, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half, &pl->d_bs_chirp, &pl->d_bs_tw, &pl->d_bs_wc, &pl->d_bs_bhp, &pl->bs_half.chirp, &pl->bs_half.bhp, &pl->bs_half.tw};
     for (void **b : bufs)
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
@@ -1394,7 +1321,6 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
     if (params->dtype == SGX_F32 && params->n_fft == 4096 && params->hop_size % 2 == 0) pl->kind = K_R64X32_F32;  // per-bin and complex outputs; filterbanks: split path
     if (params->dtype == SGX_F64 && params->n_fft == 2048 && params->hop_size % 2 == 0) pl->kind = K_D32X32_F64;  // per-bin and complex outputs
     if (pl->kind == K_R32X16_F32) build_band_schedule(pl);  // before the kind is resolved: plan_geometry_r32x16_f32 asks for it
-    if (pl->kind == K_R32X16_F32) build_band_streams(pl);
     if (pl->kind == K_R32X32_F32) build_band_schedule(pl, 8, r32x32::kSegs2, r32x32::kSch2MaxWords, 0);
     if (pl->kind == K_D32X16_F64) build_band_schedule(pl, 8, d32x16::kDSegs, d32x16::kDSchMaxWords, 0, 2);
     if (pl->kind == K_D512_F64) build_band_schedule(pl, 8, d512::kSegs, d512::kSchMaxWords, 0, 2);

@@ -32,21 +32,6 @@ constexpr int kMelMaxWordsH256 = (163840 - 2 * kExBytesH256 - kMelOff) / 4 - 16;
 constexpr int kSchedHdr = 4;
 constexpr int kSchedSegs = 4;  // the kernel always runs this many segments (empty ones have L = 0, band = none): n_mels <= 128
 
-
-// Flat band streams (round 5; n_fft 1024, one-signal tiles): the bank as 32 step streams, one per (wave, slot) of a half.  A stream is the
-// concatenation of the slot's bands, each as a run of whole TRIPS of 4 consecutive bins (zero weights in front of / behind the band; the
-// run starts at a bin = 0 mod 4 in slots 0, 1, 4, 5 and = 2 mod 4 in slots 2, 3, 6, 7 — the bank halves of the |X|^2 tile); every stream has
-// the same compile-time number of trips (a menu, kFlatMenu; streams are padded with trips of weight 0 that store nothing), so the stage is
-// straight-line code: no loop, no wave-uniform trip count, every read requestable up front.
-//   [0] trips  [1] total words  [2] trip groups TG = ceil(trips / 4)  [3] 0
-//   rec   u32 [wave 4][TG][slot 8][4]   : trip 4 g + e of the slot = (byte offset of the trip's first bin pair in the |X|^2 tile) | band << 16;
-//                                          band = the band whose sum this trip completes (stored, accumulator cleared), n_mels: none
-//   w     f32 [wave 4][trips][slot 8][4] : the trip's four weights
-constexpr int kFlatHdr = 4;
-constexpr int kFlatMenu[] = {10, 12, 16};
-constexpr int kFlatMaxTrips = 16;
-constexpr unsigned flat_words(unsigned trips) { return kFlatHdr + 4u * ((trips + 3u) / 4u) * 32u + 4u * trips * 32u; }
-
 }  // namespace r32x16
 
 // ---- k_r32x32: the tuned f32 n_fft = 2048 kernel (kernels_r32x32.hip), one 16-frame tile per 512-thread workgroup ----------

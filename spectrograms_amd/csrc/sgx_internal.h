@@ -71,9 +71,6 @@ struct StftArgs {
     // filterbank schedule of the tuned kernel (r32x16_layout.h), nullptr: bank not schedulable (matrix cores / CSR path)
     const unsigned *mel_sched;
     unsigned mel_sched_words;
-    // the same bank as flat per-slot step streams (r32x16_layout.h, "flat band streams"; n_fft 1024, one-signal tiles): nullptr / 0 = none
-    const unsigned *mel_flat;
-    unsigned mel_flat_words, mel_flat_trips;
     // tuned kernel, packed tiles (batches of short signals; set by its launcher): batch * n_frames, bytes of the whole sample buffer
     unsigned gframes, x_bytes;
 };
@@ -330,9 +327,6 @@ struct sgx_plan {
     void *d_window = nullptr, *d_tw = nullptr, *d_tw1 = nullptr, *d_tw2 = nullptr;
     void *d_mel_ptr = nullptr, *d_mel_col = nullptr, *d_mel_val = nullptr, *d_mel_pptr = nullptr, *d_mel_pcol = nullptr, *d_mel_pw = nullptr, *d_mm_frag = nullptr, *d_mm_blk = nullptr, *d_mel_sched = nullptr;
     unsigned mel_sched_words = 0;
-    void *d_mel_flat = nullptr;
-    unsigned mel_flat_trips = 0;
-    std::vector<uint32_t> h_mel_flat;   // the tuned kernel's flat band streams (plan.hip build_band_streams)
     std::vector<uint32_t> h_mel_sched;  // the tuned kernel's band schedule as built on the host (plan.hip build_band_schedule)
     unsigned mm_nblk = 0;
     unsigned mel_pchunks = 0;
