@@ -19,7 +19,7 @@ LIB = os.path.join(PKG, "libspectro_hip.so")
 OBJ = os.path.join(ROOT, "build", "obj")
 # the single source list (Makefile and tools/ read it through `python -m spectrograms_amd.build --sources`)
 SOURCES = ["plan.hip", "fft2d.hip", "shard.hip", "kernels_generic.hip", "kernels_r32x16.hip", "kernels_r32x32.hip", "kernels_istft2048.hip", "kernels_d32x16.hip", "kernels_istft_d1024.hip", "kernels_r64x32.hip", "kernels_d32x32.hip", "kernels_fft2d.hip",
-           "kernels_c2c1024.hip", "kernels_reg2d.hip", "membench.hip", "bluestein.hip"]
+           "kernels_c2c1024.hip", "kernels_reg2d.hip", "membench.hip", "bluestein.hip", "bigfft.hip"]
 ARCH = "gfx950"
 LINK_LIBS = ["-ldl"]
 

@@ -595,6 +595,8 @@ struct sgx_c2c {
     unsigned log2n = 0, tile = 0;
     void *d_tw = nullptr, *d_buf = nullptr, *d_out = nullptr;
     BsDevTables bs;  // chirp-z tables (lengths without a pass split that are not powers of two)
+    BigDev big;      // lengths past every on-chip kernel: the global-memory transforms (bigfft.hip) and their scratch
+    void *d_big = nullptr;
     mutable std::string err;
 };
 
@@ -620,7 +622,7 @@ sgx_status c2c_run(sgx_c2c *p, void *buf, size_t len, int inverse) {
     a.in_ss = p->n; a.in_is = 1; a.out_ss = p->n; a.out_is = 1;
     a.tile = p->tile; a.tiles = 1;
     a.tw = p->d_tw; a.inverse = inverse; a.in_seq_fast = 0; a.out_seq_fast = 0; a.scale = 1.0;
-    hipError_t e = launch_c2c_reg(a, p->dtype, nullptr);  // picks its own tile
+    hipError_t e = p->big.M ? launch_big_c2c(p->big, a, p->d_big, p->dtype, nullptr) : launch_c2c_reg(a, p->dtype, nullptr);  // (c2c_reg picks its own tile)
     if (e == hipErrorNotSupported && p->bs.M) e = launch_c2c_bluestein(a, p->bs, p->dtype, nullptr);
     if (e == hipErrorNotSupported) {
         if (p->tile == 0) return fail1(p, SGX_BACKEND, "hip -- FFT backend error: length too large for the on-chip tile");
@@ -680,8 +682,18 @@ sgx_status sgx_c2c_create(size_t n, int32_t dtype, int32_t device, sgx_c2c **out
             p->bs.M = h.M;
         }
     }
+    if (ok) {
+        // no register-tiled split, no chirp-z in LDS, and more than 2048 points (the LDS-tile kernel would run a two-factor or direct
+        // sum, or has no tile at all): through global memory, O(n log n) at every length (src/fft_backend.rs:372-389 plans any length)
+        unsigned fa, fb, fc;
+        BigHost bh;
+        if (!p->bs.M && n > 2048 && !reg_split_len(unsigned(n), dtype, &fa, &fb, &fc) && (p->tile == 0 || p->log2n == 0) && big_host_tables(unsigned(n), bh)) {
+            ok = big_upload(bh, dtype, p->big) == hipSuccess && hipMalloc(&p->d_big, big_scratch_bytes(p->big, dtype, 1)) == hipSuccess;
+        }
+    }
     if (!ok) {
-        for (void *b : {p->d_tw, p->d_buf, p->d_out, p->bs.chirp, p->bs.bhp, p->bs.tw}) if (b) (void)hipFree(b);
+        big_free(p->big);
+        for (void *b : {p->d_tw, p->d_buf, p->d_out, p->bs.chirp, p->bs.bhp, p->bs.tw, p->d_big}) if (b) (void)hipFree(b);
         delete p;
         return fail1(nullptr, SGX_BACKEND, "hip -- FFT backend error: could not set up the C2C plan (allocation failed)");
     }
@@ -693,7 +705,8 @@ void sgx_c2c_destroy(sgx_c2c *p) {
     if (p->device >= 0) {
         DeviceGuard dg;
         (void)dg.enter(p->device);
-        for (void *b : {p->d_tw, p->d_buf, p->d_out, p->bs.chirp, p->bs.bhp, p->bs.tw}) if (b) (void)hipFree(b);
+        for (void *b : {p->d_tw, p->d_buf, p->d_out, p->bs.chirp, p->bs.bhp, p->bs.tw, p->d_big}) if (b) (void)hipFree(b);
+        big_free(p->big);
     }
     delete p;
 }

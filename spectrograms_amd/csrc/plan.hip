@@ -29,6 +29,8 @@
 
 using namespace sgx;
 
+constexpr unsigned kBigMin = 2048;  // frame lengths above this never run an O(n^2) kernel: bigfft.hip takes what has no O(n log n) kernel on chip
+
 #ifndef SGX_BANDPF
 #define SGX_BANDPF 0  // must match kernels_r32x16.hip
 #endif
@@ -745,6 +747,11 @@ sgx_status build_device_tables(sgx_plan *pl) {
         if ((st = upload<double>(pl, &pl->d_window_half, wh)) != SGX_OK) return st;
         if ((st = upload<double>(pl, &pl->d_ones_half, oh)) != SGX_OK) return st;
     }
+    if (pl->kind == K_BIGFFT) {  // global-memory transforms (bigfft.hip): stage twiddles, the two-level W_M table, chirp + transformed chirp
+        BigHost h;
+        if (!big_host_tables(n, h)) return set_err(pl, SGX_INTERNAL, "Internal error: K_BIGFFT plan at an unsupported length");
+        SGX_HIP(pl, big_upload(h, pl->dtype, pl->big));
+    }
     if (pl->kind == K_BLUESTEIN && pl->bs_fwd_half) {  // half-length complex form: tables of length n / 2 (shared with the inverse rows)
         BsHostTables h;
         if (!bluestein_host_tables(n / 2, pl->dtype, h)) return set_err(pl, SGX_INTERNAL, "Internal error: chirp-z plan without a pass split");
@@ -878,6 +885,7 @@ bool set_geometry(const sgx_plan *pl, StftArgs &a, KernelKind kind) {
     case K_TWO_FACTOR: ok = plan_geometry_two_factor(a, pl->dtype); break;
     case K_REG_RADIX: ok = plan_geometry_reg_radix(a, pl->dtype); break;
     case K_BLUESTEIN: a.ft = 1; ok = pl->bs_M != 0 && (a.out_mode != OUT_MEL || a.mel_ptr != nullptr); break;
+    case K_BIGFFT: a.ft = 2; ok = pl->big_n != 0 && a.out_mode != OUT_MEL; break;  // two frames per complex sequence; filterbanks: split path
     }
     if (ok) a.tiles = (a.n_frames + a.ft - 1) / a.ft;
     return ok;
@@ -905,6 +913,11 @@ hipError_t launch_bluestein_plan(sgx_plan *pl, const StftArgs &a, hipStream_t s)
 
 hipError_t launch(sgx_plan *pl, const StftArgs &a, KernelKind kind, hipStream_t s) {
     switch (kind) {
+    case K_BIGFFT: {  // sequence scratch: sized by sgx_reserve, else grown here
+        const size_t need = big_scratch_bytes(pl->big, pl->dtype, size_t(a.batch) * ((a.n_frames + 1u) / 2u));
+        if (grow(pl, &pl->d_big, &pl->d_big_bytes, need) != SGX_OK) return hipErrorOutOfMemory;
+        return launch_big_stft(pl->big, a, pl->d_big, pl->dtype, s);
+    }
     case K_BLUESTEIN: return launch_bluestein_plan(pl, a, s);
     case K_R32X16_F32: return launch_r32x16_f32(a, s);
     case K_R32X32_F32: return launch_r32x32_f32(a, s);
@@ -1033,6 +1046,8 @@ void free_device(sgx_plan *pl) {
                      &pl->d_mel_val, &pl->d_dct, &pl->d_lifter, &pl->d_melbuf, &pl->d_pwbuf, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_mm_frag, &pl->d_mm_blk, &pl->d_mel_sched, &pl->d_itw, &pl->d_itwr, &pl->d_itw1, &pl->d_itwr2, &pl->d_itw12, &pl->d_itwrd, &pl->d_itw1d, &pl->d_frames, &pl->d_flag, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half, &pl->d_bs_chirp, &pl->d_bs_tw, &pl->d_bs_wc, &pl->d_bs_bhp, &pl->bs_half.chirp, &pl->bs_half.bhp, &pl->bs_half.tw};
     for (void **b : bufs)
         if (*b) { (void)hipFree(*b); *b = nullptr; }
+    big_free(pl->big);
+    if (pl->d_big) { (void)hipFree(pl->d_big); pl->d_big = nullptr; pl->d_big_bytes = 0; }
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
     if (pl->ev1) (void)hipEventDestroy(pl->ev1);
     pl->ev0 = pl->ev1 = nullptr;
@@ -1052,8 +1067,12 @@ size_t istft_length(const sgx_params &p, size_t n_frames) {  // spectrogram.rs:4
 
 template <typename T>
 sgx_status inverse_tables(sgx_plan *pl) {
-    if (pl->d_itw) return SGX_OK;
+    if (pl->d_itw || pl->d_flag) return SGX_OK;
     const size_t n = pl->p.n_fft;
+    if (pl->kind == K_BIGFFT) {  // the inverse runs on the forward tables (bigfft.hip): only the DC / Nyquist flag word
+        SGX_HIP(pl, hipMalloc(&pl->d_flag, sizeof(unsigned)));
+        return SGX_OK;
+    }
     std::vector<T> tw(2 * n);
     for (size_t k = 0; k < n; ++k) {
         const double a = -2.0 * kPi * double(k) / double(n);
@@ -1161,6 +1180,15 @@ sgx_status launch_c2r_frames(sgx_plan *pl, const void *spec, void *frames, size_
     c.in_img = (unsigned long long)pl->nb_fft * n_frames;
     if (frame_fast) { c.in_ks = n_frames; c.in_rs = 1; c.k_fast = 0; }  // [bin][frame] (StftResult layout, S9)
     else { c.in_ks = 1; c.in_rs = pl->nb_fft; c.k_fast = 1; }
+    if (pl->kind == K_BIGFFT) {  // rows through global memory (two frames per complex sequence, the forward engine behind conj)
+        c.scale = pl->dtype == SGX_F64 ? 1.0 / double(n) : double(1.0f / float(n));
+        c.win = win;
+        c.bad_flag = (unsigned *)pl->d_flag;
+        sgx_status st = grow(pl, &pl->d_big, &pl->d_big_bytes, big_scratch_bytes(pl->big, pl->dtype, batch * ((n_frames + 1) / 2)));
+        if (st != SGX_OK) return st;
+        SGX_HIP(pl, launch_big_c2r(pl->big, c, pl->d_big, pl->dtype, s));
+        return SGX_OK;
+    }
     c.tile = c2r_tile_for(n, pl->dtype, 144 * 1024);
     if (c.tile == 0) return set_err(pl, SGX_BACKEND, "hip -- FFT backend error: n_fft too large for the on-chip frame tile");
     c.tiles = unsigned((n_frames + c.tile - 1) / c.tile);
@@ -1217,7 +1245,7 @@ sgx_status run_istft(sgx_plan *pl, const void *spec, size_t batch, size_t n_fram
     }
     // fused register-tiled kernel (every length with a pass split, hop <= n_fft, at most half a tile of halo frames): the windowed
     // frames never leave the chip
-    if (n_frames <= 0xffffffffull && batch <= 0xffffffffull) {
+    if (pl->kind != K_BIGFFT && n_frames <= 0xffffffffull && batch <= 0xffffffffull) {
         const hipError_t e = launch_istft_reg(spec, out, pl->d_window, pl->d_itw, unsigned(n), unsigned(n_frames), pl->p.hop_size, unsigned(batch),
                                               start, out_len, pl->dtype == SGX_F64 ? 1.0 / double(n) : double(1.0f / float(n)),
                                               (unsigned *)pl->d_flag, pl->dtype, s);
@@ -1268,6 +1296,7 @@ const char *sgx_kernel_name(const sgx_plan *plan) {
     case K_TWO_FACTOR: return "two_factor_dft";
     case K_REG_RADIX: return "reg_radix";
     case K_BLUESTEIN: return "bluestein";
+    case K_BIGFFT: return plan->big_n & (plan->big_n - 1) ? "big_chirpz" : "big_four_step";
     default: return "direct_dft";
     }
 }
@@ -1278,9 +1307,10 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
     std::string msg;
     sgx_status st = validate(*params, msg);
     if (st != SGX_OK) return create_fail(st, msg);
-    // No kernel holds a frame of more than 160 KiB of LDS (40 960 f32 samples): such a length fails here, before gigabytes of host
-    // tables are built for it (n_fft = 2^30 + 2: 49 s and 8.7 GB to reach the same answer further down)
-    if (params->n_fft > (1u << 17)) return create_fail(SGX_BACKEND, "hip -- FFT backend error: n_fft too large for the on-chip frame tile");
+    // Frames past the global-memory transforms' range (bigfft.hip: 2^20, powers of two 2^21) fail here, before gigabytes of host tables
+    // are built for them (n_fft = 2^30 + 2: 49 s and 8.7 GB to reach the same answer further down)
+    if (params->n_fft > (1u << 15) && !big_supported(params->n_fft))
+        return create_fail(SGX_BACKEND, "hip -- FFT backend error: n_fft too large (the global-memory transforms take n_fft up to 2^20, powers of two up to 2^21)");
     sgx_plan *pl = new (std::nothrow) sgx_plan();
     if (!pl) return create_fail(SGX_INTERNAL, "Internal error: out of memory");
     pl->p = *params;
@@ -1394,9 +1424,21 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
                 ok = true;
             }
         }
+        // What is left on the O(n^2) kernels above kBigMin points — odd lengths past the LDS chirp-z (8192; f64: 4096), even ones past
+        // twice that — and every length no on-chip tile holds (f32 above 32768, f64 above 16384) goes through global memory
+        // (bigfft.hip): four-step transforms for powers of two, chirp-z on top of them for the rest, O(n log n) for every n_fft
+        // up to 2^20 like the reference's planner (src/fft_backend.rs:372-389).
+        if (big_supported(params->n_fft) && (!ok || ((kind == K_DIRECT_DFT || kind == K_TWO_FACTOR) && params->n_fft > kBigMin))) {
+            kind = K_BIGFFT;
+            pl->big_n = params->n_fft;
+            pl->split_bank = pl->out_mode == OUT_MEL;
+            pl->bs_M = 0;
+            pl->bs_fwd_half = false;
+            ok = true;
+        }
         if (!ok) {
             delete pl;
-            return create_fail(SGX_BACKEND, "hip -- FFT backend error: n_fft too large for the on-chip frame tile");
+            return create_fail(SGX_BACKEND, "hip -- FFT backend error: n_fft too large (the global-memory transforms take n_fft up to 2^20, powers of two up to 2^21)");
         }
         pl->kind = kind;
     }
@@ -1639,11 +1681,14 @@ sgx_status sgx_reserve(sgx_plan *plan, size_t batch, size_t n_samples, int32_t h
     if (!inverse && plan->split_bank &&
         (st = grow(plan, &plan->d_pwbuf, &plan->d_pwbuf_bytes, batch * size_t(plan->nb_fft) * nf * plan->elem)) != SGX_OK)
         return st;
+    if (plan->kind == K_BIGFFT &&
+        (st = grow(plan, &plan->d_big, &plan->d_big_bytes, big_scratch_bytes(plan->big, plan->dtype, batch * ((nf + 1) / 2)))) != SGX_OK)
+        return st;
     if (inverse) {  // sgx_istft of `batch` spectra whose frame count is that of n_samples-long signals
         // the same tests run_istft applies: tuned n_fft = 1024 kernel, else the fused register-tiled kernel; only the unfused
         // fallback (rows + overlap-add) touches the frame scratch
         const bool fused = (plan->d_itwr && nf * 513ull * 8ull < 0x7fffffffull) || (plan->d_itwr2 && nf * 1025ull * 8ull < 0x7fffffffull) || (plan->d_itwrd && nf * 513ull * 16ull < 0x7fffffffull) || (plan->istft_d512 && nf * 257ull * 16ull < 0x7fffffffull) ||
-                           (nf <= 0xffffffffull && batch <= 0xffffffffull &&
+                           (plan->kind != K_BIGFFT && nf <= 0xffffffffull && batch <= 0xffffffffull &&
                             istft_reg_fuses(plan->d_window, plan->p.n_fft, unsigned(nf), plan->p.hop_size, unsigned(batch), plan->dtype));
         if (!fused && (st = grow(plan, &plan->d_frames, &plan->d_frames_bytes, batch * nf * plan->p.n_fft * plan->elem)) != SGX_OK) return st;
     }

@@ -19,7 +19,7 @@ namespace sgx {
 enum OutMode : int { OUT_LINEAR = 0, OUT_MEL = 1, OUT_COMPLEX = 2 };
 // AMP_MAG_IN: the mapping consumes sqrt(power) and its output is final (chromagram: bank applied to magnitudes)
 enum AmpMode : int { AMP_POWER = 0, AMP_MAGNITUDE = 1, AMP_DB = 2, AMP_MAG_IN = 3 };
-enum KernelKind : int { K_DIRECT_DFT = 0, K_LDS_RADIX2 = 1, K_R32X16_F32 = 2, K_TWO_FACTOR = 3, K_REG_RADIX = 4, K_BLUESTEIN = 5, K_R32X32_F32 = 6, K_D32X16_F64 = 7, K_D512_F64 = 8, K_R64X32_F32 = 9, K_D32X32_F64 = 10 };
+enum KernelKind : int { K_DIRECT_DFT = 0, K_LDS_RADIX2 = 1, K_R32X16_F32 = 2, K_TWO_FACTOR = 3, K_REG_RADIX = 4, K_BLUESTEIN = 5, K_R32X32_F32 = 6, K_D32X16_F64 = 7, K_D512_F64 = 8, K_R64X32_F32 = 9, K_D32X32_F64 = 10, K_BIGFFT = 11 };
 inline bool kind_is_tuned(KernelKind k) { return k == K_R32X16_F32 || k == K_R32X32_F32 || k == K_D32X16_F64 || k == K_D512_F64 || k == K_R64X32_F32 || k == K_D32X32_F64; }  // the shape-specific kernels at the head of the chain
 
 // Kernel arguments (POD, passed by value).  Layouts in HBM:
@@ -233,6 +233,28 @@ hipError_t launch_chroma_norm(void *data, unsigned batch, unsigned n_frames, int
 hipError_t launch_pointwise(const void *x, const void *y, void *out, unsigned long long n, unsigned long long per, int mode,
                             int dtype, hipStream_t s);
 
+// ---- lengths beyond the on-chip kernels (bigfft.hip): four-step transforms through global memory for powers of two, chirp-z on top
+// of them for every other length; n_fft up to 2^20 (powers of two: 2^21), both types
+struct BigHost {  // tables as built on the host in f64, interleaved (re, im)
+    unsigned n = 0, M = 0, M1 = 0, M2 = 0, l1 = 0, l2 = 0;
+    bool chirp = false;
+    std::vector<double> wl, thi, tlo, c, bhat;
+};
+struct BigDev {
+    unsigned n = 0, M = 0, M1 = 0, M2 = 0, l1 = 0, l2 = 0;
+    bool chirp = false;
+    void *wl = nullptr, *thi = nullptr, *tlo = nullptr, *c = nullptr, *bhat = nullptr;
+};
+constexpr size_t kBigChunkBytes = size_t(256) << 20;  // scratch per buffer: a call is cut into chunks of sequences of at most this size
+bool big_supported(unsigned long long n);
+bool big_host_tables(unsigned n, BigHost &h);
+hipError_t big_upload(const BigHost &h, int dtype, BigDev &d);
+void big_free(BigDev &d);
+size_t big_scratch_bytes(const BigDev &t, int dtype, size_t nseq);  // for nseq complex sequences (a sequence carries two real frames)
+hipError_t launch_big_stft(const BigDev &t, const StftArgs &a, void *scratch, int dtype, hipStream_t s);   // per-bin and complex outputs
+hipError_t launch_big_c2r(const BigDev &t, const C2rArgs &c, void *scratch, int dtype, hipStream_t s);     // Hermitian rows -> real rows [batch][nrows][ncols]
+hipError_t launch_big_c2c(const BigDev &t, const C2cArgs &c, void *scratch, int dtype, hipStream_t s);     // complex sequences (batch == 1)
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device setting: remember which (kernel, device) pairs have been
 // configured, so a process that drives several GPUs (sgx_params.device) gets the large-LDS opt-in on each of them.
 inline hipError_t set_max_dynamic_lds(const void *fn, int bytes) {
@@ -353,6 +375,11 @@ struct sgx_plan {
     bool bs_fwd_half = false;  // K_BLUESTEIN in half-length complex form (even n_fft whose own convolution does not fit LDS)
     sgx::BsDevTables bs_half;  // inverse rows of an even n_fft whose own chirp-z does not fit: tables of length n_fft / 2 (inverse_tables)
     size_t d_frames_bytes = 0;
+    // K_BIGFFT: tables of the global-memory transforms and their sequence scratch (grown on demand, pre-sized by sgx_reserve)
+    sgx::BigDev big;
+    unsigned big_n = 0;  // set at creation when the plan's kind is K_BIGFFT (host-only plans have no tables)
+    void *d_big = nullptr;
+    size_t d_big_bytes = 0;
 
     // plan-owned staging for host-pointer execution
     void *d_in = nullptr, *d_out = nullptr;

@@ -154,9 +154,10 @@ def test_raw_abi_rejects_bad_params_without_aborting():
     assert L.sgx_plan_create(None, C.byref(h)) == _ffi.SGX_INVALID_INPUT
 
 
-@pytest.mark.parametrize("n_fft", [2 ** 30 + 2, 2 ** 31 + 6, 2 ** 32 - 1, 2 ** 17 + 1])
+@pytest.mark.parametrize("n_fft", [2 ** 30 + 2, 2 ** 31 + 6, 2 ** 32 - 1, 2 ** 20 + 1, 2 ** 21 + 2, 2 ** 22])
 def test_huge_frame_lengths_fail_fast(n_fft):
-    """Lengths above every kernel's frame tile: SGX_BACKEND at once — (2^30, 2^31] used to spin in the chirp-z length loop (a 32-bit
+    """Lengths above the global-memory transforms' range (2^20; powers of two 2^21 — round 5; before: above every kernel's frame
+    tile): SGX_BACKEND at once — (2^30, 2^31] used to spin in the chirp-z length loop (a 32-bit
     M shifted to 0), above 2^31 `2 n` wrapped and a tiny convolution length could be selected."""
     import time
     L = _ffi.lib()
@@ -210,9 +211,13 @@ def test_kernel_selection():
     assert host_plan(6000, 1500, dtype="float32").kernel_name == "bluestein"
     assert host_plan(6000, 1500, dtype="float64").kernel_name == "bluestein"  # f64: M = 16384 does not fit LDS; even: half-length complex form (M = 8192)
     assert host_plan(12000, 3000, dtype="float32").kernel_name == "bluestein"  # likewise in f32 above 8192
-    assert host_plan(6001, 1500, dtype="float64").kernel_name in ("two_factor_dft", "direct_dft")  # odd: no half-length form
-    assert host_plan(4099, 1000, dtype="float64").kernel_name == "direct_dft"
-    assert host_plan(9001, 1000, dtype="float32").kernel_name == "direct_dft"       # M = 32768: nothing but the sum
+    # round 5: what no on-chip kernel transforms in O(n log n) goes through global memory (bigfft.hip) — nothing above 2048 points is a sum
+    assert host_plan(6001, 1500, dtype="float64").kernel_name == "big_chirpz"  # odd: no half-length form
+    assert host_plan(4099, 1000, dtype="float64").kernel_name == "big_chirpz"
+    assert host_plan(9001, 1000, dtype="float32").kernel_name == "big_chirpz"       # M = 32768
+    assert host_plan(65536, 16384, dtype="float32").kernel_name == "big_four_step"
+    assert host_plan(32768, 8192, dtype="float64").kernel_name == "big_four_step"  # (f64 frames above 16384 had no tile)
+    assert host_plan(2039, 500, dtype="float64").kernel_name == "bluestein"         # (the LDS chirp-z where it fits)
 
 
 def test_shard_range_partitions_batch():

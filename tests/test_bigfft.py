@@ -1,0 +1,146 @@
+"""Frame lengths past the on-chip kernels (spectrograms_amd/csrc/bigfft.hip): four-step transforms through global memory for powers of
+two, chirp-z on top of them for every other length — the reference plans ANY length in O(n log n) (src/fft_backend.rs:372-389) and its
+one-shot `fft` / `rfft` / `power_spectrum` (src/spectrogram.rs:4490-4643) are called with n_fft = the whole signal.
+
+CPU part: plan creation (host-only) succeeds for every length up to 2^20 and names the kernel; the oracle's own O(n log n) path is
+pinned against numpy.fft in tests/test_oracle_golden.py.  GPU part: HIP against the oracle at the lengths VERDICT r4 lists."""
+import numpy as np
+import pytest
+
+import spectrograms_amd as sg
+from oracle import oracle as orc
+from spectrograms_amd import _ffi
+
+BIG = [9001, 16385, 20000, 44100, 65536, 100003]
+
+
+def _plan(n_fft, hop, amp, dtype, device=None, window=None, centre=False, mapping=None, db=None):
+    params = sg.SpectrogramParams(sg.StftParams(n_fft, hop, window or sg.WindowType.rectangular, centre), 16000.0)
+    kw = {} if device is None else {"device": device}
+    return sg.Plan(params, amp, mapping, db, dtype, **kw)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_every_length_has_a_plan(dtype):
+    """sgx_plan_create succeeds for every n_fft <= 2^20 (host-only plans: no tables are built, the decision is the same); above the
+    on-chip kernels the plan names the global-memory transforms, and nothing above 2048 points is left on an O(n^2) kernel."""
+    rng = np.random.default_rng(3)
+    lengths = sorted(set([2049, 4097, 8191, 8193, 9001, 12000, 16385, 20000, 32768, 32769, 44100, 65536, 65537, 100003, 131072, 262144, 500000,
+                          (1 << 20) - 1, 1 << 20] + [int(v) for v in rng.integers(2049, 1 << 20, 60)]))
+    for n in lengths:
+        pl = _plan(n, n, _ffi.AMP_POWER, dtype, device=_ffi.DEVICE_HOST_ONLY)
+        name = pl.kernel_name
+        assert name not in ("direct_dft", "two_factor_dft"), (n, name)
+        if n > 32768:
+            assert name in ("big_four_step", "big_chirpz"), (n, name)
+        assert pl.output_shape(n) == (n // 2 + 1, 1)
+    assert _plan(1 << 21, 1 << 21, _ffi.AMP_POWER, dtype, device=_ffi.DEVICE_HOST_ONLY).kernel_name == "big_four_step"
+    with pytest.raises(sg.FFTBackendError, match="n_fft too large"):
+        _plan((1 << 20) + 1, 1 << 20, _ffi.AMP_POWER, dtype, device=_ffi.DEVICE_HOST_ONLY)
+
+
+def _tol(dtype, ref):
+    return (1e-10 if dtype == "float64" else 1e-4) * max(1.0, float(np.max(np.abs(ref))))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("n", BIG)
+def test_gpu_one_shot_transforms(n, dtype):
+    """fft / rfft / power_spectrum / irfft with n_fft = the signal length (a single frame: the second half of the complex sequence
+    is empty), the conforming R2cPlan / C2rPlan entry points, against the oracle."""
+    rdt = np.float32 if dtype == "float32" else np.float64
+    rng = np.random.default_rng(n)
+    t = np.arange(n) / 16000.0
+    x = (0.5 * np.sin(2 * np.pi * 440.0 * t) + 0.1 * rng.standard_normal(n)).astype(rdt)
+    ref = orc.rfft(x.astype(np.float64))
+    X = sg.compute_fft(x, n, dtype=dtype)
+    assert X.shape == (n // 2 + 1,) and np.max(np.abs(X - ref)) < _tol(dtype, ref)
+    assert X[0].imag == 0 and (n % 2 or X[-1].imag == 0)  # realfft: exactly-real DC / Nyquist
+    P = sg.compute_power_spectrum(x, n, dtype=dtype)
+    refp = np.abs(ref) ** 2
+    m = refp > 1e-6 * refp.max()
+    assert np.max(np.abs(P[m] - refp[m]) / refp[m]) < (1e-9 if dtype == "float64" else 1e-4)
+    R = sg.compute_rfft(x[: n - 7], n, dtype=dtype)  # zero-padded to n_fft (tests/fft_padding_tests.rs)
+    refr = np.abs(orc.rfft(np.concatenate([x[: n - 7].astype(np.float64), np.zeros(7)])))
+    assert np.max(np.abs(R - refr)) < _tol(dtype, refr)
+    # conforming per-frame plan: R2cPlan::process / C2rPlan::process (fft_backend.rs:423-431, 526-565)
+    pl = _plan(n, n, _ffi.AMP_COMPLEX, dtype)
+    assert pl.kernel_name in ("big_four_step", "big_chirpz") or n <= 16384
+    Y = pl.r2c(x)
+    assert np.max(np.abs(Y - ref)) < _tol(dtype, ref)
+    y = sg.compute_irfft(ref.astype(np.complex64 if dtype == "float32" else np.complex128), n, dtype=dtype)
+    assert y.shape == (n,) and np.max(np.abs(y - x)) < (1e-10 if dtype == "float64" else 2e-4)
+    with pytest.raises(sg.FFTBackendError, match="imaginary part"):  # realfft's C2R rejects a complex DC bin
+        bad = ref.copy(); bad[0] += 1j
+        sg.compute_irfft(bad.astype(np.complex64 if dtype == "float32" else np.complex128), n, dtype=dtype)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("n_fft,hop,centre,window", [(9001, 2250, True, "hanning"), (16385, 8000, True, "hamming"), (20000, 5000, False, "hanning"),
+                                                     (65536, 16384, True, "hanning"), (44100, 22050, True, "blackman")])
+def test_gpu_stft_and_back(n_fft, hop, centre, window, dtype):
+    """Batched STFT with long frames: complex, power and dB outputs, odd and even frame counts (frames ride two to a sequence), and
+    the inverse through the same engine."""
+    rdt = np.float32 if dtype == "float32" else np.float64
+    nsig = 3 * n_fft + 5 * hop + 17
+    x = (0.3 * np.random.default_rng(n_fft).standard_normal((3, nsig))).astype(rdt)
+    wt = getattr(sg.WindowType, window)
+    op = orc.Params(n_fft=n_fft, hop=hop, centre=centre, window=window)
+    ref = np.stack([orc.stft(op, r.astype(np.float64)) for r in x])
+    pl = _plan(n_fft, hop, _ffi.AMP_COMPLEX, dtype, window=wt, centre=centre)
+    S = pl.compute_batch(x)
+    assert S.shape == ref.shape and np.max(np.abs(S - ref)) < _tol(dtype, ref)
+    one = pl.compute_batch(x[1:2])  # a signal's bits do not depend on its batch
+    assert np.array_equal(one[0], S[1])
+    P = _plan(n_fft, hop, _ffi.AMP_POWER, dtype, window=wt, centre=centre).compute_batch(x)
+    refp = np.abs(ref) ** 2
+    m = refp > 1e-6 * refp.max()
+    assert np.max(np.abs(P[m] - refp[m]) / refp[m]) < (1e-9 if dtype == "float64" else 1e-4)
+    D = _plan(n_fft, hop, _ffi.AMP_DECIBELS, dtype, window=wt, centre=centre, db=sg.LogParams(-80.0)).compute_batch(x)
+    refd = 10.0 * np.log10(np.maximum(refp, 1e-8))
+    assert np.max(np.abs(D[m] - refd[m])) < (1e-8 if dtype == "float64" else 1e-3)
+    y = pl.istft_batch(ref.astype(S.dtype))
+    refy = np.stack([orc.istft(s, n_fft, hop, window, centre) for s in ref])
+    # (uncentred frames: out = sum(y w) / sum(w w) divides by a vanishing window sum at the first / last samples, which amplifies the f32
+    # rounding of y in ANY implementation — compared inside the first and last frame there, as tests/test_istft.py weighs it)
+    sl = slice(None) if centre else slice(n_fft, -n_fft)
+    assert y.shape == refy.shape and np.max(np.abs(y[:, sl] - refy[:, sl])) < (1e-10 if dtype == "float64" else 2e-4) * max(1.0, np.max(np.abs(refy)))
+
+
+@pytest.mark.gpu
+def test_gpu_long_frames_filterbank_and_many_sequences():
+    """Mel on long frames takes the split path (per-bin power, then the bank's rows); a batch whose sequences exceed one scratch chunk
+    (f64 n_fft 12000: M = 32768, 512 KiB per sequence, 512 sequences per chunk) is cut into chunks."""
+    n_fft, hop = 12000, 3000
+    x = (0.3 * np.random.default_rng(1).standard_normal((4, 40000))).astype(np.float64)
+    params = sg.SpectrogramParams(sg.StftParams(n_fft, hop, sg.WindowType.hanning, True), 16000.0)
+    mel = sg.SpectrogramPlanner().mel_db_plan(params, sg.MelParams(80, 0.0, 8000.0), sg.LogParams(-80.0), dtype="float64")
+    D = mel.compute_batch(x)
+    ref = orc.spectrogram_batch(orc.Params(n_fft=n_fft, hop=hop, n_mels=80, amp="db", floor_db=-80.0), x)
+    assert D.shape == ref.shape and np.max(np.abs(D - ref)) < 1e-8
+    import torch
+    big = torch.from_numpy(np.tile(x[:, :30000], (300, 1))).cuda()  # 1200 signals x 11 frames = 7200 sequences: several chunks
+    lin = sg.SpectrogramPlanner().linear_power_plan(params, dtype="float64")
+    assert lin.kernel_name == "big_chirpz"
+    P = lin.compute_batch(big).cpu().numpy()
+    refp = orc.spectrogram_batch(orc.Params(n_fft=n_fft, hop=hop), x[:, :30000])
+    for r in (0, 5, 599, 1199):
+        assert np.max(np.abs(P[r] - refp[r % 4])) < 1e-10 * max(1.0, refp.max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("n", [9001, 20000, 65536, 100003, 1 << 20])
+def test_gpu_complex_plan(n, dtype):
+    """C2cPlan (src/fft_backend.rs:126-160) at long lengths: forward and inverse, unnormalised, against numpy.fft (f64)."""
+    cdt = np.complex64 if dtype == "float32" else np.complex128
+    rng = np.random.default_rng(n)
+    z = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(cdt)
+    p = sg.C2cPlan(n, dtype)
+    ref = np.fft.fft(z.astype(np.complex128))
+    tol = (1e-10 if dtype == "float64" else 2e-4) * np.max(np.abs(ref))
+    assert np.max(np.abs(p.forward(z) - ref)) < tol
+    back = p.inverse(ref.astype(cdt))
+    assert np.max(np.abs(back / n - z)) < (1e-10 if dtype == "float64" else 2e-4)

@@ -321,3 +321,18 @@ def test_erb_matches_reference(golden_dir, b):
     _, _, val = pl.mel_weights()
     assert np.allclose(val.reshape(nf, 513)[:, g["matrix_cols"]], g["matrix"], rtol=1e-11)
     assert np.allclose(pl.axes(4)[0], g["centres"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("n", [2048 + 1, 9001, 16385, 20000, 44100, 65536, 100003])
+def test_oracle_long_lengths_pinned_against_numpy_fft(n):
+    """From 2048 points on the oracle's non-power-of-two transforms are chirp-z in f64 (oracle/spectro_oracle.c, ORC_CZT_MIN) instead
+    of the O(n^2) definition; pinned here against numpy.fft (pocketfft) — forward, inverse and the complex transform the 2-D path uses."""
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n)
+    ref = np.fft.rfft(x)
+    X = orc.rfft(x)
+    assert np.max(np.abs(X - ref)) < 1e-12 * np.max(np.abs(ref))
+    assert np.max(np.abs(orc.irfft(ref, n) - x)) < 1e-12
+    X32 = orc.rfft(x.astype(np.float32))  # non-powers of two: the f32 oracle accumulates in f64 and rounds once, like its direct sum did; powers of two: radix-2 in f32
+    tol32 = 5e-6 if n & (n - 1) == 0 else 2e-7
+    assert X32.dtype == np.complex64 and np.max(np.abs(X32 - np.fft.rfft(x.astype(np.float32).astype(np.float64)))) < tol32 * np.max(np.abs(ref))
