@@ -39,13 +39,15 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak is ~6290 GB/s
 VALU_PEAK_TFLOPS = 157.3   # FP32 vector peak (same guide)
-FLOPS_PER_FRAME = {"linear_power": 28.1e3, "stft": 26.6e3, "mel_power": 30.1e3, "mel_db": 30.1e3}  # FFT 25.6 k + window 1 k (+ |.|^2 1.5 k, Mel 2 k)
-LEGS = ("mel_power", "mel_db", "config4", "istft", "fft2d", "convolve_fft", "chirpz_1009", "linear_power_f64", "mel_db_f64")  # the default run's extra legs (besides the headline workload)
+FLOPS_PER_FRAME = {"linear_power": 28.1e3, "stft": 26.6e3, "mel_power": 30.1e3, "mel_db": 30.1e3, "mfcc": 32.2e3}  # FFT 25.6 k + window 1 k (+ |.|^2 1.5 k, Mel 2 k)
+LEGS = ("mel_power", "mel_db", "mfcc", "config4", "istft", "fft2d", "convolve_fft", "chirpz_1009", "linear_power_f64", "mel_db_f64")  # the default run's extra legs (besides the headline workload)
 IMG_SIDE, IMG_BATCH = 1024, 512  # BASELINE configs[4]
 SR, N_FFT, HOP, N_SAMPLES = 16000.0, 1024, 256, 160000
 WORKLOADS = {  # name -> (kernel workload, utterances per GPU, BASELINE config index)
     "linear_power": ("linear_power", 256, 1), "mel_db": ("mel_db", 256, 2), "mel_power": ("mel_power", 256, 2),
     "stft": ("stft", 256, 1), "config4": ("mel_power", 1024, 3),
+    # MFCC-13 (Mel-80 dB(-80) -> DCT-II + lifter 22, src/mfcc.rs:224-316) fused into the Mel-dB launch
+    "mfcc": ("mfcc", 256, 2),
 }
 
 
@@ -60,7 +62,7 @@ def cfg_signal(b: int) -> np.ndarray:
 def bytes_per_frame(kernel_wl: str, n_frames: int):
     """Algorithmic HBM bytes per frame: every input sample read once, every output written once."""
     read = N_SAMPLES * 4.0 / n_frames
-    write = {"linear_power": 513 * 4.0, "mel_db": 80 * 4.0, "mel_power": 80 * 4.0, "stft": 513 * 8.0}[kernel_wl]
+    write = {"linear_power": 513 * 4.0, "mel_db": 80 * 4.0, "mel_power": 80 * 4.0, "stft": 513 * 8.0, "mfcc": 13 * 4.0}[kernel_wl]
     return read, write
 
 
@@ -71,7 +73,7 @@ STAMP_FILES = {
     "istft": ("kernels_c2c1024.hip", "fft_inreg.h"),
     "f64": ("kernels_d32x16.hip", "d32x16_layout.h", "fft_inreg.h"),
 }
-STAMP_FAMILY = {"linear_power": "stft", "mel_power": "stft", "mel_db": "stft", "stft": "stft", "fft2d": "2d", "convolve_fft": "2d", "istft": "istft",
+STAMP_FAMILY = {"linear_power": "stft", "mel_power": "stft", "mel_db": "stft", "mfcc": "stft", "stft": "stft", "fft2d": "2d", "convolve_fft": "2d", "istft": "istft",
                 "linear_power_f64": "f64", "mel_db_f64": "f64"}
 
 
@@ -310,6 +312,8 @@ def make_plan(sg, kernel_wl: str):
         return planner.mel_power_plan(params, sg.MelParams(80, 0.0, 8000.0), dtype="float32")
     if kernel_wl == "stft":
         return planner.stft_plan(params, dtype="float32")
+    if kernel_wl == "mfcc":
+        return planner.mfcc_plan(sg.StftParams(N_FFT, HOP, sg.WindowType.hanning, True), SR, 80, sg.MfccParams(13), dtype="float32")
     return planner.mel_db_plan(params, sg.MelParams(80, 0.0, 8000.0), sg.LogParams(-80.0), dtype="float32")
 
 

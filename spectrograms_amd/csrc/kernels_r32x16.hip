@@ -510,9 +510,11 @@ __device__ __forceinline__ v2f mul_add_unfused(float w, v2f p, v2f acc) {
     const v2f m = (v2f){w, w} * p;
     return m + acc;
 }
-template <int AMP, bool PACK = false>
+// TOLDS (fused MFCC epilogue; = the row length RL of mfcc_tile): the band's two dB values go to the LDS tile mq[band & 3][frame][band >> 2]
+// instead of the output tensor.
+template <int AMP, bool PACK = false, int TOLDS = 0>
 __device__ __forceinline__ void mel_tile_sched(const StftArgs &a, const float *pwT, const unsigned *sched, unsigned b, unsigned f0,
-                                               unsigned nf, float eps, unsigned tid SGX_STAMP_PARAMS) {
+                                               unsigned nf, float eps, unsigned tid, float *mfl SGX_STAMP_PARAMS) {
     const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u, slot = lane >> 3, fp = lane & 7u;
     // out[b][band][f0 + 2 fp ..]: one descriptor per tile; a lane without a frame or a slot without a band gets an offset past
     // its range and the hardware drops the store.  The stores are unconditional and the segment loop has a fixed trip count so
@@ -672,13 +674,75 @@ __device__ __forceinline__ void mel_tile_sched(const StftArgs &a, const float *p
 #endif
         SGX_STAMP(13);  // mel loops
         const bool have = cur.w != 0xffffffffu;
+        if constexpr (TOLDS) {
+            if (have) {
+                float *o = mfl + ((cur.w & 3u) * 16u + 2u * fp) * (unsigned)TOLDS + (cur.w >> 2);
+                o[0] = amp_f32<AMP>(acc.x, eps);
+                o[TOLDS] = amp_f32<AMP>(acc.y, eps);
+            }
+        } else {
         const unsigned bo = cur.w * a.n_frames * 4u;
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, amp_f32<AMP>(acc.x, eps)), ro, (int)((have && fo0 != kDrop) ? bo + fo0 : kDrop), 0, 0);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, amp_f32<AMP>(acc.y, eps)), ro, (int)((have && fo1 != kDrop) ? bo + fo1 : kDrop), 0, 0);
+        }
         cur = nxt;
 #ifdef SGX_STAMPS2
         SGX_STAMP(14);
 #endif
+    }
+}
+
+// ---- fused MFCC epilogue (round 5; SURVEY.md §8 f1, src/mfcc.rs:224-316) ------------------------------------------------------------
+// The DCT-II of the reference,  c[k] = fold over bands i ascending of  val_i.mul_add(basis[k][i], acc)   (src/mfcc.rs:278-292),
+// is the product [16 coefficients x n_mels] x [n_mels x 16 frames] with ONE fused-multiply-add chain per output in ascending band order —
+// what v_mfma_f32_16x16x4_f32 computes (exact f32; step s covers bands 4 s .. 4 s + 3 in order).  Lane (n = l & 15, q = l >> 4) feeds
+// A = basis[16 mt + n][4 s + q] and B = Mel-dB[band 4 s + q][frame n]; D[r] = coefficient 16 mt + 4 q + r of frame n, times the lifter
+// weight (apply_liftering :297-316; the weights ride behind the fragments, 1.0 without a lifter), stored frame-contiguous (64-byte runs)
+// without C0 when the plan drops it (:262-268).  The Mel-dB tensor never reaches HBM.
+//
+// Both operands sit in LDS with a lane's STEPS values contiguous — the band stage writes the tile's dB values as mq[q][n][s]
+// (mel_tile_sched<TOLDS>), the host lays the basis out as frag[mt][lane][s] — so a lane fetches them with STEPS / 2 16-byte reads (rows
+// of RL floats, RL / 4 odd: the 16 lanes of a read group on different banks).  Steps past the last band meet a zero weight and whatever
+// finite value the exchange left there.  One wave per half and 16 coefficients runs the chain (the f32 matrix instructions share the
+// vector pipe: all eight waves running it redundantly, threaded through the next tile's pass 1, cost 12 us per 256 x 10 s for the chain and
+// 8 for its operand reads — profiles/experiments_r05/mfcc_fusion.md), behind the band stage, where the registers are free; the
+// stores are outside the branch so that every wave issues the same vector-memory operations per tile (counted vmcnt at the loop top).
+template <int STEPS>
+constexpr int mfcc_row() { return (STEPS / 4) % 2 ? STEPS : STEPS + 4; }
+template <int STEPS>
+__device__ __forceinline__ void mfcc_tile(const StftArgs &a, const float *mq, const float *frag, unsigned mt, unsigned b, unsigned f0, unsigned nf,
+                                          unsigned lane) {
+    static_assert(STEPS % 4 == 0, "chain lengths are whole 16-byte reads");
+    constexpr int RL = mfcc_row<STEPS>();
+    const unsigned n = lane & 15u, q = lane >> 4;
+    const bool mine = mt < a.mfcc_mtiles;  // wave-uniform
+    v4acc acc = {0.f, 0.f, 0.f, 0.f};
+    if (mine) {
+        const v4f *pa = (const v4f *)(frag + ((size_t)mt * 64u + lane) * RL);
+        const v4f *pb = (const v4f *)(mq + (q * 16u + n) * RL);
+        v4f wa[STEPS / 4], vb[STEPS / 4];
+#pragma unroll
+        for (int g = 0; g < STEPS / 4; ++g) { wa[g] = pa[g]; vb[g] = pb[g]; }
+#pragma unroll
+        for (int g = 0; g < STEPS / 4; ++g) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[g].x, vb[g].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[g].y, vb[g].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[g].z, vb[g].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[g].w, vb[g].w, acc, 0, 0, 0);
+        }
+    }
+    const float *lift = frag + (size_t)a.mfcc_mtiles * 64u * RL;
+    constexpr unsigned kDrop = 0x80000000u;
+    const unsigned rows = a.n_mfcc - a.mfcc_skip;
+    const unsigned obytes = (rows * a.n_frames - f0) * 4u;
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc((const float *)a.out + (size_t)b * rows * a.n_frames + f0, obytes);
+    const unsigned mtr = mine ? mt : 0u;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const unsigned c = 16u * mtr + 4u * q + r;
+        const bool ok = mine && c >= a.mfcc_skip && c < a.n_mfcc && n < nf;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc[r] * lift[min(c, a.n_mfcc - 1u)]), ro,
+                                              (int)(ok ? ((c - a.mfcc_skip) * a.n_frames + n) * 4u : kDrop), 0, 0);
     }
 }
 
@@ -750,8 +814,10 @@ __device__ __forceinline__ void mel_tile_sched512(const StftArgs &a, const float
 // direct path, ROUNDS = 0) through one descriptor over the whole batch, each pair range-checked against its own row in the lane;
 // outputs through one descriptor from the tile's first signal.  The reference's per-frame loop costs the same per frame whatever
 // the signal length (src/spectrogram.rs:240-294).
-template <int MODE, int AMP, int ROUNDS, bool WIDE, bool XSPAD, bool PWT, int HOP512 = 0, bool PACK = false>
+template <int MODE, int AMP, int ROUNDS, bool WIDE, bool XSPAD, bool PWT, int HOP512 = 0, bool PACK = false, int MSTEPS = 0>
 __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd, unsigned total, unsigned slots) {
+    constexpr bool MFCC = MSTEPS != 0;  // fused MFCC epilogue, MSTEPS = ceil(n_mels / 4) rounded up to the menu (mfcc_tile)
+    static_assert(!MFCC || (PWT && AMP == AMP_DB && HOP512 == 0 && !PACK), "fused MFCC epilogue: Mel-dB on the schedule, n_fft 1024, one-signal tiles");
     constexpr bool P512 = HOP512 != 0;           // n_fft 512 at hop HOP512
     static_assert(!PACK || (ROUNDS == 0 && !WIDE && !XSPAD && (HOP512 == 0 ? (MODE != OUT_MEL || PWT) : MODE != OUT_MEL)),
                   "PACK: direct loads, one-half tiles; n_fft 1024: scheduled band stage, n_fft 512: per-bin outputs");
@@ -775,6 +841,9 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
     unsigned *sched = (unsigned *)(tabs + kMelOff);
     if constexpr (PWT)
         for (unsigned i = threadIdx.x; i < a.mel_sched_words; i += 512u) sched[i] = a.mel_sched[i];
+    float *mfrag = (float *)(tabs + kMelOff) + ((a.mel_sched_words + 3u) & ~3u);  // MFCC: the basis fragments behind the schedule
+    if constexpr (MFCC)
+        for (unsigned i = threadIdx.x; i < a.mfcc_frag_words; i += 512u) mfrag[i] = ((const float *)a.mfcc_frag)[i];
 
     // XCD-aware work mapping: blocks g and g+8 share an XCD (round-robin dispatch).  XCD x owns the contiguous run of
     // work ids [x*per_xcd, (x+1)*per_xcd); its `slots` resident workgroups walk that run with stride `slots`, so tiles
@@ -941,6 +1010,10 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
     unsigned long long st_acc[16] = {0}, st_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
 #endif
+    const unsigned mfcc_mt = (((threadIdx.x & 255u) >> 6) + 4u - half) & 3u;  // (the halves' first blocks sit on different SIMDs: waves w and w + 4 share one)
+    // Mel-dB tile of the fused MFCC epilogue: 64 rows of RL floats between the staged samples (<= 22 912 B) and the |X|^2 tile
+    float *const mfl = (float *)(smem + kOutOff) - 64 * mfcc_row<MFCC ? MSTEPS : 4>();
+    static_assert(!MFCC || kOutOff - 256 * mfcc_row<MFCC ? MSTEPS : 4>() >= 22912, "Mel-dB tile above the staged samples");
     while (lead < hi) {
         // (PACK: b = the tile's first signal, f0 = its first frame's index in that signal, nf = the tile's live slots)
         // (PACK at n_fft 512 packs SLOTS — frame pairs of one signal, PP per signal —: b = the first slot's signal, nf = live slots)
@@ -1013,6 +1086,8 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
                     wo[k] = w2[32 * k + 16];
                 }
             }
+            // MFCC: the previous tile's DCT chain rides under this transform (its Mel-dB tile is complete: barrier 1 / the band stage's own
+            // end; pass 1 overwrites it only behind barrier 2)
             Fft<16, true>::run(e, we);
             if constexpr (ROUNDS > 0) {
                 tie16<0>(o);
@@ -1024,7 +1099,7 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
         SGX_STAMP(2);  // column / window reads + 32-point transform
         // barrier 2: every wave has read its columns of xs; pass 1 may overwrite it with ex.  It sits behind the arithmetic:
         // by now the slowest wave's reads landed long ago, so nobody waits here.
-        if constexpr (ROUNDS > 0) __syncthreads();
+        if constexpr (ROUNDS > 0 || MFCC) __syncthreads();  // (MFCC on the direct path: the chain's wave has read the previous tile's Mel-dB values)
         SGX_STAMP(3);  // barrier 2
 #ifdef SGX_ABL_ADDTID
         {
@@ -1136,7 +1211,12 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
             if (a.n_mels == 12345u)
 #endif
             if constexpr (P512) mel_tile_sched512<AMP>(a, pwf, sched, b, f0, nf, eps, tid);
-            else if constexpr (PWT) mel_tile_sched<AMP, PACK>(a, pwf, sched, b, f0, nf, eps, tid SGX_STAMP_ARGS);
+            else if constexpr (MFCC) {  // Mel-dB tile to LDS, then its DCT (mfcc_tile)
+                mel_tile_sched<AMP, false, mfcc_row<MFCC ? MSTEPS : 4>()>(a, pwf, sched, b, f0, nf, eps, tid, mfl SGX_STAMP_ARGS);
+                __syncthreads();
+                mfcc_tile<MFCC ? MSTEPS : 4>(a, mfl, mfrag, mfcc_mt, b, f0, nf, tid & 63u);
+            }
+            else if constexpr (PWT) mel_tile_sched<AMP, PACK>(a, pwf, sched, b, f0, nf, eps, tid, nullptr SGX_STAMP_ARGS);
             else if (a.mm_frag) map_tile_mfma<AMP>(a, pwf, b, f0, nf, eps, tid, 2u * half);
             else mel_tile_csr<AMP>(a, pwf, b, f0, nf, eps, tid, 256u);
             if constexpr (!PWT) __syncthreads();  // pw consumed before the next staging overwrites it
@@ -1165,6 +1245,7 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
 // (profiles/bench_r03_short_signals.txt): packed once a quarter or more of the one-signal tiles' slots would be empty (626 frames: 2
 // of 640 slots, 40 frames: 8 of 48 — not packed; 17 frames: 15 of 32 — packed)
 static bool want_pack(const StftArgs &a, bool mel, bool pwt) {
+    if (a.mfcc_frag) return false;  // the fused MFCC epilogue works on one-signal tiles
     const bool p512 = a.n_fft == 512u;  // two frames per transform, 32-frame tiles; per-bin outputs only
     if ((a.n_fft != 1024u && !p512) || a.batch < 2u || (mel && (!pwt || p512)) || (a.hop & 1u)) return false;
     // (n_fft 512 packs slots = frame pairs of one signal: an odd frame count leaves half a slot empty either way)
@@ -1211,6 +1292,24 @@ hipError_t launch_variant(const StftArgs &a0, hipStream_t s) {
                 if (a.hop == 256u)  // the reference's Mel benchmark shape, benches/spectrogram_benchmarks.rs:105-141 (larger halves: r32x16_layout.h)
                     return go(k_r32x16<MODE, AMP, 9, false, false, true, 256>, 2u * kExBytesH256 + kMelOff + ((a.mel_sched_words * 4u + 15u) & ~15u) + 64u);
                 return hipErrorInvalidConfiguration;
+            }
+            if constexpr (AMP == AMP_DB) {
+                if (a.mfcc_frag && a.n_fft == 1024u) {  // Mel-dB -> DCT-II + lifter in the same launch (mfcc_tile)
+                    const unsigned lds = (unsigned)kLdsBytes - (unsigned)kMelMaxWords * 4u + ((a.mel_sched_words + 3u) & ~3u) * 4u + a.mfcc_frag_words * 4u + 64u;
+                    if (lds > 163840u) return hipErrorInvalidConfiguration;
+                    const unsigned ldsz = lds < (unsigned)kLdsBytes ? (unsigned)kLdsBytes : lds;
+                    auto mf = [&](auto steps) -> hipError_t {
+                        constexpr int S = decltype(steps)::value;
+                        if (a.hop == 256u) return go(k_r32x16<MODE, AMP, 5, false, true, true, 0, false, S>, ldsz);
+                        if (chunks <= 5u * 256u) return go(k_r32x16<MODE, AMP, 5, false, false, true, 0, false, S>, ldsz);
+                        return go(k_r32x16<MODE, AMP, 0, false, false, true, 0, false, S>, ldsz);
+                    };
+                    if (a.mfcc_steps == 12u) return mf(std::integral_constant<int, 12>{});  // (the host pads the fragment table to a menu length:
+                    if (a.mfcc_steps == 16u) return mf(std::integral_constant<int, 16>{});  //  zero weights)
+                    if (a.mfcc_steps == 20u) return mf(std::integral_constant<int, 20>{});
+                    if (a.mfcc_steps == 24u) return mf(std::integral_constant<int, 24>{});
+                    return hipErrorInvalidConfiguration;
+                }
             }
             if (a.hop == 256u) return go(k_r32x16<MODE, AMP, 5, false, true, true>);
             if (chunks <= 5u * 256u) return go(k_r32x16<MODE, AMP, 5, false, false, true>);

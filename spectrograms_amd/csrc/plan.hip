@@ -605,6 +605,30 @@ sgx_status build_device_tables(sgx_plan *pl) {
                 lift[i] = std::fma(double(pl->p.mfcc_lifter) / 2.0, std::sin(kPi * double(i) / double(pl->p.mfcc_lifter)), 1.0);
         if ((st = upload_cast<T>(pl, &pl->d_dct, basis)) != SGX_OK) return st;
         if ((st = upload_cast<T>(pl, &pl->d_lifter, lift)) != SGX_OK) return st;
+        // Fused epilogue of the tuned f32 kernel at n_fft 1024 (kernels_r32x16.hip mfcc_tile): the basis as matrix-core A-operands with a
+        // lane's steps contiguous, frag[mt][lane][s] = basis[16 mt + (l & 15)][4 s + (l >> 4)] in rows of RL floats (zero beyond n_mfcc /
+        // n_mels), then the lifter weights.  Needs the band schedule (Mel-dB tile in LDS), at most 96 bands (the tile sits between the staged
+        // samples and the |X|^2 tile) and 64 coefficients (one wave per 16).
+        if (std::is_same<T, float>::value && pl->kind == K_R32X16_F32 && pl->p.n_fft == 1024 && pl->d_mel_sched && pl->amp == AMP_DB && nm <= 96 && nc <= 64) {
+            const unsigned need = (nm + 3) / 4, mtiles = (nc + 15) / 16;
+            const unsigned steps = need <= 12 ? 12 : need <= 16 ? 16 : need <= 20 ? 20 : 24;  // the kernel's menu of chain lengths (48 / 64 / 80 / 96 bands)
+            const unsigned RL = (steps / 4) % 2 ? steps : steps + 4;                          // = mfcc_row<STEPS>()
+            std::vector<float> frag(size_t(mtiles) * 64 * RL + ((nc + 3) & ~3u), 0.0f);
+            for (unsigned mt = 0; mt < mtiles; ++mt)
+                for (unsigned l = 0; l < 64; ++l)
+                    for (unsigned s2 = 0; s2 < steps; ++s2) {
+                        const unsigned c = 16 * mt + (l & 15), band = 4 * s2 + (l >> 4);
+                        if (c < nc && band < nm) frag[(size_t(mt) * 64 + l) * RL + s2] = float(basis[size_t(c) * nm + band]);
+                    }
+            for (unsigned c = 0; c < ((nc + 3) & ~3u); ++c) frag[size_t(mtiles) * 64 * RL + c] = c < nc ? float(lift[c]) : 1.0f;
+            const size_t lds = size_t(r32x16::kLdsBytes) - size_t(r32x16::kMelMaxWords) * 4 + ((pl->mel_sched_words + 3u) & ~3u) * 4 + frag.size() * 4 + 64;
+            if (lds <= 163840) {
+                if ((st = upload<float>(pl, &pl->d_mfcc_frag, frag)) != SGX_OK) return st;
+                pl->mfcc_frag_words = unsigned(frag.size());
+                pl->mfcc_steps = steps;
+                pl->mfcc_mtiles = mtiles;
+            }
+        }
     }
     if (pl->kind == K_R32X16_F32) {
         // tw1[k1][n2] = W_512^(k1*n2) (pass-1 twiddles), tw2[j][k2] = W_1024^(j + 32*k2) (real-split twiddles)
@@ -985,14 +1009,30 @@ sgx_status run_device(sgx_plan *pl, const void *x, size_t batch, size_t n_sample
                       size_t n_frames, hipStream_t s, int iters, float *ms) {
     StftArgs a;
     void *stage_out = out;
-    const bool mfcc = pl->p.n_mfcc > 0;
-    if (mfcc) {  // Mel-dB goes to plan-owned scratch (sgx_reserve sizes it ahead), the DCT/lifter epilogue writes the caller's buffer
+    bool mfcc = pl->p.n_mfcc > 0;
+    KernelKind kind = pick_kernel(pl, x, stride);
+    // MFCC: fused into the tuned kernel's launch where the plan carries the basis fragments AND this call stays on that kernel (a call may
+    // step down the chain, e.g. signals of fewer frames than half a tile); else the Mel-dB tensor goes to plan-owned scratch
+    // (sgx_reserve sizes it ahead) and the DCT / lifter epilogue launch writes the caller's buffer
+    bool mfcc_fused = false;
+    if (mfcc && pl->d_mfcc_frag && !pl->split_bank) {
+        StftArgs probe;
+        fill_args(pl, probe, x, out, batch, n_samples, stride, n_frames);
+        KernelKind k2 = kind;
+        mfcc_fused = resolve_geometry(pl, probe, k2) && k2 == K_R32X16_F32;
+    }
+    if (mfcc && !mfcc_fused) {
         sgx_status st = grow(pl, &pl->d_melbuf, &pl->d_melbuf_bytes, batch * size_t(pl->n_out) * n_frames * pl->elem);
         if (st != SGX_OK) return st;
         stage_out = pl->d_melbuf;
     }
     fill_args(pl, a, x, stage_out, batch, n_samples, stride, n_frames);
-    KernelKind kind = pick_kernel(pl, x, stride);
+    const unsigned skip = pl->p.n_mfcc - pl->n_final * (mfcc ? 1u : 0u);
+    if (mfcc_fused) {
+        a.mfcc_frag = pl->d_mfcc_frag; a.mfcc_frag_words = pl->mfcc_frag_words; a.mfcc_steps = pl->mfcc_steps; a.mfcc_mtiles = pl->mfcc_mtiles;
+        a.n_mfcc = pl->p.n_mfcc; a.mfcc_skip = skip;
+        mfcc = false;  // no epilogue launch
+    }
     // Split filterbank path (decided at plan creation, `split_bank`): the per-bin power goes to a plan-owned tensor and a second
     // launch reduces it with one wave per (row, 64 frames) — the same terms in the same order, so the same bits.  Taken (i) for long
     // frames on the register-tiled kernel, where a tile holds one or two frames, the fused bank stage has 80-160 (frame, row) items
@@ -1011,7 +1051,6 @@ sgx_status run_device(sgx_plan *pl, const void *x, size_t batch, size_t n_sample
         return set_err(pl, SGX_BACKEND, "hip -- FFT backend error: n_fft too large for the on-chip frame tile");
     if (kind_is_tuned(kind)) a1.window = pl->d_window_half;
     if (ms) SGX_HIP(pl, hipEventRecord(pl->ev0, s));
-    const unsigned skip = pl->p.n_mfcc - pl->n_final * (mfcc ? 1u : 0u);
     for (int i = 0; i < iters; ++i) {
         SGX_HIP(pl, launch(pl, a1, kind, s));
         if (split_bank) SGX_HIP(pl, launch_bank_rows(pl->d_pwbuf, stage_out, a, pl->dtype, s));
@@ -1043,7 +1082,7 @@ sgx_status grow(sgx_plan *pl, void **buf, size_t *have, size_t need) {
 
 void free_device(sgx_plan *pl) {
     void **bufs[] = {&pl->d_window, &pl->d_tw, &pl->d_tw1, &pl->d_tw2, &pl->d_mel_ptr, &pl->d_mel_col,
-                     &pl->d_mel_val, &pl->d_dct, &pl->d_lifter, &pl->d_melbuf, &pl->d_pwbuf, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_mm_frag, &pl->d_mm_blk, &pl->d_mel_sched, &pl->d_itw, &pl->d_itwr, &pl->d_itw1, &pl->d_itwr2, &pl->d_itw12, &pl->d_itwrd, &pl->d_itw1d, &pl->d_frames, &pl->d_flag, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half, &pl->d_bs_chirp, &pl->d_bs_tw, &pl->d_bs_wc, &pl->d_bs_bhp, &pl->bs_half.chirp, &pl->bs_half.bhp, &pl->bs_half.tw};
+                     &pl->d_mel_val, &pl->d_dct, &pl->d_lifter, &pl->d_mfcc_frag, &pl->d_melbuf, &pl->d_pwbuf, &pl->d_mel_pptr, &pl->d_mel_pcol, &pl->d_mel_pw, &pl->d_mm_frag, &pl->d_mm_blk, &pl->d_mel_sched, &pl->d_itw, &pl->d_itwr, &pl->d_itw1, &pl->d_itwr2, &pl->d_itw12, &pl->d_itwrd, &pl->d_itw1d, &pl->d_frames, &pl->d_flag, &pl->d_ones, &pl->d_in, &pl->d_out, &pl->d_window_half, &pl->d_ones_half, &pl->d_bs_chirp, &pl->d_bs_tw, &pl->d_bs_wc, &pl->d_bs_bhp, &pl->bs_half.chirp, &pl->bs_half.bhp, &pl->bs_half.tw};
     for (void **b : bufs)
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     big_free(pl->big);

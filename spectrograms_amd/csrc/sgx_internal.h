@@ -73,6 +73,11 @@ struct StftArgs {
     unsigned mel_sched_words;
     // tuned kernel, packed tiles (batches of short signals; set by its launcher): batch * n_frames, bytes of the whole sample buffer
     unsigned gframes, x_bytes;
+    // fused MFCC epilogue of the tuned f32 kernel (kernels_r32x16.hip mfcc_tile; nullptr: separate launch_mfcc): the DCT-II basis as
+    // v_mfma_f32_16x16x4_f32 A-fragments [mtiles][steps][64 lanes] = basis[16 mt + (l & 15)][4 s + (l >> 4)] (0 beyond n_mfcc / n_mels),
+    // followed by the lifter weights [n_mfcc] (1.0 without a lifter); `out` then is the MFCC tensor [batch][n_mfcc - mfcc_skip][n_frames]
+    const void *mfcc_frag;
+    unsigned mfcc_frag_words, mfcc_steps, mfcc_mtiles, n_mfcc, mfcc_skip;
 };
 
 // launchers (kernels_generic.hip / kernels_r32x16.hip); return hipSuccess or the launch error
@@ -356,6 +361,8 @@ struct sgx_plan {
     void *d_ones = nullptr;  // rectangular window for sgx_r2c
     // MFCC epilogue: DCT-II basis [n_mfcc][n_mels] and lifter [n_mfcc] in T; Mel-dB scratch (grown on demand)
     void *d_dct = nullptr, *d_lifter = nullptr, *d_melbuf = nullptr;
+    void *d_mfcc_frag = nullptr;  // fused MFCC epilogue of the tuned f32 kernel: the basis as matrix-core fragments (null: separate launch)
+    unsigned mfcc_frag_words = 0, mfcc_steps = 0, mfcc_mtiles = 0;
     size_t d_melbuf_bytes = 0;
     // split filterbank path (long frames): the per-bin power / magnitude tensor between the two launches (grown on demand)
     void *d_pwbuf = nullptr;
