@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak is ~6290 GB/s
 VALU_PEAK_TFLOPS = 157.3   # FP32 vector peak (same guide)
 FLOPS_PER_FRAME = {"linear_power": 28.1e3, "stft": 26.6e3, "mel_power": 30.1e3, "mel_db": 30.1e3, "mfcc": 32.2e3}  # FFT 25.6 k + window 1 k (+ |.|^2 1.5 k, Mel 2 k)
-LEGS = ("mel_power", "mel_db", "mfcc", "config4", "istft", "fft2d", "convolve_fft", "chirpz_1009", "linear_power_f64", "mel_db_f64")  # the default run's extra legs (besides the headline workload)
+LEGS = ("mel_power", "mel_db", "mfcc", "config4", "istft", "fft2d", "convolve_fft", "chirpz_1009", "linear_power_f64", "mel_db_f64", "linear_db_f64")  # the default run's extra legs (besides the headline workload)
 IMG_SIDE, IMG_BATCH = 1024, 512  # BASELINE configs[4]
 SR, N_FFT, HOP, N_SAMPLES = 16000.0, 1024, 256, 160000
 WORKLOADS = {  # name -> (kernel workload, utterances per GPU, BASELINE config index)
@@ -74,7 +74,7 @@ STAMP_FILES = {
     "f64": ("kernels_d32x16.hip", "d32x16_layout.h", "fft_inreg.h"),
 }
 STAMP_FAMILY = {"linear_power": "stft", "mel_power": "stft", "mel_db": "stft", "mfcc": "stft", "stft": "stft", "fft2d": "2d", "convolve_fft": "2d", "istft": "istft",
-                "linear_power_f64": "f64", "mel_db_f64": "f64"}
+                "linear_power_f64": "f64", "mel_db_f64": "f64", "linear_db_f64": "f64"}
 
 
 def kernel_source_stamp(family: str = "stft") -> str:
@@ -418,10 +418,11 @@ def stft_leg(torch, sg, dev, name: str, xs256, args, peak):
 def f64_leg(torch, sg, dev, name: str, xs256, args, peak):
     """BASELINE configs[1] / configs[2] in the reference's other `Sample` type (f64: the Python API's default dtype, src/sample.rs:23-86):
     256 x 10 s, n_fft 1024 / hop 256 on the tuned f64 kernel k_d32x16.  Algorithmic bytes: 8-byte samples in, 8-byte outputs out."""
-    kernel_wl = {"linear_power_f64": "linear_power", "mel_db_f64": "mel_db"}[name]
+    kernel_wl = {"linear_power_f64": "linear_power", "mel_db_f64": "mel_db", "linear_db_f64": "linear_db"}[name]
     params = sg.SpectrogramParams(sg.StftParams(N_FFT, HOP, sg.WindowType.hanning, True), SR)
     planner = sg.SpectrogramPlanner()
     plan = (planner.linear_power_plan(params, dtype="float64") if kernel_wl == "linear_power" else
+            planner.linear_db_plan(params, sg.LogParams(-80.0), dtype="float64") if kernel_wl == "linear_db" else  # 82 M dB values per launch: db_f64.h
             planner.mel_db_plan(params, sg.MelParams(80, 0.0, 8000.0), sg.LogParams(-80.0), dtype="float64"))
     n_bins, n_frames = plan.output_shape(N_SAMPLES)
     xs = [x.double() for x in xs256]
@@ -447,7 +448,7 @@ def f64_leg(torch, sg, dev, name: str, xs256, args, peak):
             "frames_per_launch": frames}
     if peak and peak.get("copy"):
         roof["frac_of_measured_copy"] = roof["achieved"] / peak["copy"]
-    return {"config": f"configs[{1 if kernel_wl == 'linear_power' else 2}] in f64: 256 x 10 s 16 kHz, {kernel_wl} n_fft=1024 hop=256 Hanning centre",
+    return {"config": f"configs[{2 if kernel_wl == 'mel_db' else 1}] in f64: 256 x 10 s 16 kHz, {kernel_wl} n_fft=1024 hop=256 Hanning centre",
             "dtype": "f64", "kernel": plan.kernel_name, "steps": args.steps, "warmup": args.warmup, "preheat_steps": ph,
             "ms_per_step": dt / args.steps * 1e3, "value": frames * args.steps / dt, "unit": "frames/s", "roofline": roof}
 

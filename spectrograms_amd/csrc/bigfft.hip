@@ -25,6 +25,7 @@
 #include <cmath>
 #include <type_traits>
 
+#include "db_f64.h"
 #include "sgx_internal.h"
 
 namespace sgx {
@@ -213,7 +214,11 @@ __global__ __launch_bounds__(256) void k_big_frames(const T *x, unsigned long lo
 template <typename T>
 __device__ __forceinline__ T big_amp(T p, int amp, T eps) {
     if (amp == AMP_MAGNITUDE) return sqrt(p);
-    if (amp == AMP_DB) return T(10) * log10(p > eps ? p : eps);
+    if (amp == AMP_DB) {
+        const T v = p > eps ? p : eps;
+        if constexpr (sizeof(T) == 8) return db_f64(v);
+        else return T(10) * log10(v);
+    }
     return p;
 }
 template <typename T>

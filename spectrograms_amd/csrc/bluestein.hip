@@ -32,6 +32,7 @@
 
 #include "reg_radix.h"
 #include "rr_layout.h"
+#include "db_f64.h"
 #include "sgx_internal.h"
 #include "xcd_map.h"
 
@@ -55,7 +56,7 @@ namespace {
 __device__ __forceinline__ float bs_mul_add_unfused(float w, float p, float acc) { return __fadd_rn(__fmul_rn(w, p), acc); }
 __device__ __forceinline__ double bs_mul_add_unfused(double w, double p, double acc) { return __dadd_rn(__dmul_rn(w, p), acc); }
 __device__ __forceinline__ float bs_db(float p) { return __builtin_log2f(p) * 3.01029995663981195f; }  // as the other f32 kernels
-__device__ __forceinline__ double bs_db(double p) { return 10.0 * log10(p); }
+__device__ __forceinline__ double bs_db(double p) { return db_f64(p); }
 
 // ---- the fused kernel ----------------------------------------------------------------------------------------------------
 // One workgroup carries `tile` sequences (frame pairs) through the whole chain in LDS; the only HBM traffic is the samples in

@@ -29,6 +29,7 @@
 #include "fft_inreg.h"
 #include "d32x16_layout.h"
 #include "r32x16_layout.h"
+#include "db_f64.h"
 #include "sgx_internal.h"
 
 namespace sgx {
@@ -48,7 +49,7 @@ __host__ __device__ constexpr unsigned pwd_index(unsigned k, unsigned f) { retur
 template <int AMP>
 __device__ __forceinline__ double amp_f64(double p, double eps) {
     if constexpr (AMP == AMP_MAGNITUDE) return sqrt(p);
-    else if constexpr (AMP == AMP_DB) return 10.0 * log10(fmax(p, eps));
+    else if constexpr (AMP == AMP_DB) return db_f64(fmax(p, eps));
     else return p;
 }
 

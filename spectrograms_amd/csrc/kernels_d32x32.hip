@@ -21,6 +21,7 @@
 
 #include "buffer_ops.h"
 #include "fft_inreg.h"
+#include "db_f64.h"
 #include "sgx_internal.h"
 
 namespace sgx {
@@ -47,7 +48,7 @@ __host__ __device__ constexpr unsigned pwd8_index(unsigned k, unsigned f) { retu
 template <int AMP>
 __device__ __forceinline__ double amp_e(double p, double eps) {
     if constexpr (AMP == AMP_MAGNITUDE) return sqrt(p);
-    else if constexpr (AMP == AMP_DB) return 10.0 * log10(fmax(p, eps));
+    else if constexpr (AMP == AMP_DB) return db_f64(fmax(p, eps));
     else return p;
 }
 

@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include "buffer_ops.h"
+#include "db_f64.h"
 #include "reg_radix.h"
 #include "rr_layout.h"
 
@@ -60,9 +61,9 @@ struct Cx {
 __device__ inline float t_sqrt(float v) { return sqrtf(v); }
 __device__ inline double t_sqrt(double v) { return sqrt(v); }
 // 10 log10(v).  f32: (10 log10 2) log2(v) — the hardware's log2 and one multiply instead of log10f's extra-precision product
-// (< 2e-5 dB off at |dB| <= 100); f64: 10 log10(v)
+// (< 2e-5 dB off at |dB| <= 100); f64: db_f64.h (frexp + atanh series, branch-free)
 __device__ inline float t_db(float v) { return __builtin_log2f(v) * 3.01029995663981195f; }
-__device__ inline double t_db(double v) { return 10.0 * log10(v); }
+__device__ inline double t_db(double v) { return db_f64(v); }
 __device__ inline float t_max(float a, float b) { return fmaxf(a, b); }
 __device__ inline double t_max(double a, double b) { return fmax(a, b); }
 // un-fused multiply-add: the reference's `acc += T::from_f64(w) * x` is two roundings (rustc never contracts)

@@ -368,15 +368,15 @@ def test_long_frames_filterbank_in_a_second_launch(n_fft, hop, dtype, n_mels, no
 
 
 @pytest.mark.parametrize("n_fft,hop,dtype,kernel", [(6000, 1500, "float32", "bluestein"), (6000, 2000, "float64", "bluestein"), (8200, 2050, "float32", "bluestein"),
-                                                    (6003, 2000, "float64", "two_factor_dft"),
+                                                    (6003, 2000, "float64", "big_chirpz"),
                                                     (3000, 700, "float64", "bluestein"), (5003, 2000, "float32", "bluestein"),
-                                                    (8191, 2048, "float32", "bluestein"), (4099, 1000, "float64", "direct_dft")])
+                                                    (8191, 2048, "float32", "bluestein"), (4099, 1000, "float64", "big_chirpz")])
 @pytest.mark.parametrize("amp", ["complex", "power"])
 def test_long_frames_outside_the_register_tiled_lists(n_fft, hop, dtype, kernel, amp):
     """Frames of 2049 ... 8192 samples that are not a listed size: chirp-z with one 8192- / 16384-point sequence per workgroup in
     LDS (f32 up to n_fft 8192, f64 up to 4096 — 128 KiB of LDS either way); even lengths up to twice that take the half-length complex
-    form on the same kernels (one frame per sequence of n_fft / 2 points); odd ones keep the two-factor kernel (composites) or the
-    direct sum (primes), one frame per tile, twiddle table in global memory."""
+    form on the same kernels (one frame per sequence of n_fft / 2 points); odd ones past the LDS chirp-z go through global memory
+    (round 5, bigfft.hip: chirp-z on four-step transforms; before: the two-factor kernel / the direct sum)."""
     plan, got = run_case(n=3 * n_fft + 77, batch=2, n_fft=n_fft, hop=hop, amp=amp, dtype=dtype)
     assert plan.kernel_name == kernel
     x = signals(2, 3 * n_fft + 77, np.float32 if dtype == "float32" else np.float64, 0)
@@ -1030,3 +1030,24 @@ def test_odd_hops_on_the_tuned_kernel(hop, centre, amp, n_mels, floor):
     assert plan.kernel_name == "r32x16_f32"
     x = signals(3, n, np.float32, 0)
     assert np.array_equal(np.asarray(plan.compute_batch(x[1:2]))[0], np.asarray(got)[1])
+
+
+@pytest.mark.gpu
+def test_f64_db_epilogue():
+    """f64 dB outputs use db_f64.h (frexp + atanh series) instead of libm's log10: against the oracle's `10 * log10` over 600 dB of
+    dynamic range (powers 1e-300 .. 1e300, a floor below them), on the tuned f64 kernel (n_fft 1024), the register-tiled one (256) and
+    through a filterbank; exact at the floor."""
+    rng = np.random.default_rng(8)
+    scales = 10.0 ** np.linspace(-150, 150, 31)
+    for n_fft, hop in ((1024, 256), (256, 64)):
+        x = rng.standard_normal((31, 6 * n_fft)) * scales[:, None]
+        params = sg.SpectrogramParams(sg.StftParams(n_fft, hop, sg.WindowType.hanning, True), 16000.0)
+        D = sg.SpectrogramPlanner().linear_db_plan(params, sg.LogParams(-3050.0), dtype="float64").compute_batch(x)
+        ref = orc.spectrogram_batch(orc.Params(n_fft=n_fft, hop=hop, amp="db", floor_db=-3050.0), x)
+        assert np.all(np.isfinite(D)) and np.max(np.abs(D - ref)) < 1e-9, np.max(np.abs(D - ref))
+        assert D.min() < -2900 and D.max() > 2900
+    x = rng.standard_normal((4, 8000)) * 1e-3
+    params = sg.SpectrogramParams(sg.StftParams(1024, 256, sg.WindowType.hanning, True), 16000.0)
+    M = sg.SpectrogramPlanner().mel_db_plan(params, sg.MelParams(80, 0.0, 8000.0), sg.LogParams(-20.0), dtype="float64").compute_batch(x)
+    refm = orc.spectrogram_batch(orc.Params(n_fft=1024, hop=256, n_mels=80, amp="db", floor_db=-20.0), x)
+    assert np.max(np.abs(M - refm)) < 1e-9 and np.min(M) < -20.0 + 1e-9  # (some bands sit at the floor)
