@@ -71,9 +71,9 @@ STAMP_FILES = {
     "stft": ("kernels_r32x16.hip", "fft_inreg.h", "r32x16_layout.h"),
     "2d": ("kernels_r32x16.hip", "kernels_c2c1024.hip", "fft2d.hip", "fft_inreg.h", "r32x16_layout.h"),
     "istft": ("kernels_c2c1024.hip", "fft_inreg.h"),
-    "f64": ("kernels_d32x16.hip", "d32x16_layout.h", "fft_inreg.h"),
+    "f64": ("kernels_d32x16.hip", "d32x16_layout.h", "fft_inreg.h", "db_f64.h", "lane_pair.h"),
 }
-STAMP_FAMILY = {"linear_power": "stft", "mel_power": "stft", "mel_db": "stft", "mfcc": "stft", "stft": "stft", "fft2d": "2d", "convolve_fft": "2d", "istft": "istft",
+STAMP_FAMILY = {"linear_power": "stft", "mel_power": "stft", "mel_db": "stft", "mfcc": "stft", "config4": "stft", "stft": "stft", "fft2d": "2d", "convolve_fft": "2d", "istft": "istft",
                 "linear_power_f64": "f64", "mel_db_f64": "f64", "linear_db_f64": "f64"}
 
 
@@ -327,7 +327,7 @@ def stft_roofline(kernel_wl: str, batch: int, n_frames: int, kernel_ms: float, p
     achieved = (rd + wr) * fps / 1e9
     valu = FLOPS_PER_FRAME[kernel_wl] * fps / (VALU_PEAK_TFLOPS * 1e12)
     r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-         "traffic": measured_traffic(kernel_wl) if batch == 256 else None, "kernel_ms": kernel_ms, "kernel_ms_scope": scope,
+         "traffic": measured_traffic(kernel_wl) if batch == 256 else measured_traffic("config4") if (batch == 1024 and kernel_wl == "mel_power") else None, "kernel_ms": kernel_ms, "kernel_ms_scope": scope,
          "algorithmic_bytes_per_frame": rd + wr, "frames_per_launch": frames, "hbm_read_frac": rd * fps / 1e9 / HBM_PEAK_GBS,
          "valu_frac": valu, "flops_per_frame": FLOPS_PER_FRAME[kernel_wl], "limiter": "valu+lds" if valu > achieved / HBM_PEAK_GBS else "hbm"}
     if peak_measured:

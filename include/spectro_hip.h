@@ -112,7 +112,9 @@ typedef struct {
 
 /* Replaces StftPlan::new (:1204-1228), SpectrogramPlanner::{linear_plan :893-917, mel_plan :944-977}:
  * validates exactly like the reference constructors, builds window / twiddles / CSR filterbank on the
- * host in f64, casts to T and uploads.  On failure *out is NULL and sgx_last_create_error() has the text. */
+ * host in f64, casts to T and uploads.  On failure *out is NULL and sgx_last_create_error() has the text.
+ * Every n_fft up to 2^20 (powers of two: 2^21) has a plan in both types, like the reference's planner (src/fft_backend.rs:372-389);
+ * longer frames are SGX_BACKEND ("n_fft too large"). */
 sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out);
 void sgx_plan_destroy(sgx_plan *plan);
 
@@ -277,8 +279,9 @@ sgx_status sgx_clock_probe(int32_t device, void *hip_stream, double *mhz);
 const char *sgx_last_error(const sgx_plan *plan);
 const char *sgx_last_create_error(void);
 /* Name of the kernel variant the plan dispatches to: the shape-specific kernels "r32x16_f32", "r32x32_f32", "r64x32_f32", "d512_f64", "d32x16_f64",
- * "d32x32_f64", or "reg_radix", "lds_radix2", "two_factor_dft", "bluestein", "direct_dft" (a diagnostic: a call may step down this chain for shapes the
- * plan's kernel does not take). */
+ * "d32x32_f64", or "reg_radix", "lds_radix2", "two_factor_dft", "bluestein", "direct_dft", or — frame lengths past the on-chip kernels, every n_fft up
+ * to 2^20 (powers of two 2^21) — "big_four_step" / "big_chirpz" (transforms through global memory) (a diagnostic: a call may step down this chain for
+ * shapes the plan's kernel does not take). */
 const char *sgx_kernel_name(const sgx_plan *plan);
 int32_t sgx_abi_version(void);
 int32_t sgx_device_count(void);

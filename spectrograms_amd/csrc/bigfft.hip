@@ -43,49 +43,75 @@ template <typename V> __device__ __forceinline__ V csub(V a, V b) { V r; r.x = a
 
 constexpr unsigned kBigThreads = 512;
 
-// ---- radix-2 transforms of C sequences of L points resident in LDS: lds[c * (L + 1) + i] -------------------------------------------
-// DIT: input in bit-reversed places, output in natural order.  DIF: natural in, bit-reversed out.  `inv`: e^(+) twiddles.
-// Butterfly b of a stage = (lane c = b % C, index b / C): neighbouring threads work on different sequences, whose rows start
-// L + 1 elements apart (distinct banks).  tw[j] = W_L^j, j < L / 2, in LDS.
+// ---- transforms of C sequences of L points resident in LDS: lds[c * (L + 1) + i] ---------------------------------------------------
+// DIT: input in bit-reversed places, output in natural order.  DIF: natural in, bit-reversed out.  `inv`: e^(+) twiddles.  Radix-2
+// stages taken two at a time (lds_r4_stage), a single one where log2 L is odd.  Work item b of a stage = (lane c = b % C, index b / C):
+// neighbouring threads work on different sequences, whose rows start L + 1 elements apart (distinct banks).  tw[j] = W_L^j, j < L / 2, in LDS.
 template <typename T>
-__device__ __forceinline__ void lds_fft_dit(c2_t<T> *lds, const c2_t<T> *tw, unsigned L, unsigned lL, unsigned C, bool inv) {
+__device__ __forceinline__ void lds_r2_stage(c2_t<T> *lds, const c2_t<T> *tw, unsigned L, unsigned lL, unsigned C, unsigned s, bool inv, bool dif) {
     using V = c2_t<T>;
-    const unsigned total = C * (L >> 1);
-    for (unsigned s = 0; s < lL; ++s) {
-        const unsigned half = 1u << s;
-        for (unsigned b = threadIdx.x; b < total; b += kBigThreads) {
-            const unsigned c = b % C, q = b / C;
-            const unsigned j = q & (half - 1u);
-            const unsigned i0 = ((q >> s) << (s + 1u)) + j, i1 = i0 + half;
-            V w = tw[j << (lL - 1u - s)];
-            if (inv) w.y = -w.y;
-            V *row = lds + c * (L + 1u);
-            const V u = row[i0], v = cmul(row[i1], w);
+    const unsigned total = C * (L >> 1), half = 1u << s;
+    for (unsigned b = threadIdx.x; b < total; b += kBigThreads) {
+        const unsigned c = b % C, q = b / C;
+        const unsigned j = q & (half - 1u);
+        const unsigned i0 = ((q >> s) << (s + 1u)) + j, i1 = i0 + half;
+        V w = tw[j << (lL - 1u - s)];
+        if (inv) w.y = -w.y;
+        V *row = lds + c * (L + 1u);
+        const V u = row[i0], x1 = row[i1];
+        if (dif) {
+            row[i0] = cadd(u, x1);
+            row[i1] = cmul(csub(u, x1), w);
+        } else {
+            const V v = cmul(x1, w);
             row[i0] = cadd(u, v);
             row[i1] = csub(u, v);
         }
-        __syncthreads();
     }
+    __syncthreads();
+}
+// two radix-2 stages (halves h = 2^s and 2 h) in one pass over the tile: 4 reads, 4 writes and one barrier instead of 8, 8 and two
+template <typename T>
+__device__ __forceinline__ void lds_r4_stage(c2_t<T> *lds, const c2_t<T> *tw, unsigned L, unsigned lL, unsigned C, unsigned s, bool inv, bool dif) {
+    using V = c2_t<T>;
+    const unsigned total = C * (L >> 2), h = 1u << s;
+    for (unsigned g = threadIdx.x; g < total; g += kBigThreads) {
+        const unsigned c = g % C, q = g / C;
+        const unsigned j = q & (h - 1u);
+        const unsigned i0 = ((q >> s) << (s + 2u)) + j;
+        V w1 = tw[j << (lL - 1u - s)], w2 = tw[j << (lL - 2u - s)], w3 = tw[(j + h) << (lL - 2u - s)];  // W_2h^j, W_4h^j, W_4h^(j+h)
+        if (inv) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
+        V *row = lds + c * (L + 1u) + i0;
+        const V x0 = row[0], x1 = row[h], x2 = row[2u * h], x3 = row[3u * h];
+        if (dif) {  // half 2 h first, then h
+            const V b0 = cadd(x0, x2), b2 = cmul(csub(x0, x2), w2), b1 = cadd(x1, x3), b3 = cmul(csub(x1, x3), w3);
+            row[0] = cadd(b0, b1);
+            row[h] = cmul(csub(b0, b1), w1);
+            row[2u * h] = cadd(b2, b3);
+            row[3u * h] = cmul(csub(b2, b3), w1);
+        } else {    // half h first, then 2 h
+            const V t1 = cmul(x1, w1), t3 = cmul(x3, w1);
+            const V a0 = cadd(x0, t1), a1 = csub(x0, t1), a2 = cadd(x2, t3), a3 = csub(x2, t3);
+            const V u2 = cmul(a2, w2), u3 = cmul(a3, w3);
+            row[0] = cadd(a0, u2);
+            row[2u * h] = csub(a0, u2);
+            row[h] = cadd(a1, u3);
+            row[3u * h] = csub(a1, u3);
+        }
+    }
+    __syncthreads();
+}
+template <typename T>
+__device__ __forceinline__ void lds_fft_dit(c2_t<T> *lds, const c2_t<T> *tw, unsigned L, unsigned lL, unsigned C, bool inv) {
+    unsigned s = 0;
+    for (; s + 1u < lL; s += 2u) lds_r4_stage<T>(lds, tw, L, lL, C, s, inv, false);
+    if (s < lL) lds_r2_stage<T>(lds, tw, L, lL, C, s, inv, false);
 }
 template <typename T>
 __device__ __forceinline__ void lds_fft_dif(c2_t<T> *lds, const c2_t<T> *tw, unsigned L, unsigned lL, unsigned C, bool inv) {
-    using V = c2_t<T>;
-    const unsigned total = C * (L >> 1);
-    for (unsigned s = lL; s-- > 0;) {
-        const unsigned half = 1u << s;
-        for (unsigned b = threadIdx.x; b < total; b += kBigThreads) {
-            const unsigned c = b % C, q = b / C;
-            const unsigned j = q & (half - 1u);
-            const unsigned i0 = ((q >> s) << (s + 1u)) + j, i1 = i0 + half;
-            V w = tw[j << (lL - 1u - s)];
-            if (inv) w.y = -w.y;
-            V *row = lds + c * (L + 1u);
-            const V u = row[i0], v = row[i1];
-            row[i0] = cadd(u, v);
-            row[i1] = cmul(csub(u, v), w);
-        }
-        __syncthreads();
-    }
+    unsigned r = lL;
+    if (r & 1u) { --r; lds_r2_stage<T>(lds, tw, L, lL, C, r, inv, true); }
+    for (; r >= 2u; r -= 2u) lds_r4_stage<T>(lds, tw, L, lL, C, r - 2u, inv, true);
 }
 __device__ __forceinline__ unsigned brev(unsigned i, unsigned bits) { return bits ? __brev(i) >> (32u - bits) : 0u; }
 

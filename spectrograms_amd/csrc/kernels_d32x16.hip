@@ -30,6 +30,7 @@
 #include "d32x16_layout.h"
 #include "r32x16_layout.h"
 #include "db_f64.h"
+#include "lane_pair.h"
 #include "sgx_internal.h"
 
 namespace sgx {
@@ -53,21 +54,7 @@ __device__ __forceinline__ double amp_f64(double p, double eps) {
     else return p;
 }
 
-// lanes l and l ^ 32 trade a complex value; each receives the other's as (im, re)
-__device__ __forceinline__ void trade32(v2d &v) {
-    const double vx = v.x, vy = v.y;  // (scalars first: __builtin_bit_cast of the vector-element lvalue v.y reads element 0 with this clang)
-    v2u re = __builtin_bit_cast(v2u, vx), im = __builtin_bit_cast(v2u, vy);
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        // vdst's lanes 32..63 <-> src0's lanes 0..31.  First: re = {a.re | a.im}, im = {b.re | b.im}; second (im, re): im = {b.re | a.re}, re = {b.im | a.im}
-        const v2u s1 = __builtin_amdgcn_permlane32_swap(re[c], im[c], false, false);
-        const v2u s2 = __builtin_amdgcn_permlane32_swap(s1.y, s1.x, false, false);
-        im[c] = s2.x;
-        re[c] = s2.y;
-    }
-    v.x = __builtin_bit_cast(double, re);
-    v.y = __builtin_bit_cast(double, im);
-}
+using lanepair::trade32;  // lanes l and l ^ 32 trade a complex value, each receives the other's as (im, re): lane_pair.h
 
 __device__ __forceinline__ v2d mul_add_unfused_d(double w, v2d p, v2d acc) {  // the reference's `acc += w * x`: two roundings (spectrogram.rs:102-117)
     return (v2d){__dadd_rn(__dmul_rn(w, p.x), acc.x), __dadd_rn(__dmul_rn(w, p.y), acc.y)};

@@ -22,6 +22,7 @@
 #include "buffer_ops.h"
 #include "fft_inreg.h"
 #include "db_f64.h"
+#include "lane_pair.h"
 #include "sgx_internal.h"
 
 namespace sgx {
@@ -52,20 +53,7 @@ __device__ __forceinline__ double amp_e(double p, double eps) {
     else return p;
 }
 
-// lanes l and l ^ 32 trade a complex value; each receives the other's as (im, re) (kernels_d32x16.hip)
-__device__ __forceinline__ void trade32(v2d &v) {
-    const double vx = v.x, vy = v.y;  // (scalars first: __builtin_bit_cast of the vector-element lvalue v.y reads element 0 with this clang)
-    v2u re = __builtin_bit_cast(v2u, vx), im = __builtin_bit_cast(v2u, vy);
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const v2u s1 = __builtin_amdgcn_permlane32_swap(re[c], im[c], false, false);
-        const v2u s2 = __builtin_amdgcn_permlane32_swap(s1.y, s1.x, false, false);
-        im[c] = s2.x;
-        re[c] = s2.y;
-    }
-    v.x = __builtin_bit_cast(double, re);
-    v.y = __builtin_bit_cast(double, im);
-}
+using lanepair::trade32;  // lanes l and l ^ 32 trade a complex value, each receives the other's as (im, re): lane_pair.h
 
 __device__ __forceinline__ v2d mul_add_unfused_e(double w, v2d p, v2d acc) {  // the reference's `acc += w * x`: two roundings (spectrogram.rs:102-117)
     return (v2d){__dadd_rn(__dmul_rn(w, p.x), acc.x), __dadd_rn(__dmul_rn(w, p.y), acc.y)};

@@ -15,6 +15,7 @@
 #include <algorithm>
 
 #include "fft_inreg.h"
+#include "lane_pair.h"
 #include "sgx_internal.h"
 
 namespace sgx {
@@ -40,20 +41,7 @@ constexpr int kIDWin = kIDTw + 8192;     // the window (8192 B)
 constexpr int kIDCarry = kIDWin + 8192;  // the carry, ov * hop <= 1023 doubles
 constexpr int kIDLds = kIDCarry + 8192;  // 155 904 B: one workgroup per CU
 
-// lanes l and l ^ 32 trade a complex value; each receives the other's as (im, re) (kernels_d32x16.hip)
-__device__ __forceinline__ void trade32(v2d &v) {
-    const double vx = v.x, vy = v.y;  // (scalars first: __builtin_bit_cast of the vector-element lvalue v.y reads element 0 with this clang)
-    v2u re = __builtin_bit_cast(v2u, vx), im = __builtin_bit_cast(v2u, vy);
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const v2u s1 = __builtin_amdgcn_permlane32_swap(re[c], im[c], false, false);
-        const v2u s2 = __builtin_amdgcn_permlane32_swap(s1.y, s1.x, false, false);
-        im[c] = s2.x;
-        re[c] = s2.y;
-    }
-    v.x = __builtin_bit_cast(double, re);
-    v.y = __builtin_bit_cast(double, im);
-}
+using lanepair::trade32;  // lanes l and l ^ 32 trade a complex value, each receives the other's as (im, re): lane_pair.h
 
 // (NFFT = frame length, FPT = frames per tile: 1024 / 16 for k_istft_d1024, 512 / 32 for k_istft_d512.)
 // Interior tiles at hop NFFT / 4, / 2, / 1: every frame index a compile-time constant.  HOP >= NT: an offset belongs to one thread; HOP < NT:

@@ -19,6 +19,7 @@
 
 #include "buffer_ops.h"
 #include "fft_inreg.h"
+#include "lane_pair.h"
 #include "sgx_internal.h"
 
 namespace sgx {
@@ -48,16 +49,7 @@ __device__ __forceinline__ float amp_q(float p, float eps) {
     else return p;
 }
 
-// lanes l and l ^ 32 trade a complex value; each receives the other's as (im, re)
-__device__ __forceinline__ void trade32f(v2f &v) {
-    const float vx = v.x, vy = v.y;  // (scalars first: __builtin_bit_cast of a vector-element lvalue other than .x reads element 0 with this clang)
-    const unsigned re = __builtin_bit_cast(unsigned, vx), im = __builtin_bit_cast(unsigned, vy);
-    const v2u s1 = __builtin_amdgcn_permlane32_swap(re, im, false, false);     // re = {a.re | a.im}, im = {b.re | b.im}
-    const v2u s2 = __builtin_amdgcn_permlane32_swap(s1.y, s1.x, false, false);  // im = {b.re | a.re}, re = {b.im | a.im}
-    const unsigned nim = s2.x, nre = s2.y;
-    v.x = __builtin_bit_cast(float, nre);
-    v.y = __builtin_bit_cast(float, nim);
-}
+using lanepair::trade32;  // lanes l and l ^ 32 trade a complex value, each receives the other's as (im, re): lane_pair.h
 
 __device__ __forceinline__ v2f mul_add_unfused_q(float w, v2f p, v2f acc) {  // the reference's `acc += w * x`: two roundings (spectrogram.rs:102-117)
 #pragma clang fp contract(off)
@@ -238,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void k_r64x32(StftArgs a, unsigned per_xcd,
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             R[j] = H[16 + j];
-            trade32f(R[j]);
+            trade32(R[j]);
         }
         if (j0) {
             // row 0: both halves pair inside themselves.  Half 0 (E[m] = Z[64 m]): E[u] with E[32 - u] (u = 0: Z[0] with itself gives bins 0 and

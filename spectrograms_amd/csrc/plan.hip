@@ -1509,6 +1509,7 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
             // that `process` never allocates (src/fft_backend.rs:21-24): one frame of staging each way, the rectangular window,
             // the inverse tables and the DC/Nyquist flag.  Batched calls size their scratch through sgx_reserve.
             const size_t frame_bytes = 2 * size_t(pl->nb_fft) * pl->elem;
+            if (pl->kind == K_BIGFFT && (s2 = grow(pl, &pl->d_big, &pl->d_big_bytes, big_scratch_bytes(pl->big, pl->dtype, 1))) != SGX_OK) return s2;  // one sequence: the per-frame entry points
             if ((s2 = grow(pl, &pl->d_in, &pl->d_in_bytes, frame_bytes)) != SGX_OK) return s2;
             if ((s2 = grow(pl, &pl->d_out, &pl->d_out_bytes, frame_bytes)) != SGX_OK) return s2;
             std::vector<double> ones(pl->p.n_fft, 1.0);

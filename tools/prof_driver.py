@@ -46,6 +46,8 @@ def main():
         print(workload, tuple(y.shape), "iters", iters)
         return
     pl = sg.SpectrogramPlanner()
+    if workload == "config4":  # BASELINE configs[3]'s per-GPU shard: 1024 utterances, Mel-80 power
+        workload, batch = "mel_power", 1024
     if workload.endswith("_f64"):  # bench.py's f64 legs: configs[1] / [2] in the reference's other Sample type
         workload, dtype = workload[:-4], "float64"
     if workload == "linear_power":
@@ -54,6 +56,10 @@ def main():
         plan = pl.mel_power_plan(params, sg.MelParams(80, 0.0, 8000.0), dtype="float32")
     elif workload == "stft":
         plan = pl.stft_plan(params, dtype="float32")
+    elif workload == "mfcc":  # Mel-80 dB -> DCT-II (13) + lifter 22 in the same launch (kernels_r32x16.hip mfcc_tile)
+        plan = pl.mfcc_plan(sg.StftParams(n_fft, hop, sg.WindowType.hanning, True), bench.SR, 80, sg.MfccParams(13), dtype="float32")
+    elif workload == "linear_db":
+        plan = pl.linear_db_plan(params, sg.LogParams(-80.0), dtype=dtype)
     elif workload == "erb_power":
         plan = pl.erb_power_plan(params, sg.ErbParams(64, 0.0, 8000.0), dtype="float32")
     else:

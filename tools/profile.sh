@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/prof_${TAG}_${WL}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # the stats pass launches 800 times: the clocks need ~300 launches from idle; summarize_prof.py reports the second half's average
-case $WL in fft2d|convolve_fft) NST=120;; istft|*_f64) NST=400;; *) NST=800;; esac
+case $WL in fft2d|convolve_fft) NST=120;; istft|*_f64|config4) NST=400;; *) NST=800;; esac
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/tools/prof_driver.py $WL $NST > $OUT/stats.log 2>&1
 DRV="python3 $ROOT/tools/prof_driver.py $WL 12"
 pmc() { name=$1; shift; timeout 180 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- $DRV > $OUT/$name.log 2>&1; }

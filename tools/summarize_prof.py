@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # the kernels whose bytes make up a workload's step (substring of the demangled name); everything else in the trace — torch's fills,
 # the forward STFT that makes the istft leg's input, the one-off kernel-spectrum build — is not the leg's traffic
 LEG_KERNELS = {"linear_power": ("k_r32x16",), "mel_power": ("k_r32x16",), "mel_db": ("k_r32x16",), "stft": ("k_r32x16",),
-               "istft": ("k_istft",), "linear_power_f64": ("k_d32x16",), "mel_db_f64": ("k_d32x16",), "fft2d": ("k_r32x16", "k_c2c1024"), "convolve_fft": ("k_r32x16", "k_colconv1024", "k_c2r1024")}
+               "istft": ("k_istft",), "linear_power_f64": ("k_d32x16",), "mel_db_f64": ("k_d32x16",), "linear_db_f64": ("k_d32x16",), "mfcc": ("k_r32x16",), "config4": ("k_r32x16",), "fft2d": ("k_r32x16", "k_c2c1024"), "convolve_fft": ("k_r32x16", "k_colconv1024", "k_c2r1024")}
 
 
 def write_traffic(workload: str, per_kernel: dict, sums: dict, durations: dict, iters: int) -> None:
