@@ -43,6 +43,7 @@ template <typename V> __device__ __forceinline__ V csub(V a, V b) { V r; r.x = a
 
 constexpr unsigned kBigThreads = 512;
 
+
 // ---- transforms of C sequences of L points resident in LDS: lds[c * (L + 1) + i] ---------------------------------------------------
 // DIT: input in bit-reversed places, output in natural order.  DIF: natural in, bit-reversed out.  `inv`: e^(+) twiddles.  Radix-2
 // stages taken two at a time (lds_r4_stage), a single one where log2 L is odd.  Work item b of a stage = (lane c = b % C, index b / C):
@@ -361,12 +362,25 @@ __global__ __launch_bounds__(256) void k_big_cout(const c2_t<T> *buf, const c2_t
 
 size_t esz_of(int dtype) { return dtype == SGX_F64 ? 8 : 4; }
 
-// sequences per tile: the tile (C rows of L + 1 complex elements) and the pass's twiddles fit 144 KiB
+// sequences per tile: the smallest of 36 / 72 / 144 KiB (four / two / one workgroup per CU: the loads and stores of one under the stages
+// of the others — measured: profiles/bench_r05_bigfft.txt) whose tile (C rows of L + 1 complex elements + the pass's twiddles) still
+// gives the column pass row segments of SGX_BIG_MINSEG bytes
+#ifndef SGX_BIG_MINSEG
+#define SGX_BIG_MINSEG 64
+#endif
 unsigned tile_lanes(unsigned L, unsigned lanes, int dtype) {
     const size_t cb = 2 * esz_of(dtype);
-    unsigned C = 1;
-    while (2u * C <= lanes && size_t(2u * C) * (L + 1u) * cb + size_t(L / 2) * cb <= 144u * 1024u && 2u * C <= 64u) C *= 2u;
-    return C;
+    auto fit = [&](size_t budget) {
+        unsigned C = 1;
+        while (2u * C <= lanes && size_t(2u * C) * (L + 1u) * cb + size_t(L / 2) * cb <= budget && 2u * C <= 64u) C *= 2u;
+        return C;
+    };
+    const unsigned seg = unsigned(SGX_BIG_MINSEG / cb);
+    for (size_t budget : {size_t(36) << 10, size_t(72) << 10}) {
+        const unsigned C = fit(budget);
+        if (C >= seg || C >= lanes) return C;
+    }
+    return fit(size_t(144) << 10);
 }
 
 template <typename T>
