@@ -568,18 +568,23 @@ def multi_rank_legs(torch, dist, dev, world, plan, xs, steps, warm, reduce_max, 
             return e
 
     def run(name, step, finish=None, extra=None, frames=frames_all):
-        bad = agree(phase(warm, step, finish))
+        # (a rank whose phase failed still joins the fence — phase() has caught the error — and the ranks agree on the failure BEHIND
+        # it, so the flag's all-reduce and its host read-back stay outside the timed region)
+        err = phase(warm, step, finish)
+        fence()
+        bad = agree(err)
         if bad:
             res[name] = bad
             return
-        fence()
         t0 = time.perf_counter()
-        bad = agree(phase(steps, step, finish))
+        err = phase(steps, step, finish)
+        fence()
+        dt = time.perf_counter() - t0
+        bad = agree(err)
         if bad:
             res[name] = bad
             return
-        fence()
-        dt = reduce_max(time.perf_counter() - t0)
+        dt = reduce_max(dt)
         ms = dt / steps * 1e3
         r = {"config": label, "steps": steps, "warmup": warm, "ms_per_step": ms, "value": frames * steps / dt, "unit": "frames/s"}
         if extra:
@@ -608,12 +613,14 @@ def multi_rank_legs(torch, dist, dev, world, plan, xs, steps, warm, reduce_max, 
 
     fence()
     t0 = time.perf_counter()
-    bad = agree(phase(1, lambda i: gather_alone(), None))
+    err = phase(1, lambda i: gather_alone(), None)
+    fence()
+    gdt = time.perf_counter() - t0
+    bad = agree(err)
     if bad:
         res["config4_gather_alone"] = bad
     else:
-        fence()
-        gms = reduce_max(time.perf_counter() - t0) / 5 * 1e3
+        gms = reduce_max(gdt) / 5 * 1e3
         res["config4_gather_alone"] = {"ms": gms, "shard_MB": shard_bytes / 1e6, "GBps_per_rank": shard_bytes * (world - 1) / (gms * 1e-3) / 1e9,
                                        "GBps_per_link": shard_bytes / (gms * 1e-3) / 1e9,
                                        "note": "per link: one shard per peer over that peer's xGMI link (fully connected node); wall time of 5 back-to-back all-gathers between fences"}
