@@ -72,6 +72,19 @@ __device__ __forceinline__ void read_cols2(v2f (&x)[16], v2f (&w)[16], unsigned 
     ((ds_rd64<(2 * K + PAR) * 256>(x[K], xaddr), ds_rd64<(2 * K + PAR) * 256>(w[K], waddr)), ...);
 }
 
+// Odd hops (round 5): odd frames start on an odd sample — their pairs sit at 4-byte-aligned LDS addresses, where ds_read_b64 takes several passes;
+// ds_read2_b32 reads the pair as two dwords with no alignment to respect (as k_r32x16's read_cols_odd); one base register per 4 columns keeps
+// its 8-bit dword offsets in range (a column = 256 bytes = 64 dwords)
+template <int O0, int O1>
+__device__ __forceinline__ void ds_rd2x32(v2f &d, unsigned addr) {
+    static_assert(O0 >= 0 && O0 < 256 && O1 >= 0 && O1 < 256, "ds_read2_b32: 8-bit dword offsets");
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(d) : "v"(addr), "n"(O0), "n"(O1));
+}
+template <int PAR, int... K>
+__device__ __forceinline__ void read_cols2_odd(v2f (&x)[16], v2f (&w)[16], const unsigned (&base)[8], unsigned waddr, std::integer_sequence<int, K...>) {
+    ((ds_rd2x32<((2 * K + PAR) & 3) * 64, ((2 * K + PAR) & 3) * 64 + 1>(x[K], base[(2 * K + PAR) >> 2]), ds_rd64<(2 * K + PAR) * 256>(w[K], waddr)), ...);
+}
+
 __host__ __device__ constexpr unsigned pwt2_index(unsigned k, unsigned f) { return (k >> 1) * 32u + (f >> 1) * 4u + (k & 1u) * 2u + (f & 1u); }
 __device__ __forceinline__ v2f mul_add_unfused2(float w, v2f p, v2f acc) {
 #pragma clang fp contract(off)
@@ -192,6 +205,14 @@ __global__ __launch_bounds__(512, 2) void k_r32x32(StftArgs a, unsigned per_xcd,
             const int vo = ((int)(p1f * hop) + tile_lo + 2 * (int)n2) * 4;  // (even hop: a pair never straddles the row start)
 #pragma unroll
             for (int n1 = 0; n1 < 32; ++n1) xd[n1] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rx, vo + n1 * 256, 0, 0));
+            if (hop & 1u) {  // uniform.  Odd frames sit on odd sample offsets: the pair (x[-1], x[0]) starts outside the row, and an 8-byte access whose
+                             // first dword is out of range returns 0 for both: put x[0] back (as k_r32x16)
+                const float x0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, 0, 0, 0));
+                const int s0 = (int)(p1f * hop) + tile_lo + 2 * (int)n2;
+#pragma unroll
+                for (int n1 = 0; n1 < 32; ++n1)
+                    if (s0 + 64 * n1 == -1) xd[n1].y = x0;
+            }
         }
     };
     if (wid < hi) load_tile(wid);
@@ -211,8 +232,14 @@ __global__ __launch_bounds__(512, 2) void k_r32x32(StftArgs a, unsigned per_xcd,
 #pragma unroll
                 for (int r = 0; r < ROUNDS; ++r) *(v4f *)(smem + (r * 512u + tid) * 16u) = creg[r];
                 __syncthreads();  // barrier 1: the staged samples are complete
+                if (hop & 1u) {  // uniform
+                    const unsigned base[8] = {xaddr, xaddr + 1024u, xaddr + 2048u, xaddr + 3072u, xaddr + 4096u, xaddr + 5120u, xaddr + 6144u, xaddr + 7168u};
+                    read_cols2_odd<0>(e, we, base, waddr, std::make_integer_sequence<int, 16>{});
+                    read_cols2_odd<1>(o, wo, base, waddr, std::make_integer_sequence<int, 16>{});
+                } else {
                 read_cols2<0>(e, we, xaddr, waddr, std::make_integer_sequence<int, 16>{});
                 read_cols2<1>(o, wo, xaddr, waddr, std::make_integer_sequence<int, 16>{});
+                }
                 tie16x<15>(e);  // at most 15 of the 64 reads outstanding: the 32 of (e, we) have landed
                 tie16x<-1>(we);
             } else {
@@ -354,7 +381,7 @@ hipError_t launch_variant2(const StftArgs &a, hipStream_t s) {
 }  // namespace
 
 bool plan_geometry_r32x32_f32(StftArgs &a) {
-    if (a.n_fft != 2048 || (a.hop & 1u)) return false;
+    if (a.n_fft != 2048) return false;  // (any hop since round 5: odd ones read their staged pairs with ds_read2_b32 / patch the row-start pair)
     if (a.x != nullptr && a.n_frames < 5u) return false;  // batches of very short signals: mostly empty 16-frame tiles (16 384 x 5 frames: even with k_reg_radix)
     if (a.n_samples >= (1ull << 29)) return false;                                        // 32-bit byte offsets into a sample row
     if ((unsigned long long)a.n_frames * 1025ull * 8ull >= 0x7fffffffull) return false;  // and into one output signal

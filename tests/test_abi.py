@@ -187,7 +187,7 @@ def test_host_only_plan_refuses_compute_loudly():
 def test_kernel_selection():
     assert host_plan(1024, 256, dtype="float32").kernel_name in ("r32x16_f32", "reg_radix")
     assert host_plan(1024, 256, dtype="float64").kernel_name in ("d32x16_f64", "reg_radix")  # (as for f32: a host-only plan reports the kind it would ask for)
-    assert host_plan(1024, 255, dtype="float64").kernel_name == "reg_radix"
+    assert host_plan(1024, 255, dtype="float64").kernel_name in ("d32x16_f64", "reg_radix")  # (odd hops on the tuned f64 kernel since round 5)
     assert host_plan(1024, 256, mel=sg.MelParams(40, 0.0, 8000.0), dtype="float64").kernel_name in ("d32x16_f64", "reg_radix")
     assert host_plan(1024, 256, mel=sg.MelParams(400, 0.0, 8000.0), dtype="float64").kernel_name == "reg_radix"  # schedule too long for the LDS left
     assert host_plan(4096, 1024, dtype="float64").kernel_name == "reg_radix"

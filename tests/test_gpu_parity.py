@@ -133,8 +133,8 @@ def test_pow2_sizes(n_fft, hop, amp, dtype):
     (unaligned frames), the LDS radix-2 kernel below 32 points."""
     plan, _ = run_case(n=max(6000, 3 * n_fft), n_fft=n_fft, hop=hop, amp=amp, dtype=dtype)
     fits = n_fft <= (4096 if dtype == "float64" else 8192)  # an 8192-point f64 tile (164 KB with its tables) exceeds the CU's LDS
-    tuned = dtype == "float32" and (n_fft == 1024 or (n_fft == 512 and hop in (64, 128, 160, 256)) or (n_fft in (2048, 4096) and hop % 2 == 0))
-    tuned64 = dtype == "float64" and hop % 2 == 0 and (n_fft in (1024, 2048) or (n_fft == 512 and hop <= 260))
+    tuned = dtype == "float32" and (n_fft in (1024, 2048) or (n_fft == 512 and hop in (64, 128, 160, 256)) or (n_fft == 4096 and hop % 2 == 0))  # (2048: any hop since round 5)
+    tuned64 = dtype == "float64" and (n_fft == 1024 or (n_fft == 2048 and hop % 2 == 0) or (n_fft == 512 and hop <= 260))  # (f64 1024 / 512: any hop since round 5)
     if tuned64:
         assert plan.kernel_name == {1024: "d32x16_f64", 512: "d512_f64", 2048: "d32x32_f64"}[n_fft]
     elif 32 <= n_fft and fits and not tuned:
@@ -142,14 +142,14 @@ def test_pow2_sizes(n_fft, hop, amp, dtype):
 
 
 # ------------------------------------------------------------------ n_fft 2048, f32: the tuned kernel k_r32x32 (round 4)
-@pytest.mark.parametrize("hop", [512, 256, 1024, 2048, 100, 544, 546, 600, 2])
+@pytest.mark.parametrize("hop", [512, 256, 1024, 2048, 100, 544, 546, 600, 2, 441, 543, 545, 1023, 1])
 @pytest.mark.parametrize("amp,floor,n_mels", [("complex", None, None), ("power", None, None), ("magnitude", None, None), ("db", -80.0, None),
                                               ("power", None, 80), ("db", -80.0, 80), ("magnitude", None, 40), ("power", None, 128),
                                               ("db", -80.0, 24)])
 def test_tuned_2048(hop, amp, floor, n_mels):
     """The reference's music default n_fft 2048 / hop 512 (src/spectrogram.rs:4243-4248) and its neighbours on k_r32x32: staged samples up to
     hop 544, per-lane columns above; every output mode; frame counts that are not multiples of the 16-frame tile; centre on and off; a
-    signal's bits independent of its batch."""
+    signal's bits independent of its batch; odd hops since round 5 (staged pairs by ds_read2_b32, the row-start pair patched in the direct path)."""
     n = 23 * 1024 + 77 if hop >= 100 else 6000
     kw = dict(n_fft=2048, hop=hop, amp=amp, floor=floor, dtype="float32")
     if n_mels:
@@ -184,13 +184,13 @@ def test_tuned_f64_1024(hop, amp, floor, n_mels):
 
 
 # ------------------------------------------------------------------ n_fft 512, f64: two frames per transform on k_d512 (round 4)
-@pytest.mark.parametrize("hop", [256, 128, 64, 160, 148, 150, 260, 2])
+@pytest.mark.parametrize("hop", [256, 128, 64, 160, 148, 150, 260, 2, 147, 149, 259, 1, 255])
 @pytest.mark.parametrize("amp,floor,n_mels", [("complex", None, None), ("power", None, None), ("magnitude", None, None), ("db", -80.0, None),
                                               ("power", None, 80), ("db", -80.0, 40), ("magnitude", None, 128)])
 def test_tuned_f64_512(hop, amp, floor, n_mels):
     """f64 n_fft 512 (the reference's Mel benchmark shape 512 / 256 in its default type) on k_d512: both staging depths (hop <= 148 / <= 260),
-    odd and even frame counts (a slot's second frame may not exist), centre on and off, a signal's bits independent of its batch; hops
-    above 260 and odd hops stay on the register-tiled kernel."""
+    odd and even frame counts (a slot's second frame may not exist), centre on and off, a signal's bits independent of its batch; odd hops
+    too since round 5 (the staged samples are read one by one); hops above 260 stay on the register-tiled kernel."""
     n = 37 * 256 + 77 if hop >= 64 else 2500
     kw = dict(n_fft=512, hop=hop, amp=amp, floor=floor, dtype="float64")
     if n_mels:
@@ -1029,6 +1029,18 @@ def test_odd_hops_on_the_tuned_kernel(hop, centre, amp, n_mels, floor):
     plan, got = run_case(n=n, batch=3, n_fft=1024, hop=hop, centre=centre, amp=amp, n_mels=n_mels, floor=floor)
     assert plan.kernel_name == "r32x16_f32"
     x = signals(3, n, np.float32, 0)
+    assert np.array_equal(np.asarray(plan.compute_batch(x[1:2]))[0], np.asarray(got)[1])
+
+
+@pytest.mark.parametrize("amp,n_mels,floor", [("power", 0, None), ("complex", 0, None), ("db", 80, -80.0)])
+@pytest.mark.parametrize("hop,centre", [(255, True), (257, False), (441, True), (1, True), (1023, False), (271, True), (273, True), (275, False), (101, False)])
+def test_odd_hops_on_the_tuned_f64_kernel(hop, centre, amp, n_mels, floor):
+    """Round 5: odd hops at n_fft 1024 in f64 stay on k_d32x16 — staged path (hop <= 272): an odd frame's pairs sit at 8-byte-aligned LDS
+    addresses and are read as two doubles; direct path (above): the pair (x[-1], x[0]) straddles the row start and x[0] is put back."""
+    n = 3000 if hop == 1 else 20011
+    plan, got = run_case(n=n, batch=3, n_fft=1024, hop=hop, centre=centre, amp=amp, n_mels=n_mels, floor=floor, dtype="float64")
+    assert plan.kernel_name == "d32x16_f64"
+    x = signals(3, n, np.float64, 0)
     assert np.array_equal(np.asarray(plan.compute_batch(x[1:2]))[0], np.asarray(got)[1])
 
 
