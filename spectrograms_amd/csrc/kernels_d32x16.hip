@@ -100,7 +100,7 @@ __device__ __forceinline__ void mel_tile_sched_d(const StftArgs &a, const double
     }
 }
 
-template <int MODE, int AMP, int ROUNDS>
+template <int MODE, int AMP, int ROUNDS, bool ODD = false>  // ODD: odd hops (round 5) — a variant of its own: as a run-time branch it cost the even path spilled registers
 __global__ __launch_bounds__(512, 2) void k_d32x16(StftArgs a, unsigned per_xcd, unsigned total, unsigned slots) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned tid = threadIdx.x;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void k_d32x16(StftArgs a, unsigned per_xcd,
     v4f creg[NCR];
     v2d xd[ROUNDS > 0 ? 1 : 16];
     const unsigned hop = a.hop;
-    const bool oddhop = (hop & 1u) != 0u;  // (round 5: odd hops run here too — VERDICT r4 item 7)
+    constexpr bool oddhop = ODD;  // (round 5: odd hops run here too — VERDICT r4 item 7)
     const unsigned row_bytes = (unsigned)a.n_samples * 8u;  // host: n_samples < 2^29
     auto load_tile = [&](unsigned w) {
         const unsigned b = w / a.tiles, f0 = (w - b * a.tiles) * 16u;
@@ -339,6 +339,10 @@ hipError_t launch_variant_d(const StftArgs &a, hipStream_t s) {
         hipLaunchKernelGGL(kernel, dim3(nslots * 8), dim3(512), lds, s, a, per_xcd, total, nslots);
         return hipGetLastError();
     };
+    if (a.hop & 1u) {
+        if (chunks <= 5u * 512u) return go(k_d32x16<MODE, AMP, 5, true>);
+        return go(k_d32x16<MODE, AMP, 0, true>);
+    }
     if (chunks <= 5u * 512u) return go(k_d32x16<MODE, AMP, 5>);
     return go(k_d32x16<MODE, AMP, 0>);
 }

@@ -92,7 +92,7 @@ __device__ __forceinline__ void mel_tile_sched_e(const StftArgs &a, const double
     }
 }
 
-template <int MODE, int AMP, int ROUNDS>
+template <int MODE, int AMP, int ROUNDS, bool ODD = false>  // ODD: odd hops (round 5) — a variant of its own: as a run-time branch it spilled the even path's registers (512 / 64 x 10 s: 79 -> 225 us)
 __global__ __launch_bounds__(512, 2) void k_d32x32(StftArgs a, unsigned per_xcd, unsigned total, unsigned slots) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned tid = threadIdx.x;
@@ -167,13 +167,25 @@ __global__ __launch_bounds__(512, 2) void k_d32x32(StftArgs a, unsigned per_xcd,
             for (int n1 = 0; n1 < 16; ++n1) {
                 v2d z0, z1;
                 if constexpr (ROUNDS > 0) {
+                    if constexpr (ODD) {  // (round 5: odd hops): an odd frame's pairs sit at 8-byte-aligned addresses — two 8-byte reads
+                        z0 = (v2d){*(const double *)(xs + n1 * 512), *(const double *)(xs + n1 * 512 + 8)};
+                        z1 = (v2d){*(const double *)(xs + n1 * 512 + 8192), *(const double *)(xs + n1 * 512 + 8200)};
+                    } else {
                     z0 = *(const v2d *)(xs + n1 * 512);
                     z1 = *(const v2d *)(xs + n1 * 512 + 8192);
+                    }
                 } else {  // per-lane columns (hop > 1024): the tile is not staged and not prefetched
                     int o0 = vo + n1 * 512, o1 = vo + n1 * 512 + 8192;
                     asm("" : "+v"(o0), "+v"(o1));  // the whole offset in the lane register (buffer_ops.h)
                     z0 = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rx, o0, 0, 0));
                     z1 = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rx, o1, 0, 0));
+                    if constexpr (ODD) {  // the pair (x[-1], x[0]) of an odd frame starts outside the row: the whole 16-byte access reads 0 — put x[0] back
+                        const int s0 = (int)(p1f * hop) + (int)(f0 * hop) - (int)a.pad + 2 * (int)n2 + 64 * n1;
+                        if (s0 == -1 || s0 + 1024 == -1) {
+                            const double x0 = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rx, 0, 0, 0));
+                            if (s0 == -1) z0.y = x0; else z1.y = x0;
+                        }
+                    }
                 }
                 const v2d wa = w2[32 * n1], wb = w2[32 * n1 + 512];
                 v2d d = pfma(z1 * wb, (v2d){sg1, sg1}, z0 * wa);
@@ -293,6 +305,15 @@ hipError_t launch_variant_e(const StftArgs &a, hipStream_t s) {
         hipLaunchKernelGGL(kernel, dim3(nslots * 8), dim3(512), kELds, s, a, per_xcd, total, nslots);
         return hipGetLastError();
     };
+    if (a.hop & 1u) {
+        if (bytes <= 6u * 8192u) return go(k_d32x32<MODE, AMP, 6, true>);
+        if constexpr (MODE == OUT_MEL) {
+            return hipErrorInvalidConfiguration;
+        } else {
+            if (bytes <= 9u * 8192u) return go(k_d32x32<MODE, AMP, 9, true>);
+            return go(k_d32x32<MODE, AMP, 0, true>);
+        }
+    }
     if (bytes <= 6u * 8192u) return go(k_d32x32<MODE, AMP, 6>);
     if constexpr (MODE == OUT_MEL) {
         return hipErrorInvalidConfiguration;  // (plan_geometry_d32x32_f64 keeps such hops away)
@@ -305,7 +326,10 @@ hipError_t launch_variant_e(const StftArgs &a, hipStream_t s) {
 }  // namespace
 
 bool plan_geometry_d32x32_f64(StftArgs &a) {
-    if (a.n_fft != 2048 || (a.hop & 1u)) return false;
+    if (a.n_fft != 2048) return false;
+    // (odd hops since round 5 — while the tile is staged: the per-lane column path with the row-start patch spills and measured 98 us per 64 x 10 s at
+    // hop 1025 against ~74 on the register-tiled kernel)
+    if ((a.hop & 1u) && (7u * a.hop + 2048u) * 8u > 9u * 8192u) return false;
     // filterbank outputs: fused up to hop 585 (6 staging rounds below the |X|^2 tile) where the bank has a band schedule; else per-bin power + k_bank_rows
     if (a.out_mode == OUT_MEL && (a.mel_sched_words == 0 || (7u * a.hop + 2048u) * 8u > 6u * 8192u)) return false;
     if (a.x != nullptr && a.n_frames < 4u) return false;                                      // batches of very short signals: mostly empty tiles

@@ -145,6 +145,14 @@ __global__ __launch_bounds__(512, 2) void k_r64x32(StftArgs a, unsigned per_xcd,
                 asm("" : "+v"(o));  // the whole offset in the lane register: an immediate part is added without wrapping (buffer_ops.h)
                 xd[n1] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rx, o, 0, 0));
             }
+            if (hop & 1u) {  // uniform (round 5: odd hops).  The pair (x[-1], x[0]) of an odd frame starts outside the row, and an 8-byte access whose first
+                             // dword is out of range returns 0 for both: put x[0] back (as k_r32x16)
+                const float x0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, 0, 0, 0));
+                const int s0 = (int)(p1f * hop) + tile_lo + 2 * (int)n2;
+#pragma unroll
+                for (int n1 = 0; n1 < 32; ++n1)
+                    if (s0 + 128 * n1 == -1) xd[n1].y = x0;
+            }
         }
     };
     if (wid < hi) load_tile(wid);
@@ -166,16 +174,20 @@ __global__ __launch_bounds__(512, 2) void k_r64x32(StftArgs a, unsigned per_xcd,
             }
 #pragma unroll
             for (int k = 0; k < 16; ++k) {  // n1 = 2 k
-                if constexpr (ROUNDS > 0) e[k] = *(const v2f *)(xs + k * 1024);
-                else e[k] = xd[2 * k];
+                if constexpr (ROUNDS > 0) {  // (odd hops: an odd frame's pairs sit at 4-byte-aligned addresses — two 4-byte reads, ds_read2_b32)
+                    if (hop & 1u) e[k] = (v2f){*(const float *)(xs + k * 1024), *(const float *)(xs + k * 1024 + 4)};
+                    else e[k] = *(const v2f *)(xs + k * 1024);
+                } else e[k] = xd[2 * k];
                 we[k] = w2[128 * k];
             }
             Fft<16, true>::run(e, we);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < 16; ++k) {  // n1 = 2 k + 1
-                if constexpr (ROUNDS > 0) o[k] = *(const v2f *)(xs + k * 1024 + 512);
-                else o[k] = xd[2 * k + 1];
+                if constexpr (ROUNDS > 0) {
+                    if (hop & 1u) o[k] = (v2f){*(const float *)(xs + k * 1024 + 512), *(const float *)(xs + k * 1024 + 516)};
+                    else o[k] = *(const v2f *)(xs + k * 1024 + 512);
+                } else o[k] = xd[2 * k + 1];
                 wo[k] = w2[128 * k + 64];
             }
             Fft<16, true>::run(o, wo);
@@ -304,7 +316,7 @@ hipError_t launch_variant_q(const StftArgs &a, hipStream_t s) {
 }  // namespace
 
 bool plan_geometry_r64x32_f32(StftArgs &a) {
-    if (a.n_fft != 4096 || (a.hop & 1u)) return false;
+    if (a.n_fft != 4096) return false;  // (any hop since round 5)
     // filterbank outputs: fused up to hop 1170 (6 staging rounds below the |X|^2 tile) where the bank has a band schedule; else per-bin power + k_bank_rows
     if (a.out_mode == OUT_MEL && (a.mel_sched_words == 0 || (7u * a.hop + 4096u) * 4u > 6u * 8192u)) return false;
     if (a.x != nullptr && a.n_frames < 4u) return false;                                      // batches of very short signals: mostly empty tiles

@@ -1387,8 +1387,8 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
     if (params->dtype == SGX_F32 && params->n_fft == 2048) pl->kind = K_R32X32_F32;  // (odd hops: register-tiled kernel)
     if (params->dtype == SGX_F64 && params->n_fft == 1024) pl->kind = K_D32X16_F64;  // per-bin and complex outputs (filterbanks, odd hops: register-tiled kernel)
     if (params->dtype == SGX_F64 && params->n_fft == 512 && params->hop_size <= 260) pl->kind = K_D512_F64;  // two frames per transform
-    if (params->dtype == SGX_F32 && params->n_fft == 4096 && params->hop_size % 2 == 0) pl->kind = K_R64X32_F32;  // per-bin and complex outputs; filterbanks: split path
-    if (params->dtype == SGX_F64 && params->n_fft == 2048 && params->hop_size % 2 == 0) pl->kind = K_D32X32_F64;  // per-bin and complex outputs
+    if (params->dtype == SGX_F32 && params->n_fft == 4096) pl->kind = K_R64X32_F32;  // per-bin and complex outputs; filterbanks: split path
+    if (params->dtype == SGX_F64 && params->n_fft == 2048) pl->kind = K_D32X32_F64;  // per-bin and complex outputs
     if (pl->kind == K_R32X16_F32) build_band_schedule(pl);  // before the kind is resolved: plan_geometry_r32x16_f32 asks for it
     if (pl->kind == K_R32X32_F32) build_band_schedule(pl, 8, r32x32::kSegs2, r32x32::kSch2MaxWords, 0);
     if (pl->kind == K_D32X16_F64) build_band_schedule(pl, 8, d32x16::kDSegs, d32x16::kDSchMaxWords, 0, 2);

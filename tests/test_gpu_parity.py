@@ -133,8 +133,8 @@ def test_pow2_sizes(n_fft, hop, amp, dtype):
     (unaligned frames), the LDS radix-2 kernel below 32 points."""
     plan, _ = run_case(n=max(6000, 3 * n_fft), n_fft=n_fft, hop=hop, amp=amp, dtype=dtype)
     fits = n_fft <= (4096 if dtype == "float64" else 8192)  # an 8192-point f64 tile (164 KB with its tables) exceeds the CU's LDS
-    tuned = dtype == "float32" and (n_fft in (1024, 2048) or (n_fft == 512 and hop in (64, 128, 160, 256)) or (n_fft == 4096 and hop % 2 == 0))  # (2048: any hop since round 5)
-    tuned64 = dtype == "float64" and (n_fft == 1024 or (n_fft == 2048 and hop % 2 == 0) or (n_fft == 512 and hop <= 260))  # (f64 1024 / 512: any hop since round 5)
+    tuned = dtype == "float32" and (n_fft in (1024, 2048, 4096) or (n_fft == 512 and hop in (64, 128, 160, 256)))  # (2048 / 4096: any hop since round 5)
+    tuned64 = dtype == "float64" and (n_fft in (1024, 2048) or (n_fft == 512 and hop <= 260))  # (any hop since round 5)
     if tuned64:
         assert plan.kernel_name == {1024: "d32x16_f64", 512: "d512_f64", 2048: "d32x32_f64"}[n_fft]
     elif 32 <= n_fft and fits and not tuned:
@@ -163,7 +163,7 @@ def test_tuned_2048(hop, amp, floor, n_mels):
 
 
 # ------------------------------------------------------------------ n_fft 1024, f64: the tuned kernel k_d32x16 (round 4)
-@pytest.mark.parametrize("hop", [256, 128, 512, 1024, 64, 272, 274, 600, 2])
+@pytest.mark.parametrize("hop", [256, 128, 512, 1024, 64, 272, 274, 600, 2, 255, 273, 441, 1])
 @pytest.mark.parametrize("amp,floor,n_mels", [("complex", None, None), ("power", None, None), ("magnitude", None, None), ("db", -80.0, None),
                                               ("power", None, 80), ("db", -80.0, 80), ("magnitude", None, 40), ("power", None, 128),
                                               ("db", -80.0, 24)])
@@ -256,7 +256,7 @@ def test_tuned_kernels_many_tiles_per_workgroup(dtype, n_fft, hop, amp, n_mels):
 
 
 # ------------------------------------------------------------------ n_fft 4096, f32: the tuned kernel k_r64x32 (round 4)
-@pytest.mark.parametrize("hop", [1024, 512, 2048, 4096, 100, 1170, 1172, 2050, 2])
+@pytest.mark.parametrize("hop", [1024, 512, 2048, 4096, 100, 1170, 1172, 2050, 2, 1023, 1171, 2051, 441, 1])
 @pytest.mark.parametrize("amp,floor,n_mels", [("complex", None, None), ("power", None, None), ("magnitude", None, None), ("db", -80.0, None),
                                               ("power", None, 80), ("db", -80.0, 128), ("magnitude", None, 40), ("power", None, 20)])
 def test_tuned_4096(hop, amp, floor, n_mels):
@@ -284,7 +284,7 @@ def test_ragged_lengths_4096(n, centre):
 
 
 # ------------------------------------------------------------------ n_fft 2048, f64: the tuned kernel k_d32x32 (round 4)
-@pytest.mark.parametrize("hop", [1024, 512, 256, 2048, 100, 584, 586, 1026, 2])
+@pytest.mark.parametrize("hop", [1024, 512, 256, 2048, 100, 584, 586, 1026, 2, 511, 585, 1023, 441, 1])
 @pytest.mark.parametrize("amp,floor,n_mels", [("complex", None, None), ("power", None, None), ("magnitude", None, None), ("db", -80.0, None),
                                               ("power", None, 80), ("db", -80.0, 128), ("magnitude", None, 40), ("power", None, 20)])
 def test_tuned_f64_2048(hop, amp, floor, n_mels):
