@@ -13,8 +13,8 @@
 //     convolution of length M = 2^ceil(log2(2n-1)): pass A, then ONE row kernel that transforms a row forward, multiplies it by the
 //     transformed chirp (stored in that [k1][k2] order, 1/M folded in), transforms it back and applies conj(W_M^(n2 k1)), then the
 //     inverse column pass — the spectrum never needs reordering.
-//   * real frames ride two to a complex sequence (frames 2p and 2p+1 of one signal: a signal's bits do not depend on its batch) and
-//     come apart by Hermitian symmetry in the epilogue, which also applies |.|^2 / sqrt / dB and writes the reference's
+//   * real frames ride two to a complex sequence (frames 2p and 2p+1 of one signal: a signal's bits do not depend on its batch), built
+//     inside the first column pass straight from the signals (big_frame_elem), and come apart by Hermitian symmetry in the epilogue, which also applies |.|^2 / sqrt / dB and writes the reference's
 //     [bins][frames] layout (S9).  Filterbank outputs take the split path (per-bin power, then k_bank_rows).
 //   * the inverse (irfft / istft rows) is the same engine behind conj: idft(Z) = conj(dft(conj Z)).
 //
@@ -133,10 +133,33 @@ struct BigPass {
     const void *thi, *tlo;
     const void *bhat;   // rows kernel of the chirp-z chain: FFT_M(chirp) / M in [k1][k2] order
     int inv;            // column pass: inverse transform (the chain's last pass; no twiddle — the rows kernel applied it)
+    // FRAMES (forward STFT): pass A builds its elements from the signals instead of reading `buf` — two windowed frames per sequence
+    // (big_frame_elem), so the sequences are written once (by this pass) and the zero half of a chirp-z sequence is never read
+    const void *x, *win, *chirp;
+    unsigned long long sample_stride, n_samples, q0;
+    unsigned n, hop, pad, n_frames, PP;
 };
 
-// pass A / A': columns.  Tile = columns [n2_0, n2_0 + C) of sequence q; lds[c][n1].
+// element m of sequence q (= pair p of signal b): w[m] (xa[m] + i xb[m]), frames 2 p and 2 p + 1; out-of-range samples are the reference's zero
+// centre padding (src/spectrogram.rs:1301-1320); chirp-z: times conj(c_m); zero from n on
 template <typename T>
+__device__ __forceinline__ c2_t<T> big_frame_elem(const BigPass &a, unsigned long long q, unsigned m) {
+    using V = c2_t<T>;
+    if (m >= a.n) return mk<T>(T(0), T(0));
+    const unsigned long long b = q / a.PP;
+    const unsigned p = unsigned(q - b * a.PP);
+    const T *row = (const T *)a.x + b * a.sample_stride;
+    const long long sa = (long long)(2ull * p) * a.hop - (long long)a.pad + m, sb = sa + a.hop;
+    const T w = ((const T *)a.win)[m];
+    const T xa = (sa >= 0 && (unsigned long long)sa < a.n_samples) ? row[sa] * w : T(0);
+    const T xb = (2u * p + 1u < a.n_frames && sb >= 0 && (unsigned long long)sb < a.n_samples) ? row[sb] * w : T(0);
+    V v = mk<T>(xa, xb);
+    if (a.chirp) v = cmulc(v, ((const V *)a.chirp)[m]);
+    return v;
+}
+
+// pass A / A': columns.  Tile = columns [n2_0, n2_0 + C) of sequence q; lds[c][n1].
+template <typename T, bool FRAMES = false>
 __global__ __launch_bounds__(kBigThreads) void k_big_cols(BigPass a) {
     using V = c2_t<T>;
     extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
@@ -148,7 +171,9 @@ __global__ __launch_bounds__(kBigThreads) void k_big_cols(BigPass a) {
     V *g = (V *)a.buf + (size_t)q * a.M + n20;
     for (unsigned e = threadIdx.x; e < C * L; e += kBigThreads) {
         const unsigned c = e % C, n1 = e / C;
-        const V v = g[(size_t)n1 * a.M2 + c];
+        V v;
+        if constexpr (FRAMES) v = big_frame_elem<T>(a, a.q0 + q, n1 * a.M2 + n20 + c);
+        else v = g[(size_t)n1 * a.M2 + c];
         lds[c * (L + 1u) + (a.inv ? n1 : brev(n1, lL))] = v;
     }
     __syncthreads();
@@ -208,33 +233,6 @@ __global__ __launch_bounds__(kBigThreads) void k_big_rows(BigPass a) {
             g[(size_t)c * a.M2 + k2] = lds[c * (L + 1u) + k2];
         }
     }
-}
-
-// ---- prologue: two windowed frames -> one complex sequence ------------------------------------------------------------------------
-// sequence q of the chunk = pair p of signal b (PP = ceil(n_frames / 2) pairs per signal): z[m] = w[m] (xa[m] + i xb[m]), m < n, frames
-// 2p and 2p+1 (the second absent at an odd frame count: zeros); out-of-range samples are the reference's zero centre padding
-// (src/spectrogram.rs:1301-1320); chirp-z: times conj(c_m), and zeros from n to M.
-template <typename T>
-__global__ __launch_bounds__(256) void k_big_frames(const T *x, unsigned long long sample_stride, unsigned long long n_samples, const T *win,
-                                                    const c2_t<T> *chirp, c2_t<T> *buf, unsigned n, unsigned M, unsigned hop, unsigned pad,
-                                                    unsigned n_frames, unsigned PP, unsigned long long q0) {
-    using V = c2_t<T>;
-    const unsigned long long q = q0 + blockIdx.y;
-    const unsigned long long b = q / PP;
-    const unsigned p = unsigned(q - b * PP);
-    const unsigned m = blockIdx.x * 256u + threadIdx.x;
-    if (m >= M) return;
-    V v = mk<T>(T(0), T(0));
-    if (m < n) {
-        const T *row = x + b * sample_stride;
-        const long long sa = (long long)(2ull * p) * hop - (long long)pad + m, sb = sa + hop;
-        const T w = win[m];
-        const T xa = (sa >= 0 && (unsigned long long)sa < n_samples) ? row[sa] * w : T(0);
-        const T xb = (2u * p + 1u < n_frames && sb >= 0 && (unsigned long long)sb < n_samples) ? row[sb] * w : T(0);
-        v = mk<T>(xa, xb);
-        if (chirp) v = cmulc(v, chirp[m]);
-    }
-    buf[(size_t)blockIdx.y * M + m] = v;
 }
 
 // ---- epilogue: split the two frames, amplitude scaling, the reference's [bins][frames] layout -----------------------------------
@@ -384,7 +382,7 @@ unsigned tile_lanes(unsigned L, unsigned lanes, int dtype) {
 }
 
 template <typename T>
-hipError_t run_chain(const BigDev &t, void *buf, void *nat, unsigned nseq, hipStream_t s) {
+hipError_t run_chain(const BigDev &t, void *buf, void *nat, unsigned nseq, hipStream_t s, const BigPass *frames = nullptr) {
     // forward transform of `nseq` sequences of length t.n sitting at stride t.M in `buf` (chirp-z: already multiplied by conj(c), zero
     // padded).  Result: powers of two — natural order in `nat`; chirp-z — in `buf`, still to be multiplied by conj(c_k).
     BigPass a{};
@@ -399,7 +397,14 @@ hipError_t run_chain(const BigDev &t, void *buf, void *nat, unsigned nseq, hipSt
     a.tiles = t.M2 / a.C;
     const unsigned ca = a.C, ta = a.tiles;
     if ((e = set_max_dynamic_lds((const void *)k_big_cols<T>, 160 * 1024)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_big_cols<T>, dim3(nseq * a.tiles), dim3(kBigThreads), lds_of(a.C, t.M1), s, a);
+    if (frames) {  // pass A reads the signals themselves
+        a.x = frames->x; a.win = frames->win; a.chirp = frames->chirp; a.sample_stride = frames->sample_stride; a.n_samples = frames->n_samples;
+        a.q0 = frames->q0; a.n = frames->n; a.hop = frames->hop; a.pad = frames->pad; a.n_frames = frames->n_frames; a.PP = frames->PP;
+        if ((e = set_max_dynamic_lds((const void *)k_big_cols<T, true>, 160 * 1024)) != hipSuccess) return e;
+        hipLaunchKernelGGL((k_big_cols<T, true>), dim3(nseq * a.tiles), dim3(kBigThreads), lds_of(a.C, t.M1), s, a);
+    } else {
+        hipLaunchKernelGGL(k_big_cols<T>, dim3(nseq * a.tiles), dim3(kBigThreads), lds_of(a.C, t.M1), s, a);
+    }
     // pass B
     a.C = tile_lanes(t.M2, t.M1, sizeof(T) == 8 ? SGX_F64 : SGX_F32);
     a.tiles = t.M1 / a.C;
@@ -540,9 +545,10 @@ static hipError_t big_stft_t(const BigDev &t, const StftArgs &a, void *scratch, 
     const V *chirp = (const V *)t.c;
     for (size_t q0 = 0; q0 < nseq; q0 += chunk) {
         const unsigned cn = unsigned(std::min(chunk, nseq - q0));
-        hipLaunchKernelGGL(k_big_frames<T>, dim3((t.M + 255u) / 256u, cn), dim3(256), 0, s, (const T *)a.x, a.sample_stride, a.n_samples,
-                           (const T *)a.window, chirp, buf, a.n_fft, t.M, a.hop, a.pad, a.n_frames, PP, (unsigned long long)q0);
-        hipError_t e = run_chain<T>(t, buf, nat, cn, s);
+        BigPass fr{};  // (the prologue inside pass A: the sequences are written once, a chirp-z sequence's zero half is never read)
+        fr.x = a.x; fr.win = a.window; fr.chirp = chirp; fr.sample_stride = a.sample_stride; fr.n_samples = a.n_samples; fr.q0 = q0;
+        fr.n = a.n_fft; fr.hop = a.hop; fr.pad = a.pad; fr.n_frames = a.n_frames; fr.PP = PP;
+        hipError_t e = run_chain<T>(t, buf, nat, cn, s, &fr);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_big_split<T>, dim3((a.nb_fft + 255u) / 256u, cn), dim3(256), 0, s, (const V *)nat, chirp, (T *)a.out, a.n_fft, t.M,
                            a.nb_fft, a.n_frames, PP, (unsigned long long)q0, a.out_mode == OUT_COMPLEX ? 1 : 0, a.amp, a.eps);
