@@ -705,7 +705,8 @@ __device__ __forceinline__ void mel_tile_sched(const StftArgs &a, const float *p
 // of RL floats, RL / 4 odd: the 16 lanes of a read group on different banks).  Steps past the last band meet a zero weight and whatever
 // finite value the exchange left there.  One wave per half and 16 coefficients runs the chain (the f32 matrix instructions share the
 // vector pipe: all eight waves running it redundantly, threaded through the next tile's pass 1, cost 12 us per 256 x 10 s for the chain and
-// 8 for its operand reads — profiles/experiments_r05/mfcc_fusion.md), behind the band stage, where the registers are free; the
+// 8 for its operand reads — profiles/experiments_r05/mfcc_fusion.md), at the top of the NEXT tile behind its barrier 1, where the registers are
+// still free and the barrier that publishes the band stage's writes is one the loop has anyway; the
 // stores are outside the branch so that every wave issues the same vector-memory operations per tile (counted vmcnt at the loop top).
 template <int STEPS>
 constexpr int mfcc_row() { return (STEPS / 4) % 2 ? STEPS : STEPS + 4; }
@@ -1013,6 +1014,7 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
     const unsigned mfcc_mt = (((threadIdx.x & 255u) >> 6) + 4u - half) & 3u;  // (the halves' first blocks sit on different SIMDs: waves w and w + 4 share one)
     // Mel-dB tile of the fused MFCC epilogue: 64 rows of RL floats between the staged samples (<= 22 912 B) and the |X|^2 tile
     float *const mfl = (float *)(smem + kOutOff) - 64 * mfcc_row<MFCC ? MSTEPS : 4>();
+    unsigned pvb = 0, pvf0 = 0, pvnf = 0;  // MFCC: this half's previous tile, whose Mel-dB values wait in LDS
     static_assert(!MFCC || kOutOff - 256 * mfcc_row<MFCC ? MSTEPS : 4>() >= 22912, "Mel-dB tile above the staged samples");
     while (lead < hi) {
         // (PACK: b = the tile's first signal, f0 = its first frame's index in that signal, nf = the tile's live slots)
@@ -1040,6 +1042,9 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
                 SGX_STAMP(0);  // wait for the samples + staging writes
                 __syncthreads();  // barrier 1: xs complete
                 SGX_STAMP(1);
+                // MFCC: the PREVIOUS tile's chain runs here, behind barrier 1 (which also covers the band stage's Mel-dB writes: no barrier of its
+                // own — 126.6 -> 124.6 us per 256 x 10 s); the first tile's "previous" has nf = 0: every store dropped
+                if constexpr (MFCC) mfcc_tile<MFCC ? MSTEPS : 4>(a, mfl, mfrag, mfcc_mt, pvb, pvf0, pvnf, tid & 63u);
                 if constexpr (HOP512 == 256) {
                     // hop 256: frame 2 p + 1 starts 1024 (+ pad) bytes behind frame 2 p — out of reach of ds_read2_b32's 8-bit dword
                     // offsets — so the pair is two 4-byte reads with 16-bit immediates off one base
@@ -1086,8 +1091,6 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
                     wo[k] = w2[32 * k + 16];
                 }
             }
-            // MFCC: the previous tile's DCT chain rides under this transform (its Mel-dB tile is complete: barrier 1 / the band stage's own
-            // end; pass 1 overwrites it only behind barrier 2)
             Fft<16, true>::run(e, we);
             if constexpr (ROUNDS > 0) {
                 tie16<0>(o);
@@ -1213,8 +1216,12 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
             if constexpr (P512) mel_tile_sched512<AMP>(a, pwf, sched, b, f0, nf, eps, tid);
             else if constexpr (MFCC) {  // Mel-dB tile to LDS, then its DCT (mfcc_tile)
                 mel_tile_sched<AMP, false, mfcc_row<MFCC ? MSTEPS : 4>()>(a, pwf, sched, b, f0, nf, eps, tid, mfl SGX_STAMP_ARGS);
-                __syncthreads();
-                mfcc_tile<MFCC ? MSTEPS : 4>(a, mfl, mfrag, mfcc_mt, b, f0, nf, tid & 63u);
+                if constexpr (ROUNDS > 0) {  // the chain waits for the next tile's barrier 1 (or the end of the loop)
+                    pvb = b; pvf0 = f0; pvnf = nf;
+                } else {  // (the direct path has no barrier 1)
+                    __syncthreads();
+                    mfcc_tile<MFCC ? MSTEPS : 4>(a, mfl, mfrag, mfcc_mt, b, f0, nf, tid & 63u);
+                }
             }
             else if constexpr (PWT) mel_tile_sched<AMP, PACK>(a, pwf, sched, b, f0, nf, eps, tid, nullptr SGX_STAMP_ARGS);
             else if (a.mm_frag) map_tile_mfma<AMP>(a, pwf, b, f0, nf, eps, tid, 2u * half);
@@ -1227,6 +1234,10 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
 #ifdef SGX_STAMPS
         st_acc[15] += 1;
 #endif
+    }
+    if constexpr (MFCC && ROUNDS > 0) {  // the last tile's chain
+        __syncthreads();
+        mfcc_tile<MFCC ? MSTEPS : 4>(a, mfl, mfrag, mfcc_mt, pvb, pvf0, pvnf, tid & 63u);
     }
 #ifdef SGX_SKEW
     if (MODE == OUT_MEL && half == 0u)
