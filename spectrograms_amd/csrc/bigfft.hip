@@ -6,21 +6,22 @@
 //
 //   * powers of two M = M1 * M2 (M1 >= M2 <= 2 M2): the four-step transform.  With n = n1 M2 + n2 and k = k1 + M1 k2,
 //       X[k1 + M1 k2] = sum_n2 W_M2^(n2 k2) [ W_M^(n2 k1) sum_n1 a[n1 M2 + n2] W_M1^(n1 k1) ]
-//     pass A: for every column n2 a length-M1 transform over n1 (tile = C neighbouring columns x all rows, resident in LDS, radix-2 in
-//     place), times W_M^(n2 k1), in place;  pass B: for every row k1 a length-M2 transform over n2 (tile = C neighbouring rows), written
+//     pass A: for every column n2 a length-M1 transform over n1 (tile = C neighbouring columns x all rows, resident in LDS, radix-2
+//     stages in place, two at a time), times W_M^(n2 k1), in place;  pass B: for every row k1 a length-M2 transform over n2 (tile = C neighbouring rows), written
 //     in natural order (k1 fastest across the tile's rows: runs of C elements) or left in place as [k1][k2].
 //   * every other length n: chirp-z on top of it, X[k] = conj(c_k) sum_j (x_j conj(c_j)) c_(k-j), c_j = e^(i pi j^2 / n), as a circular
 //     convolution of length M = 2^ceil(log2(2n-1)): pass A, then ONE row kernel that transforms a row forward, multiplies it by the
 //     transformed chirp (stored in that [k1][k2] order, 1/M folded in), transforms it back and applies conj(W_M^(n2 k1)), then the
 //     inverse column pass — the spectrum never needs reordering.
 //   * real frames ride two to a complex sequence (frames 2p and 2p+1 of one signal: a signal's bits do not depend on its batch), built
-//     inside the first column pass straight from the signals (big_frame_elem), and come apart by Hermitian symmetry in the epilogue, which also applies |.|^2 / sqrt / dB and writes the reference's
-//     [bins][frames] layout (S9).  Filterbank outputs take the split path (per-bin power, then k_bank_rows).
+//     inside the first column pass straight from the signals (big_frame_elem), and come apart by Hermitian symmetry in the epilogue,
+//     which also applies |.|^2 / sqrt / dB and writes the reference's [bins][frames] layout (S9).  Filterbank outputs take the split
+//     path (per-bin power, then k_bank_rows).
 //   * the inverse (irfft / istft rows) is the same engine behind conj: idft(Z) = conj(dft(conj Z)).
 //
 // Everything sits in plan-owned scratch; a call is cut into chunks of sequences so that the scratch stays bounded (kBigChunkBytes).
-// Bound: HBM (each pass reads and writes the sequences once) next to the LDS radix-2 stages; this is the totality path, not a
-// tuned one — see DESIGN.md §3.6 for its measured rates.
+// Bound: the LDS stages next to HBM (each pass reads and writes the sequences once; two to four workgroups per CU overlap the two); this
+// is the totality path, not a tuned one — see DESIGN.md §3.6 for its measured rates.
 #include <algorithm>
 #include <cmath>
 #include <type_traits>
@@ -42,7 +43,6 @@ template <typename V> __device__ __forceinline__ V cadd(V a, V b) { V r; r.x = a
 template <typename V> __device__ __forceinline__ V csub(V a, V b) { V r; r.x = a.x - b.x; r.y = a.y - b.y; return r; }
 
 constexpr unsigned kBigThreads = 512;
-
 
 // ---- transforms of C sequences of L points resident in LDS: lds[c * (L + 1) + i] ---------------------------------------------------
 // DIT: input in bit-reversed places, output in natural order.  DIF: natural in, bit-reversed out.  `inv`: e^(+) twiddles.  Radix-2
