@@ -16,16 +16,26 @@ CASES = [("float32", 1024, 256, "complex", 0), ("float32", 1024, 256, "power", 0
          ("float64", 1024, 256, "complex", 0), ("float64", 1024, 256, "power", 0), ("float64", 1024, 256, "power", 80), ("float64", 1024, 512, "complex", 0),
          ("float64", 512, 128, "complex", 0), ("float64", 512, 256, "power", 80), ("float64", 512, 256, "power", 0), ("float32", 512, 256, "power", 80),
          ("float32", 4096, 1024, "complex", 0), ("float64", 2048, 512, "complex", 0), ("float64", 2048, 1024, "power", 0), ("float32", 4096, 1024, "power", 0), ("float32", 400, 160, "power", 80)]
+if os.environ.get("ROUND5", "1") == "1":  # round 5: the fused MFCC epilogue, odd hops on the lane-pair kernels, a frame length on the global-memory transforms
+    CASES += [("float32", 1024, 256, "mfcc", 80), ("float32", 1024, 441, "mfcc", 80), ("float64", 1024, 255, "complex", 0), ("float64", 1024, 257, "power", 80),
+              ("float32", 2048, 511, "complex", 0), ("float64", 512, 159, "power", 0), ("float32", 4096, 1023, "power", 0), ("float64", 2048, 513, "complex", 0),
+              ("float32", 9001, 2250, "power", 0)]
 bad_total = 0
 for dtype, n_fft, hop, amp, nm in CASES:
     x = base.astype(np.float64 if dtype == "float64" else np.float32)
     params = sg.SpectrogramParams(sg.StftParams(n_fft, hop, sg.WindowType.hanning, True), 16000.0)
     mel = sg.MelParams(nm, 0.0, 8000.0) if nm else None
-    plan = sg.Plan(params, _ffi.AMP_COMPLEX if amp == "complex" else _ffi.AMP_POWER, mel, None, dtype)
-    op = orc.Params(n_fft=n_fft, hop=hop, n_mels=nm, f_min=0.0, f_max=8000.0)
     x64 = base.astype(np.float64)
-    ref = orc.stft_batch(op, x64, nthreads=orc.max_threads()) if amp == "complex" else orc.spectrogram_batch(op, x64, nthreads=orc.max_threads())
-    tol = (1e-10 if dtype == "float64" else 2e-4) * max(1.0, float(np.abs(ref).max()))
+    if amp == "mfcc":  # Mel-80 dB(-80) -> DCT-II (13) + lifter 22, fused into the launch on the tuned f32 kernel
+        plan = sg.SpectrogramPlanner().mfcc_plan(sg.StftParams(n_fft, hop, sg.WindowType.hanning, True), 16000.0, nm, sg.MfccParams(13), dtype=dtype)
+        op = orc.Params(n_fft=n_fft, hop=hop, n_mels=nm, f_min=0.0, f_max=8000.0, amp="db", floor_db=-80.0)
+        ref = np.stack([orc.mfcc(op, r, 13, True, 22) for r in x64])
+        tol = 2e-2 * max(1.0, float(np.abs(ref).max()) / 100)  # (the bound of tests/test_mfcc.py: 80 dB values, each within 1e-3 dB, times the lifter gain)
+    else:
+        plan = sg.Plan(params, _ffi.AMP_COMPLEX if amp == "complex" else _ffi.AMP_POWER, mel, None, dtype)
+        op = orc.Params(n_fft=n_fft, hop=hop, n_mels=nm, f_min=0.0, f_max=8000.0)
+        ref = orc.stft_batch(op, x64, nthreads=orc.max_threads()) if amp == "complex" else orc.spectrogram_batch(op, x64, nthreads=orc.max_threads())
+        tol = (1e-10 if dtype == "float64" else 2e-4) * max(1.0, float(np.abs(ref).max()))
     xd = torch.from_numpy(x).cuda()
     counts = []
     for r in range(REPS):
