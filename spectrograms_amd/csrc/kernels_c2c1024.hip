@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256, 2) void k_istft1024c(IstftArgs a, const v2f *t
     v2f P[16], Q[16], X256;
     auto request = [&](unsigned b, unsigned t) {
         const unsigned f = 16u * t + fl;
-        const unsigned fcl = f < a.n_frames ? f : 0u;  // a frame past the signal reads frame 0 and is zeroed in the fold
+        const unsigned fcl = f < a.n_frames ? f : 0u;  // a frame past the signal reads frame 0 and is replaced by zeros in the fold
         const unsigned char *inb = (const unsigned char *)a.spec + (size_t)b * 513u * a.n_frames * 8u;
         unsigned oa = ka * nf8 + fcl * 8u, oy = (512u - ka) * nf8 + fcl * 8u;
 #pragma unroll
@@ -573,7 +573,11 @@ __global__ __launch_bounds__(256, 2) void k_istft1024c(IstftArgs a, const v2f *t
         {
             const unsigned f = F + fl;
             const bool valid = f < a.n_frames;
-            const float vm = valid ? 1.f : 0.f;
+            if (!valid) {  // a frame past the signal is zeros by a select: the frame 0 loaded in its place may hold Inf / NaN, which a product with 0 would spread into the tail (the reference poisons only the samples frame 0 covers, spectrogram.rs:4906-4925)
+#pragma unroll
+                for (int p = 0; p < 16; ++p) P[p] = Q[p] = (v2f){0.f, 0.f};
+                X256 = (v2f){0.f, 0.f};
+            }
             v2f PA[16], QB[16];
             const v2f *tp = twl + ka;
 #pragma unroll
@@ -590,8 +594,8 @@ __global__ __launch_bounds__(256, 2) void k_istft1024c(IstftArgs a, const v2f *t
                 const v2f cw = tp[32 * (p & 7)];  // conj(W_1024^kp)
                 const v2f S = pfma(Qp, (v2f){1.f, -1.f}, Pp), D = pfma(Qp, (v2f){-1.f, 1.f}, Pp);
                 const v2f T = cmulv(D, cw);
-                PA[p] = pfma(swp(T), (v2f){-vm, -vm}, S * (v2f){vm, -vm});  // conj(S + i T)
-                QB[p] = pfma(swp(T), (v2f){vm, -vm}, S * (v2f){vm, vm});    // S - i T
+                PA[p] = pfma(swp(T), (v2f){-1.f, -1.f}, S * (v2f){1.f, -1.f});  // conj(S + i T)
+                QB[p] = pfma(swp(T), (v2f){1.f, -1.f}, S);    // S - i T
             }
             v2f A[16], B[16];
 #pragma unroll
@@ -601,7 +605,7 @@ __global__ __launch_bounds__(256, 2) void k_istft1024c(IstftArgs a, const v2f *t
                 B[i] = j0 ? PA[i] : QB[15 - i];       // job 0: v[16 + 32 i]
             }
             // job 0, bin 256: v[256] = conj(Z'[256]) = 2 X[256]
-            A[8] = j0 ? X256 * (v2f){2.f * vm, 2.f * vm} : PA[8];
+            A[8] = j0 ? X256 * (v2f){2.f, 2.f} : PA[8];
 #pragma unroll
             for (int i = 1; i < 8; ++i) A[8 + i] = j0 ? QB[16 - i] : PA[8 + i];  // job 0: v[512 - 32 (8 - i)] = v[32 (8 + i)]
             IS_STAMP(0);  // wait for the pairs + fold

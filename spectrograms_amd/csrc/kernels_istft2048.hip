@@ -176,7 +176,7 @@ __global__ __launch_bounds__(512, 2) void k_istft2048(Ist2Args a, const v2f *twr
     v2f P[16], Q[16], X512;
     auto request = [&](unsigned b, unsigned t) {
         const unsigned f = 16u * t + fl;
-        const unsigned fcl = f < a.n_frames ? f : 0u;  // a frame past the signal reads frame 0 and is zeroed in the fold
+        const unsigned fcl = f < a.n_frames ? f : 0u;  // a frame past the signal reads frame 0 and is replaced by zeros in the fold
         const unsigned char *inb = (const unsigned char *)a.spec + (size_t)b * 1025u * a.n_frames * 8u;
         unsigned oa = ka * nf8 + fcl * 8u, oy = (1024u - ka) * nf8 + fcl * 8u;
 #pragma unroll
@@ -221,7 +221,11 @@ __global__ __launch_bounds__(512, 2) void k_istft2048(Ist2Args a, const v2f *twr
         {
             const unsigned f = F + fl;
             const bool valid = f < a.n_frames;
-            const float vm = valid ? 1.f : 0.f;
+            if (!valid) {  // a frame past the signal is zeros by a select: the frame 0 loaded in its place may hold Inf / NaN, which a product with 0 would spread into the tail (the reference poisons only the samples frame 0 covers, spectrogram.rs:4906-4925)
+#pragma unroll
+                for (int p = 0; p < 16; ++p) P[p] = Q[p] = (v2f){0.f, 0.f};
+                X512 = (v2f){0.f, 0.f};
+            }
             v2f PA[16], QB[16];
             const v2f *tp = twl + ka;
 #pragma unroll
@@ -238,8 +242,8 @@ __global__ __launch_bounds__(512, 2) void k_istft2048(Ist2Args a, const v2f *twr
                 const v2f cw = tp[64 * (p & 7)];  // conj(W_2048^kp)
                 const v2f S = pfma(Qp, (v2f){1.f, -1.f}, Pp), D = pfma(Qp, (v2f){-1.f, 1.f}, Pp);
                 const v2f T = cmulv(D, cw);
-                PA[p] = pfma(swp(T), (v2f){-vm, -vm}, S * (v2f){vm, -vm});  // conj(S + i T) = v[kp]
-                QB[p] = pfma(swp(T), (v2f){vm, -vm}, S * (v2f){vm, vm});    // S - i T    = v[1024 - kp]
+                PA[p] = pfma(swp(T), (v2f){-1.f, -1.f}, S * (v2f){1.f, -1.f});  // conj(S + i T) = v[kp]
+                QB[p] = pfma(swp(T), (v2f){1.f, -1.f}, S);    // S - i T    = v[1024 - kp]
             }
             // A = even-indexed elements of row J: A[m] = v[J + 64 m]; B = odd-indexed elements of row 32 - J: B[15 - p] = v[1024 - kp].
             // Job 0: A = v[64 m] (v[512] = 2 X[512], v[64 (8 + i)] = the mirror of kp = 64 (8 - i)), B = v[32 + 64 m].
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void k_istft2048(Ist2Args a, const v2f *twr
                 B[i] = j0 ? PA[8 + i] : QB[15 - i];
                 B[15 - i] = j0 ? QB[8 + i] : QB[i];
             }
-            A[8] = j0 ? X512 * (v2f){2.f * vm, 2.f * vm} : PA[8];
+            A[8] = j0 ? X512 * (v2f){2.f, 2.f} : PA[8];
 #pragma unroll
             for (int i = 1; i < 8; ++i) A[8 + i] = j0 ? QB[8 - i] : PA[8 + i];
             // the pairs are consumed: the next tile's go out now and land during the rest of this tile

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void k_istft_d1024(IstDArgs a, const v2d *t
     v2d P[8], Q[8], X256 = {0.0, 0.0};
     auto request = [&](unsigned b, unsigned t) {
         const unsigned f = 16u * t + fl;
-        const unsigned fcl = f < a.n_frames ? f : 0u;  // a frame past the signal reads frame 0 and is zeroed in the fold
+        const unsigned fcl = f < a.n_frames ? f : 0u;  // a frame past the signal reads frame 0 and is replaced by zeros in the fold
         const unsigned char *inb = (const unsigned char *)a.spec + (size_t)b * 513u * a.n_frames * 16u;
         unsigned oa = kb * nf16 + fcl * 16u, oy = (512u - kb) * nf16 + fcl * 16u;
 #pragma unroll
@@ -224,7 +224,11 @@ __global__ __launch_bounds__(512, 2) void k_istft_d1024(IstDArgs a, const v2d *t
         {
             const unsigned f = F + fl;
             const bool valid = f < a.n_frames;
-            const double vm = valid ? 1.0 : 0.0;
+            if (!valid) {  // a frame past the signal is zeros by a select: the frame 0 loaded in its place may hold Inf / NaN, which a product with 0 would spread into the tail (the reference poisons only the samples frame 0 covers, spectrogram.rs:4906-4925)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) P[u] = Q[u] = (v2d){0.0, 0.0};
+                X256 = (v2d){0.0, 0.0};
+            }
             v2d H[16], QB[8];
             const v2d *tp = twl + kb;
 #pragma unroll
@@ -240,8 +244,8 @@ __global__ __launch_bounds__(512, 2) void k_istft_d1024(IstDArgs a, const v2d *t
                 const v2d cw = tp[32 * u];  // conj(W_1024^k)
                 const v2d S = pfma(Qp, (v2d){1.0, -1.0}, Pp), D = pfma(Qp, (v2d){-1.0, 1.0}, Pp);
                 const v2d T = cmulv(D, cw);
-                H[u] = pfma(swp(T), (v2d){-vm, -vm}, S * (v2d){vm, -vm});  // conj(S + i T) = v[k]
-                QB[u] = pfma(swp(T), (v2d){vm, -vm}, S * (v2d){vm, vm});    // S - i T    = v[512 - k]
+                H[u] = pfma(swp(T), (v2d){-1.0, -1.0}, S * (v2d){1.0, -1.0});  // conj(S + i T) = v[k]
+                QB[u] = pfma(swp(T), (v2d){1.0, -1.0}, S);    // S - i T    = v[512 - k]
             }
             const v2d x256 = X256;
             // the upper 8 elements of the half row are the partner's mirrored values: H[8 + t] = partner's QB[7 - t].  Row 0 mirrors inside
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void k_istft_d1024(IstDArgs a, const v2d *t
 #pragma unroll
                     for (int tq = 0; tq < 8; ++tq) H[8 + tq] = QB[7 - tq];
                 } else {
-                    H[8] = x256 * (v2d){2.0 * vm, 2.0 * vm};
+                    H[8] = x256 * (v2d){2.0, 2.0};
 #pragma unroll
                     for (int tq = 1; tq < 8; ++tq) H[8 + tq] = QB[8 - tq];
                 }
@@ -385,11 +389,10 @@ __global__ __launch_bounds__(512, 2) void k_istft_d512(IstDArgs a, const v2d *tw
         {
             const unsigned fa = F + 2u * sl;
             const bool va = fa < a.n_frames, vb = fa + 1u < a.n_frames;
-            const double ma = va ? 1.0 : 0.0, mb = vb ? 1.0 : 0.0;
             v2d H[16], QB[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                v2d A = P[u] * (v2d){ma, ma}, B = Q[u] * (v2d){mb, mb};
+                v2d A = va ? P[u] : (v2d){0.0, 0.0}, B = vb ? Q[u] : (v2d){0.0, 0.0};  // selects, not products with 0: a non-finite stand-in frame must not reach the tail
                 if (u == 0) {  // kb = 0: bin 0 — realfft ignores (and reports) its imaginary part
                     if (kb == 0u) {
                         if (a.bad_flag && ((va && A.y != 0.0) || (vb && B.y != 0.0))) atomicOr(a.bad_flag, 1u);
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(512, 2) void k_istft_d512(IstDArgs a, const v2d *tw
             v2d x256 = {0.0, 0.0};
             if (kb == 0u) {  // bin 256 (real in both frames)
                 if (a.bad_flag && ((va && XA.y != 0.0) || (vb && XB.y != 0.0))) atomicOr(a.bad_flag, 1u);
-                x256 = (v2d){XA.x * ma, -XB.x * mb};
+                x256 = (v2d){va ? XA.x : 0.0, vb ? -XB.x : 0.0};
             }
             if (j0) {  // row 0 mirrors inside itself: filled from the lane's own values before the trade overwrites them
                 if (half) {

@@ -391,3 +391,38 @@ def test_gpu_istft_f64_512_tuned(hop, centre, n, batch):
     bad[0, 0, 0] += 1e-3j  # an imaginary part in a DC bin: realfft's C2R reports it (fft_backend.rs:559-563)
     with pytest.raises(Exception):
         plan.istft_batch(bad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,n_fft,hop", [("float32", 1024, 256), ("float32", 1024, 80), ("float32", 2048, 512), ("float64", 1024, 256), ("float64", 512, 160),
+                                             ("float64", 512, 128), ("float32", 512, 128), ("float64", 2048, 512)])
+def test_gpu_istft_non_finite_first_frame_stays_in_its_own_samples(dtype, n_fft, hop):
+    """A NaN / Inf in frame 0 poisons the samples frame 0 covers and nothing else (the reference's overlap-add, spectrogram.rs:4906-4925).
+    The fused inverses load frame 0 in place of the frames past the end of a ragged last tile; those stand-ins are replaced by zeros with a
+    select — as a product with 0 they would carry the NaN into the tail of the signal."""
+    rng = np.random.default_rng(31)
+    n = 50000 + hop * 5  # a frame count that leaves stand-in frames in the last tile of 16 (32 at f64 512)
+    x = rng.standard_normal((3, n)).astype(dtype)
+    params = sg.SpectrogramParams(sg.StftParams(n_fft, hop, sg.WindowType.hanning, True), 16000.0)
+    plan = sg.Plan(params, _ffi.AMP_COMPLEX, None, None, dtype)
+    S = np.ascontiguousarray(plan.compute_batch(x))
+    assert S.shape[2] % 32 != 0
+    clean = plan.istft_batch(S)
+    bad = S.copy()
+    bad[1, 5, 0] = np.nan
+    bad[1, 9, 0] = np.inf
+    y = plan.istft_batch(bad)
+    ref = orc.istft(bad[1].astype(np.complex128), n_fft, hop, "hanning", True)
+    fin = np.isfinite(ref)
+    assert not fin[:n_fft // 2].any() and fin[n_fft // 2:].all()  # frame 0 covers output samples [0, n_fft / 2) of a centred signal
+    if dtype == "float64" and n_fft == 512:
+        # k_istft_d512 inverts frames 2 p and 2 p + 1 as the real and imaginary parts of ONE complex transform: a non-finite value in
+        # frame 0 reaches frame 1 through the twiddle products, i.e. up to sample hop + n_fft / 2 (DESIGN.md §6) — and no further
+        fin_y = np.isfinite(y[1])
+        assert not fin_y[:n_fft // 2].any() and fin_y[hop + n_fft // 2:].all()
+        fin = fin & fin_y
+    else:
+        assert np.array_equal(np.isfinite(y[1]), fin)
+    tol = (1e-10 if dtype == "float64" else 2e-5) * max(1.0, float(np.abs(ref[fin]).max()))
+    assert np.max(np.abs(y[1][fin] - ref[fin])) < tol
+    assert np.array_equal(y[0], clean[0]) and np.array_equal(y[2], clean[2])

@@ -26,11 +26,32 @@ for dtype, n_fft, hop, amp, nm in CASES:
     params = sg.SpectrogramParams(sg.StftParams(n_fft, hop, sg.WindowType.hanning, True), 16000.0)
     mel = sg.MelParams(nm, 0.0, 8000.0) if nm else None
     x64 = base.astype(np.float64)
-    if amp == "mfcc":  # Mel-80 dB(-80) -> DCT-II (13) + lifter 22, fused into the launch on the tuned f32 kernel
+    if amp == "mfcc":  # Mel-80 dB(-80) -> DCT-II (13) + lifter 22, fused into the launch on the tuned f32 kernel.  Two checks: the Mel-dB launch
+        # against the oracle in the power domain (a pure tone leaves most bands at rounding level, where 1 ulp of f32 power is tenths of a dB:
+        # the tolerance of the power cases, carried through the log), and the fused output against the reference's f32 fold
+        # (src/mfcc.rs:278-292) of that same Mel-dB tensor, within 4 ulp of the largest coefficient (tests/test_mfcc.py)
+        assert dtype == "float32"
         plan = sg.SpectrogramPlanner().mfcc_plan(sg.StftParams(n_fft, hop, sg.WindowType.hanning, True), 16000.0, nm, sg.MfccParams(13), dtype=dtype)
+        mplan = sg.SpectrogramPlanner().mel_db_plan(params, mel, sg.LogParams(-80.0), dtype=dtype)
         op = orc.Params(n_fft=n_fft, hop=hop, n_mels=nm, f_min=0.0, f_max=8000.0, amp="db", floor_db=-80.0)
-        ref = np.stack([orc.mfcc(op, r, 13, True, 22) for r in x64])
-        tol = 2e-2 * max(1.0, float(np.abs(ref).max()) / 100)  # (the bound of tests/test_mfcc.py: 80 dB values, each within 1e-3 dB, times the lifter gain)
+        ref_db = orc.spectrogram_batch(op, x64, nthreads=orc.max_threads())
+        xd = torch.from_numpy(x).cuda()
+        basis = np.cos(np.pi * np.arange(13)[:, None] * (np.arange(nm)[None, :] + 0.5) / nm).astype(np.float32).astype(np.float64)
+        w = (1.0 + 11.0 * np.sin(np.pi * np.arange(13) / 22.0)).astype(np.float32)
+        tolp = 2e-4 * max(1.0, float((10.0 ** (ref_db / 10.0)).max()))
+        counts = []
+        for r in range(REPS):
+            mdb = mplan.compute_batch(xd).cpu().numpy()
+            got = plan.compute_batch(xd).cpu().numpy()
+            bad_mel = int(((np.abs(mdb - ref_db) > 1e-3) & (np.abs(10.0 ** (mdb.astype(np.float64) / 10.0) - 10.0 ** (ref_db / 10.0)) > tolp)).sum())
+            acc = np.zeros((B, 13, mdb.shape[2]), np.float32)
+            for i in range(nm):
+                acc = (mdb[:, i, None, :].astype(np.float64) * basis[None, :, i, None] + acc.astype(np.float64)).astype(np.float32)
+            acc = acc * w[None, :, None]
+            counts.append(bad_mel + int((np.abs(got - acc) > 4 * np.spacing(np.float32(np.abs(acc).max()))).sum()))
+        bad_total += sum(counts)
+        print(f"{dtype} {n_fft}/{hop} mfcc-mel{nm} {plan.kernel_name}: bad elements per launch {counts} (bit-equal to the f32 fold: {np.mean(got == acc):.5f})", flush=True)
+        continue
     else:
         plan = sg.Plan(params, _ffi.AMP_COMPLEX if amp == "complex" else _ffi.AMP_POWER, mel, None, dtype)
         op = orc.Params(n_fft=n_fft, hop=hop, n_mels=nm, f_min=0.0, f_max=8000.0)

@@ -9,6 +9,8 @@ from spectrograms_amd import _ffi
 rng = np.random.default_rng(0)
 CASES = [(12000, "float64"), (12000, "float32"), (9001, "float32"), (9001, "float64"), (16385, "float32"), (20000, "float32"), (44100, "float32"),
          (65536, "float32"), (65536, "float64"), (100003, "float32"), (100003, "float64"), (1 << 20, "float32")]
+if os.environ.get("CASES"):  # e.g. CASES=998:float32,514:float64 — any length: forward and inverse beside each other (twice-a-prime lengths)
+    CASES = [(int(c.split(":")[0]), c.split(":")[1]) for c in os.environ["CASES"].split(",")]
 for n_fft, dt in CASES:
     hop = n_fft // 4
     B, N = (64, 160000) if n_fft <= 65536 else (64, n_fft)
