@@ -36,6 +36,11 @@ struct sgx_fft2d {
     size_t kspec_rows = 0, kspec_cols = 0;
     hipStream_t kspec_stream = nullptr;
     bool kspec_valid = false, mask_valid = false;
+    // a rank-1 kernel (an outer product, e.g. gaussian_kernel_2d: image_ops.rs:188-220) on the fused f32 path: d_kouter holds the two 1-D
+    // factors of its spectrum (1024 + cb complex values, 12 KB) and d_kspec is not built — k_colconv1024<MUL_OUTER> multiplies them in
+    bool kspec_outer = false, kspec_outer_allowed = true;
+    void *d_kouter = nullptr;
+    size_t kouter_bytes = 0;
     int mask_kind = -1;
     double mask_lo = 0.0, mask_hi = 0.0;
     hipStream_t mask_stream = nullptr;
@@ -223,22 +228,32 @@ sgx_status inverse_dev(sgx_fft2d *p, const void *spec, size_t batch, void *img, 
 #endif
 constexpr size_t kConvChunk = SGX_CONV_CHUNK;
 
-sgx_status fused_product_chunk(sgx_fft2d *p, const void *img, size_t batch, const void *mul, bool real_mask, void *out, void *inter,
+// The spectrum between the column kernel and the inverse row pass is the plan's own scratch, so its row pitch is ours to choose: with the
+// tuned inverse row pass (1024 columns: 513 bins) the rows are padded to 528 bins = 33 whole 128-byte lines.  k_colconv1024's 128-byte
+// store segments (16 columns of one row) then are whole lines; at 513 bins (4104 B) every segment straddled two, and the partial-line
+// writes cost 5.1 MB of WRITE_SIZE per image for 4.2 MB of data (round-5 PMC pass; the complex STFT's pitch experiment).
+#ifdef SGX_SPEC_PITCH_OFF  // (A/B: the unpadded rows)
+size_t fused_spec_pitch(const sgx_fft2d *p) { return p->cb; }
+#else
+size_t fused_spec_pitch(const sgx_fft2d *p) { return p->d_twr ? (p->cb + 15) / 16 * 16 : p->cb; }
+#endif
+
+sgx_status fused_product_chunk(sgx_fft2d *p, const void *img, size_t batch, const void *mul, int mul_kind, void *out, void *inter,
                                void *spec, hipStream_t s) {
-    const size_t R = p->nrows, C = p->ncols, Cb = p->cb;
+    const size_t R = p->nrows, C = p->ncols, Cb = p->cb, Cp = fused_spec_pitch(p);
     sgx_status st = sgx_execute(p->rows, img, batch, R * C, R * C, inter, batch * Cb * R * 2, SGX_MEM_DEVICE, s);
     if (st != SGX_OK) return fail(p, st, sgx_last_error(p->rows));
     C2cArgs a{};
     a.in = inter; a.out = spec;
     a.n = unsigned(R); a.log2n = p->log2r; a.nseq = unsigned(Cb); a.batch = unsigned(batch);
-    a.in_img = Cb * R; a.out_img = R * Cb;
-    a.in_ss = R; a.in_is = 1; a.out_ss = 1; a.out_is = Cb;
+    a.in_img = Cb * R; a.out_img = R * Cp;
+    a.in_ss = R; a.in_is = 1; a.out_ss = 1; a.out_is = Cp;
     a.tile = 16; a.tiles = unsigned((Cb + 15) / 16);
-    F2_HIP(p, launch_colconv1024(a, p->d_tw1c, mul, Cb, real_mask, s));
+    F2_HIP(p, launch_colconv1024(a, p->d_tw1c, mul, Cb, mul_kind, s));
     C2rArgs c{};
     c.in = spec; c.out = out;
     c.nrows = unsigned(R); c.ncols = unsigned(C); c.log2c = p->log2c; c.batch = unsigned(batch);
-    c.in_img = Cb * R; c.in_ks = 1; c.in_rs = Cb; c.k_fast = 1;
+    c.in_img = Cp * R; c.in_ks = 1; c.in_rs = Cp; c.k_fast = 1;
     c.tw = p->d_tw_c; c.scale = 1.0 / (double(R) * double(C));
     if (p->d_twr) {
         c.tile = 16; c.tiles = unsigned((R + 15) / 16);
@@ -263,13 +278,14 @@ sgx_status fused_streams(sgx_fft2d *p) {
     return SGX_OK;
 }
 
-sgx_status fused_product_dev(sgx_fft2d *p, const void *img, size_t batch, const void *mul, bool real_mask, void *out, hipStream_t s) {
+sgx_status fused_product_dev(sgx_fft2d *p, const void *img, size_t batch, const void *mul, int mul_kind, void *out, hipStream_t s) {
     const size_t R = p->nrows, C = p->ncols, Cb = p->cb;
     const size_t slice = Cb * R * 2 * p->elem;  // one image's intermediate / spectrum
     sgx_status st = grow2(p, &p->d_inter, &p->inter_bytes, fused_scratch_images(p, batch) * slice);
     if (st != SGX_OK) return st;
-    if ((st = grow2(p, &p->d_spec, &p->spec_bytes, fused_scratch_images(p, batch) * slice)) != SGX_OK) return st;
-    if (!fused_chunked(p, batch)) return fused_product_chunk(p, img, batch, mul, real_mask, out, p->d_inter, p->d_spec, s);
+    const size_t pslice = fused_spec_pitch(p) * R * 2 * p->elem;  // one image's spectrum at the padded pitch
+    if ((st = grow2(p, &p->d_spec, &p->spec_bytes, fused_scratch_images(p, batch) * pslice)) != SGX_OK) return st;
+    if (!fused_chunked(p, batch)) return fused_product_chunk(p, img, batch, mul, mul_kind, out, p->d_inter, p->d_spec, s);
     if ((st = fused_streams(p)) != SGX_OK) return st;
     F2_HIP(p, hipEventRecord(p->ev_fork, s));
     F2_HIP(p, hipStreamWaitEvent(p->aux_stream, p->ev_fork, 0));
@@ -277,9 +293,9 @@ sgx_status fused_product_dev(sgx_fft2d *p, const void *img, size_t batch, const 
     size_t idx = 0;
     for (size_t b0 = 0; b0 < batch; b0 += kConvChunk, ++idx) {
         const size_t nb = std::min(kConvChunk, batch - b0), half = idx & 1;  // each stream owns one half of the scratch
-        st = fused_product_chunk(p, static_cast<const char *>(img) + b0 * img_bytes, nb, mul, real_mask,
+        st = fused_product_chunk(p, static_cast<const char *>(img) + b0 * img_bytes, nb, mul, mul_kind,
                                  static_cast<char *>(out) + b0 * img_bytes, static_cast<char *>(p->d_inter) + half * kConvChunk * slice,
-                                 static_cast<char *>(p->d_spec) + half * kConvChunk * slice, half ? p->aux_stream : s);
+                                 static_cast<char *>(p->d_spec) + half * kConvChunk * pslice, half ? p->aux_stream : s);
         if (st != SGX_OK) break;
     }
     // join even after a failed launch: the caller's stream must not run ahead of work already queued on the second one
@@ -291,6 +307,54 @@ sgx_status fused_product_dev(sgx_fft2d *p, const void *img, size_t batch, const 
 }
 
 bool use_fused(const sgx_fft2d *p) { return p->d_tw1c != nullptr; }
+
+// Is the kernel an outer product u v^T to f32 rounding?  Pivot on the largest |K|: u = its column, v = its row / the pivot, in f64; every
+// element within 2^-22 max|K| of u_i v_j (gaussian_kernel_2d, computed in f64 and rounded once to f32, is within 1.8e-7).  The kernel's
+// padded image (pad_kernel_for_fft, image_ops.rs:123-152: centre to (0,0), wrapped) is then the outer product of the two padded vectors
+// and its 2-D spectrum the outer product of their 1-D spectra, built here in f64 from the definition (angles reduced in integers):
+// U[k] = sum_i u_i e^{-2 pi i k t(i) / R}, t(i) = (i - krows / 2) mod R; V[c] likewise over the columns, c = 0 .. C / 2.
+bool outer_product_spectrum(const float *K, size_t krows, size_t kcols, size_t R, size_t C, size_t Cb, std::vector<float> &uv) {
+    size_t pi = 0, pj = 0;
+    double big = 0.0;
+    for (size_t i = 0; i < krows; ++i)
+        for (size_t j = 0; j < kcols; ++j) {
+            const double m = std::fabs(double(K[i * kcols + j]));
+            if (!(m <= 3.0e38)) return false;  // non-finite: the general path carries it as the reference does
+            if (m > big) { big = m; pi = i; pj = j; }
+        }
+    if (big == 0.0) return false;
+    std::vector<double> u(krows), v(kcols);
+    const double piv = double(K[pi * kcols + pj]);
+    for (size_t i = 0; i < krows; ++i) u[i] = double(K[i * kcols + pj]);
+    for (size_t j = 0; j < kcols; ++j) v[j] = double(K[pi * kcols + j]) / piv;
+    const double tol = big * 0x1p-22;
+    for (size_t i = 0; i < krows; ++i)
+        for (size_t j = 0; j < kcols; ++j)
+            if (std::fabs(double(K[i * kcols + j]) - u[i] * v[j]) > tol) return false;
+    uv.assign((R + Cb) * 2, 0.f);
+    auto spectrum = [&](const std::vector<double> &w, size_t n, size_t bins, float *dst) {
+        std::vector<double> cs(n), sn(n);
+        for (size_t q = 0; q < n; ++q) {
+            const double a = -2.0 * kPi2 * double(q) / double(n);
+            cs[q] = std::cos(a);
+            sn[q] = std::sin(a);
+        }
+        const size_t centre = w.size() / 2;
+        for (size_t k = 0; k < bins; ++k) {
+            double re = 0.0, im = 0.0;
+            for (size_t i = 0; i < w.size(); ++i) {
+                const size_t t = (i + n - centre % n) % n, q = (k * t) % n;
+                re += w[i] * cs[q];
+                im += w[i] * sn[q];
+            }
+            dst[2 * k] = float(re);
+            dst[2 * k + 1] = float(im);
+        }
+    };
+    spectrum(u, R, R, uv.data());
+    spectrum(v, C, Cb, uv.data() + 2 * R);
+    return true;
+}
 
 // create_lowpass_mask (image_ops.rs:236-267) on the half spectrum's own dims (quirk S14), f64 logic
 void lowpass_mask(size_t nrows, size_t ncols, double cutoff, std::vector<double> &m) {
@@ -344,7 +408,7 @@ sgx_status sgx_fft2d_reserve(sgx_fft2d *p, size_t batch, int32_t host_staging) {
     const size_t R = p->nrows, C = p->ncols, Cb = p->cb;
     sgx_status st;
     if ((st = grow2(p, &p->d_inter, &p->inter_bytes, batch * Cb * R * 2 * p->elem)) != SGX_OK) return st;
-    if ((st = grow2(p, &p->d_spec, &p->spec_bytes, batch * R * Cb * 2 * p->elem)) != SGX_OK) return st;
+    if ((st = grow2(p, &p->d_spec, &p->spec_bytes, batch * R * fused_spec_pitch(p) * 2 * p->elem)) != SGX_OK) return st;  // (the fused path pads its rows)
     if (fused_chunked(p, batch) && (st = fused_streams(p)) != SGX_OK) return st;
     if ((st = grow_half(p, batch)) != SGX_OK) return st;  // nothing left to create inside a graph capture
     if (host_staging) {
@@ -458,7 +522,7 @@ void sgx_fft2d_destroy(sgx_fft2d *p) {
     if (p->rows) {
         DeviceGuard dg;
         (void)dg.enter(p->device);
-        void *bufs[] = {p->d_tw_r, p->d_tw_c, p->d_tw1c, p->d_twr, p->d_tw1r, p->d_inter, p->d_spec, p->d_kspec, p->d_mask, p->d_in, p->d_out, p->d_kimg,
+        void *bufs[] = {p->d_tw_r, p->d_tw_c, p->d_tw1c, p->d_twr, p->d_tw1r, p->d_inter, p->d_spec, p->d_kspec, p->d_kouter, p->d_mask, p->d_in, p->d_out, p->d_kimg,
                         p->bs_r.chirp, p->bs_r.bhp, p->bs_r.tw, p->bs_c.chirp, p->bs_c.bhp, p->bs_c.tw, p->bs_ch.chirp, p->bs_ch.bhp, p->bs_ch.tw, p->bs_rh.chirp, p->bs_rh.bhp, p->bs_rh.tw, p->d_half};
         for (void *b : bufs)
             if (b) (void)hipFree(b);
@@ -501,10 +565,23 @@ sgx_status sgx_fft2d_convolve(sgx_fft2d *p, const void *images, size_t batch, co
     DeviceGuard dg;
     F2_HIP(p, dg.enter(p->device));
     const size_t kbytes = krows * kcols * p->elem;
+    // (SGX_CONV_RANK1=0: every kernel through its full 2-D spectrum — the A/B and parity switch of tests/test_fft2d.py)
+    const char *r1 = std::getenv("SGX_CONV_RANK1");
+    const bool outer_allowed = !(r1 && r1[0] == '0');
     const bool same_kernel = p->kspec_valid && p->kspec_rows == krows && p->kspec_cols == kcols && p->kspec_stream == s &&
-                             p->kspec_of.size() == kbytes && std::memcmp(p->kspec_of.data(), kernel_host, kbytes) == 0;
-    if (!same_kernel) {
+                             p->kspec_outer_allowed == outer_allowed && p->kspec_of.size() == kbytes &&
+                             std::memcmp(p->kspec_of.data(), kernel_host, kbytes) == 0;
+    std::vector<float> uv;
+    if (!same_kernel && outer_allowed && use_fused(p) && p->elem == 4 &&
+        outer_product_spectrum(static_cast<const float *>(kernel_host), krows, kcols, R, C, Cb, uv)) {
         p->kspec_valid = false;
+        if ((st = grow2(p, &p->d_kouter, &p->kouter_bytes, uv.size() * sizeof(float))) != SGX_OK) return st;
+        F2_HIP(p, hipMemcpyAsync(p->d_kouter, uv.data(), uv.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        F2_HIP(p, hipStreamSynchronize(s));  // `uv` goes out of scope
+        p->kspec_outer = true;
+    } else if (!same_kernel) {
+        p->kspec_valid = false;
+        p->kspec_outer = false;
         // pad_kernel_for_fft (image_ops.rs:123-152): kernel centre -> (0,0), wrapped
         std::vector<unsigned char> padded(R * C * p->elem, 0);
         const long cr = long(krows / 2), cc = long(kcols / 2);
@@ -518,6 +595,9 @@ sgx_status sgx_fft2d_convolve(sgx_fft2d *p, const void *images, size_t batch, co
         F2_HIP(p, hipMemcpyAsync(p->d_kimg, padded.data(), padded.size(), hipMemcpyHostToDevice, s));
         F2_HIP(p, hipStreamSynchronize(s));  // `padded` goes out of scope
         if ((st = forward_dev(p, p->d_kimg, 1, p->d_kspec, s)) != SGX_OK) return st;
+    }
+    if (!same_kernel) {
+        p->kspec_outer_allowed = outer_allowed;
         p->kspec_of.assign((const unsigned char *)kernel_host, (const unsigned char *)kernel_host + kbytes);
         p->kspec_rows = krows;
         p->kspec_cols = kcols;
@@ -526,7 +606,7 @@ sgx_status sgx_fft2d_convolve(sgx_fft2d *p, const void *images, size_t batch, co
     }
     const size_t imgb = batch * R * C * p->elem;
     return with_staging(p, images, imgb, out, imgb, mem_kind, s, [&](const void *i, void *o) -> sgx_status {
-        if (use_fused(p)) return fused_product_dev(p, i, batch, p->d_kspec, false, o, s);
+        if (use_fused(p)) return p->kspec_outer ? fused_product_dev(p, i, batch, p->d_kouter, MUL_OUTER, o, s) : fused_product_dev(p, i, batch, p->d_kspec, MUL_SPECTRUM, o, s);
         sgx_status s2 = grow2(p, &p->d_spec, &p->spec_bytes, batch * R * Cb * 2 * p->elem);
         if (s2 != SGX_OK) return s2;
         if ((s2 = forward_dev(p, i, batch, p->d_spec, s, p->d_kspec, 0)) != SGX_OK) return s2;
@@ -575,7 +655,7 @@ sgx_status sgx_fft2d_filter(sgx_fft2d *p, const void *images, size_t batch, int3
     }
     const size_t imgb = batch * R * C * p->elem;
     return with_staging(p, images, imgb, out, imgb, mem_kind, s, [&](const void *i, void *o) -> sgx_status {
-        if (use_fused(p)) return fused_product_dev(p, i, batch, p->d_mask, true, o, s);
+        if (use_fused(p)) return fused_product_dev(p, i, batch, p->d_mask, MUL_MASK, o, s);
         sgx_status s2 = grow2(p, &p->d_spec, &p->spec_bytes, batch * R * Cb * 2 * p->elem);
         if (s2 != SGX_OK) return s2;
         if ((s2 = forward_dev(p, i, batch, p->d_spec, s, p->d_mask, 1)) != SGX_OK) return s2;

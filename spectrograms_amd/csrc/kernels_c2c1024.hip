@@ -103,6 +103,8 @@ __global__ __launch_bounds__(32 * NS, 2) void k_c2c1024(C2cArgs a, const v2f *tw
 // image before; 8.4 MB now).
 //   forward   as k_c2c1024: k = k1 + 32 k2 ends up in registers of thread (k1, s), k2 = 0..31
 //   product   X[k] *= K[k][col] (lanes walk the 16 columns: 128-byte segments of the [row][col] kernel spectrum / mask)
+//             or, for a rank-1 kernel (MUL_OUTER, round 5), K[k][col] = U[k] V[col] from 12 KB of factors: the 4.2 MB spectrum is
+//             neither built nor read once per image
 //   inverse   y = conj(FFT(conj(X))) with the index split mirrored: FFT32 over k2 IN REGISTERS -> n_b, twiddle
 //             W_1024^(k1 n_b), second LDS exchange (same buffer), FFT32 over k1 -> n = 32 n_a + n_b
 //   store     out[n][col] (the [row][col] layout k_c2r1024 reads), 128-byte segments; unnormalised (C2R applies 1/(R C))
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(32 * NS, 2) void k_c2c1024(C2cArgs a, const v2f *tw
 // for its 262 KB at a CU's share of the HBM.
 constexpr int kCTwOff = kCLds;              // W_1024^(k1 n2), 32 x 32 complex f32
 constexpr int kCLdsP = kCLds + 32 * 32 * 8;  // 139 520 B
-template <bool REAL_MASK>
+template <int MUL>
 __global__ __launch_bounds__(512, 2) void k_colconv1024(C2cArgs a, const v2f *tw1c, const void *mul, unsigned long long mul_row, unsigned per_xcd,
                                                         unsigned total) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -176,12 +178,20 @@ __global__ __launch_bounds__(512, 2) void k_colconv1024(C2cArgs a, const v2f *tw
         __syncthreads();  // every row has been read: the buffer is free for the second exchange
         Fft<32, false>::run(x, x);  // X[k1 + 32 k2]
         {   // product with the kernel spectrum / mask (a column past the image reads zeros: its lanes hold zeros anyway)
-            const unsigned mrow = (unsigned)mul_row * (REAL_MASK ? 4u : 8u);
-            const __amdgpu_buffer_rsrc_t rm = make_rsrc(mul, 1024u * mrow);
-            const unsigned mo = valid ? k1 * mrow + (s0 + s) * (REAL_MASK ? 4u : 8u) : kOob;
+            constexpr bool REAL_MASK = MUL == MUL_MASK;
+            const unsigned mrow = MUL == MUL_OUTER ? 8u : (unsigned)mul_row * (REAL_MASK ? 4u : 8u);
+            const __amdgpu_buffer_rsrc_t rm = make_rsrc(mul, MUL == MUL_OUTER ? (1024u + a.nseq) * 8u : 1024u * mrow);
+            const unsigned mo = MUL == MUL_OUTER ? k1 * 8u : valid ? k1 * mrow + (s0 + s) * (REAL_MASK ? 4u : 8u) : kOob;
+            v2f vc = {0.f, 0.f};  // MUL_OUTER: the column's factor V[col], one load per tile; the row factors U[k] come from an 8 KB table
+            if constexpr (MUL == MUL_OUTER)
+                vc = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rm, (int)(valid ? (1024u + s0 + s) * 8u : kOob), 0, 0));
 #pragma unroll
             for (int k2 = 0; k2 < 32; ++k2) {
-                if constexpr (REAL_MASK) {
+                if constexpr (MUL == MUL_OUTER) {
+                    const v2f u = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rm, (int)mo, k2 * 32 * 8, 0));
+                    const v2f r = cmulv(x[k2], cmulv(u, vc));  // K[k][col] = U[k] V[col], rounded to f32 like a stored spectrum
+                    x[k2] = (v2f){r.x, -r.y};
+                } else if constexpr (REAL_MASK) {
                     const float m = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, (int)mo, k2 * 32 * (int)mrow, 0));
                     x[k2] = x[k2] * (v2f){m, -m};  // product, then conj for the forward-FFT inverse trick
                 } else {
@@ -257,11 +267,25 @@ __global__ __launch_bounds__(256, 2) void k_c2r1024(C2rArgs a, const v2f *twr /*
         const v2f *row = in + (size_t)(r0 + r) * a.in_rs;  // in_ks == 1
         v2f v[32];
         const v2f wl = twr[n2];  // conj(W_1024^(16 n1 + n2)) = e^{+2 pi i n1 / 64} (constant) * conj(W_1024^n2) (this load)
+        // Every element of the row is read twice: as X[k] by lane k and as X[512 - k] by lane 512 - k.  Issued in the order of the fold
+        // the two reads of a line are 32 - 2 n1 instructions apart and a third of the second ones reached the fabric again
+        // (FETCH_SIZE 5.5 MB per image for 4.2); issued as neighbours — X[16 j + n2] next to X[16 (j + 1) - n2], the same 128 bytes
+        // shifted by one element — the second read meets the first in the L1.
+        v2f XA[32], XY[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            XA[j] = valid ? row[16u * j + n2] : (v2f){0.f, 0.f};
+#ifdef SGX_C2R_FOLD_ORDER  // (A/B: the loads in the order of the fold)
+            XY[j] = valid ? row[512u - (16u * j + n2)] : (v2f){0.f, 0.f};
+#else
+            XY[31 - j] = valid ? row[16u * (j + 1) - n2] : (v2f){0.f, 0.f};  // = row[512 - k] of n1 = 31 - j
+#endif
+        }
 #pragma unroll
         for (int n1 = 0; n1 < 32; ++n1) {
             const unsigned k = 16u * n1 + n2;
-            v2f A = valid ? row[k] : (v2f){0.f, 0.f};
-            v2f Y = valid ? row[512u - k] : (v2f){0.f, 0.f};
+            v2f A = XA[n1];
+            v2f Y = XY[n1];
             if (k == 0) { A.y = 0.f; Y.y = 0.f; }  // DC (k = 0) and Nyquist (512 - 0) columns are forced real
             const v2f B = (v2f){Y.x, -Y.y};        // conj(X[512-k])
             const v2f S = A + B, D = A - B;
@@ -708,7 +732,7 @@ hipError_t launch_istft1024(const void *spec, void *out, const void *win, unsign
     return hipGetLastError();
 }
 
-hipError_t launch_colconv1024(const C2cArgs &a, const void *tw1c, const void *mul, unsigned long long mul_row, bool real_mask,
+hipError_t launch_colconv1024(const C2cArgs &a, const void *tw1c, const void *mul, unsigned long long mul_row, int mul_kind,
                               hipStream_t s) {
     const unsigned long long g = (unsigned long long)a.tiles * a.batch;
     if (g == 0 || g >= 0x7fffffffull || a.n != 1024) return hipErrorInvalidConfiguration;
@@ -716,16 +740,19 @@ hipError_t launch_colconv1024(const C2cArgs &a, const void *tw1c, const void *mu
     if (a.in_img * 8ull >= (1ull << 31) || a.out_img * 8ull >= (1ull << 31) || 1024ull * mul_row * 8ull >= (1ull << 31)) return hipErrorInvalidConfiguration;
     {
         hipError_t e;
-        if ((e = set_max_dynamic_lds((const void *)k_colconv1024<false>, kCLdsP)) != hipSuccess) return e;
-        if ((e = set_max_dynamic_lds((const void *)k_colconv1024<true>, kCLdsP)) != hipSuccess) return e;
+        if ((e = set_max_dynamic_lds((const void *)k_colconv1024<MUL_SPECTRUM>, kCLdsP)) != hipSuccess) return e;
+        if ((e = set_max_dynamic_lds((const void *)k_colconv1024<MUL_MASK>, kCLdsP)) != hipSuccess) return e;
+        if ((e = set_max_dynamic_lds((const void *)k_colconv1024<MUL_OUTER>, kCLdsP)) != hipSuccess) return e;
     }
     const unsigned cus = device_cu_count();  // of the current device = the plan's (DeviceGuard)
     // persistent: one workgroup per CU; XCD x (blockIdx mod 8) walks the contiguous run [x per_xcd, (x + 1) per_xcd) of tiles
     const unsigned total = (unsigned)g, per_xcd = (total + 7u) / 8u;
     const unsigned slots = std::max(1u, std::min(cus / 8u, per_xcd));
     const dim3 grid(slots * 8u);
-    if (real_mask) hipLaunchKernelGGL((k_colconv1024<true>), grid, dim3(512), kCLdsP, s, a, (const v2f *)tw1c, mul, mul_row, per_xcd, total);
-    else hipLaunchKernelGGL((k_colconv1024<false>), grid, dim3(512), kCLdsP, s, a, (const v2f *)tw1c, mul, mul_row, per_xcd, total);
+    if (mul_kind == MUL_MASK) hipLaunchKernelGGL((k_colconv1024<MUL_MASK>), grid, dim3(512), kCLdsP, s, a, (const v2f *)tw1c, mul, mul_row, per_xcd, total);
+    else if (mul_kind == MUL_OUTER) hipLaunchKernelGGL((k_colconv1024<MUL_OUTER>), grid, dim3(512), kCLdsP, s, a, (const v2f *)tw1c, mul, mul_row, per_xcd, total);
+    else if (mul_kind == MUL_SPECTRUM) hipLaunchKernelGGL((k_colconv1024<MUL_SPECTRUM>), grid, dim3(512), kCLdsP, s, a, (const v2f *)tw1c, mul, mul_row, per_xcd, total);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

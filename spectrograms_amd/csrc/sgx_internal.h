@@ -214,10 +214,12 @@ inline hipError_t launch_c2r_any(const C2rArgs &a, int dtype, hipStream_t s) {
 // tuned f32 1024-point C2C, 16 sequences per workgroup; tw1c = W_1024^(k1*n2), [32][32] complex f32; output must be
 // sequence-contiguous for coalesced stores (a.out_ss == 1)
 hipError_t launch_c2c1024(const C2cArgs &a, const void *tw1c, hipStream_t s);
-// fused column stage of the 2-D convolution / filters for 1024 rows, f32: forward FFT, product with `mul` (complex kernel
-// spectrum or real mask, [row][col] with row stride mul_row), inverse FFT; in = [col][row] (a.in_ss = rows, a.in_is = 1),
-// out = [row][col] (a.out_ss = 1, a.out_is = cols)
-hipError_t launch_colconv1024(const C2cArgs &a, const void *tw1c, const void *mul, unsigned long long mul_row, bool real_mask,
+// fused column stage of the 2-D convolution / filters for 1024 rows, f32: forward FFT, product with `mul`, inverse FFT;
+// in = [col][row] (a.in_ss = rows, a.in_is = 1), out = [row][col] (a.out_ss = 1, a.out_is = cols).  `mul` by mul_kind:
+// MUL_SPECTRUM a complex kernel spectrum, MUL_MASK a real mask (both [row][col] with row stride mul_row), MUL_OUTER the two factors
+// of a rank-1 kernel's spectrum K[row][col] = U[row] V[col]: 1024 complex U, then a.nseq complex V (mul_row unused)
+enum { MUL_SPECTRUM = 0, MUL_MASK = 1, MUL_OUTER = 2 };
+hipError_t launch_colconv1024(const C2cArgs &a, const void *tw1c, const void *mul, unsigned long long mul_row, int mul_kind,
                               hipStream_t s);
 // tuned f32 inverse row pass for ncols == 1024 on a [r][k]-major half spectrum (a.in_ks == 1), 16 rows per workgroup
 hipError_t launch_c2r1024(const C2rArgs &a, const void *twr, const void *tw1, hipStream_t s);

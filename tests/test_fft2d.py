@@ -226,6 +226,65 @@ def test_gpu_fused_column_stage_1024_rows(shape):
         for i in range(3):
             ref = orc.filter2d(x[i].astype(np.float64), kind, *args)
             assert np.max(np.abs(got[i] - ref)) <= 2e-5 * max(1.0, np.max(np.abs(ref)))
+    kq = np.random.default_rng(5).standard_normal((min(7, shape[0]), min(5, shape[1]))).astype(np.float32)  # not an outer product: the full 2-D kernel spectrum
+    got = plan.convolve(x, kq)
+    for i in range(3):
+        ref = orc.convolve_fft(x[i].astype(np.float64), kq.astype(np.float64))
+        assert np.max(np.abs(got[i] - ref)) <= 2e-5 * max(1.0, np.max(np.abs(ref)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1024, 1024), (1024, 100), (1024, 7)])
+def test_gpu_rank1_kernels_multiply_in_their_two_factors(shape, monkeypatch):
+    """A kernel that is an outer product u v^T to f32 rounding (gaussian_kernel_2d, image_ops.rs:188-220; a box; any separable filter)
+    has the 2-D spectrum U[k] V[col]: the fused column kernel takes the two 1-D factors (12 KB) instead of building and re-reading a
+    4.2 MB spectrum per image (fft2d.hip outer_product_spectrum, k_colconv1024<MUL_OUTER>).  Against the oracle, and against the same
+    call with the detection switched off (SGX_CONV_RANK1=0: the general path) — even kernel sizes and a 1 x n kernel check the
+    centring of pad_kernel_for_fft (image_ops.rs:123-152) in both factors; a kernel one element away from rank 1 stays general."""
+    rng = np.random.default_rng(9)
+    x = np.stack([img(shape, 21 + k, np.float32) for k in range(3)])
+    kernels = [sg.gaussian_kernel_2d(9 if shape[1] >= 9 else 5, 2.0, dtype="float32"),
+               np.outer(rng.standard_normal(4), rng.standard_normal(6 if shape[1] >= 6 else 3)).astype(np.float32),
+               np.ones((1, 5), np.float32) / 5, np.ones((31, 1), np.float32) / 31,
+               np.outer(np.hanning(shape[0] // 2), np.hanning(min(64, shape[1]) - 1)).astype(np.float32)]
+    near = kernels[0].copy()
+    near[1, 2] *= 1.001
+    for k in kernels + [near]:
+        monkeypatch.delenv("SGX_CONV_RANK1", raising=False)
+        got = sg.Fft2dPlan(shape[0], shape[1], "float32").convolve(x, k)
+        monkeypatch.setenv("SGX_CONV_RANK1", "0")
+        general = sg.Fft2dPlan(shape[0], shape[1], "float32").convolve(x, k)
+        scale = 0.0
+        for i in range(3):
+            ref = orc.convolve_fft(x[i].astype(np.float64), k.astype(np.float64))
+            scale = max(1.0, float(np.max(np.abs(ref))))
+            assert np.max(np.abs(got[i] - ref)) <= 2e-5 * scale, k.shape
+            assert np.max(np.abs(general[i] - ref)) <= 2e-5 * scale, k.shape
+        assert np.max(np.abs(got - general)) <= 4e-6 * scale
+        if k is near:
+            assert np.array_equal(got, general)  # not rank 1 within 2^-22: the same path either way
+    monkeypatch.delenv("SGX_CONV_RANK1", raising=False)
+
+
+@pytest.mark.gpu
+def test_gpu_convolve_config5_full_batch_gaussian():
+    """BASELINE configs[4] at its full size through convolve_fft with the 9 x 9 Gaussian: 512 x 1024 x 1024 f32 in one call (chunks of 64 on
+    two streams, the rank-1 product), first and last image against the oracle, and every image against the same plan convolving it alone."""
+    torch = pytest.importorskip("torch")
+    B = 512
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn((B, 1024, 1024), generator=g, device="cuda", dtype=torch.float32)
+    k = sg.gaussian_kernel_2d(9, 2.0, dtype="float32")
+    plan = sg.Fft2dPlan(1024, 1024, "float32")
+    y = plan.convolve_torch(x, k)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(y).all())
+    for i in (0, B - 1):
+        ref = orc.convolve_fft(x[i].cpu().numpy().astype(np.float64), k.astype(np.float64))
+        assert np.max(np.abs(y[i].cpu().numpy() - ref)) <= 2e-5 * max(1.0, np.max(np.abs(ref)))
+    small = sg.Fft2dPlan(1024, 1024, "float32")
+    for i in (0, 63, 64, 300, B - 1):
+        assert torch.equal(small.convolve_torch(x[i:i + 1], k)[0], y[i])
 
 
 @pytest.mark.gpu
