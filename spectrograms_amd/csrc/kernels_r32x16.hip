@@ -1258,11 +1258,14 @@ __global__ __launch_bounds__(512, 2) void k_r32x16(StftArgs a, unsigned per_xcd,
 static bool want_pack(const StftArgs &a, bool mel, bool pwt) {
     if (a.mfcc_frag) return false;  // the fused MFCC epilogue works on one-signal tiles
     const bool p512 = a.n_fft == 512u;  // two frames per transform, 32-frame tiles; per-bin outputs only
-    if ((a.n_fft != 1024u && !p512) || a.batch < 2u || (mel && (!pwt || p512)) || (a.hop & 1u)) return false;
+    // n_fft 512 at a hop without a staged variant (round 5): the packed form's per-lane loads take any even hop, so it runs whatever the
+    // slot fill and for one signal too — 256 x 10 s linear power, hop 100 / 320 / 384: 240 -> 195, 79 -> 66, 72 -> 59 us against k_reg_radix
+    const bool unlisted512 = p512 && !(a.hop == 64u || a.hop == 128u || a.hop == 160u || a.hop == 256u);
+    if ((a.n_fft != 1024u && !p512) || (a.batch < 2u && !unlisted512) || (mel && (!pwt || p512)) || (a.hop & 1u)) return false;
     // (n_fft 512 packs slots = frame pairs of one signal: an odd frame count leaves half a slot empty either way)
     const unsigned long long slots = (unsigned long long)a.tiles * a.ft, g = (unsigned long long)a.batch * a.n_frames;
     const unsigned long long used = p512 ? 2ull * ((a.n_frames + 1ull) / 2ull) : a.n_frames;
-    if ((slots - used) * 4ull < slots) return false;
+    if ((slots - used) * 4ull < slots && !unlisted512) return false;
     if (g >= 0x7fffffffull || (unsigned long long)a.batch * a.sample_stride * 4ull >= 0xfffffff0ull) return false;  // 32-bit offsets
     return (a.ft + 1ull) * (a.n_fft / 2u + 1ull) * a.n_frames * 8ull < 0x7fffffffull;
 }
@@ -1362,6 +1365,14 @@ bool plan_geometry_r32x16_f32(StftArgs &a) {
     if (a.n_fft == 512 && a.out_mode == OUT_MEL && a.mel_sched_words == 0) return false;
     if (a.n_fft == 512 && (a.hop == 64 || a.hop == 128 || a.hop == 160 || a.hop == 256)) {
         if (a.n_samples >= (1ull << 29) || (unsigned long long)a.n_frames * 257ull * 8ull >= 0x7fffffffull) return false;
+        a.ft = 32;
+        return true;
+    }
+    if (a.n_fft == 512) {  // any other even hop, per-bin outputs: the packed form (want_pack's limits)
+        if (a.out_mode == OUT_MEL || (a.hop & 1u) || a.hop > 512u) return false;
+        if (a.n_samples >= (1ull << 29) || (unsigned long long)a.batch * a.n_frames >= 0x7fffffffull ||
+            (unsigned long long)a.batch * a.sample_stride * 4ull >= 0xfffffff0ull || 33ull * 257ull * a.n_frames * 8ull >= 0x7fffffffull)
+            return false;
         a.ft = 32;
         return true;
     }

@@ -1383,7 +1383,8 @@ sgx_status sgx_plan_create(const sgx_params *params, sgx_plan **out) {
     // other composite lengths: two-factor DFT; primes fall through to the direct sum
     pl->kind = (pow2 || params->n_fft % 2 == 0) ? K_REG_RADIX : K_TWO_FACTOR;  // (even sizes outside the register-tiled list fall through)
     if (params->dtype == SGX_F32 && params->n_fft == 1024 && (SGX_ODDHOP || params->hop_size % 2 == 0)) pl->kind = K_R32X16_F32;
-    if (params->dtype == SGX_F32 && params->n_fft == 512 && (params->hop_size == 64 || params->hop_size == 128 || params->hop_size == 160 || params->hop_size == 256)) pl->kind = K_R32X16_F32;  // per-bin outputs (else falls back)
+    // n_fft 512 (two frames per transform): staged variants at hops 64 / 128 / 160 / 256, the packed form's per-lane loads at every other even hop (per-bin outputs)
+    if (params->dtype == SGX_F32 && params->n_fft == 512 && params->hop_size % 2 == 0 && params->hop_size <= 512) pl->kind = K_R32X16_F32;  // per-bin outputs (else falls back)
     if (params->dtype == SGX_F32 && params->n_fft == 2048) pl->kind = K_R32X32_F32;  // (odd hops: register-tiled kernel)
     if (params->dtype == SGX_F64 && params->n_fft == 1024) pl->kind = K_D32X16_F64;  // per-bin and complex outputs (filterbanks, odd hops: register-tiled kernel)
     if (params->dtype == SGX_F64 && params->n_fft == 512 && params->hop_size <= 260) pl->kind = K_D512_F64;  // two frames per transform

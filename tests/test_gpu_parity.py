@@ -581,6 +581,21 @@ def test_tuned_kernel_512_other_hops(n, centre, hop, amp, floor):
     assert np.array_equal(np.asarray(one)[0], np.asarray(got)[1])
 
 
+@pytest.mark.parametrize("amp,floor", [("power", None), ("db", -80.0), ("complex", None), ("magnitude", None)])
+@pytest.mark.parametrize("hop", [2, 30, 100, 200, 320, 384, 510, 512])
+@pytest.mark.parametrize("n,centre,batch", [(1, True, 1), (703, False, 3), (5121, True, 1), (21000, False, 3), (40001, True, 5)])
+def test_tuned_kernel_512_every_even_hop(n, centre, batch, hop, amp, floor):
+    """n_fft 512 at an even hop without a staged variant (round 5): the packed form of the two-frames-per-transform mode — per-lane loads,
+    tiles that run on into the next signal — whatever the slot fill and for a single signal too; per-bin and complex outputs (filterbanks
+    at such hops stay on the register-tiled kernel).  Against the oracle; a signal alone gives the bits of its row in the batch."""
+    plan, got = run_case(n=n, batch=batch, n_fft=512, hop=hop, centre=centre, amp=amp, floor=floor, dtype="float32")
+    assert plan.kernel_name == "r32x16_f32"
+    one = plan.compute_batch(signals(batch, n, np.float32, 0)[batch - 1:batch])
+    assert np.array_equal(np.asarray(one)[0], np.asarray(got)[batch - 1])
+    assert make(512, hop, n_mels=40, dtype="float32")[0].kernel_name == "reg_radix"
+    assert make(512, 101, dtype="float32")[0].kernel_name == "reg_radix"  # odd hops: the register-tiled kernel
+
+
 @pytest.mark.parametrize("hop", [64, 160])
 @pytest.mark.parametrize("n,n_mels,norm,amp,floor", [(40000, 80, None, "db", -80.0), (4100, 40, "slaney", "power", None), (161, 128, "l1", "magnitude", None)])
 def test_tuned_kernel_512_mel_other_hops(n, n_mels, norm, amp, floor, hop):
