@@ -39,6 +39,9 @@ struct sgx_fft2d {
     // a rank-1 kernel (an outer product, e.g. gaussian_kernel_2d: image_ops.rs:188-220) on the fused f32 path: d_kouter holds the two 1-D
     // factors of its spectrum (1024 + cb complex values, 12 KB) and d_kspec is not built — k_colconv1024<MUL_OUTER> multiplies them in
     bool kspec_outer = false, kspec_outer_allowed = true;
+    // ... and on 1024 x 1024 images the whole convolution runs as two passes of k_colconv1024 over pairs of REAL rows (rows, then columns:
+    // fused_separable_chunk); d_kouter then also holds U / 1024 and the full-length V / 1024 behind the first two tables
+    bool kspec_separable = false, kspec_separable_allowed = true;
     void *d_kouter = nullptr;
     size_t kouter_bytes = 0;
     int mask_kind = -1;
@@ -238,6 +241,27 @@ size_t fused_spec_pitch(const sgx_fft2d *p) { return p->cb; }
 size_t fused_spec_pitch(const sgx_fft2d *p) { return p->d_twr ? (p->cb + 15) / 16 * 16 : p->cb; }
 #endif
 
+// A rank-1 kernel on a 1024 x 1024 image: the 2-D transform pair factors into (row FFT . V . row IFFT) and (column FFT . U . column IFFT) —
+// the same linear operators as fft2d . (U V^T) . ifft2d in another order — and each factor is k_colconv1024 on pairs of real rows packed
+// as one complex sequence (a real kernel's spectrum is Hermitian: real part = the first row's convolution, imaginary = the second's).
+// The kernel's transposing store puts the pair back side by side, so pass 1 (rows of the image) leaves the transposed image in `inter`
+// and pass 2 (its rows = the image's columns) the result in place: two passes of 4 MiB read + 4 MiB written per image instead of
+// three of 8.4 MB.  Each table carries 1 / 1024 (exact), so nothing is left to normalise.
+sgx_status fused_separable_chunk(sgx_fft2d *p, const void *img, size_t batch, const void *tables, void *out, void *inter, hipStream_t s) {
+    const size_t R = p->nrows, C = p->ncols;
+    const char *t = static_cast<const char *>(tables);
+    const void *vfull = t + (R + p->cb + R) * 2 * sizeof(float), *uscaled = t + (R + p->cb) * 2 * sizeof(float);
+    C2cArgs a{};
+    a.n = 1024; a.log2n = 10; a.batch = unsigned(batch);
+    a.in_img = R * C; a.out_img = R * C;
+    a.tile = 16;
+    a.in = img; a.out = inter; a.nseq = unsigned(R / 2); a.in_ss = C; a.out_is = R; a.tiles = unsigned((a.nseq + 15) / 16);
+    F2_HIP(p, launch_colconv1024(a, p->d_tw1c, vfull, 0, MUL_VEC, s, true));   // rows: inter[col][row]
+    a.in = inter; a.out = out; a.nseq = unsigned(C / 2); a.in_ss = R; a.out_is = C; a.tiles = unsigned((a.nseq + 15) / 16);
+    F2_HIP(p, launch_colconv1024(a, p->d_tw1c, uscaled, 0, MUL_VEC, s, true));  // columns: out[row][col]
+    return SGX_OK;
+}
+
 sgx_status fused_product_chunk(sgx_fft2d *p, const void *img, size_t batch, const void *mul, int mul_kind, void *out, void *inter,
                                void *spec, hipStream_t s) {
     const size_t R = p->nrows, C = p->ncols, Cb = p->cb, Cp = fused_spec_pitch(p);
@@ -281,8 +305,23 @@ sgx_status fused_streams(sgx_fft2d *p) {
 sgx_status fused_product_dev(sgx_fft2d *p, const void *img, size_t batch, const void *mul, int mul_kind, void *out, hipStream_t s) {
     const size_t R = p->nrows, C = p->ncols, Cb = p->cb;
     const size_t slice = Cb * R * 2 * p->elem;  // one image's intermediate / spectrum
-    sgx_status st = grow2(p, &p->d_inter, &p->inter_bytes, fused_scratch_images(p, batch) * slice);
-    if (st != SGX_OK) return st;
+    sgx_status st;
+    if (mul_kind == MUL_VEC) {
+        // The separable passes are one kind of kernel: a second stream has nothing of another kind to overlap, and every launch boundary
+        // is a tail of idle CUs.  512 images: chunks of 16 / 32 / 64 / 128 on two streams 2.09 / 1.95 / 1.83 / 1.79 ms, groups of 128 one
+        // after the other 1.90, one launch pair 1.78.  So: groups of up to kSepGroup images on the caller's stream, the transposed
+        // intermediate (4 MiB per image) in d_inter.
+        size_t kSepGroup = 512;
+        if (const char *g = std::getenv("SGX_SEP_GROUP")) kSepGroup = std::max<size_t>(1, std::strtoull(g, nullptr, 10));  // (tests: several groups in a small batch)
+        const size_t group = std::min(batch, kSepGroup), img_bytes = R * C * p->elem;
+        if ((st = grow2(p, &p->d_inter, &p->inter_bytes, group * img_bytes)) != SGX_OK) return st;
+        for (size_t b0 = 0; b0 < batch; b0 += group)
+            if ((st = fused_separable_chunk(p, static_cast<const char *>(img) + b0 * img_bytes, std::min(group, batch - b0), mul,
+                                            static_cast<char *>(out) + b0 * img_bytes, p->d_inter, s)) != SGX_OK)
+                return st;
+        return SGX_OK;
+    }
+    if ((st = grow2(p, &p->d_inter, &p->inter_bytes, fused_scratch_images(p, batch) * slice)) != SGX_OK) return st;
     const size_t pslice = fused_spec_pitch(p) * R * 2 * p->elem;  // one image's spectrum at the padded pitch
     if ((st = grow2(p, &p->d_spec, &p->spec_bytes, fused_scratch_images(p, batch) * pslice)) != SGX_OK) return st;
     if (!fused_chunked(p, batch)) return fused_product_chunk(p, img, batch, mul, mul_kind, out, p->d_inter, p->d_spec, s);
@@ -331,8 +370,8 @@ bool outer_product_spectrum(const float *K, size_t krows, size_t kcols, size_t R
     for (size_t i = 0; i < krows; ++i)
         for (size_t j = 0; j < kcols; ++j)
             if (std::fabs(double(K[i * kcols + j]) - u[i] * v[j]) > tol) return false;
-    uv.assign((R + Cb) * 2, 0.f);
-    auto spectrum = [&](const std::vector<double> &w, size_t n, size_t bins, float *dst) {
+    uv.assign((R + Cb + R + C) * 2, 0.f);  // U, V (half), then for the separable passes U / R and the full-length V / C
+    auto spectrum = [&](const std::vector<double> &w, size_t n, size_t bins, float *dst, double scale) {
         std::vector<double> cs(n), sn(n);
         for (size_t q = 0; q < n; ++q) {
             const double a = -2.0 * kPi2 * double(q) / double(n);
@@ -347,12 +386,14 @@ bool outer_product_spectrum(const float *K, size_t krows, size_t kcols, size_t R
                 re += w[i] * cs[q];
                 im += w[i] * sn[q];
             }
-            dst[2 * k] = float(re);
-            dst[2 * k + 1] = float(im);
+            dst[2 * k] = float(re * scale);
+            dst[2 * k + 1] = float(im * scale);
         }
     };
-    spectrum(u, R, R, uv.data());
-    spectrum(v, C, Cb, uv.data() + 2 * R);
+    spectrum(u, R, R, uv.data(), 1.0);
+    spectrum(v, C, Cb, uv.data() + 2 * R, 1.0);
+    spectrum(u, R, R, uv.data() + 2 * (R + Cb), 1.0 / double(R));
+    spectrum(v, C, C, uv.data() + 2 * (R + Cb + R), 1.0 / double(C));
     return true;
 }
 
@@ -568,8 +609,10 @@ sgx_status sgx_fft2d_convolve(sgx_fft2d *p, const void *images, size_t batch, co
     // (SGX_CONV_RANK1=0: every kernel through its full 2-D spectrum — the A/B and parity switch of tests/test_fft2d.py)
     const char *r1 = std::getenv("SGX_CONV_RANK1");
     const bool outer_allowed = !(r1 && r1[0] == '0');
+    const char *r2 = std::getenv("SGX_CONV_SEPARABLE");  // (=0: a rank-1 kernel through the three passes with the outer-product multiplier)
+    const bool separable_allowed = !(r2 && r2[0] == '0');
     const bool same_kernel = p->kspec_valid && p->kspec_rows == krows && p->kspec_cols == kcols && p->kspec_stream == s &&
-                             p->kspec_outer_allowed == outer_allowed && p->kspec_of.size() == kbytes &&
+                             p->kspec_outer_allowed == outer_allowed && p->kspec_separable_allowed == separable_allowed && p->kspec_of.size() == kbytes &&
                              std::memcmp(p->kspec_of.data(), kernel_host, kbytes) == 0;
     std::vector<float> uv;
     if (!same_kernel && outer_allowed && use_fused(p) && p->elem == 4 &&
@@ -579,6 +622,7 @@ sgx_status sgx_fft2d_convolve(sgx_fft2d *p, const void *images, size_t batch, co
         F2_HIP(p, hipMemcpyAsync(p->d_kouter, uv.data(), uv.size() * sizeof(float), hipMemcpyHostToDevice, s));
         F2_HIP(p, hipStreamSynchronize(s));  // `uv` goes out of scope
         p->kspec_outer = true;
+        p->kspec_separable = separable_allowed && R == 1024 && C == 1024;
     } else if (!same_kernel) {
         p->kspec_valid = false;
         p->kspec_outer = false;
@@ -598,6 +642,7 @@ sgx_status sgx_fft2d_convolve(sgx_fft2d *p, const void *images, size_t batch, co
     }
     if (!same_kernel) {
         p->kspec_outer_allowed = outer_allowed;
+        p->kspec_separable_allowed = separable_allowed;
         p->kspec_of.assign((const unsigned char *)kernel_host, (const unsigned char *)kernel_host + kbytes);
         p->kspec_rows = krows;
         p->kspec_cols = kcols;
@@ -606,7 +651,8 @@ sgx_status sgx_fft2d_convolve(sgx_fft2d *p, const void *images, size_t batch, co
     }
     const size_t imgb = batch * R * C * p->elem;
     return with_staging(p, images, imgb, out, imgb, mem_kind, s, [&](const void *i, void *o) -> sgx_status {
-        if (use_fused(p)) return p->kspec_outer ? fused_product_dev(p, i, batch, p->d_kouter, MUL_OUTER, o, s) : fused_product_dev(p, i, batch, p->d_kspec, MUL_SPECTRUM, o, s);
+        if (use_fused(p) && p->kspec_outer) return fused_product_dev(p, i, batch, p->d_kouter, p->kspec_separable ? MUL_VEC : MUL_OUTER, o, s);
+        if (use_fused(p)) return fused_product_dev(p, i, batch, p->d_kspec, MUL_SPECTRUM, o, s);
         sgx_status s2 = grow2(p, &p->d_spec, &p->spec_bytes, batch * R * Cb * 2 * p->elem);
         if (s2 != SGX_OK) return s2;
         if ((s2 = forward_dev(p, i, batch, p->d_spec, s, p->d_kspec, 0)) != SGX_OK) return s2;

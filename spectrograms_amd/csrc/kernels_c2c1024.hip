@@ -117,7 +117,7 @@ __global__ __launch_bounds__(32 * NS, 2) void k_c2c1024(C2cArgs a, const v2f *tw
 // for its 262 KB at a CU's share of the HBM.
 constexpr int kCTwOff = kCLds;              // W_1024^(k1 n2), 32 x 32 complex f32
 constexpr int kCLdsP = kCLds + 32 * 32 * 8;  // 139 520 B
-template <int MUL>
+template <int MUL, bool REAL_IO = false>
 __global__ __launch_bounds__(512, 2) void k_colconv1024(C2cArgs a, const v2f *tw1c, const void *mul, unsigned long long mul_row, unsigned per_xcd,
                                                         unsigned total) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -131,16 +131,29 @@ __global__ __launch_bounds__(512, 2) void k_colconv1024(C2cArgs a, const v2f *tw
     const unsigned s1 = tid >> 5, n2 = tid & 31u;
     const unsigned w = tid >> 6, l = tid & 63u, jq = l >> 4, s = l & 15u;
     const unsigned k1 = w * 4u + jq;  // forward: row k1; inverse step B: row n_b
-    const unsigned in_bytes = (unsigned)a.in_img * 8u, out_bytes = (unsigned)a.out_img * 8u;  // host: < 2^31
+    // (REAL_IO: strides and image sizes count f32 elements of real arrays)
+    const unsigned in_bytes = (unsigned)a.in_img * (REAL_IO ? 4u : 8u), out_bytes = (unsigned)a.out_img * (REAL_IO ? 4u : 8u);  // host: < 2^31
     const int istep = (int)(32u * (unsigned)a.in_is * 8u);
     constexpr unsigned kOob = 0x80000000u;
     v2f v[32];
     auto load_tile = [&](unsigned wt, bool live) {  // !live (past the run): the same instructions, out of range — no branch around them
         const unsigned t = wt % a.tiles, b = live ? wt / a.tiles : 0u, s0 = t * 16u;
+        if constexpr (REAL_IO) {
+            // sequence s = the rows 2 s and 2 s + 1 of a real [rows][1024] array (pitch a.in_ss) as ONE complex sequence z = row_a + i row_b:
+            // a real kernel convolves both at once (its spectrum is Hermitian: the result's real part is row_a's, the imaginary row_b's)
+            // Loaded 8 bytes at a time: the even lane of a pair takes (row_a[c], row_a[c + 1]), the odd lane (row_b[c], row_b[c + 1]), c = its
+            // even column; pair_rows() below trades the halves so that lane n2 holds z[n2 + 32 n1].  (As two 4-byte loads per element a
+            // tile had 64 loads and 32 stores in flight — more than the 6-bit vmcnt counts: tiles came out with their first rows unread.)
+            const __amdgpu_buffer_rsrc_t ri = make_rsrc((const float *)a.in + (size_t)b * a.in_img, in_bytes);
+            const unsigned va = live && s0 + s1 < a.nseq ? ((2u * (s0 + s1) + (n2 & 1u)) * (unsigned)a.in_ss + (n2 & ~1u)) * 4u : kOob;
+#pragma unroll
+            for (int n1 = 0; n1 < 32; ++n1) v[n1] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(ri, (int)va, n1 * 128, 0));
+        } else {
         const __amdgpu_buffer_rsrc_t ri = make_rsrc((const v2f *)a.in + (size_t)b * a.in_img, in_bytes);
         const unsigned vo = live && s0 + s1 < a.nseq ? ((s0 + s1) * (unsigned)a.in_ss + n2 * (unsigned)a.in_is) * 8u : kOob;
 #pragma unroll
         for (int n1 = 0; n1 < 32; ++n1) v[n1] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(ri, (int)vo, n1 * istep, 0));
+        }
     };
     unsigned wt = lo + slot;
     load_tile(wt, wt < hi);
@@ -151,6 +164,15 @@ __global__ __launch_bounds__(512, 2) void k_colconv1024(C2cArgs a, const v2f *tw
     __syncthreads();  // twiddles visible
     while (wt < hi) {
         const unsigned t = wt % a.tiles, b = wt / a.tiles, s0 = t * 16u;
+        if constexpr (REAL_IO) {  // (row_a[c], row_a[c + 1]) | (row_b[c], row_b[c + 1]) in lanes 2 j | 2 j + 1  ->  z[c] | z[c + 1], z = row_a + i row_b
+            const bool odd = n2 & 1u;
+#pragma unroll
+            for (int n1 = 0; n1 < 32; ++n1) {
+                const float send = odd ? v[n1].x : v[n1].y;
+                const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, false));  // quad_perm [1, 0, 3, 2]
+                v[n1] = odd ? (v2f){recv, v[n1].y} : (v2f){v[n1].x, recv};
+            }
+        }
         {   // forward pass 1
             Fft<32, false>::run(v, v);
             unsigned char *dst = smem + s1 * kCFS + n2 * 8;
@@ -179,15 +201,19 @@ __global__ __launch_bounds__(512, 2) void k_colconv1024(C2cArgs a, const v2f *tw
         Fft<32, false>::run(x, x);  // X[k1 + 32 k2]
         {   // product with the kernel spectrum / mask (a column past the image reads zeros: its lanes hold zeros anyway)
             constexpr bool REAL_MASK = MUL == MUL_MASK;
-            const unsigned mrow = MUL == MUL_OUTER ? 8u : (unsigned)mul_row * (REAL_MASK ? 4u : 8u);
+            constexpr bool VEC = MUL == MUL_OUTER || MUL == MUL_VEC;  // a 1024-entry table indexed by k alone
+            const unsigned mrow = VEC ? 8u : (unsigned)mul_row * (REAL_MASK ? 4u : 8u);
             const __amdgpu_buffer_rsrc_t rm = make_rsrc(mul, MUL == MUL_OUTER ? (1024u + a.nseq) * 8u : 1024u * mrow);
-            const unsigned mo = MUL == MUL_OUTER ? k1 * 8u : valid ? k1 * mrow + (s0 + s) * (REAL_MASK ? 4u : 8u) : kOob;
+            const unsigned mo = VEC ? k1 * 8u : valid ? k1 * mrow + (s0 + s) * (REAL_MASK ? 4u : 8u) : kOob;
             v2f vc = {0.f, 0.f};  // MUL_OUTER: the column's factor V[col], one load per tile; the row factors U[k] come from an 8 KB table
             if constexpr (MUL == MUL_OUTER)
                 vc = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rm, (int)(valid ? (1024u + s0 + s) * 8u : kOob), 0, 0));
 #pragma unroll
             for (int k2 = 0; k2 < 32; ++k2) {
-                if constexpr (MUL == MUL_OUTER) {
+                if constexpr (MUL == MUL_VEC) {  // one factor of a rank-1 kernel's spectrum, the same for every sequence (the separable passes)
+                    const v2f r = cmulv(x[k2], __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rm, (int)mo, k2 * 32 * 8, 0)));
+                    x[k2] = (v2f){r.x, -r.y};
+                } else if constexpr (MUL == MUL_OUTER) {
                     const v2f u = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rm, (int)mo, k2 * 32 * 8, 0));
                     const v2f r = cmulv(x[k2], cmulv(u, vc));  // K[k][col] = U[k] V[col], rounded to f32 like a stored spectrum
                     x[k2] = (v2f){r.x, -r.y};
@@ -229,9 +255,13 @@ __global__ __launch_bounds__(512, 2) void k_colconv1024(C2cArgs a, const v2f *tw
         __syncthreads();  // rows read: the next tile's pass 1 may overwrite the buffer while this tile finishes
         Fft<32, false>::run(x, x);  // over k1 -> n_a: Y[32 n_a + n_b]
         {
-            const __amdgpu_buffer_rsrc_t ro = make_rsrc((v2f *)a.out + (size_t)b * a.out_img, out_bytes);
-            const unsigned oo = valid ? ((s0 + s) * (unsigned)a.out_ss + k1 * (unsigned)a.out_is) * 8u : kOob;
-            const int ostep = (int)(32u * (unsigned)a.out_is * 8u);
+            // (REAL_IO: element n of the pair (rows 2 q, 2 q + 1) goes to out[n][2 q .. 2 q + 1] — the transposed real array, the pair side
+            // by side again; 16 lanes write the 128 bytes of 32 consecutive input rows)
+            const __amdgpu_buffer_rsrc_t ro = REAL_IO ? make_rsrc((float *)a.out + (size_t)b * a.out_img, out_bytes)
+                                                      : make_rsrc((v2f *)a.out + (size_t)b * a.out_img, out_bytes);
+            const unsigned oo = !valid ? kOob : REAL_IO ? (k1 * (unsigned)a.out_is + 2u * (s0 + s)) * 4u
+                                                        : ((s0 + s) * (unsigned)a.out_ss + k1 * (unsigned)a.out_is) * 8u;
+            const int ostep = (int)(32u * (unsigned)a.out_is * (REAL_IO ? 4u : 8u));
 #pragma unroll
             for (int na = 0; na < 32; ++na) {
                 typedef unsigned U2 __attribute__((ext_vector_type(2)));
@@ -733,7 +763,7 @@ hipError_t launch_istft1024(const void *spec, void *out, const void *win, unsign
 }
 
 hipError_t launch_colconv1024(const C2cArgs &a, const void *tw1c, const void *mul, unsigned long long mul_row, int mul_kind,
-                              hipStream_t s) {
+                              hipStream_t s, bool real_io) {
     const unsigned long long g = (unsigned long long)a.tiles * a.batch;
     if (g == 0 || g >= 0x7fffffffull || a.n != 1024) return hipErrorInvalidConfiguration;
     // the kernel addresses an image, and the kernel spectrum / mask, with 32-bit byte offsets
@@ -743,13 +773,16 @@ hipError_t launch_colconv1024(const C2cArgs &a, const void *tw1c, const void *mu
         if ((e = set_max_dynamic_lds((const void *)k_colconv1024<MUL_SPECTRUM>, kCLdsP)) != hipSuccess) return e;
         if ((e = set_max_dynamic_lds((const void *)k_colconv1024<MUL_MASK>, kCLdsP)) != hipSuccess) return e;
         if ((e = set_max_dynamic_lds((const void *)k_colconv1024<MUL_OUTER>, kCLdsP)) != hipSuccess) return e;
+        if ((e = set_max_dynamic_lds((const void *)k_colconv1024<MUL_VEC, true>, kCLdsP)) != hipSuccess) return e;
     }
     const unsigned cus = device_cu_count();  // of the current device = the plan's (DeviceGuard)
     // persistent: one workgroup per CU; XCD x (blockIdx mod 8) walks the contiguous run [x per_xcd, (x + 1) per_xcd) of tiles
     const unsigned total = (unsigned)g, per_xcd = (total + 7u) / 8u;
     const unsigned slots = std::max(1u, std::min(cus / 8u, per_xcd));
     const dim3 grid(slots * 8u);
-    if (mul_kind == MUL_MASK) hipLaunchKernelGGL((k_colconv1024<MUL_MASK>), grid, dim3(512), kCLdsP, s, a, (const v2f *)tw1c, mul, mul_row, per_xcd, total);
+    if (real_io != (mul_kind == MUL_VEC)) return hipErrorInvalidValue;  // the real-pair form exists for the separable passes only
+    if (real_io) hipLaunchKernelGGL((k_colconv1024<MUL_VEC, true>), grid, dim3(512), kCLdsP, s, a, (const v2f *)tw1c, mul, mul_row, per_xcd, total);
+    else if (mul_kind == MUL_MASK) hipLaunchKernelGGL((k_colconv1024<MUL_MASK>), grid, dim3(512), kCLdsP, s, a, (const v2f *)tw1c, mul, mul_row, per_xcd, total);
     else if (mul_kind == MUL_OUTER) hipLaunchKernelGGL((k_colconv1024<MUL_OUTER>), grid, dim3(512), kCLdsP, s, a, (const v2f *)tw1c, mul, mul_row, per_xcd, total);
     else if (mul_kind == MUL_SPECTRUM) hipLaunchKernelGGL((k_colconv1024<MUL_SPECTRUM>), grid, dim3(512), kCLdsP, s, a, (const v2f *)tw1c, mul, mul_row, per_xcd, total);
     else return hipErrorInvalidValue;

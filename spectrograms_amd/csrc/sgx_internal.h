@@ -218,9 +218,12 @@ hipError_t launch_c2c1024(const C2cArgs &a, const void *tw1c, hipStream_t s);
 // in = [col][row] (a.in_ss = rows, a.in_is = 1), out = [row][col] (a.out_ss = 1, a.out_is = cols).  `mul` by mul_kind:
 // MUL_SPECTRUM a complex kernel spectrum, MUL_MASK a real mask (both [row][col] with row stride mul_row), MUL_OUTER the two factors
 // of a rank-1 kernel's spectrum K[row][col] = U[row] V[col]: 1024 complex U, then a.nseq complex V (mul_row unused)
-enum { MUL_SPECTRUM = 0, MUL_MASK = 1, MUL_OUTER = 2 };
+// real_io (with MUL_VEC: `mul` = 1024 complex values, one factor of a rank-1 kernel's spectrum): a sequence is the pair of rows (2 q, 2 q + 1)
+// of a real [2 nseq][1024] array (a.in_ss = its pitch, a.in_img = floats per image), written to the transposed real array
+// out[n][2 q .. 2 q + 1] (a.out_is = its pitch, a.out_img = floats per image)
+enum { MUL_SPECTRUM = 0, MUL_MASK = 1, MUL_OUTER = 2, MUL_VEC = 3 };
 hipError_t launch_colconv1024(const C2cArgs &a, const void *tw1c, const void *mul, unsigned long long mul_row, int mul_kind,
-                              hipStream_t s);
+                              hipStream_t s, bool real_io = false);
 // tuned f32 inverse row pass for ncols == 1024 on a [r][k]-major half spectrum (a.in_ks == 1), 16 rows per workgroup
 hipError_t launch_c2r1024(const C2rArgs &a, const void *twr, const void *tw1, hipStream_t s);
 // fused f32 n_fft = 1024 inverse STFT (C2R + window + overlap-add + normalise + trim); hop >= 64; twr/tw1 as launch_c2r1024

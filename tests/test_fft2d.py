@@ -251,7 +251,10 @@ def test_gpu_rank1_kernels_multiply_in_their_two_factors(shape, monkeypatch):
     near[1, 2] *= 1.001
     for k in kernels + [near]:
         monkeypatch.delenv("SGX_CONV_RANK1", raising=False)
-        got = sg.Fft2dPlan(shape[0], shape[1], "float32").convolve(x, k)
+        monkeypatch.delenv("SGX_CONV_SEPARABLE", raising=False)
+        got = sg.Fft2dPlan(shape[0], shape[1], "float32").convolve(x, k)  # (1024 x 1024: the two separable passes over pairs of real rows)
+        monkeypatch.setenv("SGX_CONV_SEPARABLE", "0")
+        outer = sg.Fft2dPlan(shape[0], shape[1], "float32").convolve(x, k)  # three passes, the outer-product multiplier in the column kernel
         monkeypatch.setenv("SGX_CONV_RANK1", "0")
         general = sg.Fft2dPlan(shape[0], shape[1], "float32").convolve(x, k)
         scale = 0.0
@@ -260,16 +263,20 @@ def test_gpu_rank1_kernels_multiply_in_their_two_factors(shape, monkeypatch):
             scale = max(1.0, float(np.max(np.abs(ref))))
             assert np.max(np.abs(got[i] - ref)) <= 2e-5 * scale, k.shape
             assert np.max(np.abs(general[i] - ref)) <= 2e-5 * scale, k.shape
-        assert np.max(np.abs(got - general)) <= 4e-6 * scale
+            assert np.max(np.abs(outer[i] - ref)) <= 2e-5 * scale, k.shape
+        assert np.max(np.abs(got - general)) <= 4e-6 * scale and np.max(np.abs(outer - general)) <= 4e-6 * scale
         if k is near:
-            assert np.array_equal(got, general)  # not rank 1 within 2^-22: the same path either way
+            assert np.array_equal(got, general) and np.array_equal(outer, general)  # not rank 1 within 2^-22: the same path either way
+        elif shape != (1024, 1024):
+            assert np.array_equal(got, outer)  # the separable passes need 1024 points along both axes
     monkeypatch.delenv("SGX_CONV_RANK1", raising=False)
+    monkeypatch.delenv("SGX_CONV_SEPARABLE", raising=False)
 
 
 @pytest.mark.gpu
 def test_gpu_convolve_config5_full_batch_gaussian():
-    """BASELINE configs[4] at its full size through convolve_fft with the 9 x 9 Gaussian: 512 x 1024 x 1024 f32 in one call (chunks of 64 on
-    two streams, the rank-1 product), first and last image against the oracle, and every image against the same plan convolving it alone."""
+    """BASELINE configs[4] at its full size through convolve_fft with the 9 x 9 Gaussian: 512 x 1024 x 1024 f32 in one call (one launch
+    of each of the two separable passes), first and last image against the oracle, and every image against the same plan convolving it alone."""
     torch = pytest.importorskip("torch")
     B = 512
     g = torch.Generator(device="cuda").manual_seed(11)
@@ -288,16 +295,19 @@ def test_gpu_convolve_config5_full_batch_gaussian():
 
 
 @pytest.mark.gpu
-def test_gpu_convolve_large_batch_runs_in_chunks_on_two_streams():
+@pytest.mark.parametrize("kernel", ["general", "gaussian"])
+def test_gpu_convolve_large_batch_runs_in_chunks_on_two_streams(kernel, monkeypatch):
     """From 128 images of 1024 x 1024 f32 on, convolve_fft runs as chunks of 64 alternating between the caller's stream and a
-    plan-owned second one (fft2d.hip: fused_product_dev).  The result must be, bit for bit, what the same images give in small
+    plan-owned second one (fft2d.hip: fused_product_dev) — a rank-1 kernel (the Gaussian) as groups of up to 512 images (here 100, by
+    SGX_SEP_GROUP) through its two separable passes on the caller's stream.  The result must be, bit for bit, what the same images give in small
     batches (which take the single-stream schedule); the call must behave as ONE operation of the caller's stream — work queued
     behind it sees all of its output, work queued before it is seen by all of its chunks — and must replay from a hipGraph."""
     torch = pytest.importorskip("torch")
-    B, R, Cn = 168, 1024, 1024  # 64 + 64 + 40: both streams, a ragged last chunk
+    B, R, Cn = 168, 1024, 1024  # 64 + 64 + 40: both streams, a ragged last chunk (100 + 68 for the separable passes)
+    monkeypatch.setenv("SGX_SEP_GROUP", "100")
     g = torch.Generator(device="cuda").manual_seed(21)
     x = torch.randn((B, R, Cn), generator=g, device="cuda", dtype=torch.float32)
-    k = sg.gaussian_kernel_2d(9, 2.0, dtype="float32")
+    k = sg.gaussian_kernel_2d(9, 2.0, dtype="float32") if kernel == "gaussian" else np.random.default_rng(3).standard_normal((5, 7)).astype(np.float32)
     small = sg.Fft2dPlan(R, Cn, "float32")
     ref = torch.cat([small.convolve_torch(x[i:i + 24], k) for i in range(0, B, 24)])
     plan = sg.Fft2dPlan(R, Cn, "float32")
