@@ -716,7 +716,8 @@ def make_images(torch, dev, batch: int = IMG_BATCH):
 def fft2d_legs(torch, sg, dev, which, args, peak):
     """BASELINE configs[4]: 512 x 1024 x 1024 f32 images, img[r, c] = sin(0.01 r) + cos(0.02 c) + N(0, 0.05^2) (32 distinct noise
     fields, tiled): `fft2d` alone and `convolve_fft` with gaussian_kernel_2d(9, 2.0).  Algorithmic bytes per image: fft2d 4 MiB
-    read + 1024 * 513 * 8 B written; convolve_fft 4 MiB read + 4 MiB written (kernel spectrum cached by the plan)."""
+    read + 1024 * 513 * 8 B written; convolve_fft 4 MiB read + 4 MiB written (kernel spectrum cached by the plan; the Gaussian is an outer
+    product, which the plan runs as two separable passes over pairs of real rows: DESIGN.md §4)."""
     R = C = IMG_SIDE
     x = make_images(torch, dev)
     plan = sg.Fft2dPlan(R, C, "float32")
