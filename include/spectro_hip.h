@@ -241,7 +241,12 @@ sgx_status sgx_fft2d_inverse(sgx_fft2d *plan, const void *spectrum, size_t batch
 /* convolve_fft(image, kernel): kernel (krows x kcols, host pointer, T) is wrapped so its centre sits at (0,0)
  * (pad_kernel_for_fft, image_ops.rs:123-152), transformed once and multiplied into every image's spectrum.  The plan keeps
  * that spectrum on the device: a later call with the same kernel bytes and shape on the same stream reuses it (the kernel is
- * read from `kernel_host` during the call, never afterwards); sgx_fft2d_filter keeps its mask per (kind, cut-offs, stream). */
+ * read from `kernel_host` during the call, never afterwards); sgx_fft2d_filter keeps its mask per (kind, cut-offs, stream).
+ * f32 images with 1024 rows (the fused column stage): a kernel that is an outer product u v^T to f32 rounding (gaussian_kernel_2d is,
+ * image_ops.rs:188-220) is multiplied in as the two 1-D spectra of u and v, and on 1024 x 1024 images its convolution runs as two
+ * separable passes (rows, then columns) — the same linear operators as fft2d . product . ifft2d, within the f32 tolerance of the
+ * general path.  Test switches, read at the call: SGX_CONV_RANK1=0 (every kernel through its full 2-D spectrum),
+ * SGX_CONV_SEPARABLE=0 (rank-1 kernels through the three passes), SGX_SEP_GROUP=n (images per launch pair of the separable passes). */
 sgx_status sgx_fft2d_convolve(sgx_fft2d *plan, const void *images, size_t batch, const void *kernel_host, size_t krows,
                               size_t kcols, void *out, int32_t mem_kind, void *hip_stream);
 /* lowpass (kind 0, cut_lo), highpass (1, cut_lo), bandpass (2, cut_lo..cut_hi): binary radial masks built on the HALF
