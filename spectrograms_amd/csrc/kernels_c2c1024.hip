@@ -206,6 +206,9 @@ __global__ __launch_bounds__(512, 2) void k_colconv1024(C2cArgs a, const v2f *tw
             const __amdgpu_buffer_rsrc_t rm = make_rsrc(mul, MUL == MUL_OUTER ? (1024u + a.nseq) * 8u : 1024u * mrow);
             const unsigned mo = VEC ? k1 * 8u : valid ? k1 * mrow + (s0 + s) * (REAL_MASK ? 4u : 8u) : kOob;
             v2f vc = {0.f, 0.f};  // MUL_OUTER: the column's factor V[col], one load per tile; the row factors U[k] come from an 8 KB table
+            // (33 loads here: with the previous tile's 32 stores still counted that would be 65 vector-memory operations in flight, one more than
+            // this file allows itself — see load_tile's REAL_IO note; the stores have had a whole pass to drain)
+            if constexpr (MUL == MUL_OUTER) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if constexpr (MUL == MUL_OUTER)
                 vc = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rm, (int)(valid ? (1024u + s0 + s) * 8u : kOob), 0, 0));
 #pragma unroll
