@@ -142,8 +142,10 @@ __global__ __launch_bounds__(512, 2) void k_colconv1024(C2cArgs a, const v2f *tw
             // sequence s = the rows 2 s and 2 s + 1 of a real [rows][1024] array (pitch a.in_ss) as ONE complex sequence z = row_a + i row_b:
             // a real kernel convolves both at once (its spectrum is Hermitian: the result's real part is row_a's, the imaginary row_b's)
             // Loaded 8 bytes at a time: the even lane of a pair takes (row_a[c], row_a[c + 1]), the odd lane (row_b[c], row_b[c + 1]), c = its
-            // even column; pair_rows() below trades the halves so that lane n2 holds z[n2 + 32 n1].  (As two 4-byte loads per element a
-            // tile had 64 loads and 32 stores in flight — more than the 6-bit vmcnt counts: tiles came out with their first rows unread.)
+            // even column; the trade at the top of the tile loop makes lane n2 hold z[n2 + 32 n1].  (The first form — two 4-byte loads per
+            // element — gave wrong tiles whenever a workgroup ran more than one tile; four experiments did not cure it: at most 64
+            // operations in flight, immediate instead of scalar offsets, `s_waitcnt vmcnt(0)` at the top of every tile, the same tied to
+            // the loaded registers.  Cause not found, form not used: DESIGN.md §4.)
             const __amdgpu_buffer_rsrc_t ri = make_rsrc((const float *)a.in + (size_t)b * a.in_img, in_bytes);
             const unsigned va = live && s0 + s1 < a.nseq ? ((2u * (s0 + s1) + (n2 & 1u)) * (unsigned)a.in_ss + (n2 & ~1u)) * 4u : kOob;
 #pragma unroll
@@ -206,9 +208,6 @@ __global__ __launch_bounds__(512, 2) void k_colconv1024(C2cArgs a, const v2f *tw
             const __amdgpu_buffer_rsrc_t rm = make_rsrc(mul, MUL == MUL_OUTER ? (1024u + a.nseq) * 8u : 1024u * mrow);
             const unsigned mo = VEC ? k1 * 8u : valid ? k1 * mrow + (s0 + s) * (REAL_MASK ? 4u : 8u) : kOob;
             v2f vc = {0.f, 0.f};  // MUL_OUTER: the column's factor V[col], one load per tile; the row factors U[k] come from an 8 KB table
-            // (33 loads here: with the previous tile's 32 stores still counted that would be 65 vector-memory operations in flight, one more than
-            // this file allows itself — see load_tile's REAL_IO note; the stores have had a whole pass to drain)
-            if constexpr (MUL == MUL_OUTER) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if constexpr (MUL == MUL_OUTER)
                 vc = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rm, (int)(valid ? (1024u + s0 + s) * 8u : kOob), 0, 0));
 #pragma unroll
