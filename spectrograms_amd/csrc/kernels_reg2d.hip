@@ -394,7 +394,10 @@ static hipError_t c2r_reg_plan(const C2rArgs &a0, int dtype, C2rArgs &a, unsigne
 #endif
     // rows per workgroup: up to 32, within a quarter of a CU's LDS — four workgroups per CU overlap their load, transform and
     // store phases (measured: f32 n_fft 512 inverse STFT 0.65 ms with 32-frame tiles at two per CU, 0.49 ms with 16-frame tiles)
-    const size_t c2r_budget = dtype == SGX_F64 ? kR2Budget : (size_t)SGX_C2R_KB * 1024;  // (f64: n_fft 400 0.90 vs 1.14 ms with the larger tile)
+    // (f64: n_fft 400 0.90 vs 1.14 ms with the larger tile; f32 frames of 16 KB and more — n_fft >= 4096 — too, round 5: 40 KB is two frames
+    // there, i.e. 16-byte runs of the [bin][frame] spectrum: 64 x 10 s inverse STFT n_fft 4096 / 1024 223 -> 216 us, 8192 / 2048 295 -> 258;
+    // 144 KB: 236 / 266; shorter frames lose with the larger tile: 512 / 160 73 -> 97 us, 2048 / 100 0.90 -> 0.96 ms)
+    const size_t c2r_budget = dtype == SGX_F64 || per >= 16384 ? kR2Budget : (size_t)SGX_C2R_KB * 1024;
     ltile = 5;
     const size_t ola_tab = ola ? ((size_t)a0.hop + a0.ncols) * es : 0;  // the overlap-add's norm table and window copy behind the tile
     while (ltile > 0 && ((size_t)(1u << ltile) * per + ola_tab > c2r_budget || (!ola && (1u << (ltile - 1)) >= a0.nrows))) --ltile;
