@@ -1,10 +1,11 @@
-"""Device time per 256 x 10 s batch: Mel-dB alone vs MFCC (Mel-dB + DCT-II/lifter epilogue kernel) vs chromagram."""
+"""Device time per 256 x 10 s batch: Mel-dB alone vs MFCC (fused into the Mel-dB launch at n_fft 1024 f32; elsewhere Mel-dB + the DCT-II / lifter
+epilogue kernel) vs chromagram.  N_FFT / HOP from the environment (default 1024 / 256; 512 / 160 is the reference's speech default)."""
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import spectrograms_amd as sg
 from tests import helpers as H
 x = torch.from_numpy(H.cfg2_batch(256)).cuda()
-st = sg.StftParams(1024, 256, sg.WindowType.hanning, True)
+st = sg.StftParams(int(os.environ.get("N_FFT", 1024)), int(os.environ.get("HOP", 256)), sg.WindowType.hanning, True)
 params = sg.SpectrogramParams(st, 16000.0)
 pl = sg.SpectrogramPlanner()
 plans = {"mel_db_80": pl.mel_db_plan(params, sg.MelParams(80, 0.0, 8000.0), sg.LogParams(-80.0), dtype="float32"),
