@@ -774,7 +774,7 @@ def test_fuzz_shapes():
     """Seeded random sweep over (n_fft, hop, centre, window, length, dtype, output) — every kernel family (tuned, register-tiled
     power-of-two / mixed radix, LDS radix-2, two-factor, direct) against the oracle, including hops that do not divide n_fft,
     odd hops (unaligned frames), signals shorter than a frame and lengths that leave partial tiles."""
-    rng = np.random.default_rng(20260)
+    rng = np.random.default_rng(int(os.environ.get("SGX_FUZZ_SEED", 20260)))
     pool = [4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048] + MIXED + [6, 10, 30, 50, 100, 250, 330, 441, 97, 127, 509, 1006, 1009, 7, 11, 13, 3000]
     seen = set()
     for case in range(90):
@@ -801,28 +801,29 @@ def test_fuzz_shapes():
                 kw.update(n_mels=int(rng.integers(4, 41)), fmin=0.0, fmax=8000.0, amp="power")
         plan, _ = run_case(n=n, batch=int(rng.integers(1, 4)), seed=case, **kw)
         seen.add(plan.kernel_name)
-    assert {"reg_radix", "direct_dft", "lds_radix2", "bluestein"} <= seen, seen  # (two-factor: its own tests above)
+    assert "SGX_FUZZ_SEED" in os.environ or {"reg_radix", "direct_dft", "lds_radix2", "bluestein"} <= seen, seen  # (two-factor: its own tests above; the coverage claim is the default sweep's)
 
 
 def test_fuzz_tuned_kernels():
-    """Seeded random sweep over the shape-specific kernels only (even hops): every staging depth and the per-lane-column variants, windows,
-    centre on / off, signals from shorter than a frame to dozens of tiles, batches up to several tiles per workgroup, every output mode —
-    against the oracle; the batch's last signal against its own launch, bit for bit."""
-    rng = np.random.default_rng(424242)
+    """Seeded random sweep over the six (n_fft, type) pairs with shape-specific kernels, EVERY hop from 1 to n_fft (round 5: odd hops and
+    f32 512 at unlisted hops stay on the tuned kernels; the few that do not — f32 512 odd, f64 512 above 260, f64 2048 odd above 1024,
+    filterbanks at f32 512's unlisted hops — run the register-tiled kernel through the same checks): every staging depth and the
+    per-lane-column variants, windows, centre on / off, signals from shorter than a frame to dozens of tiles, batches up to several
+    tiles per workgroup, every output mode — against the oracle; the batch's last signal against its own launch, bit for bit.
+    SGX_FUZZ_SEED draws another sweep (tools: hunting runs on the GPU box)."""
+    rng = np.random.default_rng(int(os.environ.get("SGX_FUZZ_SEED", 424242)))
     shapes = [("float32", 512), ("float32", 1024), ("float32", 2048), ("float32", 4096), ("float64", 512), ("float64", 1024), ("float64", 2048)]
     seen = set()
-    for case in range(70):
+    for case in range(84):
         dtype, n_fft = shapes[case % len(shapes)]
-        if n_fft == 512:
-            hop = int(rng.choice([64, 128, 160, 256])) if dtype == "float32" else 2 * int(rng.integers(1, 131))
-        else:
-            hop = 2 * int(rng.integers(1, n_fft // 2 + 1))
+        hop = int(rng.integers(1, n_fft + 1)) if rng.integers(4) else int(rng.choice([n_fft // 8, n_fft // 4, n_fft // 2, 160]))
         centre = bool(rng.integers(2))
         window = sorted(WINDOWS)[rng.integers(len(WINDOWS))]
         n = int(rng.integers(1, 60 * n_fft)) if rng.integers(3) else int(rng.integers(1, 3 * n_fft))
         if not centre and n < n_fft:
             n = n_fft + int(rng.integers(0, 3 * n_fft))
         batch = int(rng.choice([1, 2, 3, 9, 40]))
+        n = max(1 if centre else n_fft, min(n, hop * max(2, 12_000_000 // (batch * (n_fft // 2 + 1)))))  # (a short hop: bounded output)
         kind = rng.integers(4)
         kw = dict(n_fft=n_fft, hop=hop, centre=centre, window=window, dtype=dtype)
         if kind == 0:
@@ -837,14 +838,14 @@ def test_fuzz_tuned_kernels():
         seen.add(plan.kernel_name)
         x = signals(batch, n, np.float32 if dtype == "float32" else np.float64, 1000 + case)
         assert np.array_equal(np.asarray(plan.compute_batch(x[batch - 1:]))[0], np.asarray(got)[batch - 1]), (case, kw, n, batch)
-    assert {"r32x16_f32", "r32x32_f32", "r64x32_f32", "d512_f64", "d32x16_f64", "d32x32_f64"} <= seen, seen
+    assert "SGX_FUZZ_SEED" in os.environ or {"r32x16_f32", "r32x32_f32", "r64x32_f32", "d512_f64", "d32x16_f64", "d32x32_f64"} <= seen, seen
 
 
 def test_fuzz_chirpz_lengths():
     """Seeded sweep over frame lengths that take the chirp-z kernel (primes, 2 x prime, odd composites, unlisted even sizes; every
     convolution length from 64 to 16384): random hop, centre, window, signal length (shorter than a frame included), batch, output
     mode, both dtypes — against the oracle; a batch's last signal against its own launch."""
-    rng = np.random.default_rng(31337)
+    rng = np.random.default_rng(int(os.environ.get("SGX_FUZZ_SEED", 31337)))
     pool = [17, 23, 37, 61, 97, 127, 129, 251, 257, 509, 521, 1009, 1021, 1023, 1025, 2003, 2039, 2049, 3000, 4093, 100, 441, 98, 1006, 2900]
     seen_m = set()
     for case in range(60):
@@ -888,7 +889,7 @@ def test_fuzz_chirpz_lengths():
         x = signals(batch, n, np.float32 if dtype == "float32" else np.float64, 1000 + case)
         assert np.array_equal(np.asarray(plan.compute_batch(x[batch - 1:]))[0], np.asarray(got)[batch - 1]), (n_fft, dtype, kw)
         seen_m.add(m)
-    assert {64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384} <= seen_m, sorted(seen_m)
+    assert "SGX_FUZZ_SEED" in os.environ or {64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384} <= seen_m, sorted(seen_m)
 
 
 def test_config4_shard_full_size_mel_power():
