@@ -98,6 +98,35 @@ def test_lowpass_mask_uses_half_spectrum_dims():
     assert m[0, 33 - int(r)] == 1.0  # "wrapped" on the half width — the quirk
 
 
+def test_rank1_kernel_spectrum_is_the_outer_product_of_two_1d_spectra():
+    """The identity behind the rank-1 routes of convolve_fft (fft2d.hip outer_product_spectrum), checked without a GPU against
+    the oracle: a kernel u v^T, wrapped as pad_kernel_for_fft does (centre to (0, 0): image_ops.rs:123-152), has the half spectrum
+    U[k] V[c] with U, V the 1-D transforms of the wrapped u and v — so convolving with it equals convolving the rows with v and the
+    columns with u.  Even and odd kernel sizes (the centre index is size // 2 in both), a 1 x n and an n x 1 kernel."""
+    rng = np.random.default_rng(12)
+    R, C = 64, 48
+    x = img((R, C), 3, np.float64)
+    for kr, kc in ((5, 5), (4, 6), (1, 7), (9, 1), (8, 3)):
+        u, v = rng.standard_normal(kr), rng.standard_normal(kc)
+        k = np.outer(u, v)
+
+        def wrapped_spectrum(w, n, bins):
+            t = (np.arange(w.size) - w.size // 2) % n
+            kk = np.arange(bins)[:, None]
+            return (w[None, :] * np.exp(-2j * np.pi * ((kk * t[None, :]) % n) / n)).sum(axis=1)
+
+        U, V = wrapped_spectrum(u, R, R), wrapped_spectrum(v, C, C // 2 + 1)
+        ref = orc.convolve_fft(x, k)
+        X = orc.fft2d(x)
+        got = orc.ifft2d(X * np.outer(U, V), C)
+        assert np.max(np.abs(got - ref)) <= 1e-11 * max(1.0, np.max(np.abs(ref))), (kr, kc)
+        # ... and the two separable passes: rows with v, then columns with u (full-length spectra, circular)
+        Vf, Uf = wrapped_spectrum(v, C, C), wrapped_spectrum(u, R, R)
+        rows = np.fft.ifft(np.fft.fft(x, axis=1) * Vf[None, :], axis=1).real
+        sep = np.fft.ifft(np.fft.fft(rows, axis=0) * Uf[:, None], axis=0).real
+        assert np.max(np.abs(sep - ref)) <= 1e-11 * max(1.0, np.max(np.abs(ref))), (kr, kc)
+
+
 def test_host_validation():
     with pytest.raises(sg.InvalidInputError):
         sg.Fft2dPlan(0, 4, device=_ffi.DEVICE_HOST_ONLY)
