@@ -84,8 +84,10 @@ def test_gpu_mfcc_matches_oracle(n_fft, hop, n_mels, mp, dtype):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hop,mp", [(256, sg.MfccParams(13)), (200, sg.MfccParams(20).with_c0(False)), (320, sg.MfccParams(40).with_lifter(0))])
-def test_gpu_fused_mfcc_keeps_the_reference_chain(hop, mp):
+@pytest.mark.parametrize("hop,mp,nm", [(256, sg.MfccParams(13), 80), (200, sg.MfccParams(20).with_c0(False), 80), (320, sg.MfccParams(40).with_lifter(0), 80),
+                                       (256, sg.MfccParams(64), 96), (441, sg.MfccParams(20), 40), (256, sg.MfccParams(33).with_c0(False), 64),
+                                       (256, sg.MfccParams(24), 24), (255, sg.MfccParams(13), 48)])
+def test_gpu_fused_mfcc_keeps_the_reference_chain(hop, mp, nm):
     """f32, n_fft 1024: the DCT-II runs inside the Mel-dB launch on the matrix cores (kernels_r32x16.hip mfcc_tile; staged hop 256 /
     other staged hops / per-lane loads).  v_mfma_f32_16x16x4_f32 is an exact fused-multiply-add chain in ascending band order, i.e. the
     reference's `val.mul_add(basis, acc)` fold (src/mfcc.rs:278-292): checked against that chain evaluated on the host from the SAME
@@ -93,13 +95,13 @@ def test_gpu_fused_mfcc_keeps_the_reference_chain(hop, mp):
     x = np.stack([sig(50000, s, np.float32) for s in range(5)])
     st = sg.StftParams(1024, hop, sg.WindowType.hanning, True)
     params = sg.SpectrogramParams(st, 16000.0)
-    mel = sg.SpectrogramPlanner().mel_db_plan(params, sg.MelParams(80, 0.0, 8000.0), sg.LogParams(-80.0), dtype="float32").compute_batch(x)
-    plan = sg.SpectrogramPlanner().mfcc_plan(st, 16000.0, 80, mp, dtype="float32")
+    mel = sg.SpectrogramPlanner().mel_db_plan(params, sg.MelParams(nm, 0.0, 8000.0), sg.LogParams(-80.0), dtype="float32").compute_batch(x)
+    plan = sg.SpectrogramPlanner().mfcc_plan(st, 16000.0, nm, mp, dtype="float32")  # (the menu of chain lengths: 12 / 16 / 20 / 24 steps of 4 bands; 1 .. 4 tiles of 16 coefficients)
     assert plan.kernel_name == "r32x16_f32"
     got = plan.compute_batch(x)
-    basis = np.cos(np.pi * np.arange(mp.n_mfcc)[:, None] * (np.arange(80)[None, :] + 0.5) / 80).astype(np.float32)
+    basis = np.cos(np.pi * np.arange(mp.n_mfcc)[:, None] * (np.arange(nm)[None, :] + 0.5) / nm).astype(np.float32)
     acc = np.zeros((5, mp.n_mfcc, mel.shape[2]), np.float32)
-    for i in range(80):
+    for i in range(nm):
         acc = (mel[:, i, :][:, None, :].astype(np.float64) * basis[None, :, i, None].astype(np.float64) + acc.astype(np.float64)).astype(np.float32)
     if mp.lifter > 0:
         w = (1.0 + (mp.lifter / 2.0) * np.sin(np.pi * np.arange(mp.n_mfcc) / mp.lifter)).astype(np.float32)
