@@ -44,6 +44,22 @@ def _tol(dtype, ref):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,dtype", [((1 << 20) - 1, "float32"), ((1 << 20) - 1, "float64"), (1 << 20, "float64"), (1 << 21, "float32"), (1 << 21, "float64"),
+                                     (999_983, "float32")])
+def test_gpu_largest_lengths(n, dtype):
+    """The ends of the range sgx_plan_create accepts (bigfft.hip big_supported): the largest odd length (chirp-z at M = 2^21), the largest
+    prime below 10^6, 2^20 and 2^21 (four-step) — one-shot rfft against the oracle and irfft back."""
+    rdt = np.float32 if dtype == "float32" else np.float64
+    rng = np.random.default_rng(n % 1000)
+    x = (0.5 * np.sin(2 * np.pi * 440.0 * np.arange(n) / 16000.0) + 0.1 * rng.standard_normal(n)).astype(rdt)
+    ref = orc.rfft(x.astype(np.float64))
+    X = sg.compute_fft(x, n, dtype=dtype)
+    assert X.shape == (n // 2 + 1,) and np.max(np.abs(X - ref)) < _tol(dtype, ref)
+    y = sg.compute_irfft(ref.astype(np.complex64 if dtype == "float32" else np.complex128), n, dtype=dtype)
+    assert y.shape == (n,) and np.max(np.abs(y - x)) < (1e-10 if dtype == "float64" else 3e-4)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
 @pytest.mark.parametrize("n", BIG)
 def test_gpu_one_shot_transforms(n, dtype):
