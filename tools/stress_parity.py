@@ -19,7 +19,7 @@ CASES = [("float32", 1024, 256, "complex", 0), ("float32", 1024, 256, "power", 0
 if os.environ.get("ROUND5", "1") == "1":  # round 5: the fused MFCC epilogue, odd hops on the lane-pair kernels, a frame length on the global-memory transforms
     CASES += [("float32", 1024, 256, "mfcc", 80), ("float32", 1024, 441, "mfcc", 80), ("float64", 1024, 255, "complex", 0), ("float64", 1024, 257, "power", 80),
               ("float32", 2048, 511, "complex", 0), ("float64", 512, 159, "power", 0), ("float32", 4096, 1023, "power", 0), ("float64", 2048, 513, "complex", 0),
-              ("float32", 9001, 2250, "power", 0)]
+              ("float32", 9001, 2250, "power", 0), ("float32", 512, 100, "power", 0), ("float32", 512, 384, "complex", 0)]  # (the last two: n_fft 512 at hops without a staged variant — the packed form)
 bad_total = 0
 for dtype, n_fft, hop, amp, nm in CASES:
     x = base.astype(np.float64 if dtype == "float64" else np.float32)
